@@ -1,0 +1,722 @@
+// abi.hip — the extern "C" entry points declared in include/spmv_abi.h.
+//
+// This file is glue: argument checking, handle life cycle, host<->device copies, and dispatch to the
+// format kernels (kernels_*.hip), the conversions (convert.hip) and the generators (generate.hip).
+// There is deliberately no CPU implementation of anything behind these entry points.
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "common.hpp"
+
+namespace spmv
+{
+static thread_local char g_last_error[512] = "";
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+    va_end(ap);
+}
+
+int ensure_scratch(spmv_ctx* ctx, size_t bytes)
+{
+    if (ctx->scratch_bytes >= bytes) return SPMV_OK;
+    if (ctx->scratch)
+    {
+        SPMV_HIP(hipStreamSynchronize(ctx->stream));
+        SPMV_HIP(hipFree(ctx->scratch));
+        ctx->scratch       = nullptr;
+        ctx->scratch_bytes = 0;
+    }
+    const size_t want = std::max<size_t>(bytes, 1 << 16);
+    SPMV_HIP(hipMalloc(&ctx->scratch, want));
+    ctx->scratch_bytes = want;
+    return SPMV_OK;
+}
+
+int mat_alloc(spmv_ctx* ctx, int32_t format, int32_t nrow, int32_t ncol, int64_t nnz, int32_t k, size_t a_count,
+              size_t b_count, size_t v_count, spmv_mat** out)
+{
+    spmv_mat* m = new (std::nothrow) spmv_mat();
+    if (!m) SPMV_FAIL(SPMV_ERR_ALLOC, "out of host memory");
+    m->ctx    = ctx;
+    m->format = format;
+    m->nrow   = nrow;
+    m->ncol   = ncol;
+    m->nnz    = nnz;
+    m->k      = k;
+    m->owned  = true;
+    void *a = nullptr, *b = nullptr, *v = nullptr;
+    hipError_t e = hipSuccess;
+    // a zero-length array still gets a valid (tiny) allocation so that kernels never see nullptr
+    if (e == hipSuccess) e = hipMalloc(&a, std::max<size_t>(a_count, 1) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&b, std::max<size_t>(b_count, 1) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&v, std::max<size_t>(v_count, 1) * sizeof(double));
+    if (e != hipSuccess)
+    {
+        if (a) hipFree(a);
+        if (b) hipFree(b);
+        if (v) hipFree(v);
+        delete m;
+        SPMV_FAIL(SPMV_ERR_ALLOC, "device allocation of %zu+%zu int32 and %zu fp64 failed: %s", a_count, b_count,
+                  v_count, hipGetErrorString(e));
+    }
+    m->a            = (const int32_t*)a;
+    m->b            = (const int32_t*)b;
+    m->v            = (const double*)v;
+    m->device_bytes = (int64_t)((a_count + b_count) * sizeof(int32_t) + v_count * sizeof(double));
+    *out            = m;
+    return SPMV_OK;
+}
+
+void mat_free(spmv_mat* m)
+{
+    if (!m) return;
+    if (m->owned)
+    {
+        if (m->a) hipFree(const_cast<int32_t*>(m->a));
+        if (m->b) hipFree(const_cast<int32_t*>(m->b));
+        if (m->v) hipFree(const_cast<double*>(m->v));
+    }
+    if (m->win_lo) hipFree(m->win_lo);
+    if (m->win_span) hipFree(m->win_span);
+    if (m->coo_carry_row) hipFree(m->coo_carry_row);
+    if (m->coo_carry_val) hipFree(m->coo_carry_val);
+    delete m;
+}
+
+static int use_device(const spmv_ctx* ctx)
+{
+    SPMV_HIP(hipSetDevice(ctx->device));
+    return SPMV_OK;
+}
+
+static int upload(void* dst, const void* src, size_t bytes, spmv_ctx* ctx)
+{
+    if (bytes == 0) return SPMV_OK;
+    SPMV_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SPMV_HIP(hipStreamSynchronize(ctx->stream));  // pageable host memory: the caller may free it on return
+    return SPMV_OK;
+}
+
+static int wrap(spmv_ctx* ctx, int32_t format, int32_t nrow, int32_t ncol, int64_t nnz, int32_t k, const int32_t* a,
+                const int32_t* b, const double* v, spmv_mat** out)
+{
+    spmv_mat* m = new (std::nothrow) spmv_mat();
+    if (!m) SPMV_FAIL(SPMV_ERR_ALLOC, "out of host memory");
+    m->ctx    = ctx;
+    m->format = format;
+    m->nrow   = nrow;
+    m->ncol   = ncol;
+    m->nnz    = nnz;
+    m->k      = k;
+    m->a      = a;
+    m->b      = b;
+    m->v      = v;
+    m->owned  = false;
+    *out      = m;
+    return SPMV_OK;
+}
+
+static int finish(spmv_mat* m, spmv_mat** out)
+{
+    int rc = SPMV_OK;
+    if (m->format == SPMV_FMT_CSR) rc = csr_analyse(m);
+    if (m->format == SPMV_FMT_COO) rc = coo_analyse(m);
+    if (rc != SPMV_OK)
+    {
+        mat_free(m);
+        return rc;
+    }
+    *out = m;
+    return SPMV_OK;
+}
+}  // namespace spmv
+
+using namespace spmv;
+
+extern "C" {
+
+int         spmv_abi_version(void) { return SPMV_ABI_VERSION; }
+const char* spmv_last_error(void) { return g_last_error; }
+
+int spmv_device_count(int* count)
+{
+    SPMV_REQUIRE(count, "count is null");
+    int        n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess)
+    {
+        *count = 0;
+        SPMV_FAIL(SPMV_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return SPMV_OK;
+}
+
+static int ctx_create_common(int device, void* borrowed_stream, bool borrow, spmv_ctx** out)
+{
+    SPMV_REQUIRE(out, "out is null");
+    *out  = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        SPMV_FAIL(SPMV_ERR_NO_DEVICE, "no HIP device is visible; libspmv_hip has no CPU fallback");
+    if (device < 0 || device >= n) SPMV_FAIL(SPMV_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, n);
+    SPMV_HIP(hipSetDevice(device));
+    spmv_ctx* ctx = new (std::nothrow) spmv_ctx();
+    if (!ctx) SPMV_FAIL(SPMV_ERR_ALLOC, "out of host memory");
+    ctx->device = device;
+    if (borrow)
+    {
+        ctx->stream      = (hipStream_t)borrowed_stream;
+        ctx->owns_stream = false;
+    }
+    else
+    {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess)
+        {
+            delete ctx;
+            SPMV_FAIL(SPMV_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+        }
+        ctx->owns_stream = true;
+    }
+    hipError_t e = hipEventCreate(&ctx->ev_begin);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_end);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->host_pinned, 64, hipHostMallocDefault);
+    if (e != hipSuccess)
+    {
+        spmv_ctx_destroy(ctx);
+        SPMV_FAIL(SPMV_ERR_HIP, "context setup: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
+    return SPMV_OK;
+}
+
+int spmv_ctx_create(int device, spmv_ctx** out) { return ctx_create_common(device, nullptr, false, out); }
+int spmv_ctx_create_on_stream(int device, void* hip_stream, spmv_ctx** out)
+{
+    return ctx_create_common(device, hip_stream, true, out);
+}
+
+int spmv_ctx_destroy(spmv_ctx* ctx)
+{
+    if (!ctx) return SPMV_OK;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) hipFree(ctx->scratch);
+    if (ctx->host_pinned) hipHostFree(ctx->host_pinned);
+    if (ctx->ev_begin) hipEventDestroy(ctx->ev_begin);
+    if (ctx->ev_end) hipEventDestroy(ctx->ev_end);
+    if (ctx->owns_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return SPMV_OK;
+}
+
+int spmv_sync(spmv_ctx* ctx)
+{
+    SPMV_REQUIRE(ctx, "ctx is null");
+    SPMV_HIP(hipStreamSynchronize(ctx->stream));
+    return SPMV_OK;
+}
+
+int spmv_ctx_device(const spmv_ctx* ctx, int* device)
+{
+    SPMV_REQUIRE(ctx && device, "null argument");
+    *device = ctx->device;
+    return SPMV_OK;
+}
+
+// ---- vectors ----------------------------------------------------------------------------------------------
+int spmv_vec_create(spmv_ctx* ctx, int64_t n, spmv_vec** out)
+{
+    SPMV_REQUIRE(ctx && out && n >= 0, "spmv_vec_create: bad argument");
+    SPMV_TRY(use_device(ctx));
+    spmv_vec* v = new (std::nothrow) spmv_vec();
+    if (!v) SPMV_FAIL(SPMV_ERR_ALLOC, "out of host memory");
+    hipError_t e = hipMalloc((void**)&v->d, std::max<int64_t>(n, 1) * sizeof(double));
+    if (e != hipSuccess)
+    {
+        delete v;
+        SPMV_FAIL(SPMV_ERR_ALLOC, "device allocation of %lld fp64 failed: %s", (long long)n, hipGetErrorString(e));
+    }
+    v->ctx   = ctx;
+    v->n     = n;
+    v->owned = true;
+    *out     = v;
+    return SPMV_OK;
+}
+
+int spmv_vec_wrap_device(spmv_ctx* ctx, int64_t n, double* device_ptr, spmv_vec** out)
+{
+    SPMV_REQUIRE(ctx && out && n >= 0 && (device_ptr || n == 0), "spmv_vec_wrap_device: bad argument");
+    spmv_vec* v = new (std::nothrow) spmv_vec();
+    if (!v) SPMV_FAIL(SPMV_ERR_ALLOC, "out of host memory");
+    v->ctx   = ctx;
+    v->n     = n;
+    v->d     = device_ptr;
+    v->owned = false;
+    *out     = v;
+    return SPMV_OK;
+}
+
+int spmv_vec_destroy(spmv_vec* v)
+{
+    if (!v) return SPMV_OK;
+    if (v->owned && v->d)
+    {
+        hipSetDevice(v->ctx->device);
+        hipFree(v->d);
+    }
+    delete v;
+    return SPMV_OK;
+}
+
+int spmv_vec_size(const spmv_vec* v, int64_t* n)
+{
+    SPMV_REQUIRE(v && n, "null argument");
+    *n = v->n;
+    return SPMV_OK;
+}
+
+int spmv_vec_device_ptr(const spmv_vec* v, double** device_ptr)
+{
+    SPMV_REQUIRE(v && device_ptr, "null argument");
+    *device_ptr = v->d;
+    return SPMV_OK;
+}
+
+int spmv_vec_upload(spmv_vec* v, int64_t offset, int64_t n, const double* host)
+{
+    SPMV_REQUIRE(v && offset >= 0 && n >= 0 && offset + n <= v->n && (host || n == 0),
+                 "spmv_vec_upload: range [%lld,+%lld) outside vector of %lld", (long long)offset, (long long)n,
+                 v ? (long long)v->n : -1LL);
+    SPMV_TRY(use_device(v->ctx));
+    return upload(v->d + offset, host, (size_t)n * sizeof(double), v->ctx);
+}
+
+int spmv_vec_download(const spmv_vec* v, int64_t offset, int64_t n, double* host)
+{
+    SPMV_REQUIRE(v && offset >= 0 && n >= 0 && offset + n <= v->n && (host || n == 0),
+                 "spmv_vec_download: range [%lld,+%lld) outside vector of %lld", (long long)offset, (long long)n,
+                 v ? (long long)v->n : -1LL);
+    if (n == 0) return SPMV_OK;
+    SPMV_TRY(use_device(v->ctx));
+    SPMV_HIP(hipMemcpyAsync(host, v->d + offset, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, v->ctx->stream));
+    SPMV_HIP(hipStreamSynchronize(v->ctx->stream));
+    return SPMV_OK;
+}
+
+int spmv_vec_fill(spmv_vec* v, double a)
+{
+    SPMV_REQUIRE(v, "null vector");
+    SPMV_TRY(use_device(v->ctx));
+    return vec_fill(v->ctx, v->d, v->n, a);
+}
+
+// ---- matrices ---------------------------------------------------------------------------------------------
+int spmv_csr_upload(spmv_ctx* ctx, int32_t nrow, int32_t ncol, const int32_t* row_ptr, const int32_t* col_ind,
+                    const double* values, spmv_mat** out)
+{
+    SPMV_REQUIRE(ctx && out && nrow >= 0 && ncol >= 0 && row_ptr, "spmv_csr_upload: bad argument");
+    const int64_t nnz = (int64_t)row_ptr[nrow] - row_ptr[0];
+    SPMV_REQUIRE(row_ptr[0] == 0 && nnz >= 0 && (nnz == 0 || (col_ind && values)),
+                 "spmv_csr_upload: row_ptr[0]=%d, nnz=%lld", row_ptr[0], (long long)nnz);
+    SPMV_TRY(use_device(ctx));
+    spmv_mat* m = nullptr;
+    SPMV_TRY(mat_alloc(ctx, SPMV_FMT_CSR, nrow, ncol, nnz, 0, (size_t)nrow + 1, (size_t)nnz, (size_t)nnz, &m));
+    int rc = upload(const_cast<int32_t*>(m->a), row_ptr, sizeof(int32_t) * ((size_t)nrow + 1), ctx);
+    if (rc == SPMV_OK) rc = upload(const_cast<int32_t*>(m->b), col_ind, sizeof(int32_t) * (size_t)nnz, ctx);
+    if (rc == SPMV_OK) rc = upload(const_cast<double*>(m->v), values, sizeof(double) * (size_t)nnz, ctx);
+    if (rc != SPMV_OK)
+    {
+        mat_free(m);
+        return rc;
+    }
+    return finish(m, out);
+}
+
+int spmv_csr_wrap_device(spmv_ctx* ctx, int32_t nrow, int32_t ncol, const int32_t* d_row_ptr, const int32_t* d_col_ind,
+                         const double* d_values, spmv_mat** out)
+{
+    SPMV_REQUIRE(ctx && out && nrow >= 0 && ncol >= 0 && d_row_ptr, "spmv_csr_wrap_device: bad argument");
+    SPMV_TRY(use_device(ctx));
+    int32_t ends[2] = {0, 0};
+    SPMV_HIP(hipMemcpyAsync(&ends[0], d_row_ptr, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SPMV_HIP(hipMemcpyAsync(&ends[1], d_row_ptr + nrow, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SPMV_HIP(hipStreamSynchronize(ctx->stream));
+    SPMV_REQUIRE(ends[0] == 0 && ends[1] >= 0, "spmv_csr_wrap_device: row_ptr[0]=%d row_ptr[nrow]=%d", ends[0], ends[1]);
+    spmv_mat* m = nullptr;
+    SPMV_TRY(wrap(ctx, SPMV_FMT_CSR, nrow, ncol, ends[1], 0, d_row_ptr, d_col_ind, d_values, &m));
+    return finish(m, out);
+}
+
+int spmv_csr_upload_shard(spmv_ctx* ctx, int64_t row_begin, int64_t row_end, int32_t ncol, const int64_t* row_ptr64,
+                          const int32_t* col_ind, const double* values, spmv_mat** out)
+{
+    SPMV_REQUIRE(ctx && out && row_ptr64 && row_begin >= 0 && row_end >= row_begin && row_end - row_begin <= INT32_MAX,
+                 "spmv_csr_upload_shard: bad row range");
+    const int32_t nrow = (int32_t)(row_end - row_begin);
+    const int64_t base = row_ptr64[row_begin];
+    const int64_t nnz  = row_ptr64[row_end] - base;
+    SPMV_REQUIRE(nnz >= 0 && nnz <= INT32_MAX, "spmv_csr_upload_shard: shard holds %lld entries (int32 offsets)",
+                 (long long)nnz);
+    SPMV_TRY(use_device(ctx));
+    // rebase exactly like src/mat_vec.cpp:260-263
+    std::vector<int32_t> sub((size_t)nrow + 1);
+    for (int32_t j = 0; j <= nrow; ++j) sub[j] = (int32_t)(row_ptr64[row_begin + j] - base);
+    spmv_mat* m = nullptr;
+    SPMV_TRY(mat_alloc(ctx, SPMV_FMT_CSR, nrow, ncol, nnz, 0, (size_t)nrow + 1, (size_t)nnz, (size_t)nnz, &m));
+    int rc = upload(const_cast<int32_t*>(m->a), sub.data(), sizeof(int32_t) * sub.size(), ctx);
+    if (rc == SPMV_OK) rc = upload(const_cast<int32_t*>(m->b), col_ind + base, sizeof(int32_t) * (size_t)nnz, ctx);
+    if (rc == SPMV_OK) rc = upload(const_cast<double*>(m->v), values + base, sizeof(double) * (size_t)nnz, ctx);
+    if (rc != SPMV_OK)
+    {
+        mat_free(m);
+        return rc;
+    }
+    m->row_begin = row_begin;
+    return finish(m, out);
+}
+
+int spmv_coo_upload(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int64_t nnz, const int32_t* row_ind,
+                    const int32_t* col_ind, const double* values, spmv_mat** out)
+{
+    SPMV_REQUIRE(ctx && out && nrow >= 0 && ncol >= 0 && nnz >= 0 && (nnz == 0 || (row_ind && col_ind && values)),
+                 "spmv_coo_upload: bad argument");
+    SPMV_TRY(use_device(ctx));
+    spmv_mat* m = nullptr;
+    SPMV_TRY(mat_alloc(ctx, SPMV_FMT_COO, nrow, ncol, nnz, 0, (size_t)nnz, (size_t)nnz, (size_t)nnz, &m));
+    int rc = upload(const_cast<int32_t*>(m->a), row_ind, sizeof(int32_t) * (size_t)nnz, ctx);
+    if (rc == SPMV_OK) rc = upload(const_cast<int32_t*>(m->b), col_ind, sizeof(int32_t) * (size_t)nnz, ctx);
+    if (rc == SPMV_OK) rc = upload(const_cast<double*>(m->v), values, sizeof(double) * (size_t)nnz, ctx);
+    if (rc != SPMV_OK)
+    {
+        mat_free(m);
+        return rc;
+    }
+    return finish(m, out);
+}
+
+int spmv_coo_wrap_device(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int64_t nnz, const int32_t* d_row_ind,
+                         const int32_t* d_col_ind, const double* d_values, spmv_mat** out)
+{
+    SPMV_REQUIRE(ctx && out && nrow >= 0 && ncol >= 0 && nnz >= 0, "spmv_coo_wrap_device: bad argument");
+    SPMV_TRY(use_device(ctx));
+    spmv_mat* m = nullptr;
+    SPMV_TRY(wrap(ctx, SPMV_FMT_COO, nrow, ncol, nnz, 0, d_row_ind, d_col_ind, d_values, &m));
+    return finish(m, out);
+}
+
+int spmv_ell_upload(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t k, int64_t nnz, const int32_t* col_ind,
+                    const double* values, spmv_mat** out)
+{
+    SPMV_REQUIRE(ctx && out && nrow >= 0 && ncol >= 0 && k >= 0, "spmv_ell_upload: bad argument");
+    const size_t total = (size_t)nrow * (size_t)k;
+    SPMV_REQUIRE(total == 0 || (col_ind && values), "spmv_ell_upload: null arrays");
+    SPMV_TRY(use_device(ctx));
+    spmv_mat* m = nullptr;
+    SPMV_TRY(mat_alloc(ctx, SPMV_FMT_ELL, nrow, ncol, nnz, k, 0, total, total, &m));
+    int rc = upload(const_cast<int32_t*>(m->b), col_ind, sizeof(int32_t) * total, ctx);
+    if (rc == SPMV_OK) rc = upload(const_cast<double*>(m->v), values, sizeof(double) * total, ctx);
+    if (rc != SPMV_OK)
+    {
+        mat_free(m);
+        return rc;
+    }
+    m->max_row_nnz = k;
+    return finish(m, out);
+}
+
+int spmv_ell_wrap_device(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t k, int64_t nnz, const int32_t* d_col_ind,
+                         const double* d_values, spmv_mat** out)
+{
+    SPMV_REQUIRE(ctx && out && nrow >= 0 && ncol >= 0 && k >= 0, "spmv_ell_wrap_device: bad argument");
+    spmv_mat* m = nullptr;
+    SPMV_TRY(wrap(ctx, SPMV_FMT_ELL, nrow, ncol, nnz, k, nullptr, d_col_ind, d_values, &m));
+    m->max_row_nnz = k;
+    return finish(m, out);
+}
+
+int spmv_csc_upload(spmv_ctx* ctx, int32_t nrow, int32_t ncol, const int32_t* col_ptr, const int32_t* row_ind,
+                    const double* values, spmv_mat** out)
+{
+    SPMV_REQUIRE(ctx && out && nrow >= 0 && ncol >= 0 && col_ptr, "spmv_csc_upload: bad argument");
+    const int64_t nnz = (int64_t)col_ptr[ncol];
+    SPMV_REQUIRE(col_ptr[0] == 0 && nnz >= 0 && (nnz == 0 || (row_ind && values)), "spmv_csc_upload: bad col_ptr");
+    SPMV_TRY(use_device(ctx));
+    spmv_mat* m = nullptr;
+    SPMV_TRY(mat_alloc(ctx, SPMV_FMT_CSC, nrow, ncol, nnz, 0, (size_t)ncol + 1, (size_t)nnz, (size_t)nnz, &m));
+    int rc = upload(const_cast<int32_t*>(m->a), col_ptr, sizeof(int32_t) * ((size_t)ncol + 1), ctx);
+    if (rc == SPMV_OK) rc = upload(const_cast<int32_t*>(m->b), row_ind, sizeof(int32_t) * (size_t)nnz, ctx);
+    if (rc == SPMV_OK) rc = upload(const_cast<double*>(m->v), values, sizeof(double) * (size_t)nnz, ctx);
+    if (rc != SPMV_OK)
+    {
+        mat_free(m);
+        return rc;
+    }
+    return finish(m, out);
+}
+
+int spmv_dia_upload(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t ndiags, const int32_t* offsets,
+                    const double* values, spmv_mat** out)
+{
+    SPMV_REQUIRE(ctx && out && nrow >= 0 && ncol >= 0 && ndiags >= 0, "spmv_dia_upload: bad argument");
+    const size_t total = (size_t)nrow * (size_t)ndiags;
+    SPMV_REQUIRE(ndiags == 0 || offsets, "spmv_dia_upload: null offsets");
+    SPMV_REQUIRE(total == 0 || values, "spmv_dia_upload: null values");
+    SPMV_TRY(use_device(ctx));
+    spmv_mat* m = nullptr;
+    SPMV_TRY(mat_alloc(ctx, SPMV_FMT_DIA, nrow, ncol, 0, ndiags, (size_t)ndiags, 0, total, &m));
+    int rc = upload(const_cast<int32_t*>(m->a), offsets, sizeof(int32_t) * (size_t)ndiags, ctx);
+    if (rc == SPMV_OK) rc = upload(const_cast<double*>(m->v), values, sizeof(double) * total, ctx);
+    if (rc != SPMV_OK)
+    {
+        mat_free(m);
+        return rc;
+    }
+    return finish(m, out);
+}
+
+int spmv_mat_destroy(spmv_mat* m)
+{
+    if (!m) return SPMV_OK;
+    hipSetDevice(m->ctx->device);
+    hipStreamSynchronize(m->ctx->stream);
+    mat_free(m);
+    return SPMV_OK;
+}
+
+int spmv_mat_get_info(const spmv_mat* m, spmv_mat_info* info)
+{
+    SPMV_REQUIRE(m && info, "null argument");
+    info->format        = m->format;
+    info->nrow          = m->nrow;
+    info->ncol          = m->ncol;
+    info->ell_k         = m->k;
+    info->nnz           = m->nnz;
+    info->row_begin     = m->row_begin;
+    info->max_row_nnz   = m->max_row_nnz;
+    info->kernel        = m->kernel;
+    info->lanes_per_row = m->lanes_per_row;
+    info->sorted_rows   = m->sorted_rows;
+    info->device_bytes  = m->device_bytes;
+    return SPMV_OK;
+}
+
+int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
+{
+    SPMV_REQUIRE(m, "null matrix");
+    SPMV_REQUIRE(kernel >= SPMV_CSR_AUTO && kernel <= SPMV_CSR_SCALAR, "unknown kernel id %d", kernel);
+    SPMV_REQUIRE(lanes_per_row == 0 || (lanes_per_row >= 1 && lanes_per_row <= 64 &&
+                                        (lanes_per_row & (lanes_per_row - 1)) == 0),
+                 "lanes_per_row must be 0 or a power of two in 1..64, got %d", lanes_per_row);
+    if (lanes_per_row > 0) m->lanes_per_row = lanes_per_row;
+    if (kernel == SPMV_CSR_AUTO)
+    {
+        m->kernel_forced = false;
+        if (m->format == SPMV_FMT_CSR) csr_choose_kernel(m);
+    }
+    else
+    {
+        m->kernel        = kernel;
+        m->kernel_forced = true;
+    }
+    return SPMV_OK;
+}
+
+int spmv_mat_set_flags(spmv_mat* m, uint32_t flags)
+{
+    SPMV_REQUIRE(m, "null matrix");
+    m->flags = flags;
+    return SPMV_OK;
+}
+
+int spmv_mat_download(const spmv_mat* m, int32_t* a, int32_t* b, double* v)
+{
+    SPMV_REQUIRE(m, "null matrix");
+    SPMV_TRY(use_device(m->ctx));
+    size_t na = 0, nb = 0, nv = 0;
+    switch (m->format)
+    {
+        case SPMV_FMT_CSR: na = (size_t)m->nrow + 1; nb = nv = (size_t)m->nnz; break;
+        case SPMV_FMT_COO: na = nb = nv = (size_t)m->nnz; break;
+        case SPMV_FMT_ELL: nb = nv = (size_t)m->nrow * (size_t)m->k; break;
+        case SPMV_FMT_CSC: na = (size_t)m->ncol + 1; nb = nv = (size_t)m->nnz; break;
+        case SPMV_FMT_DIA: na = (size_t)m->k; nv = (size_t)m->nrow * (size_t)m->k; break;
+        default: SPMV_FAIL(SPMV_ERR_INVALID, "unknown format %d", m->format);
+    }
+    hipStream_t s = m->ctx->stream;
+    if (a && na) SPMV_HIP(hipMemcpyAsync(a, m->a, na * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (b && nb) SPMV_HIP(hipMemcpyAsync(b, m->b, nb * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (v && nv) SPMV_HIP(hipMemcpyAsync(v, m->v, nv * sizeof(double), hipMemcpyDeviceToHost, s));
+    SPMV_HIP(hipStreamSynchronize(s));
+    return SPMV_OK;
+}
+
+int spmv_mat_device_ptrs(const spmv_mat* m, const int32_t** a, const int32_t** b, const double** v)
+{
+    SPMV_REQUIRE(m, "null matrix");
+    if (a) *a = m->a;
+    if (b) *b = m->b;
+    if (v) *v = m->v;
+    return SPMV_OK;
+}
+
+// ---- the hot path -----------------------------------------------------------------------------------------
+static int apply_checked(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* x, spmv_vec* y)
+{
+    switch (A->format)
+    {
+        case SPMV_FMT_CSR: return csr_apply(ctx, A, x->d, y->d);
+        case SPMV_FMT_ELL: return ell_apply(ctx, A, x->d, y->d);
+        case SPMV_FMT_COO: return coo_apply(ctx, A, x->d, y->d);
+        case SPMV_FMT_CSC: return csc_apply(ctx, A, x->d, y->d);
+        case SPMV_FMT_DIA: return dia_apply(ctx, A, x->d, y->d);
+        default: SPMV_FAIL(SPMV_ERR_INVALID, "unknown format %d", A->format);
+    }
+}
+
+static int check_apply_args(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* x, spmv_vec* y)
+{
+    SPMV_REQUIRE(ctx && A && x && y, "spmv_apply: null argument");
+    SPMV_REQUIRE(x->n == A->ncol, "spmv_apply: x has %lld entries, matrix has %d columns", (long long)x->n, A->ncol);
+    SPMV_REQUIRE(y->n == A->nrow, "spmv_apply: y has %lld entries, matrix (shard) has %d rows", (long long)y->n,
+                 A->nrow);
+    SPMV_REQUIRE(x->d != y->d || x->n == 0, "spmv_apply: x and y must not alias");
+    return SPMV_OK;
+}
+
+int spmv_apply(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* x, spmv_vec* y)
+{
+    SPMV_TRY(check_apply_args(ctx, A, x, y));
+    SPMV_TRY(use_device(ctx));
+    return apply_checked(ctx, A, x, y);
+}
+
+int spmv_apply_timed(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* x, spmv_vec* y, int32_t reps,
+                     double* ms_per_apply)
+{
+    SPMV_TRY(check_apply_args(ctx, A, x, y));
+    SPMV_REQUIRE(reps > 0 && ms_per_apply, "spmv_apply_timed: reps=%d", reps);
+    SPMV_TRY(use_device(ctx));
+    SPMV_HIP(hipEventRecord(ctx->ev_begin, ctx->stream));
+    for (int32_t i = 0; i < reps; ++i) SPMV_TRY(apply_checked(ctx, A, x, y));
+    SPMV_HIP(hipEventRecord(ctx->ev_end, ctx->stream));
+    SPMV_HIP(hipEventSynchronize(ctx->ev_end));
+    float ms = 0.f;
+    SPMV_HIP(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
+    *ms_per_apply = (double)ms / reps;
+    return SPMV_OK;
+}
+
+// ---- BLAS-1 -----------------------------------------------------------------------------------------------
+int spmv_dot(spmv_ctx* ctx, const spmv_vec* x, const spmv_vec* y, double* result)
+{
+    SPMV_REQUIRE(ctx && x && y && result, "spmv_dot: null argument");
+    SPMV_REQUIRE(x->n == y->n, "spmv_dot: sizes %lld and %lld differ", (long long)x->n, (long long)y->n);
+    SPMV_TRY(use_device(ctx));
+    return vec_dot(ctx, x->d, y->d, x->n, result);
+}
+
+int spmv_axpby(spmv_ctx* ctx, double alpha, const spmv_vec* x, double beta, const spmv_vec* y, spmv_vec* w)
+{
+    SPMV_REQUIRE(ctx && x && y && w, "spmv_axpby: null argument");
+    // the reference sizes the loop by w (src/vec_vec.cpp:33)
+    SPMV_REQUIRE(x->n >= w->n && y->n >= w->n, "spmv_axpby: w has %lld entries, x %lld, y %lld", (long long)w->n,
+                 (long long)x->n, (long long)y->n);
+    SPMV_TRY(use_device(ctx));
+    return vec_axpby(ctx, alpha, x->d, beta, y->d, w->d, w->n);
+}
+
+// ---- conversions ------------------------------------------------------------------------------------------
+int spmv_coo_to_csr(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out_csr)
+{
+    SPMV_REQUIRE(ctx && coo && out_csr, "spmv_coo_to_csr: null argument");
+    SPMV_TRY(use_device(ctx));
+    return coo_to_csr(ctx, coo, out_csr);
+}
+
+int spmv_csr_to_ell(spmv_ctx* ctx, const spmv_mat* csr, spmv_mat** out_ell)
+{
+    SPMV_REQUIRE(ctx && csr && out_ell, "spmv_csr_to_ell: null argument");
+    SPMV_TRY(use_device(ctx));
+    return csr_to_ell(ctx, csr, out_ell);
+}
+
+int spmv_coo_to_ell(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out_ell)
+{
+    SPMV_REQUIRE(ctx && coo && out_ell, "spmv_coo_to_ell: null argument");
+    SPMV_TRY(use_device(ctx));
+    spmv_mat* csr = nullptr;
+    SPMV_TRY(coo_to_csr(ctx, coo, &csr));
+    int rc = csr_to_ell(ctx, csr, out_ell);
+    mat_free(csr);
+    return rc;
+}
+
+// ---- sharding ---------------------------------------------------------------------------------------------
+int spmv_partition_rows(int64_t nrow, int32_t nparts, int32_t part, int64_t* row_begin, int64_t* row_end)
+{
+    SPMV_REQUIRE(nrow >= 0 && nparts > 0 && part >= 0 && part < nparts && row_begin && row_end,
+                 "spmv_partition_rows: nrow=%lld nparts=%d part=%d", (long long)nrow, nparts, part);
+    // src/mat_vec.cpp:233,245-246: rows_per_thread = nrow / nthreads, the last part takes the remainder
+    const int64_t per = nrow / nparts;
+    *row_begin        = (int64_t)part * per;
+    *row_end          = (part == nparts - 1) ? nrow : *row_begin + per;
+    return SPMV_OK;
+}
+
+int spmv_partition_rows_balanced(int64_t nrow, const int64_t* row_ptr64, int32_t nparts, int64_t* bounds)
+{
+    SPMV_REQUIRE(nrow >= 0 && row_ptr64 && nparts > 0 && bounds, "spmv_partition_rows_balanced: bad argument");
+    const int64_t nnz = row_ptr64[nrow] - row_ptr64[0];
+    bounds[0]         = 0;
+    for (int32_t p = 1; p < nparts; ++p)
+    {
+        // first row whose starting offset reaches p/nparts of the entries
+        const int64_t  target = row_ptr64[0] + (int64_t)(((__int128)nnz * p) / nparts);
+        const int64_t* it     = std::lower_bound(row_ptr64, row_ptr64 + nrow + 1, target);
+        int64_t        r      = it - row_ptr64;
+        if (r > nrow) r = nrow;
+        if (r < bounds[p - 1]) r = bounds[p - 1];
+        bounds[p] = r;
+    }
+    bounds[nparts] = nrow;
+    return SPMV_OK;
+}
+
+// ---- generators -------------------------------------------------------------------------------------------
+int spmv_gen_csr_uniform(spmv_ctx* ctx, int64_t row_begin, int64_t row_end, int32_t ncol, int32_t k, int32_t band,
+                         uint64_t seed, spmv_mat** out)
+{
+    SPMV_REQUIRE(ctx && out, "spmv_gen_csr_uniform: null argument");
+    SPMV_TRY(use_device(ctx));
+    return gen_csr_uniform(ctx, row_begin, row_end, ncol, k, band, seed, out);
+}
+
+int spmv_gen_ell_banded(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t k, uint64_t seed, spmv_mat** out)
+{
+    SPMV_REQUIRE(ctx && out, "spmv_gen_ell_banded: null argument");
+    SPMV_TRY(use_device(ctx));
+    return gen_ell_banded(ctx, nrow, ncol, k, seed, out);
+}
+
+int spmv_gen_coo_powerlaw(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t max_len, uint64_t seed, spmv_mat** out)
+{
+    SPMV_REQUIRE(ctx && out, "spmv_gen_coo_powerlaw: null argument");
+    SPMV_TRY(use_device(ctx));
+    return gen_coo_powerlaw(ctx, nrow, ncol, max_len, seed, out);
+}
+
+int spmv_gen_vec_uniform(spmv_ctx* ctx, spmv_vec* v, int64_t index_offset, uint64_t seed)
+{
+    SPMV_REQUIRE(ctx && v, "spmv_gen_vec_uniform: null argument");
+    SPMV_TRY(use_device(ctx));
+    return gen_vec_uniform(ctx, v->d, v->n, index_offset, seed);
+}
+
+}  // extern "C"

@@ -1,0 +1,189 @@
+// common.hpp — internal types shared by the translation units of libspmv_hip.so.
+// Not part of the ABI (include/spmv_abi.h is).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "spmv_abi.h"
+
+namespace spmv
+{
+// ---- error plumbing -----------------------------------------------------------------------------
+void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+
+#define SPMV_FAIL(code, ...)            \
+    do                                  \
+    {                                   \
+        ::spmv::set_error(__VA_ARGS__); \
+        return (code);                  \
+    } while (0)
+
+#define SPMV_HIP(call)                                                                     \
+    do                                                                                     \
+    {                                                                                      \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            SPMV_FAIL(SPMV_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                      __FILE__, __LINE__);                                                 \
+    } while (0)
+
+#define SPMV_TRY(call)          \
+    do                          \
+    {                           \
+        int rc_ = (call);       \
+        if (rc_ != 0) return rc_; \
+    } while (0)
+
+#define SPMV_REQUIRE(cond, ...) \
+    do                          \
+    {                           \
+        if (!(cond)) SPMV_FAIL(SPMV_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+// ---- chip constants (MI355X / gfx950) -------------------------------------------------------------
+constexpr int kWave      = 64;   // wavefront width
+constexpr int kBlock     = 256;  // default workgroup: 4 waves, one per SIMD
+constexpr int kNumXcd    = 8;
+constexpr int kNumCu     = 256;
+constexpr int kMaxGrid   = kNumCu * 8;  // grid-stride cap for streaming kernels (8 blocks / CU)
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- counter-based PRNG shared by the device generators and their numpy twin ------------------------
+// splitmix64 finaliser; stream keys are derived on the host, the device adds the element index.
+__host__ __device__ static inline uint64_t splitmix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+enum : uint64_t
+{
+    kStreamCol = 1,
+    kStreamVal = 2,
+    kStreamVec = 3,
+    kStreamLen = 4
+};
+static inline uint64_t stream_key(uint64_t seed, uint64_t stream)
+{
+    return splitmix64(seed ^ (0x9E3779B97F4A7C15ull * (stream + 1)));
+}
+__host__ __device__ static inline double u64_to_unit(uint64_t r)  // [0,1)
+{
+    return (double)(r >> 11) * 0x1.0p-53;
+}
+__host__ __device__ static inline double u64_to_sym(uint64_t r)  // [-1,1)
+{
+    return (double)(r >> 11) * 0x1.0p-52 - 1.0;
+}
+__host__ __device__ static inline uint32_t u64_to_range(uint64_t r, uint32_t n)  // [0,n)
+{
+    return (uint32_t)(((r >> 32) * (uint64_t)n) >> 32);
+}
+}  // namespace spmv
+
+// ---- the opaque ABI types ---------------------------------------------------------------------------
+struct spmv_ctx
+{
+    int         device      = 0;
+    hipStream_t stream      = nullptr;
+    bool        owns_stream = false;
+    hipEvent_t  ev_begin    = nullptr;
+    hipEvent_t  ev_end      = nullptr;
+    // small persistent scratch (dot partials, flags); grown on demand outside hot loops
+    void*  scratch       = nullptr;
+    size_t scratch_bytes = 0;
+    double* host_pinned  = nullptr;  // 64 B of pinned host memory for scalar results
+};
+
+struct spmv_vec
+{
+    spmv_ctx* ctx   = nullptr;
+    int64_t   n     = 0;
+    double*   d     = nullptr;
+    bool      owned = false;
+};
+
+struct spmv_mat
+{
+    spmv_ctx* ctx       = nullptr;
+    int32_t   format    = 0;
+    int32_t   nrow      = 0;
+    int32_t   ncol      = 0;
+    int32_t   k         = 0;  // ELL slots / DIA ndiags
+    int64_t   nnz       = 0;
+    int64_t   row_begin = 0;
+    // a: row_ptr | row_ind | -       | col_ptr | offsets
+    // b: col_ind | col_ind | col_ind | row_ind | -
+    const int32_t* a = nullptr;
+    const int32_t* b = nullptr;
+    const double*  v = nullptr;
+    bool           owned        = false;
+    int64_t        device_bytes = 0;
+
+    // ---- analysis results (filled by analyse_*) ----
+    int32_t max_row_nnz   = 0;
+    int32_t kernel        = SPMV_CSR_AUTO;
+    int32_t lanes_per_row = 0;
+    int32_t sorted_rows   = 0;
+    bool    kernel_forced = false;
+    uint32_t flags        = 0;  // SPMV_FLAG_* tuning bits
+
+    // CSR LDS-window kernel: per row-block [lo, hi) column window
+    int32_t  win_rows  = 0;        // rows per workgroup
+    int32_t* win_lo    = nullptr;  // [nblocks] first column touched by the block
+    int32_t* win_span  = nullptr;  // [nblocks] hi - lo
+    int32_t  win_max_span = 0;
+
+    // COO: per-workgroup carry-out (row, partial) pairs for the sorted path
+    int32_t* coo_carry_row = nullptr;
+    double*  coo_carry_val = nullptr;
+    int32_t  coo_nblocks   = 0;
+};
+
+namespace spmv
+{
+int ensure_scratch(spmv_ctx* ctx, size_t bytes);
+
+// kernels_csr.hip
+int csr_analyse(spmv_mat* m);
+void csr_choose_kernel(spmv_mat* m);
+int csr_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
+// kernels_ell.hip
+int ell_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
+// kernels_coo.hip
+int coo_analyse(spmv_mat* m);
+int coo_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
+// kernels_misc.hip (CSC, DIA, BLAS-1, fill)
+int csc_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
+int dia_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
+int vec_fill(spmv_ctx* ctx, double* d, int64_t n, double a);
+int vec_dot(spmv_ctx* ctx, const double* x, const double* y, int64_t n, double* result);
+int vec_axpby(spmv_ctx* ctx, double alpha, const double* x, double beta, const double* y, double* w,
+              int64_t n);
+// convert.hip
+int exclusive_scan_i32(spmv_ctx* ctx, const int32_t* in, int32_t* out, int64_t n);
+int coo_to_csr(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out);
+int csr_to_ell(spmv_ctx* ctx, const spmv_mat* csr, spmv_mat** out);
+int reduce_max_i32(spmv_ctx* ctx, const int32_t* in, int64_t n, int32_t* result);
+// generate.hip
+int gen_csr_uniform(spmv_ctx* ctx, int64_t row_begin, int64_t row_end, int32_t ncol, int32_t k,
+                    int32_t band, uint64_t seed, spmv_mat** out);
+int gen_ell_banded(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t k, uint64_t seed,
+                   spmv_mat** out);
+int gen_coo_powerlaw(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t max_len, uint64_t seed,
+                     spmv_mat** out);
+int gen_vec_uniform(spmv_ctx* ctx, double* d, int64_t n, int64_t index_offset, uint64_t seed);
+
+// abi.hip helpers used by the other units
+int  mat_alloc(spmv_ctx* ctx, int32_t format, int32_t nrow, int32_t ncol, int64_t nnz, int32_t k,
+               size_t a_count, size_t b_count, size_t v_count, spmv_mat** out);
+void mat_free(spmv_mat* m);
+}  // namespace spmv

@@ -1,0 +1,376 @@
+// kernels_csr.hip — y += A*x for CSR on CDNA4 (gfx950).
+//
+// Replaces CSRMatrixMatVector (reference src/mat_vec.cpp:44-67; hot loop :60-63) and the
+// per-thread body of its NUMA driver (src/mat_vec.cpp:507-530).
+//
+// Roofline: HBM-bound.  Algorithmic bytes per application:
+//     12*nnz (values + column indices, read once)  + 4*(nrow+1) (row_ptr)
+//   +  8*ncol (x, counted once)                    + 16*nrow    (y read + write, `+=`)
+//
+// Kernels
+//   csr_vector_kernel<LPR>  LPR = 2^k lanes cooperate on one row (a 64-lane wavefront holds 64/LPR
+//                           rows); lane l of the group walks entries l, l+LPR, ... so each load
+//                           instruction reads 64/LPR contiguous runs of LPR*8 bytes; four
+//                           independent (col, val, x) triples are in flight per lane before the first
+//                           fma; partial sums meet through ds_swizzle/ds_bpermute (or DPP).
+//   csr_scalar_kernel       one lane per row, strictly left to right with fma: bit-identical to the
+//                           oracle's orc_csr_spmv_fma.  Used for parity pinning and for very short rows.
+//   csr_ldswin_kernel       banded matrices: a workgroup stages the x window its rows touch into LDS
+//                           with coalesced loads, then gathers from LDS instead of L2/HBM.
+#include "common.hpp"
+#include "wave.hpp"
+
+namespace spmv
+{
+namespace
+{
+// Blocks are dealt round-robin to the 8 XCDs (block b and b+8 share an L2).  With XCD_REMAP each XCD
+// walks one contiguous eighth of the rows, so neighbouring row blocks — which on banded matrices
+// touch overlapping x windows — share an L2.  Speed only; any placement is correct.
+__device__ __forceinline__ int remap_block(int bid, int nblocks)
+{
+    const int per = nblocks / kNumXcd;  // blocks in the evenly divisible part
+    const int cut = per * kNumXcd;
+    if (bid >= cut) return bid;  // ragged tail keeps its id
+    return (bid % kNumXcd) * per + bid / kNumXcd;
+}
+
+template <int LPR, bool USE_DPP, bool XCD_REMAP>
+__global__ __launch_bounds__(kBlock) void csr_vector_kernel(
+    int nrow, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+    const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y)
+{
+    constexpr int ROWS = kBlock / LPR;
+    int bid = blockIdx.x;
+    if constexpr (XCD_REMAP) bid = remap_block(bid, gridDim.x);
+    const int row = bid * ROWS + threadIdx.x / LPR;
+    const int sub = threadIdx.x % LPR;
+
+    double sum = 0.0;
+    if (row < nrow)
+    {
+        int       j   = row_ptr[row] + sub;
+        const int end = row_ptr[row + 1];
+        for (; j + 3 * LPR < end; j += 4 * LPR)
+        {
+            const int    c0 = load_stream(col + j);
+            const int    c1 = load_stream(col + j + LPR);
+            const int    c2 = load_stream(col + j + 2 * LPR);
+            const int    c3 = load_stream(col + j + 3 * LPR);
+            const double v0 = load_stream(val + j);
+            const double v1 = load_stream(val + j + LPR);
+            const double v2 = load_stream(val + j + 2 * LPR);
+            const double v3 = load_stream(val + j + 3 * LPR);
+            const double x0 = x[c0];
+            const double x1 = x[c1];
+            const double x2 = x[c2];
+            const double x3 = x[c3];
+            sum = fma(v0, x0, sum);
+            sum = fma(v1, x1, sum);
+            sum = fma(v2, x2, sum);
+            sum = fma(v3, x3, sum);
+        }
+        for (; j < end; j += LPR) sum = fma(load_stream(val + j), x[load_stream(col + j)], sum);
+    }
+    // every lane of the wave takes part in the cross-lane step (no early exit above)
+    sum = group_sum<LPR, USE_DPP>(sum);
+    if (row < nrow && sub == 0) y[row] += sum;
+}
+
+__global__ __launch_bounds__(kBlock) void csr_scalar_kernel(
+    int nrow, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+    const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y)
+{
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    if (row >= nrow) return;
+    double    sum = 0.0;
+    const int end = row_ptr[row + 1];
+    for (int j = row_ptr[row]; j < end; ++j) sum = fma(val[j], x[col[j]], sum);
+    y[row] += sum;
+}
+
+// ---- LDS-window kernel ---------------------------------------------------------------------------------
+// A workgroup owns WIN_ROWS consecutive rows.  csr_window_scan_kernel (run once, at analysis) records the
+// smallest column `lo` and the span touched by those rows.  If the span fits the LDS tile the workgroup
+// copies x[lo, lo+span) into LDS with fully coalesced loads (each x element is fetched once per
+// workgroup instead of once per nonzero) and the gathers become ds_read_b64.
+constexpr int kWinRows    = 256;       // rows per workgroup (LPR lanes each -> loop over row slabs)
+constexpr int kWinDoubles = 16 * 1024; // 128 KiB x tile; leaves 32 KiB of the CU's 160 KiB unused
+
+__global__ __launch_bounds__(kBlock) void csr_window_scan_kernel(
+    int nrow, int win_rows, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+    int32_t* __restrict__ win_lo, int32_t* __restrict__ win_span)
+{
+    const int b     = blockIdx.x;
+    const int r0    = b * win_rows;
+    const int r1    = min(nrow, r0 + win_rows);
+    const int begin = row_ptr[r0];
+    const int end   = row_ptr[r1];
+    int       lo = INT32_MAX, hi = -1;
+    for (int j = begin + threadIdx.x; j < end; j += kBlock)
+    {
+        const int c = col[j];
+        lo          = min(lo, c);
+        hi          = max(hi, c);
+    }
+    __shared__ int s_lo[kBlock / kWave], s_hi[kBlock / kWave];
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        lo = min(lo, __shfl_xor(lo, off));
+        hi = max(hi, __shfl_xor(hi, off));
+    }
+    if ((threadIdx.x & 63) == 0)
+    {
+        s_lo[threadIdx.x >> 6] = lo;
+        s_hi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        for (int w = 1; w < kBlock / kWave; ++w)
+        {
+            lo = min(lo, s_lo[w]);
+            hi = max(hi, s_hi[w]);
+        }
+        if (hi < 0)
+        {
+            lo = 0;
+            hi = -1;
+        }
+        win_lo[b]   = lo;
+        win_span[b] = hi - lo + 1;
+    }
+}
+
+template <int LPR, bool USE_DPP>
+__global__ __launch_bounds__(kBlock) void csr_ldswin_kernel(
+    int nrow, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+    const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y,
+    const int32_t* __restrict__ win_lo, const int32_t* __restrict__ win_span)
+{
+    extern __shared__ double xs[];  // win_max_span doubles (<= kWinDoubles)
+    int bid = remap_block(blockIdx.x, gridDim.x);
+    const int lo   = win_lo[bid];
+    const int span = win_span[bid];
+    // stage x[lo, lo+span): lane-contiguous 8-byte loads; x stays default-policy (it is re-read by
+    // the neighbouring workgroups from L2)
+    for (int i = threadIdx.x; i < span; i += kBlock) xs[i] = x[lo + i];
+    __syncthreads();
+
+    constexpr int ROWS = kBlock / LPR;
+    const int     sub  = threadIdx.x % LPR;
+    const int     r0   = bid * kWinRows;
+#pragma unroll 1
+    for (int slab = 0; slab < kWinRows; slab += ROWS)
+    {
+        const int row = r0 + slab + threadIdx.x / LPR;
+        double    sum = 0.0;
+        if (row < nrow)
+        {
+            int       j   = row_ptr[row] + sub;
+            const int end = row_ptr[row + 1];
+            for (; j + 3 * LPR < end; j += 4 * LPR)
+            {
+                const int    c0 = load_stream(col + j) - lo;
+                const int    c1 = load_stream(col + j + LPR) - lo;
+                const int    c2 = load_stream(col + j + 2 * LPR) - lo;
+                const int    c3 = load_stream(col + j + 3 * LPR) - lo;
+                const double v0 = load_stream(val + j);
+                const double v1 = load_stream(val + j + LPR);
+                const double v2 = load_stream(val + j + 2 * LPR);
+                const double v3 = load_stream(val + j + 3 * LPR);
+                sum = fma(v0, xs[c0], sum);
+                sum = fma(v1, xs[c1], sum);
+                sum = fma(v2, xs[c2], sum);
+                sum = fma(v3, xs[c3], sum);
+            }
+            for (; j < end; j += LPR)
+                sum = fma(load_stream(val + j), xs[load_stream(col + j) - lo], sum);
+        }
+        sum = group_sum<LPR, USE_DPP>(sum);
+        if (row < nrow && sub == 0) y[row] += sum;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void row_len_max_kernel(int nrow, const int32_t* __restrict__ row_ptr,
+                                                             int32_t* __restrict__ out_max)
+{
+    int mx = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nrow; i += (int64_t)gridDim.x * kBlock)
+        mx = max(mx, row_ptr[i + 1] - row_ptr[i]);
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
+    if ((threadIdx.x & 63) == 0 && mx > 0) atomicMax(out_max, mx);
+}
+
+__global__ void max_i32_kernel(const int32_t* __restrict__ in, int n, int32_t* __restrict__ out_max)
+{
+    int mx = INT32_MIN;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) mx = max(mx, in[i]);
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_max, mx);
+}
+
+int pick_lanes(double mean_row)
+{
+    // about four entries per lane: enough independent gathers per lane to cover the latency of x,
+    // few enough lanes per row that 64/LPR rows keep a wavefront's loads spread over few lines
+    int lanes = 1;
+    while (lanes < 64 && lanes * 4 < mean_row) lanes <<= 1;
+    return lanes;
+}
+
+template <bool USE_DPP, bool XCD_REMAP>
+int launch_vector(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, int lanes)
+{
+    const int   nrow = A->nrow;
+    hipStream_t s    = ctx->stream;
+#define SPMV_LAUNCH_LPR(L)                                                                              \
+    case L:                                                                                             \
+        hipLaunchKernelGGL((csr_vector_kernel<L, USE_DPP, XCD_REMAP>), dim3((unsigned)ceil_div(nrow, kBlock / L)), \
+                           dim3(kBlock), 0, s, nrow, A->a, A->b, A->v, x, y);                           \
+        break;
+    switch (lanes)
+    {
+        SPMV_LAUNCH_LPR(1)
+        SPMV_LAUNCH_LPR(2)
+        SPMV_LAUNCH_LPR(4)
+        SPMV_LAUNCH_LPR(8)
+        SPMV_LAUNCH_LPR(16)
+        SPMV_LAUNCH_LPR(32)
+        SPMV_LAUNCH_LPR(64)
+        default: SPMV_FAIL(SPMV_ERR_INVALID, "lanes_per_row must be a power of two in 1..64, got %d", lanes);
+    }
+#undef SPMV_LAUNCH_LPR
+    SPMV_HIP(hipGetLastError());
+    return SPMV_OK;
+}
+
+int launch_ldswin(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, int lanes)
+{
+    const int    nblocks = (int)ceil_div(A->nrow, kWinRows);
+    const size_t lds     = (size_t)A->win_max_span * sizeof(double);
+    hipStream_t  s       = ctx->stream;
+    // more than 64 KiB of dynamic LDS has to be granted per kernel; once per instantiation is enough
+#define SPMV_LAUNCH_LPR(L)                                                                                      \
+    case L:                                                                                                     \
+    {                                                                                                           \
+        static bool granted = false;                                                                            \
+        if (!granted)                                                                                           \
+        {                                                                                                       \
+            SPMV_HIP(hipFuncSetAttribute((const void*)csr_ldswin_kernel<L, false>,                              \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, kWinDoubles * 8));         \
+            granted = true;                                                                                     \
+        }                                                                                                       \
+        hipLaunchKernelGGL((csr_ldswin_kernel<L, false>), dim3(nblocks), dim3(kBlock), lds, s, A->nrow, A->a, A->b, \
+                           A->v, x, y, A->win_lo, A->win_span);                                                 \
+        break;                                                                                                  \
+    }
+    switch (lanes)
+    {
+        SPMV_LAUNCH_LPR(1)
+        SPMV_LAUNCH_LPR(2)
+        SPMV_LAUNCH_LPR(4)
+        SPMV_LAUNCH_LPR(8)
+        SPMV_LAUNCH_LPR(16)
+        SPMV_LAUNCH_LPR(32)
+        SPMV_LAUNCH_LPR(64)
+        default: SPMV_FAIL(SPMV_ERR_INVALID, "lanes_per_row must be a power of two in 1..64, got %d", lanes);
+    }
+#undef SPMV_LAUNCH_LPR
+    SPMV_HIP(hipGetLastError());
+    return SPMV_OK;
+}
+}  // namespace
+
+int reduce_max_i32(spmv_ctx* ctx, const int32_t* in, int64_t n, int32_t* result)
+{
+    SPMV_TRY(ensure_scratch(ctx, 64));
+    int32_t* d  = (int32_t*)ctx->scratch;
+    int32_t  lo = INT32_MIN;
+    SPMV_HIP(hipMemcpyAsync(d, &lo, sizeof(lo), hipMemcpyHostToDevice, ctx->stream));
+    if (n > 0)
+    {
+        const int grid = (int)std::min<int64_t>(kMaxGrid, ceil_div(n, kBlock));
+        hipLaunchKernelGGL(max_i32_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, in, (int)n, d);
+        SPMV_HIP(hipGetLastError());
+    }
+    SPMV_HIP(hipMemcpyAsync(result, d, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SPMV_HIP(hipStreamSynchronize(ctx->stream));
+    return SPMV_OK;
+}
+
+// AUTO policy: stage x in LDS when every row block's column window fits the tile and is re-used
+// (entries per block well above the window length); otherwise gather x through L2.
+void csr_choose_kernel(spmv_mat* m)
+{
+    const double mean  = m->nrow > 0 ? (double)m->nnz / (double)m->nrow : 0.0;
+    const bool   fits  = m->win_max_span > 0 && m->win_max_span <= kWinDoubles;
+    const double reuse = m->win_max_span > 0 ? mean * kWinRows / (double)m->win_max_span : 0.0;
+    m->kernel          = (fits && reuse >= 2.0) ? SPMV_CSR_LDSWIN : SPMV_CSR_VECTOR;
+}
+
+// Row statistics + kernel choice.  Runs once when a CSR handle is created.
+int csr_analyse(spmv_mat* m)
+{
+    spmv_ctx* ctx = m->ctx;
+    SPMV_TRY(ensure_scratch(ctx, 64));
+    int32_t* d_max = (int32_t*)ctx->scratch;
+    SPMV_HIP(hipMemsetAsync(d_max, 0, sizeof(int32_t), ctx->stream));
+    if (m->nrow > 0)
+    {
+        const int grid = (int)std::min<int64_t>(kMaxGrid, ceil_div(m->nrow, kBlock));
+        hipLaunchKernelGGL(row_len_max_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, m->nrow, m->a, d_max);
+        SPMV_HIP(hipGetLastError());
+    }
+    SPMV_HIP(hipMemcpyAsync(&m->max_row_nnz, d_max, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SPMV_HIP(hipStreamSynchronize(ctx->stream));
+
+    const double mean = m->nrow > 0 ? (double)m->nnz / (double)m->nrow : 0.0;
+    m->lanes_per_row  = pick_lanes(mean);
+
+    // column windows per block of kWinRows rows
+    m->win_rows = kWinRows;
+    if (m->nrow > 0 && m->nnz > 0)
+    {
+        const int nblocks = (int)ceil_div(m->nrow, kWinRows);
+        SPMV_HIP(hipMalloc(&m->win_lo, sizeof(int32_t) * nblocks));
+        SPMV_HIP(hipMalloc(&m->win_span, sizeof(int32_t) * nblocks));
+        m->device_bytes += 2 * (int64_t)sizeof(int32_t) * nblocks;
+        hipLaunchKernelGGL(csr_window_scan_kernel, dim3(nblocks), dim3(kBlock), 0, ctx->stream, m->nrow, kWinRows,
+                           m->a, m->b, m->win_lo, m->win_span);
+        SPMV_HIP(hipGetLastError());
+        SPMV_TRY(reduce_max_i32(ctx, m->win_span, nblocks, &m->win_max_span));
+    }
+    if (!m->kernel_forced) csr_choose_kernel(m);
+    return SPMV_OK;
+}
+
+int csr_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
+{
+    if (A->nrow == 0) return SPMV_OK;
+    const int lanes = A->lanes_per_row > 0 ? A->lanes_per_row : 8;
+    switch (A->kernel)
+    {
+        case SPMV_CSR_SCALAR:
+            hipLaunchKernelGGL(csr_scalar_kernel, dim3((unsigned)ceil_div(A->nrow, kBlock)), dim3(kBlock), 0,
+                               ctx->stream, A->nrow, A->a, A->b, A->v, x, y);
+            SPMV_HIP(hipGetLastError());
+            return SPMV_OK;
+        case SPMV_CSR_LDSWIN:
+            if (A->win_max_span <= 0 || A->win_max_span > kWinDoubles)
+                SPMV_FAIL(SPMV_ERR_UNSUPPORTED, "LDS-window kernel: widest block window is %d columns, tile holds %d",
+                          A->win_max_span, kWinDoubles);
+            return launch_ldswin(ctx, A, x, y, lanes);
+        case SPMV_CSR_VECTOR:
+        case SPMV_CSR_AUTO:
+        default:
+        {
+            const bool dpp = A->flags & SPMV_FLAG_DPP_REDUCE, remap = A->flags & SPMV_FLAG_XCD_REMAP;
+            if (dpp && remap) return launch_vector<true, true>(ctx, A, x, y, lanes);
+            if (dpp) return launch_vector<true, false>(ctx, A, x, y, lanes);
+            if (remap) return launch_vector<false, true>(ctx, A, x, y, lanes);
+            return launch_vector<false, false>(ctx, A, x, y, lanes);
+        }
+    }
+}
+}  // namespace spmv

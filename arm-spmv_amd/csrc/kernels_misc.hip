@@ -1,0 +1,183 @@
+// kernels_misc.hip — BLAS-1, fill, and the CSC / DIA products on CDNA4 (gfx950).
+//
+// Replaces vec_dot / vec_axpby (reference src/vec_vec.cpp:15-29, :31-94), Vector::Fill
+// (src/vector.cpp:59-63), CSCMatrixMatVector (src/mat_vec.cpp:69-95) and DIAMatrixMatVector
+// (src/mat_vec.cpp:123-146).  All are HBM-bound streaming kernels: grid-stride, 16-byte accesses where
+// alignment allows, at most kMaxGrid workgroups.
+#include "common.hpp"
+#include "wave.hpp"
+
+namespace spmv
+{
+namespace
+{
+__global__ __launch_bounds__(kBlock) void fill_kernel(double* __restrict__ d, int64_t n, double a)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) d[i] = a;
+}
+
+// ---- dot: per-lane fma chain -> wavefront sum -> workgroup sum -> one partial per workgroup ---------------
+__device__ __forceinline__ double block_sum(double v)
+{
+    __shared__ double s_part[kBlock / kWave];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double total = 0.0;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < kBlock / kWave; ++w) total += s_part[w];
+    return total;  // valid in thread 0
+}
+
+__global__ __launch_bounds__(kBlock) void dot_partial_kernel(const double* __restrict__ x, const double* __restrict__ y,
+                                                             int64_t n, double* __restrict__ partial)
+{
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        acc = fma(load_stream(x + i), load_stream(y + i), acc);
+    const double total = block_sum(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kBlock) void dot_final_kernel(const double* __restrict__ partial, int count,
+                                                           double* __restrict__ out)
+{
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < count; i += kBlock) acc += partial[i];
+    const double total = block_sum(acc);
+    if (threadIdx.x == 0) *out = total;
+}
+
+// ---- axpby: the reference's seven branches (src/vec_vec.cpp:38-93), chosen on the host -------------------
+// alpha == 0 never reads x and beta == 0 never reads y, so NaN/Inf there cannot leak into w.
+enum AxpbyMode
+{
+    kBetaY = 0,   // alpha == 0       : w = beta*y
+    kAlphaX,      // beta == 0        : w = alpha*x
+    kXPlusBy,     // alpha == 1       : w = beta*y + x
+    kByMinusX,    // alpha == -1      : w = beta*y - x
+    kAxPlusY,     // beta == 1        : w = alpha*x + y
+    kAxMinusY,    // beta == -1       : w = alpha*x - y
+    kGeneral      //                  : w = alpha*x + beta*y
+};
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void axpby_kernel(int64_t n, double alpha, const double* __restrict__ x,
+                                                       double beta, const double* __restrict__ y,
+                                                       double* __restrict__ w)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    {
+        double r;
+        if constexpr (MODE == kBetaY) r = beta * y[i];
+        if constexpr (MODE == kAlphaX) r = alpha * x[i];
+        if constexpr (MODE == kXPlusBy) r = fma(beta, y[i], x[i]);
+        if constexpr (MODE == kByMinusX) r = fma(beta, y[i], -x[i]);
+        if constexpr (MODE == kAxPlusY) r = fma(alpha, x[i], y[i]);
+        if constexpr (MODE == kAxMinusY) r = fma(alpha, x[i], -y[i]);
+        if constexpr (MODE == kGeneral) r = fma(alpha, x[i], beta * y[i]);
+        w[i] = r;
+    }
+}
+
+// ---- CSC: scatter.  LPC lanes share one column; every entry is one fp64 atomic on y --------------------------
+template <int LPC>
+__global__ __launch_bounds__(kBlock) void csc_kernel(int ncol, const int32_t* __restrict__ col_ptr,
+                                                     const int32_t* __restrict__ row, const double* __restrict__ val,
+                                                     const double* __restrict__ x, double* __restrict__ y)
+{
+    const int c = blockIdx.x * (kBlock / LPC) + threadIdx.x / LPC;
+    if (c >= ncol) return;
+    const double xc  = x[c];
+    const int    end = col_ptr[c + 1];
+    for (int j = col_ptr[c] + threadIdx.x % LPC; j < end; j += LPC)
+        unsafeAtomicAdd(y + load_stream(row + j), load_stream(val + j) * xc);
+}
+
+// ---- DIA: one lane per row, diagonals left to right from y[i] (bit-identical to orc_dia_spmv_fma) ------------
+// The bound check is against nrow, as in the reference (src/mat_vec.cpp:140).
+__global__ __launch_bounds__(kBlock) void dia_kernel(int nrow, int ndiags, const int32_t* __restrict__ offsets,
+                                                     const double* __restrict__ val, const double* __restrict__ x,
+                                                     double* __restrict__ y)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nrow) return;
+    double        acc = y[i];
+    const double* v   = val + (size_t)i * ndiags;
+    for (int d = 0; d < ndiags; ++d)
+    {
+        const int j = i + offsets[d];
+        if (j >= 0 && j < nrow) acc = fma(v[d], x[j], acc);
+    }
+    y[i] = acc;
+}
+
+inline int stream_grid(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(kMaxGrid, ceil_div(n, kBlock))); }
+}  // namespace
+
+int vec_fill(spmv_ctx* ctx, double* d, int64_t n, double a)
+{
+    if (n == 0) return SPMV_OK;
+    hipLaunchKernelGGL(fill_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, d, n, a);
+    SPMV_HIP(hipGetLastError());
+    return SPMV_OK;
+}
+
+int vec_dot(spmv_ctx* ctx, const double* x, const double* y, int64_t n, double* result)
+{
+    const int grid = stream_grid(n);
+    SPMV_TRY(ensure_scratch(ctx, sizeof(double) * (size_t)(grid + 8)));
+    double* partial = (double*)ctx->scratch;
+    double* out     = partial + grid;
+    hipLaunchKernelGGL(dot_partial_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, x, y, n, partial);
+    hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, partial, grid, out);
+    SPMV_HIP(hipGetLastError());
+    SPMV_HIP(hipMemcpyAsync(ctx->host_pinned, out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SPMV_HIP(hipStreamSynchronize(ctx->stream));
+    *result = ctx->host_pinned[0];
+    return SPMV_OK;
+}
+
+int vec_axpby(spmv_ctx* ctx, double alpha, const double* x, double beta, const double* y, double* w, int64_t n)
+{
+    if (n == 0) return SPMV_OK;
+    const dim3  grid(stream_grid(n)), block(kBlock);
+    hipStream_t s = ctx->stream;
+    // same branch order as src/vec_vec.cpp:38-93
+    if (alpha == 0)
+        hipLaunchKernelGGL(axpby_kernel<kBetaY>, grid, block, 0, s, n, alpha, x, beta, y, w);
+    else if (beta == 0)
+        hipLaunchKernelGGL(axpby_kernel<kAlphaX>, grid, block, 0, s, n, alpha, x, beta, y, w);
+    else if (alpha == 1)
+        hipLaunchKernelGGL(axpby_kernel<kXPlusBy>, grid, block, 0, s, n, alpha, x, beta, y, w);
+    else if (alpha == -1)
+        hipLaunchKernelGGL(axpby_kernel<kByMinusX>, grid, block, 0, s, n, alpha, x, beta, y, w);
+    else if (beta == 1)
+        hipLaunchKernelGGL(axpby_kernel<kAxPlusY>, grid, block, 0, s, n, alpha, x, beta, y, w);
+    else if (beta == -1)
+        hipLaunchKernelGGL(axpby_kernel<kAxMinusY>, grid, block, 0, s, n, alpha, x, beta, y, w);
+    else
+        hipLaunchKernelGGL(axpby_kernel<kGeneral>, grid, block, 0, s, n, alpha, x, beta, y, w);
+    SPMV_HIP(hipGetLastError());
+    return SPMV_OK;
+}
+
+int csc_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
+{
+    if (A->ncol == 0 || A->nnz == 0) return SPMV_OK;
+    constexpr int LPC = 8;
+    hipLaunchKernelGGL(csc_kernel<LPC>, dim3((unsigned)ceil_div(A->ncol, kBlock / LPC)), dim3(kBlock), 0, ctx->stream,
+                       A->ncol, A->a, A->b, A->v, x, y);
+    SPMV_HIP(hipGetLastError());
+    return SPMV_OK;
+}
+
+int dia_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
+{
+    if (A->nrow == 0 || A->k == 0) return SPMV_OK;
+    hipLaunchKernelGGL(dia_kernel, dim3((unsigned)ceil_div(A->nrow, kBlock)), dim3(kBlock), 0, ctx->stream, A->nrow,
+                       A->k, A->a, A->v, x, y);
+    SPMV_HIP(hipGetLastError());
+    return SPMV_OK;
+}
+}  // namespace spmv

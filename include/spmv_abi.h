@@ -1,0 +1,202 @@
+/*
+ * spmv_abi.h — the drop-in boundary of the MI355X SpMV engine (libspmv_hip.so).
+ *
+ * Plain C ABI: opaque handles, raw pointers, sizes.  No C++ types, no torch types.  Everything
+ * the reference's hot path does (`y += A*x` for its storage formats, the format conversions, the
+ * BLAS-1 helpers and the row-range sharding of its NUMA drivers) is reachable from here; the
+ * C++ classes of the reference (include/matrix.h, include/vector.h, include/mat_vec.h in the
+ * reference tree) are re-created as a thin source-compatible shim over this ABI in
+ * include/arm_spmv_compat.hpp, so the reference's main.cpp recompiles unchanged.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative spmv_status otherwise; the message of the
+ *     last failure on the calling thread is spmv_last_error().  (The reference has no error
+ *     convention: ops return void, I/O failures printf + exit(1), src/data_io.cpp:53-75.)
+ *   - values are fp64, indices int32 (as in the reference, include/matrix.h:9-16); counts that can
+ *     exceed 2^31 across shards (nnz) are int64 in this ABI.
+ *   - semantics are ACCUMULATING: spmv_apply computes y += A*x (src/mat_vec.cpp:39,64,91,116,142);
+ *     the caller zeroes y (main.cpp:55,65,85).
+ *   - host arrays passed to *_upload stay owned by the caller and may be freed on return; device
+ *     pointers passed to *_wrap_device are borrowed and must outlive the handle.
+ *   - work is queued on the context's HIP stream and is asynchronous; spmv_sync() waits.
+ *   - the library is HIP-only.  There is no CPU fallback: without a usable GPU spmv_ctx_create
+ *     fails with SPMV_ERR_NO_DEVICE and nothing else can be called.
+ */
+#ifndef SPMV_ABI_H
+#define SPMV_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPMV_ABI_VERSION 1
+
+typedef enum spmv_status
+{
+    SPMV_OK             = 0,
+    SPMV_ERR_INVALID    = -1, /* bad argument (null handle, negative size, shape mismatch) */
+    SPMV_ERR_NO_DEVICE  = -2, /* no HIP device / device index out of range */
+    SPMV_ERR_HIP        = -3, /* a HIP runtime call failed (message has hipGetErrorString) */
+    SPMV_ERR_ALLOC      = -4, /* device or host allocation failed */
+    SPMV_ERR_UNSUPPORTED = -5 /* valid request the engine does not implement */
+} spmv_status;
+
+typedef enum spmv_format
+{
+    SPMV_FMT_COO = 0, /* include/matrix.h:7-25  (reference) */
+    SPMV_FMT_CSR = 1, /* include/matrix.h:27-47 */
+    SPMV_FMT_CSC = 2, /* include/matrix.h:49-68 */
+    SPMV_FMT_ELL = 3, /* include/matrix.h:70-92, column-major: (row i, slot k) at i + k*nrow */
+    SPMV_FMT_DIA = 4  /* include/matrix.h:117-138, row-major: (row i, diag d) at i*ndiags + d */
+} spmv_format;
+
+/* CSR kernel selection (spmv_mat_set_kernel).  AUTO picks from the row-length statistics
+ * gathered when the matrix is created. */
+typedef enum spmv_csr_kernel
+{
+    SPMV_CSR_AUTO     = 0,
+    SPMV_CSR_VECTOR   = 1, /* 2^k lanes per row, ds_swizzle/DPP segment reduction */
+    SPMV_CSR_LDSWIN   = 2, /* row blocks whose x window is staged in LDS (banded matrices) */
+    SPMV_CSR_SCALAR   = 3  /* one lane per row, strictly left-to-right (bitwise = oracle _fma) */
+} spmv_csr_kernel;
+
+/* Tuning bits for spmv_mat_set_flags (speed only; results stay within the parity tolerance). */
+#define SPMV_FLAG_DPP_REDUCE 1u /* CSR vector kernel: DPP row shifts instead of ds_swizzle for the <=16-lane steps */
+#define SPMV_FLAG_XCD_REMAP  2u /* CSR vector kernel: each XCD walks one contiguous eighth of the rows */
+
+typedef struct spmv_ctx spmv_ctx; /* one HIP device + one stream */
+typedef struct spmv_vec spmv_vec; /* device-resident fp64 vector         (reference: class Vector) */
+typedef struct spmv_mat spmv_mat; /* device-resident sparse matrix/shard (reference: XMatrix) */
+
+typedef struct spmv_mat_info
+{
+    int32_t format;   /* spmv_format */
+    int32_t nrow;     /* rows held by this handle (a shard holds its own rows only) */
+    int32_t ncol;     /* columns = length of x (always global: x is a full replica, mat_vec.cpp:257) */
+    int32_t ell_k;    /* ELL: slots per row (nonzeros_in_row); DIA: ndiags; else 0 */
+    int64_t nnz;      /* stored nonzeros (ELL: true nnz given at creation, not nrow*k) */
+    int64_t row_begin; /* first global row of this shard (0 for an unsharded matrix) */
+    int32_t max_row_nnz;
+    int32_t kernel;   /* spmv_csr_kernel actually selected (CSR only) */
+    int32_t lanes_per_row; /* CSR vector kernel: lanes cooperating on one row */
+    int32_t sorted_rows;   /* COO: 1 if row indices are non-decreasing */
+    int64_t device_bytes;  /* bytes of device memory owned by the handle */
+} spmv_mat_info;
+
+/* ---- library / context ---------------------------------------------------------------------- */
+int         spmv_abi_version(void);
+const char* spmv_last_error(void);
+int         spmv_device_count(int* count);
+/* Creates a context on `device` with its own non-blocking stream. */
+int spmv_ctx_create(int device, spmv_ctx** out);
+/* Same, but queues all work on a caller-owned hipStream_t (e.g. torch's current stream). */
+int spmv_ctx_create_on_stream(int device, void* hip_stream, spmv_ctx** out);
+int spmv_ctx_destroy(spmv_ctx* ctx);
+int spmv_sync(spmv_ctx* ctx);
+int spmv_ctx_device(const spmv_ctx* ctx, int* device);
+
+/* ---- vectors  (reference: include/vector.h:4-26 {int size; double* values}) --------------------- */
+int spmv_vec_create(spmv_ctx* ctx, int64_t n, spmv_vec** out);
+int spmv_vec_wrap_device(spmv_ctx* ctx, int64_t n, double* device_ptr, spmv_vec** out);
+int spmv_vec_destroy(spmv_vec* v);
+int spmv_vec_size(const spmv_vec* v, int64_t* n);
+int spmv_vec_device_ptr(const spmv_vec* v, double** device_ptr);
+/* copy host[0..n) -> v[offset..offset+n)  /  v[offset..offset+n) -> host[0..n); both synchronous */
+int spmv_vec_upload(spmv_vec* v, int64_t offset, int64_t n, const double* host);
+int spmv_vec_download(const spmv_vec* v, int64_t offset, int64_t n, double* host);
+int spmv_vec_fill(spmv_vec* v, double a); /* Vector::Fill, src/vector.cpp:59-63 */
+
+/* ---- matrices ------------------------------------------------------------------------------ */
+/* CSR (include/matrix.h:27-47).  nnz = row_ptr[nrow]. */
+int spmv_csr_upload(spmv_ctx* ctx, int32_t nrow, int32_t ncol, const int32_t* row_ptr,
+                    const int32_t* col_ind, const double* values, spmv_mat** out);
+int spmv_csr_wrap_device(spmv_ctx* ctx, int32_t nrow, int32_t ncol, const int32_t* d_row_ptr,
+                         const int32_t* d_col_ind, const double* d_values, spmv_mat** out);
+/* One row-range shard [row_begin,row_end) of a host CSR matrix whose offsets may exceed int32:
+ * row_ptr64 is the GLOBAL 64-bit offset array; the shard keeps a rebased int32 row_ptr and global
+ * column indices, exactly as src/mat_vec.cpp:250-265 builds NumaNode4CSR. */
+int spmv_csr_upload_shard(spmv_ctx* ctx, int64_t row_begin, int64_t row_end, int32_t ncol,
+                          const int64_t* row_ptr64, const int32_t* col_ind, const double* values,
+                          spmv_mat** out);
+/* COO (include/matrix.h:7-25): file order, unsorted and duplicate entries allowed (summed). */
+int spmv_coo_upload(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int64_t nnz, const int32_t* row_ind,
+                    const int32_t* col_ind, const double* values, spmv_mat** out);
+int spmv_coo_wrap_device(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int64_t nnz,
+                         const int32_t* d_row_ind, const int32_t* d_col_ind, const double* d_values,
+                         spmv_mat** out);
+/* ELL (include/matrix.h:70-92): column-major nrow*k arrays, padding col 0 / val 0.0
+ * (src/matrix.cpp:473-474).  nnz = true nonzero count (used for the flop count only). */
+int spmv_ell_upload(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t k, int64_t nnz,
+                    const int32_t* col_ind, const double* values, spmv_mat** out);
+int spmv_ell_wrap_device(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t k, int64_t nnz,
+                         const int32_t* d_col_ind, const double* d_values, spmv_mat** out);
+/* CSC (include/matrix.h:49-68) and DIA (include/matrix.h:117-138). */
+int spmv_csc_upload(spmv_ctx* ctx, int32_t nrow, int32_t ncol, const int32_t* col_ptr,
+                    const int32_t* row_ind, const double* values, spmv_mat** out);
+int spmv_dia_upload(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t ndiags,
+                    const int32_t* offsets, const double* values, spmv_mat** out);
+
+int spmv_mat_destroy(spmv_mat* m);
+int spmv_mat_get_info(const spmv_mat* m, spmv_mat_info* info);
+/* Force a CSR kernel (and, for VECTOR, lanes_per_row in {1,2,4,...,64}; 0 = keep auto choice). */
+int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row);
+int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
+/* Copy the arrays of a handle back to the host (any pointer may be NULL to skip it).
+ *   CSR: a=row_ptr[nrow+1]  b=col_ind[nnz]      v=values[nnz]
+ *   COO: a=row_ind[nnz]     b=col_ind[nnz]      v=values[nnz]
+ *   ELL: a=NULL             b=col_ind[nrow*k]   v=values[nrow*k]
+ *   CSC: a=col_ptr[ncol+1]  b=row_ind[nnz]      v=values[nnz]
+ *   DIA: a=offsets[ndiags]  b=NULL              v=values[nrow*ndiags] */
+int spmv_mat_download(const spmv_mat* m, int32_t* a, int32_t* b, double* v);
+/* Device pointers of the same three arrays (borrowed; NULL where the format has none). */
+int spmv_mat_device_ptrs(const spmv_mat* m, const int32_t** a, const int32_t** b, const double** v);
+
+/* ---- the hot path: y += A*x  (include/mat_vec.h:7-11) ------------------------------------------ */
+/* x must have ncol entries, y nrow entries (the shard's rows).  Asynchronous. */
+int spmv_apply(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* x, spmv_vec* y);
+/* `reps` back-to-back applications between two HIP events on the context's stream (the reference's
+ * NUM_TEST loop, main.cpp:56-59).  Returns the mean milliseconds per application.  Synchronous. */
+int spmv_apply_timed(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* x, spmv_vec* y, int32_t reps,
+                     double* ms_per_apply);
+
+/* ---- BLAS-1 (include/vec_vec.h:6-7) ---------------------------------------------------------- */
+int spmv_dot(spmv_ctx* ctx, const spmv_vec* x, const spmv_vec* y, double* result); /* synchronous */
+int spmv_axpby(spmv_ctx* ctx, double alpha, const spmv_vec* x, double beta, const spmv_vec* y,
+               spmv_vec* w);
+
+/* ---- format conversion on the device (src/matrix.cpp:115-154, :450-500) -------------------------- */
+/* Both keep the COO order of the entries inside each row (stable), like the reference's backward
+ * scatter, so the result is identical to the reference's arrays, not merely equivalent. */
+int spmv_coo_to_csr(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out_csr);
+int spmv_coo_to_ell(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out_ell);
+int spmv_csr_to_ell(spmv_ctx* ctx, const spmv_mat* csr, spmv_mat** out_ell);
+
+/* ---- row-range sharding (src/mat_vec.cpp:233,245-246) ------------------------------------------- */
+/* Equal rows per part, the last part takes the remainder.  Pure host arithmetic. */
+int spmv_partition_rows(int64_t nrow, int32_t nparts, int32_t part, int64_t* row_begin,
+                        int64_t* row_end);
+/* nnz-balanced alternative: bounds[nparts+1], bounds[p] = first row of part p. */
+int spmv_partition_rows_balanced(int64_t nrow, const int64_t* row_ptr64, int32_t nparts,
+                                 int64_t* bounds);
+
+/* ---- synthetic inputs (counter-based splitmix64) ------------- */
+/* CSR shard with exactly k entries in each of rows [row_begin,row_end) of a (nrow_global x ncol)
+ * matrix.  band == 0: columns uniform over [0,ncol); band > 0: uniform in a window of `band`
+ * columns centred on the diagonal (wrapping).  values U(-1,1). */
+int spmv_gen_csr_uniform(spmv_ctx* ctx, int64_t row_begin, int64_t row_end, int32_t ncol, int32_t k,
+                         int32_t band, uint64_t seed, spmv_mat** out);
+/* ELL with k slots per row, circulant band col = (i + d - k/2) mod ncol, values U(-1,1). */
+int spmv_gen_ell_banded(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t k, uint64_t seed,
+                        spmv_mat** out);
+/* Row-sorted COO with power-law row lengths min(max_len, floor(8/u)), u ~ U(0,1], uniform columns. */
+int spmv_gen_coo_powerlaw(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t max_len, uint64_t seed,
+                          spmv_mat** out);
+/* v[i] = U(0,1) drawn from (seed, global index index_offset + i). */
+int spmv_gen_vec_uniform(spmv_ctx* ctx, spmv_vec* v, int64_t index_offset, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPMV_ABI_H */

@@ -1,0 +1,270 @@
+/*
+ * spmv_oracle.c — CPU restatement of the arm-spmv hot path.  TEST INFRASTRUCTURE ONLY
+ * (see spmv_oracle.h: never part of the product path).
+ *
+ * Compiled twice by oracle/Makefile:
+ *   plain   : -ffp-contract=off            -> orc_<name>       (+ conversions, sharding)
+ *   -DORC_FMA -mfma                        -> orc_<name>_fma   (arithmetic loops only)
+ * Each function cites the reference loop it follows (paths relative to the reference root).
+ */
+#include "spmv_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef ORC_FMA
+#define ORC_NAME(n) n##_fma
+#define MULADD(acc, a, b) fma((a), (b), (acc))
+#else
+#define ORC_NAME(n) n
+#define MULADD(acc, a, b) ((acc) + (a) * (b))
+#endif
+
+/* src/mat_vec.cpp:32-40 */
+void ORC_NAME(orc_coo_spmv)(int64_t nnz, const int32_t* row, const int32_t* col,
+                            const double* val, const double* x, double* y)
+{
+    for (int64_t i = 0; i < nnz; i++)
+        y[row[i]] = MULADD(y[row[i]], val[i], x[col[i]]);
+}
+
+/* src/mat_vec.cpp:57-65 */
+void ORC_NAME(orc_csr_spmv)(int32_t nrow, const int32_t* row_ptr, const int32_t* col,
+                            const double* val, const double* x, double* y)
+{
+    for (int32_t i = 0; i < nrow; i++)
+    {
+        double sum = 0.0;
+        for (int32_t j = row_ptr[i]; j < row_ptr[i + 1]; j++)
+            sum = MULADD(sum, val[j], x[col[j]]);
+        y[i] += sum;
+    }
+}
+
+/* src/mat_vec.cpp:82-93: the product is formed first (`value = val*x`), then added, so there is
+ * nothing to fuse even on aarch64; both flavours are identical and exist only for symmetry. */
+void ORC_NAME(orc_csc_spmv)(int32_t ncol, const int32_t* col_ptr, const int32_t* row,
+                            const double* val, const double* x, double* y)
+{
+    for (int32_t i = 0; i < ncol; i++)
+        for (int32_t j = col_ptr[i]; j < col_ptr[i + 1]; j++)
+            y[row[j]] = MULADD(y[row[j]], val[j], x[i]);
+}
+
+/* src/mat_vec.cpp:107-118 */
+void ORC_NAME(orc_ell_spmv)(int32_t nrow, int32_t k, const int32_t* col, const double* val,
+                            const double* x, double* y)
+{
+    for (int32_t s = 0; s < k; s++)
+        for (int32_t i = 0; i < nrow; i++)
+        {
+            size_t at = (size_t)i + (size_t)s * (size_t)nrow;
+            y[i]      = MULADD(y[i], val[at], x[col[at]]);
+        }
+}
+
+/* src/mat_vec.cpp:135-145 */
+void ORC_NAME(orc_dia_spmv)(int32_t nrow, int32_t ndiags, const int32_t* offsets,
+                            const double* val, const double* x, double* y)
+{
+    for (int32_t i = 0; i < nrow; ++i)
+        for (int32_t d = 0; d < ndiags; ++d)
+        {
+            int32_t j = i + offsets[d];
+            if (j >= 0 && j < nrow)
+                y[i] = MULADD(y[i], val[(size_t)i * ndiags + d], x[j]);
+        }
+}
+
+/* src/vec_vec.cpp:21-28 (serial order) */
+double ORC_NAME(orc_dot)(int64_t n, const double* x, const double* y)
+{
+    double result = 0.0;
+    for (int64_t i = 0; i < n; ++i)
+        result = MULADD(result, x[i], y[i]);
+    return result;
+}
+
+/* src/vec_vec.cpp:38-93: the seven branches; alpha==0 never reads x, beta==0 never reads y */
+void ORC_NAME(orc_axpby)(int64_t n, double alpha, const double* x, double beta, const double* y,
+                         double* w)
+{
+    if (alpha == 0)
+        for (int64_t i = 0; i < n; ++i) w[i] = beta * y[i];
+    else if (beta == 0)
+        for (int64_t i = 0; i < n; ++i) w[i] = alpha * x[i];
+    else if (alpha == 1)
+        for (int64_t i = 0; i < n; ++i) w[i] = MULADD(x[i], beta, y[i]);
+    else if (alpha == -1)
+        for (int64_t i = 0; i < n; ++i) w[i] = MULADD(-x[i], beta, y[i]);
+    else if (beta == 1)
+        for (int64_t i = 0; i < n; ++i) w[i] = MULADD(y[i], alpha, x[i]);
+    else if (beta == -1)
+        for (int64_t i = 0; i < n; ++i) w[i] = MULADD(-y[i], alpha, x[i]);
+    else
+#ifdef ORC_FMA
+        /* aarch64 g++ -O2 contracts a*x + b*y to fmadd(a, x, b*y) */
+        for (int64_t i = 0; i < n; ++i) w[i] = fma(alpha, x[i], beta * y[i]);
+#else
+        for (int64_t i = 0; i < n; ++i) w[i] = alpha * x[i] + beta * y[i];
+#endif
+}
+
+#ifndef ORC_FMA
+/* ======================= everything below: integer work, one flavour ===================== */
+
+/* src/mat_vec.cpp:54-65 with the OpenMP pragma kept (cpu_baseline "port" leg) */
+void orc_csr_spmv_omp(int32_t nrow, const int32_t* row_ptr, const int32_t* col,
+                      const double* val, const double* x, double* y)
+{
+#pragma omp parallel for
+    for (int32_t i = 0; i < nrow; i++)
+    {
+        double sum = 0.0;
+        for (int32_t j = row_ptr[i]; j < row_ptr[i + 1]; j++)
+            sum += val[j] * x[col[j]];
+        y[i] += sum;
+    }
+}
+
+/* src/matrix.cpp:125-153 */
+int32_t orc_coo_to_csr(int32_t nrow, int64_t nnz, const int32_t* row, const int32_t* col,
+                       const double* val, int32_t* row_ptr, int32_t* out_col, double* out_val,
+                       double* diagonal)
+{
+    for (int32_t i = 0; i <= nrow; ++i) row_ptr[i] = 0;
+    for (int64_t k = 0; k < nnz; ++k) ++row_ptr[row[k]];
+    for (int32_t i = 0; i < nrow; ++i) row_ptr[i + 1] += row_ptr[i];
+    for (int64_t k = nnz - 1; k >= 0; --k)
+    {
+        int32_t at  = --row_ptr[row[k]];
+        out_col[at] = col[k];
+        out_val[at] = val[k];
+    }
+    int32_t count = 0;
+    if (diagonal)
+        for (int64_t k = 0; k < nnz; ++k)
+            if (row[k] == col[k]) diagonal[count++] = val[k];
+    return count;
+}
+
+/* src/matrix.cpp:305-324 */
+void orc_coo_to_csc(int32_t ncol, int64_t nnz, const int32_t* row, const int32_t* col,
+                    const double* val, int32_t* col_ptr, int32_t* out_row, double* out_val)
+{
+    for (int32_t j = 0; j <= ncol; ++j) col_ptr[j] = 0;
+    for (int64_t k = 0; k < nnz; ++k) ++col_ptr[col[k]];
+    for (int32_t j = 0; j < ncol; ++j) col_ptr[j + 1] += col_ptr[j];
+    for (int64_t k = nnz - 1; k >= 0; --k)
+    {
+        int32_t at  = --col_ptr[col[k]];
+        out_row[at] = row[k];
+        out_val[at] = val[k];
+    }
+}
+
+/* src/matrix.cpp:456-470 */
+int32_t orc_coo_max_row_nnz(int32_t nrow, int64_t nnz, const int32_t* row)
+{
+    int32_t* cnt = (int32_t*)calloc((size_t)nrow > 0 ? (size_t)nrow : 1, sizeof(int32_t));
+    for (int64_t k = 0; k < nnz; ++k) cnt[row[k]]++;
+    int32_t mx = 0;
+    for (int32_t i = 0; i < nrow; ++i) mx = cnt[i] > mx ? cnt[i] : mx;
+    free(cnt);
+    return mx;
+}
+
+/* src/matrix.cpp:472-489 */
+void orc_coo_to_ell(int32_t nrow, int32_t k, int64_t nnz, const int32_t* row,
+                    const int32_t* col, const double* val, int32_t* out_col, double* out_val)
+{
+    size_t   total = (size_t)nrow * (size_t)k;
+    int32_t* cnt   = (int32_t*)calloc((size_t)nrow > 0 ? (size_t)nrow : 1, sizeof(int32_t));
+    for (int64_t e = 0; e < nnz; ++e) cnt[row[e]]++;
+    memset(out_col, 0, total * sizeof(int32_t));
+    for (size_t e = 0; e < total; ++e) out_val[e] = 0.0;
+    for (int64_t e = nnz - 1; e >= 0; --e)
+    {
+        int32_t r  = row[e];
+        int32_t s  = --cnt[r];
+        size_t  at = (size_t)r + (size_t)s * (size_t)nrow;
+        out_col[at] = col[e];
+        out_val[at] = val[e];
+    }
+    free(cnt);
+}
+
+/* src/matrix.cpp:675-709: map index (nrow - i) + j, offsets[d] = n - nrow, ascending */
+int32_t orc_csr_count_diags(int32_t nrow, int32_t ncol, const int32_t* row_ptr,
+                            const int32_t* col, int32_t* offsets)
+{
+    size_t   span = (size_t)nrow + (size_t)ncol; /* reference: nrow+ncol-1 (one short) */
+    int32_t* map  = (int32_t*)calloc(span, sizeof(int32_t));
+    int32_t  nd   = 0;
+    for (int32_t i = 0; i < nrow; ++i)
+        for (int32_t jj = row_ptr[i]; jj < row_ptr[i + 1]; ++jj)
+        {
+            size_t at = (size_t)(nrow - i) + (size_t)col[jj];
+            if (!map[at])
+            {
+                map[at] = 1;
+                nd++;
+            }
+        }
+    if (offsets)
+    {
+        int32_t d = 0;
+        for (size_t n = 0; n < span; ++n)
+            if (map[n]) offsets[d++] = (int32_t)n - nrow;
+    }
+    free(map);
+    return nd;
+}
+
+/* src/matrix.cpp:711-723 */
+void orc_csr_to_dia(int32_t nrow, int32_t ncol, const int32_t* row_ptr, const int32_t* col,
+                    const double* val, int32_t ndiags, const int32_t* offsets, double* out_val)
+{
+    size_t   span = (size_t)nrow + (size_t)ncol;
+    int32_t* map  = (int32_t*)calloc(span, sizeof(int32_t));
+    for (int32_t d = 0; d < ndiags; ++d) map[(size_t)(offsets[d] + nrow)] = d;
+    for (size_t e = 0; e < (size_t)nrow * (size_t)ndiags; ++e) out_val[e] = 0.0;
+    for (int32_t i = 0; i < nrow; ++i)
+        for (int32_t jj = row_ptr[i]; jj < row_ptr[i + 1]; ++jj)
+        {
+            size_t at = (size_t)(nrow - i) + (size_t)col[jj];
+            out_val[(size_t)i * ndiags + map[at]] = val[jj];
+        }
+    free(map);
+}
+
+/* src/mat_vec.cpp:233,245-246 */
+void orc_partition_rows(int64_t nrow, int32_t nparts, int32_t part, int64_t* begin,
+                        int64_t* end)
+{
+    int64_t per = nrow / nparts;
+    *begin      = (int64_t)part * per;
+    *end        = (part == nparts - 1) ? nrow : *begin + per;
+}
+
+/* src/mat_vec.cpp:260-263 */
+void orc_csr_shard_row_ptr(const int32_t* row_ptr, int64_t begin, int64_t end,
+                           int32_t* sub_row_ptr)
+{
+    int32_t base = row_ptr[begin];
+    for (int64_t j = 0; j <= end - begin; j++) sub_row_ptr[j] = row_ptr[begin + j] - base;
+}
+
+void orc_csr_abs_row_sums(int32_t nrow, const int32_t* row_ptr, const int32_t* col,
+                          const double* val, const double* x, double* s)
+{
+    for (int32_t i = 0; i < nrow; i++)
+    {
+        double acc = 0.0;
+        for (int32_t j = row_ptr[i]; j < row_ptr[i + 1]; j++)
+            acc += fabs(val[j]) * fabs(x[col[j]]);
+        s[i] = acc;
+    }
+}
+#endif /* !ORC_FMA */

@@ -1,0 +1,384 @@
+"""GPU parity tests proper: the HIP engine, called through the C ABI, against the oracle and the golden
+vectors produced by the real reference.  Run on the MI355X box with `pytest -m gpu`.
+
+Tolerance (BASELINE.json north_star): after 1 call from y = 0 and after 50 accumulating calls
+    max|y - y_ref| / max|y_ref| <= 1e-10   and   max_i |y_i - y_ref,i| / (|A||x|)_i <= 1e-10.
+Kernels that add in the reference's order (ELL, scalar CSR, DIA) are additionally bit-identical to the
+oracle's fused-multiply-add flavour; integer work (conversions, generators, sharding) is bit-exact.
+"""
+import numpy as np
+import pytest
+
+import cases
+import oracle_lib as ol
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+NUM_TEST = 50  # main.cpp:16
+
+
+def _csr_of(orc, c):
+    return ol.coo_to_csr(orc, c["nrow"], ol.i32(c["row"]), ol.i32(c["col"]), ol.f64(c["val"]))
+
+
+def _scale(orc, c):
+    rp, cc, cv = _csr_of(orc, c)
+    s = np.zeros(c["nrow"])
+    ol.csr_abs_row_sums(orc, rp, cc, cv, ol.f64(c["x"]), s)
+    return s
+
+
+def _apply_n(ctx, A, x, nrow, reps):
+    dx = ctx.vector_from(x)
+    dy = ctx.vector(nrow)
+    dy.fill(0.0)
+    out = []
+    for r in range(1, reps + 1):
+        ctx.apply(A, dx, dy)
+        if r in (1, reps):
+            ctx.sync()
+            out.append(dy.download())
+    return out[0], out[-1]
+
+
+@pytest.mark.parametrize("make", cases.ALL_CASES, ids=lambda f: f.__name__)
+def test_csr_matches_reference_golden(ctx, orc, pkg, make):
+    c = make()
+    g = golden(c["name"])
+    rp, cc, cv = _csr_of(orc, c)
+    scale = _scale(orc, c)
+    capi = pkg.capi
+    for kernel, lanes in ((capi.CSR_AUTO, 0), (capi.CSR_VECTOR, 1), (capi.CSR_VECTOR, 2), (capi.CSR_VECTOR, 4),
+                          (capi.CSR_VECTOR, 8), (capi.CSR_VECTOR, 16), (capi.CSR_VECTOR, 32), (capi.CSR_VECTOR, 64),
+                          (capi.CSR_SCALAR, 0)):
+        for flags in (0, capi.FLAG_DPP_REDUCE, capi.FLAG_XCD_REMAP):
+            if kernel != capi.CSR_VECTOR and flags:
+                continue
+            A = ctx.csr(c["nrow"], c["ncol"], rp, cc, cv)
+            A.set_kernel(kernel, lanes)
+            A.set_flags(flags)
+            y1, y50 = _apply_n(ctx, A, c["x"], c["nrow"], NUM_TEST)
+            what = f"{c['name']} csr kernel={kernel} lanes={lanes} flags={flags}"
+            ol.assert_parity(y1, g["y1_csr"], scale, what + " 1 call")
+            ol.assert_parity(y50, g["y50_csr"], scale, what + " 50 calls", reps=NUM_TEST)
+
+
+@pytest.mark.parametrize("make", cases.ALL_CASES, ids=lambda f: f.__name__)
+def test_csr_scalar_kernel_is_bitwise_oracle_fma(ctx, orc, pkg, make):
+    c = make()
+    rp, cc, cv = _csr_of(orc, c)
+    A = ctx.csr(c["nrow"], c["ncol"], rp, cc, cv)
+    A.set_kernel(pkg.capi.CSR_SCALAR)
+    y1, y50 = _apply_n(ctx, A, c["x"], c["nrow"], NUM_TEST)
+    ref = np.zeros(c["nrow"])
+    x = ol.f64(c["x"])
+    ol.csr_spmv(orc, rp, cc, cv, x, ref, fma=True)
+    assert np.array_equal(y1, ref)
+    for _ in range(NUM_TEST - 1):
+        ol.csr_spmv(orc, rp, cc, cv, x, ref, fma=True)
+    assert np.array_equal(y50, ref)
+
+
+@pytest.mark.parametrize("make", cases.ALL_CASES, ids=lambda f: f.__name__)
+def test_ell_matches_reference_and_is_bitwise_oracle_fma(ctx, orc, make):
+    c = make()
+    g = golden(c["name"])
+    k, ec, ev = ol.coo_to_ell(orc, c["nrow"], ol.i32(c["row"]), ol.i32(c["col"]), ol.f64(c["val"]))
+    assert k == int(g["ell_k"])
+    scale = _scale(orc, c)
+    A = ctx.ell(c["nrow"], c["ncol"], k, len(c["val"]), ec, ev)
+    y1, y50 = _apply_n(ctx, A, c["x"], c["nrow"], NUM_TEST)
+    ol.assert_parity(y1, g["y1_ell"], scale, c["name"] + " ell 1 call")
+    ol.assert_parity(y50, g["y50_ell"], scale, c["name"] + " ell 50 calls", reps=NUM_TEST)
+    ref = np.zeros(c["nrow"])
+    ol.ell_spmv(orc, c["nrow"], k, ec, ev, ol.f64(c["x"]), ref, fma=True)
+    assert np.array_equal(y1, ref), "ELL kernel adds in the reference's per-row order: must equal the fma oracle exactly"
+
+
+def test_ell_odd_row_count_uses_one_row_kernel(ctx, orc):
+    """nrow odd -> the 16-byte two-rows-per-lane kernel is not applicable; same answers"""
+    rng = np.random.RandomState(3)
+    nrow, ncol, k = 1001, 777, 5
+    col = rng.randint(0, ncol, size=nrow * k).astype(np.int32)
+    val = rng.uniform(-1, 1, size=nrow * k)
+    x = rng.uniform(0, 1, size=ncol)
+    A = ctx.ell(nrow, ncol, k, nrow * k, col, val)
+    y1, _ = _apply_n(ctx, A, x, nrow, 1)
+    ref = np.zeros(nrow)
+    ol.ell_spmv(orc, nrow, k, col, val, x, ref, fma=True)
+    assert np.array_equal(y1, ref)
+
+
+@pytest.mark.parametrize("make", cases.ALL_CASES, ids=lambda f: f.__name__)
+def test_coo_matches_reference_golden(ctx, orc, make):
+    c = make()
+    g = golden(c["name"])
+    scale = _scale(orc, c)
+    A = ctx.coo(c["nrow"], c["ncol"], c["row"], c["col"], c["val"])
+    sorted_in = bool(np.all(np.diff(c["row"].astype(np.int64)) >= 0))
+    assert bool(A.info.sorted_rows) == sorted_in
+    y1, y50 = _apply_n(ctx, A, c["x"], c["nrow"], NUM_TEST)
+    ol.assert_parity(y1, g["y1_coo"], scale, c["name"] + " coo 1 call")
+    ol.assert_parity(y50, g["y50_coo"], scale, c["name"] + " coo 50 calls", reps=NUM_TEST)
+
+
+def test_coo_ragged_chunk_boundaries(ctx, orc):
+    """runs that straddle wavefront chunks (512 entries) and workgroup chunks (2048), sorted and shuffled"""
+    rng = np.random.RandomState(11)
+    nrow, ncol = 4000, 3000
+    lens = rng.choice([0, 1, 2, 3, 63, 64, 65, 511, 512, 513, 700, 2047, 2049], size=nrow, p=[.3, .2, .1, .1, .05, .05, .05, .03, .03, .03, .03, .02, .01])
+    row = np.repeat(np.arange(nrow, dtype=np.int32), lens)
+    col = rng.randint(0, ncol, size=row.size).astype(np.int32)
+    val = rng.uniform(-1, 1, size=row.size)
+    x = rng.uniform(0, 1, size=ncol)
+    rp, cc, cv = ol.coo_to_csr(orc, nrow, row, col, val)
+    scale = np.zeros(nrow)
+    ol.csr_abs_row_sums(orc, rp, cc, cv, x, scale)
+    for shuffle in (False, True):
+        if shuffle:
+            p = rng.permutation(row.size)
+            row, col, val = row[p], col[p], val[p]
+        ref = np.zeros(nrow)
+        ol.coo_spmv(orc, row, col, val, x, ref)
+        A = ctx.coo(nrow, ncol, row, col, val)
+        assert bool(A.info.sorted_rows) == (not shuffle)
+        y1, _ = _apply_n(ctx, A, x, nrow, 1)
+        ol.assert_parity(y1, ref, scale, f"coo ragged shuffle={shuffle}")
+
+
+def test_empty_and_degenerate_inputs(ctx):
+    x = np.ones(5)
+    for A in (ctx.csr(0, 5, np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0)),
+              ctx.coo(0, 5, np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0)),
+              ctx.ell(0, 5, 0, 0, np.zeros(0, np.int32), np.zeros(0))):
+        dy = ctx.vector(0)
+        ctx.apply(A, ctx.vector_from(x), dy)
+        ctx.sync()
+    # rows but no entries: y must stay what it was
+    A = ctx.csr(7, 5, np.zeros(8, np.int32), np.zeros(0, np.int32), np.zeros(0))
+    dy = ctx.vector_from(np.arange(7.0))
+    ctx.apply(A, ctx.vector_from(x), dy)
+    ctx.sync()
+    assert np.array_equal(dy.download(), np.arange(7.0))
+    A = ctx.coo(7, 5, np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0))
+    ctx.apply(A, ctx.vector_from(x), dy)
+    ctx.sync()
+    assert np.array_equal(dy.download(), np.arange(7.0))
+
+
+def test_apply_rejects_shape_mismatch(ctx, pkg):
+    A = ctx.csr(2, 3, np.array([0, 1, 2], np.int32), np.array([0, 2], np.int32), np.array([1.0, 2.0]))
+    with pytest.raises(pkg.capi.SpmvError):
+        ctx.apply(A, ctx.vector(2), ctx.vector(2))  # x must have ncol = 3 entries
+    with pytest.raises(pkg.capi.SpmvError):
+        ctx.apply(A, ctx.vector(3), ctx.vector(3))  # y must have nrow = 2 entries
+
+
+# ---------------------------------------------------------------------------------- conversions (bit-exact)
+@pytest.mark.parametrize("make", cases.ALL_CASES, ids=lambda f: f.__name__)
+def test_coo_to_csr_and_ell_equal_reference_arrays(ctx, orc, make):
+    c = make()
+    g = golden(c["name"])
+    coo = ctx.coo(c["nrow"], c["ncol"], c["row"], c["col"], c["val"])
+    csr = ctx.coo_to_csr(coo)
+    rp, cc, cv = csr.download()
+    ell = ctx.coo_to_ell(coo)
+    _, ec, ev = ell.download()
+    assert ell.info.ell_k == int(g["ell_k"])
+    if c["name"] == "c1":
+        assert cases.digest(rp, cc, cv) == str(g["sha_csr"])
+        assert cases.digest(ec, ev) == str(g["sha_ell"])
+    else:
+        assert np.array_equal(rp, g["csr_row_ptr"]) and np.array_equal(cc, g["csr_col"]) and np.array_equal(cv, g["csr_val"])
+        assert np.array_equal(ec, g["ell_col"]) and np.array_equal(ev, g["ell_val"])
+    ell2 = ctx.csr_to_ell(csr)
+    _, ec2, ev2 = ell2.download()
+    assert np.array_equal(ec, ec2) and np.array_equal(ev, ev2)
+
+
+def test_coo_to_csr_large_unsorted(ctx, orc):
+    rng = np.random.RandomState(5)
+    nrow, ncol, nnz = 50_000, 40_000, 700_000
+    row = rng.randint(0, nrow, size=nnz).astype(np.int32)
+    col = rng.randint(0, ncol, size=nnz).astype(np.int32)
+    val = rng.uniform(-1, 1, size=nnz)
+    rp, cc, cv = ol.coo_to_csr(orc, nrow, row, col, val)
+    got = ctx.coo_to_csr(ctx.coo(nrow, ncol, row, col, val)).download()
+    assert np.array_equal(got[0], rp) and np.array_equal(got[1], cc) and np.array_equal(got[2], cv)
+
+
+# ---------------------------------------------------------------------------------- CSC / DIA ("next" rows)
+@pytest.mark.parametrize("make", cases.SMALL_CASES, ids=lambda f: f.__name__)
+def test_csc_matches_reference_golden(ctx, orc, make):
+    c = make()
+    g = golden(c["name"])
+    A = ctx.csc(c["nrow"], c["ncol"], g["csc_col_ptr"], g["csc_row"], g["csc_val"])
+    y1, y50 = _apply_n(ctx, A, c["x"], c["nrow"], NUM_TEST)
+    scale = _scale(orc, c)
+    ol.assert_parity(y1, g["y1_csc"], scale, c["name"] + " csc 1 call")
+    ol.assert_parity(y50, g["y50_csc"], scale, c["name"] + " csc 50 calls", reps=NUM_TEST)
+
+
+def test_dia_matches_reference_golden(ctx, orc):
+    c = cases.tri8()
+    g = golden("tri8")
+    A = ctx.dia(c["nrow"], c["ncol"], g["dia_offsets"], g["dia_val"])
+    y1, y50 = _apply_n(ctx, A, c["x"], c["nrow"], NUM_TEST)
+    scale = _scale(orc, c)
+    ol.assert_parity(y1, g["y1_dia"], scale, "dia 1 call")
+    ol.assert_parity(y50, g["y50_dia"], scale, "dia 50 calls", reps=NUM_TEST)
+    ref = np.zeros(c["nrow"])
+    ol.dia_spmv(orc, c["nrow"], ol.i32(g["dia_offsets"]), ol.f64(g["dia_val"]), ol.f64(c["x"]), ref, fma=True)
+    assert np.array_equal(y1, ref)
+
+
+# ---------------------------------------------------------------------------------- BLAS-1
+def test_dot_and_axpby(ctx, orc):
+    g = golden("tri8")
+    x = ol.f64(g["x"])
+    dx = ctx.vector_from(x)
+    assert abs(ctx.dot(dx, dx) - float(g["dot_xx"])) <= 1e-13 * abs(float(g["dot_xx"]))
+    yv = ol.f64(g["y1_csr"])
+    dyv = ctx.vector_from(yv)
+    for tag, (a, b) in dict(g=(0.75, -1.25), a0=(0.0, 2.0), b0=(3.0, 0.0), a1=(1.0, 0.5), am1=(-1.0, 0.5), b1=(0.5, 1.0),
+                            bm1=(0.5, -1.0)).items():
+        dw = ctx.vector(len(x))
+        ctx.axpby(a, dx, b, dyv, dw)
+        ctx.sync()
+        w = dw.download()
+        assert np.allclose(w, g[f"axpby_{tag}"], rtol=1e-14, atol=1e-15), tag
+        ref = np.zeros(len(x))
+        ol.axpby(orc, a, x, b, yv, ref, fma=True)
+        assert np.array_equal(w, ref), f"axpby {tag}: not bitwise equal to the fma oracle"
+    # alpha == 0 must not read x (NaN there must not leak), beta == 0 must not read y
+    bad = ctx.vector_from(np.full(len(x), np.nan))
+    dw = ctx.vector(len(x))
+    ctx.axpby(0.0, bad, 2.0, dyv, dw)
+    ctx.sync()
+    assert np.array_equal(dw.download(), 2.0 * yv)
+    ctx.axpby(3.0, dx, 0.0, bad, dw)
+    ctx.sync()
+    assert np.array_equal(dw.download(), 3.0 * x)
+    # a long dot against the oracle (different summation tree -> tolerance)
+    rng = np.random.RandomState(9)
+    a, b = rng.uniform(-1, 1, 1_000_003), rng.uniform(-1, 1, 1_000_003)
+    got = ctx.dot(ctx.vector_from(a), ctx.vector_from(b))
+    assert abs(got - ol.dot(orc, a, b)) <= 1e-10 * float(np.sum(np.abs(a * b)))
+
+
+# ---------------------------------------------------------------------------------- generators (bit-exact)
+def test_device_generators_equal_numpy_twin(ctx, pkg):
+    synth = pkg.synth
+    for band in (0, 4096):
+        A = ctx.gen_csr_uniform(1000, 3500, 100_000, 32, band=band, seed=42)
+        rp, cc, cv = A.download()
+        erp, ec, ev = synth.csr_uniform(1000, 3500, 100_000, 32, band=band, seed=42)
+        assert np.array_equal(rp, erp) and np.array_equal(cc, ec) and np.array_equal(cv, ev)
+        assert A.info.row_begin == 1000 and A.info.max_row_nnz == 32
+    E = ctx.gen_ell_banded(5000, 5000, 64, seed=3)
+    _, ec, ev = E.download()
+    xc, xv = synth.ell_banded(5000, 5000, 64, seed=3)
+    assert np.array_equal(ec, xc) and np.array_equal(ev, xv)
+    P = ctx.gen_coo_powerlaw(20_000, 20_000, 4096, seed=5)
+    r, c, v = P.download()
+    er, ec, ev = synth.coo_powerlaw(20_000, 20_000, 4096, seed=5)
+    assert np.array_equal(r, er) and np.array_equal(c, ec) and np.array_equal(v, ev)
+    assert P.info.sorted_rows == 1
+    assert np.array_equal(ctx.gen_vector(10_000, index_offset=77, seed=8).download(), synth.vec_uniform(10_000, 77, 8))
+
+
+# ---------------------------------------------------------------------------------- LDS-window kernel (banded)
+def test_csr_ldswin_on_banded_matrix(ctx, orc, pkg):
+    synth = pkg.synth
+    n, k, band = 60_000, 32, 2048
+    rp, cc, cv = synth.csr_uniform(0, n, n, k, band=band, seed=12)
+    x = synth.vec_uniform(n, seed=12)
+    ref = np.zeros(n)
+    ol.csr_spmv(orc, rp, cc, cv, x, ref)
+    scale = np.zeros(n)
+    ol.csr_abs_row_sums(orc, rp, cc, cv, x, scale)
+    A = ctx.csr(n, n, rp, cc, cv)
+    # the first and last row blocks wrap around the matrix edge: their window spans all columns, so AUTO must
+    # not pick the LDS kernel for this matrix, and forcing it must fail loudly rather than read out of bounds
+    assert A.info.kernel == pkg.capi.CSR_VECTOR
+    A.set_kernel(pkg.capi.CSR_LDSWIN)
+    with pytest.raises(pkg.capi.SpmvError):
+        ctx.apply(A, ctx.vector_from(x), ctx.vector(n))
+    # the same band without wrap-around rows: every window fits
+    lo, hi = 4096, n - 4096
+    rp2 = (rp[lo:hi + 1] - rp[lo]).astype(np.int32)
+    cc2, cv2 = cc[rp[lo]:rp[hi]], cv[rp[lo]:rp[hi]]
+    B = ctx.csr(hi - lo, n, rp2, cc2, cv2)
+    assert B.info.kernel == pkg.capi.CSR_LDSWIN
+    y1, _ = _apply_n(ctx, B, x, hi - lo, 1)
+    ol.assert_parity(y1, ref[lo:hi], scale[lo:hi], "csr ldswin")
+    B.set_kernel(pkg.capi.CSR_VECTOR)
+    y2, _ = _apply_n(ctx, B, x, hi - lo, 1)
+    ol.assert_parity(y2, ref[lo:hi], scale[lo:hi], "csr vector on banded")
+
+
+# ---------------------------------------------------------------------------------- sharding on one device
+def test_row_shards_concatenate_to_unsharded_result(ctx, orc, pkg):
+    """the NUMA driver's partition (src/mat_vec.cpp:240-268) emulated with 8 shards on one GPU"""
+    synth, capi = pkg.synth, pkg.capi
+    n, k, parts = 100_003, 16, 8
+    rp, cc, cv = synth.csr_uniform(0, n, n, k, seed=21)
+    x = synth.vec_uniform(n, seed=21)
+    ref = np.zeros(n)
+    ol.csr_spmv(orc, rp, cc, cv, x, ref)
+    scale = np.zeros(n)
+    ol.csr_abs_row_sums(orc, rp, cc, cv, x, scale)
+    dx = ctx.vector_from(x)
+    rp64 = rp.astype(np.int64)
+    pieces = []
+    for p in range(parts):
+        b, e = capi.partition_rows(n, parts, p)
+        assert (b, e) == ol.partition_rows(orc, n, parts, p)
+        S = ctx.csr_shard(b, e, n, rp64, cc, cv)
+        srp, _, _ = S.download()
+        assert np.array_equal(srp, ol.csr_shard_row_ptr(orc, rp, b, e))
+        assert S.info.row_begin == b and S.info.nrow == e - b
+        dy = ctx.vector(e - b)
+        dy.fill(0.0)
+        ctx.apply(S, dx, dy)
+        ctx.sync()
+        pieces.append(dy.download())
+    ol.assert_parity(np.concatenate(pieces), ref, scale, "8 row shards")
+
+
+# ---------------------------------------------------------------------------------- full-size properties
+def test_full_size_csr_linearity_and_row_sample(ctx, orc, pkg):
+    """BASELINE config 2 shape at reduced N would not exercise int32 limits; run the real N = 10M, 32/row.
+    Size-independent checks: (i) a sample of rows recomputed by the oracle from the regenerated rows,
+    (ii) linearity A(ax1 + bx2) = aAx1 + bAx2, (iii) accumulation: two calls = 2 * one call."""
+    synth = pkg.synth
+    n, k = 10_000_000, 32
+    A = ctx.gen_csr_uniform(0, n, n, k, band=0, seed=1)
+    assert A.info.nnz == n * k
+    x1 = ctx.gen_vector(n, seed=1)
+    x2 = ctx.gen_vector(n, seed=2)
+    y1, y2, y3 = ctx.vector(n), ctx.vector(n), ctx.vector(n)
+    for v in (y1, y2, y3):
+        v.fill(0.0)
+    ctx.apply(A, x1, y1)
+    ctx.apply(A, x2, y2)
+    x3 = ctx.vector(n)
+    ctx.axpby(0.5, x1, -2.0, x2, x3)
+    ctx.apply(A, x3, y3)
+    ctx.sync()
+    h1, h2, h3 = y1.download(), y2.download(), y3.download()
+    # (i) rows [r0, r0+2000) at three places, against the oracle on the regenerated rows
+    hx1 = synth.vec_uniform(n, seed=1)
+    for r0 in (0, 4_999_000, n - 2000):
+        rp, cc, cv = synth.csr_uniform(r0, r0 + 2000, n, k, seed=1)
+        ref = np.zeros(2000)
+        ol.csr_spmv(orc, rp, cc, cv, hx1, ref)
+        scale = np.zeros(2000)
+        ol.csr_abs_row_sums(orc, rp, cc, cv, hx1, scale)
+        ol.assert_parity(h1[r0:r0 + 2000], ref, scale, f"full-size rows {r0}..")
+    # (ii) linearity; |A||x| <= 32 per row, so 1e-10 * 32 bounds the scaled error generously
+    assert np.max(np.abs(h3 - (0.5 * h1 - 2.0 * h2))) <= 1e-10 * 32
+    # (iii) y += : a second application doubles y
+    ctx.apply(A, x1, y1)
+    ctx.sync()
+    assert np.max(np.abs(y1.download() - 2.0 * h1)) <= 1e-12 * 32

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""tools/tune.py — in-process A/B of kernel variants on the BASELINE configurations (GPU box only).
+
+Interleaved rounds in ONE process (guide rule: perf deltas come from interleaved A/B, median + min).
+    python tools/tune.py csr [--n 10000000 --k 32 --band 0]      lanes x flags sweep of the CSR kernels
+    python tools/tune.py ell | coo                               C3 / C4
+"""
+import argparse
+import statistics
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from __graft_entry__ import load_package  # noqa: E402
+from bench import algorithmic_bytes  # noqa: E402
+
+capi = load_package().capi
+
+
+def sweep(ctx, A, x, y, variants, rounds, reps, bytes_launch, nnz):
+    res = {name: [] for name, _ in variants}
+    for _ in range(rounds):
+        for name, setup in variants:
+            setup(A)
+            ctx.apply(A, x, y)  # warm
+            res[name].append(ctx.apply_timed(A, x, y, reps))
+    print(f"{'variant':28s} {'med ms':>9s} {'min ms':>9s} {'GFLOP/s':>9s} {'alg GB/s':>9s} {'%8TB/s':>7s}")
+    for name, ts in res.items():
+        med, mn = statistics.median(ts), min(ts)
+        print(f"{name:28s} {med:9.4f} {mn:9.4f} {2*nnz/mn/1e6:9.1f} {bytes_launch/mn/1e6:9.1f} {bytes_launch/mn/1e6/80:7.2f}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["csr", "ell", "coo"])
+    ap.add_argument("--n", type=int, default=0)
+    ap.add_argument("--k", type=int, default=0)
+    ap.add_argument("--band", type=int, default=0)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=10)
+    a = ap.parse_args()
+    ctx = capi.Context(0)
+    if a.what == "csr":
+        n, k = a.n or 10_000_000, a.k or 32
+        A = ctx.gen_csr_uniform(0, n, n, k, band=a.band, seed=1)
+        x, y = ctx.gen_vector(n, seed=1), ctx.vector(n)
+        y.fill(0.0)
+        info = A.info
+        print(f"CSR n={n} k={k} band={a.band} auto: kernel={info.kernel} lanes={info.lanes_per_row}")
+        variants = []
+        for lanes in (2, 4, 8, 16, 32):
+            for fl, tag in ((0, ""), (1, "+dpp"), (2, "+xcd"), (3, "+dpp+xcd")):
+                def setup(A, lanes=lanes, fl=fl):
+                    A.set_kernel(capi.CSR_VECTOR, lanes)
+                    A.set_flags(fl)
+                variants.append((f"vector L={lanes}{tag}", setup))
+        variants.append(("scalar", lambda A: A.set_kernel(capi.CSR_SCALAR)))
+        if a.band and a.band <= 8192:
+            for lanes in (4, 8, 16):
+                variants.append((f"ldswin L={lanes}", lambda A, lanes=lanes: A.set_kernel(capi.CSR_LDSWIN, lanes)))
+        sweep(ctx, A, x, y, variants, a.rounds, a.reps, algorithmic_bytes("csr", n, n, n * k), n * k)
+    elif a.what == "ell":
+        n, k = a.n or 4_000_000, a.k or 64
+        A = ctx.gen_ell_banded(n, n, k, seed=1)
+        x, y = ctx.gen_vector(n, seed=1), ctx.vector(n)
+        y.fill(0.0)
+        variants = [("ell x2 (16B loads)", lambda A: A.set_kernel(0, 0)), ("ell x1", lambda A: A.set_kernel(0, 1))]
+        # lanes_per_row == 1 forces the one-row-per-lane kernel; restore with a fresh handle is not needed (x2 needs lanes != 1)
+        variants[0] = ("ell x2 (16B loads)", lambda A: A.set_kernel(0, 2))
+        sweep(ctx, A, x, y, variants, a.rounds, a.reps, algorithmic_bytes("ell", n, n, n * k, k), n * k)
+    else:
+        n = a.n or 2_000_000
+        A = ctx.gen_coo_powerlaw(n, n, 4096, seed=1)
+        nnz = A.info.nnz
+        print(f"COO power-law n={n} nnz={nnz} mean={nnz/n:.1f} sorted={A.info.sorted_rows}")
+        x, y = ctx.gen_vector(n, seed=1), ctx.vector(n)
+        y.fill(0.0)
+        sweep(ctx, A, x, y, [("coo segscan", lambda A: None)], a.rounds, a.reps, algorithmic_bytes("coo", n, n, nnz), nnz)
+        csr = ctx.coo_to_csr(A)
+        print(f"same matrix as CSR: auto kernel={csr.info.kernel} lanes={csr.info.lanes_per_row} max_row={csr.info.max_row_nnz}")
+        variants = [(f"csr vector L={l}", lambda A, l=l: A.set_kernel(capi.CSR_VECTOR, l)) for l in (8, 16, 32, 64)]
+        sweep(ctx, csr, x, y, variants, a.rounds, a.reps, algorithmic_bytes("csr", n, n, nnz), nnz)
+
+
+if __name__ == "__main__":
+    main()
