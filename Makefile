@@ -9,7 +9,7 @@ PKG      := arm-spmv_amd
 CSRC     := $(PKG)/csrc
 LIBDIR   := $(PKG)/lib
 OBJDIR   := build/obj
-HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wall -Wno-unused-function -ffp-contract=on
+HIPFLAGS := -O3 -Wno-unused-result -Wno-unused-value -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wall -Wno-unused-function -ffp-contract=on
 
 ENGINE_SRCS := $(wildcard $(CSRC)/*.hip)
 ENGINE_OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(ENGINE_SRCS))

@@ -17,7 +17,7 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "lib" / "libspmv_hip.so"
 
 FMT_COO, FMT_CSR, FMT_CSC, FMT_ELL, FMT_DIA = 0, 1, 2, 3, 4
-CSR_AUTO, CSR_VECTOR, CSR_LDSWIN, CSR_SCALAR = 0, 1, 2, 3
+CSR_AUTO, CSR_VECTOR, CSR_LDSWIN, CSR_SCALAR, CSR_PANEL = 0, 1, 2, 3, 4
 FLAG_DPP_REDUCE, FLAG_XCD_REMAP = 1, 2
 
 _i32p = C.POINTER(C.c_int32)
@@ -73,6 +73,7 @@ SIGNATURES = {
     "spmv_mat_get_info": (C.c_int, [_vp, C.POINTER(MatInfo)]),
     "spmv_mat_set_kernel": (C.c_int, [_vp, C.c_int32, C.c_int32]),
     "spmv_mat_set_flags": (C.c_int, [_vp, C.c_uint32]),
+    "spmv_mat_set_param": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
     "spmv_mat_download": (C.c_int, [_vp, _vp, _vp, _vp]),
     "spmv_mat_device_ptrs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "spmv_apply": (C.c_int, [_vp, _vp, _vp, _vp]),
@@ -377,6 +378,9 @@ class Matrix:
 
     def set_kernel(self, kernel: int, lanes_per_row: int = 0) -> None:
         _check(self.ctx._lib.spmv_mat_set_kernel(self.h, kernel, lanes_per_row))
+
+    def set_param(self, name: str, value: int) -> None:
+        _check(self.ctx._lib.spmv_mat_set_param(self.h, name.encode(), value))
 
     def set_flags(self, flags: int) -> None:
         _check(self.ctx._lib.spmv_mat_set_flags(self.h, flags))

@@ -83,8 +83,7 @@ void mat_free(spmv_mat* m)
     }
     if (m->win_lo) hipFree(m->win_lo);
     if (m->win_span) hipFree(m->win_span);
-    if (m->coo_carry_row) hipFree(m->coo_carry_row);
-    if (m->coo_carry_val) hipFree(m->coo_carry_val);
+    csr_panel_free(m);
     delete m;
 }
 
@@ -510,7 +509,7 @@ int spmv_mat_get_info(const spmv_mat* m, spmv_mat_info* info)
 int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
 {
     SPMV_REQUIRE(m, "null matrix");
-    SPMV_REQUIRE(kernel >= SPMV_CSR_AUTO && kernel <= SPMV_CSR_SCALAR, "unknown kernel id %d", kernel);
+    SPMV_REQUIRE(kernel >= SPMV_CSR_AUTO && kernel <= SPMV_CSR_PANEL, "unknown kernel id %d", kernel);
     SPMV_REQUIRE(lanes_per_row == 0 || (lanes_per_row >= 1 && lanes_per_row <= 64 &&
                                         (lanes_per_row & (lanes_per_row - 1)) == 0),
                  "lanes_per_row must be 0 or a power of two in 1..64, got %d", lanes_per_row);
@@ -525,6 +524,25 @@ int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
         m->kernel        = kernel;
         m->kernel_forced = true;
     }
+    if (m->format == SPMV_FMT_CSR && m->kernel == SPMV_CSR_PANEL)
+    {
+        SPMV_HIP(hipSetDevice(m->ctx->device));
+        SPMV_TRY(csr_panel_build(m));  // (re)build with the current parameters
+    }
+    return SPMV_OK;
+}
+
+int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
+{
+    SPMV_REQUIRE(m && name, "null argument");
+    if (!strcmp(name, "panel_rows"))
+        m->pb_group_rows = (int32_t)value;
+    else if (!strcmp(name, "panel_width"))
+        m->pb_panel_width = (int32_t)value;
+    else if (!strcmp(name, "panel_sort"))
+        m->pb_sort = (int32_t)value;
+    else
+        SPMV_FAIL(SPMV_ERR_INVALID, "unknown parameter '%s'", name);
     return SPMV_OK;
 }
 

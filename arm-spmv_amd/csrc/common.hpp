@@ -142,10 +142,18 @@ struct spmv_mat
     int32_t* win_span  = nullptr;  // [nblocks] hi - lo
     int32_t  win_max_span = 0;
 
-    // COO: per-workgroup carry-out (row, partial) pairs for the sorted path
-    int32_t* coo_carry_row = nullptr;
-    double*  coo_carry_val = nullptr;
-    int32_t  coo_nblocks   = 0;
+    double   win_avg_span = 0.0;   // mean over row blocks: how local the columns are
+
+    // CSR panel kernel (kernels_csr_panel.hip): entries re-ordered per row group by column panel / x line
+    int32_t*  pb_col         = nullptr;  // [nnz] global column
+    uint16_t* pb_row         = nullptr;  // [nnz] row inside its group
+    double*   pb_val         = nullptr;  // [nnz]
+    int32_t   pb_group_rows  = 0;        // G (0 = choose)
+    int32_t   pb_panel_width = 0;        // W (0 = default)
+    int32_t   pb_sort        = 1;        // bucket tile entries by 128-byte line of x
+    int32_t   pb_ngroups     = 0;
+    int32_t   pb_built_rows = 0, pb_built_width = 0, pb_built_sort = -1;  // parameters of the layout in memory
+    int64_t   pb_bytes       = 0;
 };
 
 namespace spmv
@@ -155,6 +163,10 @@ int ensure_scratch(spmv_ctx* ctx, size_t bytes);
 // kernels_csr.hip
 int csr_analyse(spmv_mat* m);
 void csr_choose_kernel(spmv_mat* m);
+// kernels_csr_panel.hip
+int  csr_panel_build(spmv_mat* m);
+void csr_panel_free(spmv_mat* m);
+int  csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 int csr_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 // kernels_ell.hip
 int ell_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);

@@ -202,6 +202,14 @@ __global__ __launch_bounds__(kBlock) void row_len_max_kernel(int nrow, const int
     if ((threadIdx.x & 63) == 0 && mx > 0) atomicMax(out_max, mx);
 }
 
+__global__ void sum_i32_kernel(const int32_t* __restrict__ in, int n, unsigned long long* __restrict__ out_sum)
+{
+    unsigned long long acc = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) acc += (unsigned)in[i];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out_sum, acc);
+}
+
 __global__ void max_i32_kernel(const int32_t* __restrict__ in, int n, int32_t* __restrict__ out_max)
 {
     int mx = INT32_MIN;
@@ -306,13 +314,26 @@ void csr_choose_kernel(spmv_mat* m)
     const double mean  = m->nrow > 0 ? (double)m->nnz / (double)m->nrow : 0.0;
     const bool   fits  = m->win_max_span > 0 && m->win_max_span <= kWinDoubles;
     const double reuse = m->win_max_span > 0 ? mean * kWinRows / (double)m->win_max_span : 0.0;
-    m->kernel          = (fits && reuse >= 2.0) ? SPMV_CSR_LDSWIN : SPMV_CSR_VECTOR;
+    if (fits && reuse >= 2.0)
+        m->kernel = SPMV_CSR_LDSWIN;
+    else
+    {
+        // no column locality (the row blocks' windows average more than L2 can hold) and an x well beyond L2:
+        // re-order into row groups x column panels.  Small problems stay with the row-parallel kernel.
+        const bool x_beyond_l2 = (double)m->ncol * 8.0 > 4.0 * 1048576.0;
+        const bool no_locality = m->win_avg_span * 8.0 > 2.0 * 1048576.0;
+        const bool big_enough  = m->nnz >= (int64_t)4 << 20 && mean >= 2.0;
+        m->kernel              = (x_beyond_l2 && no_locality && big_enough) ? SPMV_CSR_PANEL : SPMV_CSR_VECTOR;
+    }
 }
 
 // Row statistics + kernel choice.  Runs once when a CSR handle is created.
 int csr_analyse(spmv_mat* m)
 {
     spmv_ctx* ctx = m->ctx;
+    // the kernels step their entry index in int32 (j + 3*LPR, e + 3*1024): keep clear of the wrap
+    SPMV_REQUIRE(m->nnz <= (int64_t)INT32_MAX - 65536, "CSR handle with %lld entries: shard it (int32 offsets)",
+                 (long long)m->nnz);
     SPMV_TRY(ensure_scratch(ctx, 64));
     int32_t* d_max = (int32_t*)ctx->scratch;
     SPMV_HIP(hipMemsetAsync(d_max, 0, sizeof(int32_t), ctx->stream));
@@ -340,8 +361,17 @@ int csr_analyse(spmv_mat* m)
                            m->a, m->b, m->win_lo, m->win_span);
         SPMV_HIP(hipGetLastError());
         SPMV_TRY(reduce_max_i32(ctx, m->win_span, nblocks, &m->win_max_span));
+        unsigned long long* d_sum = (unsigned long long*)ctx->scratch;
+        unsigned long long  total = 0;
+        SPMV_HIP(hipMemsetAsync(d_sum, 0, sizeof(*d_sum), ctx->stream));
+        hipLaunchKernelGGL(sum_i32_kernel, dim3((unsigned)std::min<int64_t>(kMaxGrid, ceil_div(nblocks, kBlock))),
+                           dim3(kBlock), 0, ctx->stream, m->win_span, nblocks, d_sum);
+        SPMV_HIP(hipMemcpyAsync(&total, d_sum, sizeof(total), hipMemcpyDeviceToHost, ctx->stream));
+        SPMV_HIP(hipStreamSynchronize(ctx->stream));
+        m->win_avg_span = (double)total / nblocks;
     }
     if (!m->kernel_forced) csr_choose_kernel(m);
+    if (m->kernel == SPMV_CSR_PANEL) SPMV_TRY(csr_panel_build(m));
     return SPMV_OK;
 }
 
@@ -361,6 +391,7 @@ int csr_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
                 SPMV_FAIL(SPMV_ERR_UNSUPPORTED, "LDS-window kernel: widest block window is %d columns, tile holds %d",
                           A->win_max_span, kWinDoubles);
             return launch_ldswin(ctx, A, x, y, lanes);
+        case SPMV_CSR_PANEL: return csr_panel_apply(ctx, A, x, y);
         case SPMV_CSR_VECTOR:
         case SPMV_CSR_AUTO:
         default:

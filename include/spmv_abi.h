@@ -59,7 +59,8 @@ typedef enum spmv_csr_kernel
     SPMV_CSR_AUTO     = 0,
     SPMV_CSR_VECTOR   = 1, /* 2^k lanes per row, ds_swizzle/DPP segment reduction */
     SPMV_CSR_LDSWIN   = 2, /* row blocks whose x window is staged in LDS (banded matrices) */
-    SPMV_CSR_SCALAR   = 3  /* one lane per row, strictly left-to-right (bitwise = oracle _fma) */
+    SPMV_CSR_SCALAR   = 3, /* one lane per row, strictly left-to-right (bitwise = oracle _fma) */
+    SPMV_CSR_PANEL    = 4  /* row groups x column panels: x gathered from L2, y accumulated in LDS */
 } spmv_csr_kernel;
 
 /* Tuning bits for spmv_mat_set_flags (speed only; results stay within the parity tolerance). */
@@ -143,6 +144,11 @@ int spmv_mat_get_info(const spmv_mat* m, spmv_mat_info* info);
 /* Force a CSR kernel (and, for VECTOR, lanes_per_row in {1,2,4,...,64}; 0 = keep auto choice). */
 int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row);
 int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
+/* Named tuning parameters, applied by the next spmv_mat_set_kernel:
+ *   "panel_rows"  rows per group of the panel kernel (0 = choose; at most 20000)
+ *   "panel_width" columns per panel (0 = 131072)
+ *   "panel_sort"  1 = bucket the entries of a panel by 128-byte line of x (default), 0 = leave unordered */
+int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value);
 /* Copy the arrays of a handle back to the host (any pointer may be NULL to skip it).
  *   CSR: a=row_ptr[nrow+1]  b=col_ind[nnz]      v=values[nnz]
  *   COO: a=row_ind[nnz]     b=col_ind[nnz]      v=values[nnz]

@@ -1,0 +1,86 @@
+"""CPU-side checks of the boundary: the shared library loads, exports every symbol the header declares, the
+ctypes table matches the header, and the engine refuses to run without a GPU instead of falling back."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+HEADER = (ROOT / "include" / "spmv_abi.h").read_text()
+
+
+def declared_symbols():
+    body = re.sub(r"/\*.*?\*/", "", HEADER, flags=re.S)
+    return sorted(set(re.findall(r"\b(spmv_[a-z0-9_]+)\s*\(", body)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.capi.load()
+    names = declared_symbols()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/spmv_abi.h but not exported by libspmv_hip.so"
+
+
+def test_ctypes_table_covers_the_header(pkg):
+    assert sorted(pkg.capi.SIGNATURES) == declared_symbols()
+    assert pkg.capi.load().spmv_abi_version() == 1
+
+
+def test_mat_info_layout_matches_header(pkg):
+    fields = re.search(r"typedef struct spmv_mat_info\s*\{(.*?)\}\s*spmv_mat_info;", HEADER, re.S).group(1)
+    names = re.findall(r"int(?:32|64)_t\s+(\w+);", fields)
+    assert names == [f[0] for f in pkg.capi.MatInfo._fields_]
+    assert C.sizeof(pkg.capi.MatInfo) == 56
+
+
+def test_no_gpu_means_loud_failure_not_fallback(pkg):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.capi.SpmvError) as e:
+        pkg.capi.Context(0)
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+
+
+def test_partition_rows_host_arithmetic(pkg, orc):
+    import oracle_lib as ol
+
+    capi = pkg.capi
+    for nrow, parts in ((10, 4), (3, 8), (80_000_000, 8), (10_000_001, 7), (0, 3)):
+        got = [capi.partition_rows(nrow, parts, p) for p in range(parts)]
+        assert got == [ol.partition_rows(orc, nrow, parts, p) for p in range(parts)]
+        assert got[0][0] == 0 and got[-1][1] == nrow
+        assert all(got[i][1] == got[i + 1][0] for i in range(parts - 1))
+    with pytest.raises(capi.SpmvError):
+        capi.partition_rows(10, 0, 0)
+    # nnz-balanced split of a skewed matrix: every part within one row of its share
+    lens = np.array([1] * 1000 + [4096] + [1] * 1000 + [300] * 10, dtype=np.int64)
+    rp = np.concatenate(([0], np.cumsum(lens)))
+    b = capi.partition_rows_balanced(rp, 4)
+    assert b[0] == 0 and b[-1] == len(lens) and np.all(np.diff(b) >= 0)
+    share = rp[b[1:]] - rp[b[:-1]]
+    assert share.sum() == rp[-1] and share.max() <= rp[-1] / 4 + 4096
+
+
+def test_synth_generators_are_index_addressable(pkg):
+    s = pkg.synth
+    rp, c, v = s.csr_uniform(0, 1000, 5000, 8, seed=3)
+    rp2, c2, v2 = s.csr_uniform(400, 600, 5000, 8, seed=3)
+    assert np.array_equal(c[400 * 8:600 * 8], c2) and np.array_equal(v[400 * 8:600 * 8], v2)
+    assert rp2[0] == 0 and rp2[-1] == 200 * 8
+    assert c.min() >= 0 and c.max() < 5000 and v.min() >= -1 and v.max() < 1
+    _, cb, _ = s.csr_uniform(0, 1000, 5000, 8, band=64, seed=3)
+    d = (cb.reshape(1000, 8).astype(np.int64) - np.arange(1000)[:, None]) % 5000
+    assert np.all((d < 32) | (d >= 5000 - 32))
+    assert np.array_equal(s.vec_uniform(100, 50, 9), s.vec_uniform(150, 0, 9)[50:])
+    ln = s.powerlaw_lengths(200_000, 4096, seed=1)
+    assert ln.min() >= 8 and ln.max() == 4096 and 40 < ln.mean() < 80
+    r, cc, vv = s.coo_powerlaw(2000, 3000, 4096, seed=1)
+    assert np.all(np.diff(r) >= 0) and len(r) == s.powerlaw_lengths(2000, 4096, 1).sum()
+    # known answers pin the generator itself (splitmix64 reference values)
+    assert int(s.splitmix64(np.array([0], dtype=np.uint64))[0]) == 0xE220A8397B1DCDAF
+    assert int(s.splitmix64(np.array([1], dtype=np.uint64))[0]) == 0x910A2DEC89025CC1

@@ -382,3 +382,46 @@ def test_full_size_csr_linearity_and_row_sample(ctx, orc, pkg):
     ctx.apply(A, x1, y1)
     ctx.sync()
     assert np.max(np.abs(y1.download() - 2.0 * h1)) <= 1e-12 * 32
+
+
+# ---------------------------------------------------------------------------------- panel kernel (no locality)
+@pytest.mark.parametrize("make", cases.ALL_CASES, ids=lambda f: f.__name__)
+def test_csr_panel_kernel_matches_reference_golden(ctx, orc, pkg, make):
+    c = make()
+    g = golden(c["name"])
+    rp, cc, cv = _csr_of(orc, c)
+    scale = _scale(orc, c)
+    for rows, width, srt in ((0, 0, 1), (0, 0, 0), (37, 16, 1), (1000, 1024, 1), (20000, 4096, 0), (5, 48, 1)):
+        A = ctx.csr(c["nrow"], c["ncol"], rp, cc, cv)
+        A.set_param("panel_rows", rows)
+        A.set_param("panel_width", width)
+        A.set_param("panel_sort", srt)
+        A.set_kernel(pkg.capi.CSR_PANEL)
+        y1, y50 = _apply_n(ctx, A, c["x"], c["nrow"], NUM_TEST)
+        what = f"{c['name']} panel rows={rows} width={width} sort={srt}"
+        ol.assert_parity(y1, g["y1_csr"], scale, what + " 1 call")
+        ol.assert_parity(y50, g["y50_csr"], scale, what + " 50 calls", reps=NUM_TEST)
+
+
+def test_csr_auto_picks_panel_for_large_random_and_agrees_with_vector(ctx, orc, pkg):
+    synth, capi = pkg.synth, pkg.capi
+    n, k = 2_000_000, 16
+    A = ctx.gen_csr_uniform(0, n, n, k, seed=77)
+    assert A.info.kernel == capi.CSR_PANEL
+    x = ctx.gen_vector(n, seed=77)
+    yp, yv = ctx.vector(n), ctx.vector(n)
+    yp.fill(0.0)
+    yv.fill(0.0)
+    ctx.apply(A, x, yp)
+    A.set_kernel(capi.CSR_VECTOR)
+    ctx.apply(A, x, yv)
+    ctx.sync()
+    hp, hv = yp.download(), yv.download()
+    assert np.max(np.abs(hp - hv)) <= 1e-10 * k  # |A||x| <= k
+    hx = synth.vec_uniform(n, seed=77)
+    for r0 in (0, 1_234_567, n - 3000):
+        rp, cc, cv = synth.csr_uniform(r0, r0 + 3000, n, k, seed=77)
+        ref, scale = np.zeros(3000), np.zeros(3000)
+        ol.csr_spmv(orc, rp, cc, cv, hx, ref)
+        ol.csr_abs_row_sums(orc, rp, cc, cv, hx, scale)
+        ol.assert_parity(hp[r0:r0 + 3000], ref, scale, f"panel rows {r0}..")

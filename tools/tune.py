@@ -22,9 +22,13 @@ def sweep(ctx, A, x, y, variants, rounds, reps, bytes_launch, nnz):
     res = {name: [] for name, _ in variants}
     for _ in range(rounds):
         for name, setup in variants:
-            setup(A)
-            ctx.apply(A, x, y)  # warm
-            res[name].append(ctx.apply_timed(A, x, y, reps))
+            try:
+                setup(A)
+                ctx.apply(A, x, y)  # warm
+                res[name].append(ctx.apply_timed(A, x, y, reps))
+            except capi.SpmvError as e:
+                print(f"# {name}: {e}")
+                res[name].append(float("inf"))
     print(f"{'variant':28s} {'med ms':>9s} {'min ms':>9s} {'GFLOP/s':>9s} {'alg GB/s':>9s} {'%8TB/s':>7s}")
     for name, ts in res.items():
         med, mn = statistics.median(ts), min(ts)
@@ -39,6 +43,7 @@ def main():
     ap.add_argument("--band", type=int, default=0)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--full", action="store_true", help="every lanes x flags combination")
     a = ap.parse_args()
     ctx = capi.Context(0)
     if a.what == "csr":
@@ -55,7 +60,17 @@ def main():
                     A.set_kernel(capi.CSR_VECTOR, lanes)
                     A.set_flags(fl)
                 variants.append((f"vector L={lanes}{tag}", setup))
-        variants.append(("scalar", lambda A: A.set_kernel(capi.CSR_SCALAR)))
+        if a.full:
+            variants.append(("scalar", lambda A: A.set_kernel(capi.CSR_SCALAR)))
+        else:
+            variants = [v for v in variants if v[0] in ("vector L=8", "vector L=32", "vector L=8+xcd")]
+        for rows, width, srt in ((0, 0, 1), (0, 0, 0), (0, 65536, 1), (0, 262144, 1), (13021, 0, 1), (9766, 0, 1)):
+            def setup(A, rows=rows, width=width, srt=srt):
+                A.set_param("panel_rows", rows)
+                A.set_param("panel_width", width)
+                A.set_param("panel_sort", srt)
+                A.set_kernel(capi.CSR_PANEL)  # rebuilds the layout when the parameters changed
+            variants.append((f"panel G={rows or 'auto'} W={width or '128K'} sort={srt}", setup))
         if a.band and a.band <= 8192:
             for lanes in (4, 8, 16):
                 variants.append((f"ldswin L={lanes}", lambda A, lanes=lanes: A.set_kernel(capi.CSR_LDSWIN, lanes)))
