@@ -541,6 +541,12 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         m->pb_panel_width = (int32_t)value;
     else if (!strcmp(name, "panel_sort"))
         m->pb_sort = (int32_t)value;
+    else if (!strcmp(name, "panel_unroll"))
+        m->pb_unroll = (int32_t)value;
+    else if (!strcmp(name, "panel_pipe"))
+        m->pb_pipe = (int32_t)value;
+    else if (!strcmp(name, "panel_two_per_cu"))
+        m->pb_two_per_cu = (int32_t)value;
     else
         SPMV_FAIL(SPMV_ERR_INVALID, "unknown parameter '%s'", name);
     return SPMV_OK;

@@ -152,7 +152,38 @@ __global__ __launch_bounds__(256) void panel_line_sort_kernel(int G, int W, int 
 }
 
 // ---- the product --------------------------------------------------------------------------------------------
+// UNROLL entries per lane are in flight between the streamed loads and the LDS adds.  With PIPE the streamed
+// loads of the NEXT batch are issued before the gathers of the current one, so the HBM latency of the
+// stream and the L2 latency of the gathers overlap instead of adding up (one workgroup per CU = 16
+// wavefronts is all the thread-level parallelism the LDS footprint allows).
 template <int UNROLL>
+struct PanelBatch
+{
+    int      c[UNROLL];
+    unsigned r[UNROLL];
+    double   v[UNROLL];
+    __device__ __forceinline__ void load(const int32_t* __restrict__ pcol, const uint16_t* __restrict__ prow,
+                                         const double* __restrict__ pval, int e)
+    {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+        {
+            c[u] = load_stream(pcol + e + u * kPanelThreads);
+            r[u] = load_stream(prow + e + u * kPanelThreads);
+            v[u] = load_stream(pval + e + u * kPanelThreads);
+        }
+    }
+    __device__ __forceinline__ void apply(const double* __restrict__ x, double* acc) const
+    {
+        double xv[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) xv[u] = x[c[u]];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) atomicAdd(&acc[r[u]], v[u] * xv[u]);  // ds_add_f64
+    }
+};
+
+template <int UNROLL, bool PIPE>
 __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(int nrow, int G, int ngroups,
                                                                   const int32_t* __restrict__ row_ptr,
                                                                   const int32_t* __restrict__ pcol,
@@ -161,6 +192,7 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(int nrow, int 
                                                                   const double* __restrict__ x, double* __restrict__ y)
 {
     extern __shared__ double acc[];  // G accumulators
+    constexpr int STEP = UNROLL * kPanelThreads;
     for (int g = blockIdx.x; g < ngroups; g += gridDim.x)
     {
         const int r0   = g * G;
@@ -168,23 +200,29 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(int nrow, int 
         for (int i = threadIdx.x; i < rows; i += kPanelThreads) acc[i] = 0.0;
         __syncthreads();
         const int begin = row_ptr[r0], end = row_ptr[r0 + rows];
+        const int nfull = (end - begin) / STEP;  // batches in which every lane has UNROLL valid entries
         int       e     = begin + threadIdx.x;
-        for (; e + (UNROLL - 1) * kPanelThreads < end; e += UNROLL * kPanelThreads)
+        if constexpr (PIPE)
         {
-            int      c[UNROLL];
-            unsigned r[UNROLL];
-            double   v[UNROLL], xv[UNROLL];
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u)
+            PanelBatch<UNROLL> cur, nxt;
+            if (nfull > 0) cur.load(pcol, prow, pval, e);
+            for (int b = 0; b < nfull; ++b)
             {
-                c[u] = load_stream(pcol + e + u * kPanelThreads);
-                r[u] = load_stream(prow + e + u * kPanelThreads);
-                v[u] = load_stream(pval + e + u * kPanelThreads);
+                if (b + 1 < nfull) nxt.load(pcol, prow, pval, e + STEP);
+                cur.apply(x, acc);
+                cur = nxt;
+                e += STEP;
             }
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) xv[u] = x[c[u]];
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) atomicAdd(&acc[r[u]], v[u] * xv[u]);  // ds_add_f64
+        }
+        else
+        {
+            for (int b = 0; b < nfull; ++b)
+            {
+                PanelBatch<UNROLL> cur;
+                cur.load(pcol, prow, pval, e);
+                cur.apply(x, acc);
+                e += STEP;
+            }
         }
         for (; e < end; e += kPanelThreads)
             atomicAdd(&acc[load_stream(prow + e)], load_stream(pval + e) * x[load_stream(pcol + e)]);
@@ -294,16 +332,34 @@ int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y
     if (!A->pb_col) SPMV_FAIL(SPMV_ERR_INVALID, "panel kernel selected but its layout was not built");
     const int    G   = A->pb_built_rows;
     const size_t lds = (size_t)G * sizeof(double);
-    static bool granted = false;
-    if (!granted)
-    {
-        SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160000));
-        granted = true;
+    // two workgroups share a CU when their accumulators fit twice into the 160 KiB LDS
+    const int per_cu = (lds <= 80000 && A->pb_two_per_cu) ? 2 : 1;
+    const int grid   = std::min(A->pb_ngroups, kNumCu * per_cu);
+    const int unroll = A->pb_unroll > 0 ? A->pb_unroll : 8;
+    const bool pipe  = A->pb_pipe != 0;
+#define SPMV_PANEL_CASE(U, P)                                                                                        \
+    if (unroll == U && pipe == P)                                                                                    \
+    {                                                                                                                \
+        static bool granted = false;                                                                                 \
+        if (!granted)                                                                                                \
+        {                                                                                                            \
+            SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_kernel<U, P>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         160000));                                                                   \
+            granted = true;                                                                                          \
+        }                                                                                                            \
+        hipLaunchKernelGGL((csr_panel_kernel<U, P>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream, A->nrow, G,    \
+                           A->pb_ngroups, A->a, A->pb_col, A->pb_row, A->pb_val, x, y);                               \
+        SPMV_HIP(hipGetLastError());                                                                                 \
+        return SPMV_OK;                                                                                              \
     }
-    const int grid = std::min(A->pb_ngroups, kNumCu);
-    hipLaunchKernelGGL(csr_panel_kernel<4>, dim3(grid), dim3(kPanelThreads), lds, ctx->stream, A->nrow, G, A->pb_ngroups,
-                       A->a, A->pb_col, A->pb_row, A->pb_val, x, y);
-    SPMV_HIP(hipGetLastError());
-    return SPMV_OK;
+    SPMV_PANEL_CASE(2, false)
+    SPMV_PANEL_CASE(4, false)
+    SPMV_PANEL_CASE(8, false)
+    SPMV_PANEL_CASE(16, false)
+    SPMV_PANEL_CASE(2, true)
+    SPMV_PANEL_CASE(4, true)
+    SPMV_PANEL_CASE(8, true)
+#undef SPMV_PANEL_CASE
+    SPMV_FAIL(SPMV_ERR_INVALID, "panel kernel: unroll=%d pipe=%d is not instantiated", unroll, (int)pipe);
 }
 }  // namespace spmv
