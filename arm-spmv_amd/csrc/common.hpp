@@ -152,7 +152,8 @@ struct spmv_mat
     int32_t   pb_panel_width = 0;        // W (0 = default)
     int32_t   pb_sort        = 1;        // bucket tile entries by 128-byte line of x
     int32_t   pb_unroll      = 0;        // entries in flight per lane (0 = default)
-    int32_t   pb_pipe        = 1;        // prefetch the next batch of streamed entries
+    int32_t   pb_skew        = 2;        // progress gate: chunks a workgroup may run ahead of the slowest (0 = off)
+    int64_t   pb_max_group_nnz = 0;      // entries of the fullest row group
     int32_t   pb_two_per_cu  = 1;        // allow two workgroups per CU when the accumulators fit twice
     int32_t   pb_ngroups     = 0;
     int32_t   pb_built_rows = 0, pb_built_width = 0, pb_built_sort = -1;  // parameters of the layout in memory

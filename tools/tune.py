@@ -64,18 +64,18 @@ def main():
             variants.append(("scalar", lambda A: A.set_kernel(capi.CSR_SCALAR)))
         else:
             variants = [v for v in variants if v[0] in ("vector L=8", "vector L=32", "vector L=8+xcd")]
-        combos = [(0, 0, 1, u, p, 1) for u, p in ((2, 0), (4, 0), (8, 0), (16, 0), (2, 1), (4, 1), (8, 1))]
-        combos += [(9766, 0, 1, 4, 1, 1), (9766, 0, 1, 8, 0, 1), (9766, 0, 1, 8, 0, 0), (0, 0, 0, 8, 0, 1)]
-        for rows, width, srt, unroll, pipe, two in combos:
-            def setup(A, rows=rows, width=width, srt=srt, unroll=unroll, pipe=pipe, two=two):
+        combos = [(0, 0, 1, u, sk, 1) for u in (4, 8, 16) for sk in (0, 1, 2, 3, 4)]
+        combos += [(0, 0, 1, 2, 2, 1), (0, 0, 1, 2, 4, 1), (9766, 0, 1, 8, 2, 1), (9766, 0, 1, 4, 2, 1)]
+        for rows, width, srt, unroll, skew, two in combos:
+            def setup(A, rows=rows, width=width, srt=srt, unroll=unroll, skew=skew, two=two):
                 A.set_param("panel_rows", rows)
                 A.set_param("panel_width", width)
                 A.set_param("panel_sort", srt)
                 A.set_param("panel_unroll", unroll)
-                A.set_param("panel_pipe", pipe)
+                A.set_param("panel_skew", skew)
                 A.set_param("panel_two_per_cu", two)
                 A.set_kernel(capi.CSR_PANEL)  # rebuilds the layout when the parameters changed
-            variants.append((f"panel G={rows or 'auto'} s={srt} U={unroll} pipe={pipe} 2cu={two}", setup))
+            variants.append((f"panel G={rows or 'auto'} U={unroll} skew={skew}", setup))
         if a.band and a.band <= 8192:
             for lanes in (4, 8, 16):
                 variants.append((f"ldswin L={lanes}", lambda A, lanes=lanes: A.set_kernel(capi.CSR_LDSWIN, lanes)))
