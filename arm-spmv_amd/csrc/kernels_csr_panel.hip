@@ -192,21 +192,57 @@ __global__ void group_nnz_max_kernel(int nrow, int G, int ngroups, const int32_t
 }
 
 // ---- progress gate ------------------------------------------------------------------------------------------
-// Purely a throttle, never needed for correctness: it keeps the 256 workgroups within `skew` chunks of each
-// other so that the x lines one CU pulled into its XCD's L2 are still there when the other 31 CUs of the XCD
-// gather from them.  Without it the workgroups drift apart, the L2 turns over every ~10 us under the
-// streamed entries, and the kernel issues ~4x the fabric reads it needs (measured: 176M vs ~45M requests).
-//   gate[round*nchunk + b] counts the workgroups that finished chunk b of their round-th group.
-//   A wavefront may start chunk b once gate[.. b - skew] has reached the number of workgroups active in the
-//   round.  The counter is read one chunk ahead (the load's latency hides behind the chunk's own work), polled
-//   by lane 0 with relaxed agent-scope loads when that early read was not enough, and every spin is bounded:
-//   if the workgroups are not all resident (shared GPU) the kernel only loses the throttle.
-//   No data is handed over through the gate, so no fences: relaxed agent-scope atomics on both sides.
-constexpr int kGateSpinLimit = 4096;
+// Purely a throttle, never needed for correctness: it keeps the workgroups that share an XCD (and hence an L2)
+// within `skew` chunks of each other, so that the x lines one CU pulled into the L2 are still there when the
+// other CUs of the XCD gather from them.  Without it the workgroups drift apart, the L2 turns over every
+// ~10 us under the streamed entries, and the kernel issues ~4x the fabric reads it needs (measured: 176M
+// requests against ~45M).
+//   gate[(round*8 + xcd)*nchunk + b] counts the workgroups on that XCD that finished chunk b of the round.
+//   pop [ round*8 + xcd ]            counts the workgroups of the XCD that entered the round.
+// A wavefront starts chunk b only when chunk b - skew is complete on its XCD.  What is known to be complete is
+// kept in LDS (`released`); when that is not enough, ONE wavefront of the workgroup (LDS lock) polls the
+// counter with relaxed agent-scope loads and s_sleep, the others watch LDS.  So a counter word has at most 32
+// pollers and 32 adders.  No data is handed over through the gate, hence no fences.  Every spin is bounded:
+// if the workgroups are not all resident, or the XCD id is not what it seems, only the throttle is lost.
+constexpr int kGateSpinLimit = 2048;
+
+struct GateLds
+{
+    unsigned released;      // chunks [0, released) are complete on this XCD
+    unsigned lock;          // 1 while a wavefront of this workgroup polls the global counter
+    unsigned wave_done[16]; // per chunk slot: wavefronts of this workgroup that finished the chunk
+};
 
 __device__ __forceinline__ unsigned gate_read(const unsigned* p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned lds_read(const unsigned* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ int xcd_id()
+{
+    return __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 7;  // hwreg(HW_REG_XCC_ID, 0, 4)
+}
+
+// lane 0 of a wavefront: block until chunk `need` is complete on this XCD (bounded)
+__device__ __forceinline__ void gate_wait(GateLds* lds, const unsigned* gate_x, const unsigned* pop_x, unsigned need)
+{
+    int spins = 0;
+    while (lds_read(&lds->released) <= need && spins < kGateSpinLimit)
+    {
+        if (atomicCAS(&lds->lock, 0u, 1u) == 0u)
+        {
+            const unsigned expected = gate_read(pop_x);  // every workgroup of the XCD registered long ago
+            while (gate_read(gate_x + need) < expected && ++spins < kGateSpinLimit) __builtin_amdgcn_s_sleep(4);
+            atomicMax(&lds->released, need + 1);
+            __hip_atomic_store(&lds->lock, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return;
+        }
+        __builtin_amdgcn_s_sleep(2);
+        ++spins;
+    }
 }
 
 template <int UNROLL, bool GATED>
@@ -216,38 +252,44 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(int nrow, int 
                                                                   const uint16_t* __restrict__ prow,
                                                                   const double* __restrict__ pval,
                                                                   const double* __restrict__ x, double* __restrict__ y,
-                                                                  unsigned* __restrict__ gate, int nchunk, int skew)
+                                                                  unsigned* __restrict__ gate, unsigned* __restrict__ pop,
+                                                                  int nchunk, int skew)
 {
-    extern __shared__ double acc[];              // G accumulators
-    __shared__ unsigned      wave_done[8];       // per chunk slot: wavefronts of this workgroup that finished it
+    extern __shared__ double acc[];  // G accumulators
+    __shared__ GateLds       gl;
     constexpr int STEP   = UNROLL * kPanelThreads;
     constexpr int NWAVES = kPanelThreads / kWave;
     const int     lane   = threadIdx.x & 63;
-    if (GATED && threadIdx.x < 8) wave_done[threadIdx.x] = 0;
+    const int     xcd    = GATED ? xcd_id() : 0;
+    if (GATED && threadIdx.x < 16) gl.wave_done[threadIdx.x] = 0;
     int round = 0;
     for (int g = blockIdx.x; g < ngroups; g += gridDim.x, ++round)
     {
         const int r0   = g * G;
         const int rows = min(G, nrow - r0);
         for (int i = threadIdx.x; i < rows; i += kPanelThreads) acc[i] = 0.0;
+        unsigned*       gate_x = nullptr;
+        const unsigned* pop_x  = nullptr;
+        if constexpr (GATED)
+        {
+            gate_x = gate + ((size_t)round * kNumXcd + xcd) * nchunk;
+            pop_x  = pop + round * kNumXcd + xcd;
+            if (threadIdx.x == 0)
+            {
+                gl.released = 0;
+                gl.lock     = 0;
+                __hip_atomic_fetch_add(pop + round * kNumXcd + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         __syncthreads();
         const int begin = row_ptr[r0], end = row_ptr[r0 + rows];
         const int nfull = (end - begin) / STEP;  // chunks in which every lane has UNROLL valid entries
         int       e     = begin + threadIdx.x;
-        // workgroups that take part in this round (the last round may be ragged)
-        const unsigned active = (unsigned)min((int)gridDim.x, ngroups - round * (int)gridDim.x);
-        unsigned*      rgate  = gate + (size_t)round * nchunk;
-        unsigned       seen   = 0;  // early read of the gate for the NEXT chunk
         for (int b = 0; b < nfull; ++b)
         {
             if constexpr (GATED)
             {
-                if (b >= skew && seen < active && lane == 0)
-                {
-                    int spins = 0;
-                    while (gate_read(rgate + b - skew) < active && ++spins < kGateSpinLimit) __builtin_amdgcn_s_sleep(8);
-                }
-                if (b + 1 >= skew && b + 1 < nfull) seen = gate_read(rgate + b + 1 - skew);
+                if (b >= skew && lane == 0) gate_wait(&gl, gate_x, pop_x, (unsigned)(b - skew));
             }
             PanelBatch<UNROLL> cur;
             cur.load(pcol, prow, pval, e);
@@ -258,9 +300,9 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(int nrow, int 
                 // the LDS adds above consumed the gathered values, so this wavefront's loads of chunk b are back
                 if (lane == 0)
                 {
-                    const unsigned before = atomicAdd(&wave_done[b & 7], 1u);
+                    const unsigned before = atomicAdd(&gl.wave_done[b & 15], 1u);
                     if ((before % NWAVES) == NWAVES - 1)
-                        __hip_atomic_fetch_add(rgate + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_add(gate_x + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
@@ -269,7 +311,7 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(int nrow, int 
             // a group with fewer chunks than the longest one must not hold the others back
             if (threadIdx.x < kWave)
                 for (int b = nfull + lane; b < nchunk; b += kWave)
-                    __hip_atomic_fetch_add(rgate + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(gate_x + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         for (; e < end; e += kPanelThreads)
             atomicAdd(&acc[load_stream(prow + e)], load_stream(pval + e) * x[load_stream(pcol + e)]);
@@ -395,19 +437,22 @@ int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y
     const int per_cu = (lds <= 80000 && A->pb_two_per_cu) ? 2 : 1;
     const int grid   = std::min(A->pb_ngroups, kNumCu * per_cu);
     const int unroll = A->pb_unroll > 0 ? A->pb_unroll : 8;
-    const int skew   = A->pb_skew;
+    const int skew   = std::min(A->pb_skew, 12);  // the per-workgroup completion slots wrap at 16
     const int rounds = (int)ceil_div(A->pb_ngroups, grid);
     // longest group in chunks (uniform bound: the whole matrix in one group)
     const int step   = unroll * kPanelThreads;
     const int nchunk = (int)std::min<int64_t>(A->pb_max_group_nnz / step + 1, 1 << 20);
     unsigned* gate   = nullptr;
     const bool gated = skew > 0 && grid > 1;
+    unsigned* pop = nullptr;
     if (gated)
     {
-        const size_t bytes = sizeof(unsigned) * (size_t)rounds * nchunk;
-        SPMV_TRY(ensure_scratch(ctx, bytes + 256));
-        gate = (unsigned*)((char*)ctx->scratch + 256);  // the first 256 B of the scratch serve the reductions
-        SPMV_HIP(hipMemsetAsync(gate, 0, bytes, ctx->stream));
+        // [rounds*8 population words][rounds*8*nchunk gate words], zeroed before every launch
+        const size_t words = (size_t)rounds * kNumXcd * ((size_t)nchunk + 1);
+        SPMV_TRY(ensure_scratch(ctx, words * sizeof(unsigned) + 256));
+        pop  = (unsigned*)((char*)ctx->scratch + 256);  // the first 256 B of the scratch serve the reductions
+        gate = pop + (size_t)rounds * kNumXcd;
+        SPMV_HIP(hipMemsetAsync(pop, 0, words * sizeof(unsigned), ctx->stream));
     }
 #define SPMV_PANEL_CASE(U, GT)                                                                                       \
     if (unroll == U && gated == GT)                                                                                  \
@@ -420,7 +465,7 @@ int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y
             granted = true;                                                                                          \
         }                                                                                                            \
         hipLaunchKernelGGL((csr_panel_kernel<U, GT>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream, A->nrow, G,   \
-                           A->pb_ngroups, A->a, A->pb_col, A->pb_row, A->pb_val, x, y, gate, nchunk, skew);           \
+                           A->pb_ngroups, A->a, A->pb_col, A->pb_row, A->pb_val, x, y, gate, pop, nchunk, skew);           \
         SPMV_HIP(hipGetLastError());                                                                                 \
         return SPMV_OK;                                                                                              \
     }

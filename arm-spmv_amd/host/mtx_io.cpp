@@ -1,0 +1,212 @@
+// mtx_io.cpp — the harness I/O of the reference, re-implemented: Matrix Market coordinate reader, the plain-text
+// vector files and the wall-clock timer (reference src/data_io.cpp, src/mytime.cpp; the banner rules are those of
+// the NIST Matrix Market format the reference parses with its vendored mmio.c).
+//
+// Behaviour kept identical to the reference's COOMatrixRead (src/data_io.cpp:45-105) because tools scrape it:
+//   * the progress lines and `### ROW=%d, COL=%d, NNZ=%d`
+//   * only `matrix coordinate complex` is refused (:66-71); `symmetric` files are NOT expanded and `pattern`
+//     files are read with the same three-field format (a pattern file therefore mis-parses, as it does there)
+//   * entries are read as "%d %d %lg", 1-based -> 0-based (:83-88); failures print and exit(1)
+#include <cctype>
+#include <cstring>
+#include <string>
+#include <sys/time.h>
+
+#include "arm_spmv_compat.hpp"
+#include "mm_banner.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// Matrix Market banner / size line
+// ---------------------------------------------------------------------------------------------------------
+static std::string lower(std::string s)
+{
+    for (char& c : s) c = (char)std::tolower((unsigned char)c);
+    return s;
+}
+
+int mm_banner_read(FILE* fp, mm_banner* out)
+{
+    char line[1100];
+    if (!fgets(line, sizeof(line), fp)) return MM_BANNER_PREMATURE_EOF;
+    char tag[64], object[64], layout[64], field[64], symmetry[64];
+    if (sscanf(line, "%63s %63s %63s %63s %63s", tag, object, layout, field, symmetry) != 5) return MM_BANNER_PREMATURE_EOF;
+    if (strcmp(tag, "%%MatrixMarket") != 0) return MM_BANNER_NO_HEADER;
+    const std::string o = lower(object), l = lower(layout), f = lower(field), s = lower(symmetry);
+    if (o != "matrix") return MM_BANNER_UNSUPPORTED;
+    out->is_matrix = 1;
+    if (l == "coordinate")
+        out->is_sparse = 1;
+    else if (l == "array")
+        out->is_sparse = 0;
+    else
+        return MM_BANNER_UNSUPPORTED;
+    if (f == "real")
+        out->field = 'R';
+    else if (f == "complex")
+        out->field = 'C';
+    else if (f == "pattern")
+        out->field = 'P';
+    else if (f == "integer")
+        out->field = 'I';
+    else
+        return MM_BANNER_UNSUPPORTED;
+    if (s == "general")
+        out->symmetry = 'G';
+    else if (s == "symmetric")
+        out->symmetry = 'S';
+    else if (s == "hermitian")
+        out->symmetry = 'H';
+    else if (s == "skew-symmetric")
+        out->symmetry = 'K';
+    else
+        return MM_BANNER_UNSUPPORTED;
+    snprintf(out->text, sizeof(out->text), "%s %s %s %s", o.c_str(), l.c_str(), f.c_str(), s.c_str());
+    return 0;
+}
+
+int mm_size_read(FILE* fp, int* rows, int* cols, int* entries)
+{
+    char line[1100];
+    *rows = *cols = *entries = 0;
+    do
+    {
+        if (!fgets(line, sizeof(line), fp)) return MM_BANNER_PREMATURE_EOF;
+    } while (line[0] == '%');  // comment lines
+    for (;;)
+    {
+        if (sscanf(line, "%d %d %d", rows, cols, entries) == 3) return 0;
+        if (!fgets(line, sizeof(line), fp)) return MM_BANNER_PREMATURE_EOF;  // blank lines before the size line
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// COO / CSR / CSC / ELL readers (include/data_io.h:12-15)
+// ---------------------------------------------------------------------------------------------------------
+void COOMatrixRead(const char* filename, COOMatrix& A)
+{
+    printf("\tOpening matrix market file\n");
+    FILE* fp = fopen(filename, "r");
+    if (!fp)
+    {
+        printf("***Failed to open MatrixMarket file %s ***\n", filename);
+        exit(1);
+    }
+    printf("\tReading MatrixMarket banner\n");
+    mm_banner banner;
+    if (mm_banner_read(fp, &banner) != 0)
+    {
+        printf("*** Could not process Matrix Market banner ***\n");
+        exit(1);
+    }
+    if (banner.field == 'C' && banner.is_matrix && banner.is_sparse)
+    {
+        printf("Sorry, this application does not support ");
+        printf("Market Market type: [%s]\n", banner.text);
+        exit(1);
+    }
+    printf("\tReading sparse matrix size...");
+    int nrow, ncol, nz;
+    if (mm_size_read(fp, &nrow, &ncol, &nz) != 0) exit(1);
+
+    printf("\tAllocating memory for matrix\n");
+    int*    ii = new int[nz > 0 ? nz : 1];
+    int*    jj = new int[nz > 0 ? nz : 1];
+    double* vv = new double[nz > 0 ? nz : 1];
+
+    printf("\tReading matrix entries from file\n");
+    for (int k = 0; k < nz; ++k)
+    {
+        if (fscanf(fp, "%d %d %lg\n", &ii[k], &jj[k], &vv[k]) != 3)
+        {
+            printf("*** Matrix Market file ends after %d of %d entries ***\n", k, nz);
+            exit(1);
+        }
+        --ii[k];
+        --jj[k];
+    }
+    fclose(fp);
+    printf("### ROW=%d, COL=%d, NNZ=%d\n", nrow, ncol, nz);
+
+    A.Free();
+    A.nrow    = nrow;
+    A.ncol    = ncol;
+    A.nnz     = nz;
+    A.row_ind = ii;
+    A.col_ind = jj;
+    A.values  = vv;
+}
+
+void CSRMatrixRead(const char* filename, CSRMatrix& A)
+{
+    COOMatrix B;
+    COOMatrixRead(filename, B);
+    A = B;
+}
+
+void CSCMatrixRead(const char* filename, CSCMatrix& A)
+{
+    COOMatrix B;
+    COOMatrixRead(filename, B);
+    A = B;
+}
+
+void ELLMatrixRead(const char* filename, ELLMatrix& A)
+{
+    COOMatrix B;
+    COOMatrixRead(filename, B);
+    A = B;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Vector files: first line n, then one value per line (src/data_io.cpp:10-40).  The writer keeps the reference's
+// "%20.16g" (16 significant digits: not round-trip exact — do not use these files for golden vectors).
+// ---------------------------------------------------------------------------------------------------------
+void VectorRead(const char* filename, Vector& x)
+{
+    FILE* fp = fopen(filename, "r");
+    if (!fp)
+    {
+        printf("***Failed to open vector file %s ***\n", filename);
+        exit(1);
+    }
+    int n = 0;
+    if (fscanf(fp, "%d", &n) != 1 || n < 0) n = 0;
+    double* v = new double[n > 0 ? n : 1];
+    for (int i = 0; i < n; ++i)
+        if (fscanf(fp, "%lg", &v[i]) != 1) v[i] = 0.0;
+    fclose(fp);
+    x.Free();
+    x.size   = n;
+    x.values = v;
+}
+
+void VectorWrite(const char* filename, const Vector& x)
+{
+    FILE* fp = fopen(filename, "w");
+    if (!fp)
+    {
+        printf("***Failed to open vector file %s ***\n", filename);
+        exit(1);
+    }
+    fprintf(fp, "%d", x.size);
+    for (int i = 0; i < x.size; ++i) fprintf(fp, "\n%20.16g", x.values[i]);
+    fclose(fp);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Timer: seconds since the first call, which itself returns 0.0 (src/mytime.cpp:6-18)
+// ---------------------------------------------------------------------------------------------------------
+double mytimer(void)
+{
+    static bool   started = false;
+    static timeval origin;
+    timeval        now;
+    gettimeofday(&now, 0);
+    if (!started)
+    {
+        started = true;
+        origin  = now;
+        return 0.0;
+    }
+    return (double)(now.tv_sec - origin.tv_sec) + (double)(now.tv_usec - origin.tv_usec) / 1e6;
+}

@@ -1,0 +1,246 @@
+// spmv_main.cpp — the engine's harness.  Same job as the reference's main.cpp (read a Matrix Market file, build
+// the formats, time NUM_TEST = 50 accumulating products per format, print `### <FMT> ... GFLOPS` lines), with what
+// main.cpp lacks for large inputs: per-format selection (main.cpp builds all five formats unconditionally and DIA
+// explodes on unstructured matrices), synthetic inputs generated on the GPU, a device-resident
+// timing next to the drop-in (host-vector) one, and a verification that actually compares (main.cpp:42-52
+// computes y_ref and never reads it).
+//
+//   spmv_main <file.mtx> <nshards> [options]          nshards plays the role of main.cpp's nthreads (argv[2])
+//   spmv_main --synthetic uniform|band|banded-ell|powerlaw --n N [--k K] [--band W] [--seed S] <nshards> [options]
+// options: --format coo,csr,csc,ell,dia   (default coo,csr,ell)     --reps R (default 50)
+//          --no-dropin   skip the host-vector timing       --no-numa  skip the sharded drivers
+//          --verify      compare every format's y with the COO result (norm-wise 1e-10)
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "arm_spmv_compat.hpp"
+#include "engine.hpp"
+
+using armspmv::check;
+using armspmv::Engine;
+
+namespace
+{
+struct Options
+{
+    std::string file, synthetic, formats = "coo,csr,ell";
+    int         shards = 1, reps = 50, n = 0, k = 32, band = 0;
+    unsigned long long seed = 1;
+    bool dropin = true, numa = true, verify = false;
+    bool has(const char* f) const { return ("," + formats + ",").find(std::string(",") + f + ",") != std::string::npos; }
+};
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// GFLOPS as main.cpp prints it: 2*nnz / t_ms / 1e6 (main.cpp:60-61), without the stray "+ dt/1000" term
+double gflops(double nnz, double seconds, int reps) { return 2.0 * nnz / (seconds * 1000.0 / reps) / 1e6; }
+
+double rel_diff(const Vector& a, const Vector& b)
+{
+    double num = 0.0, den = 0.0;
+    for (int i = 0; i < a.size; ++i)
+    {
+        num = std::fmax(num, std::fabs(a.values[i] - b.values[i]));
+        den = std::fmax(den, std::fabs(b.values[i]));
+    }
+    return den > 0 ? num / den : num;
+}
+
+// device-resident timing of an uploaded/cached container
+template <class Upload>
+void resident(const char* name, double nnz, int nrow, const Vector& x, int reps, Upload upload)
+{
+    Engine&   E = Engine::get();
+    spmv_mat* m = upload(E.ctx(0));
+    spmv_vec *dx = nullptr, *dy = nullptr;
+    check(spmv_vec_create(E.ctx(0), x.size, &dx), "spmv_vec_create");
+    check(spmv_vec_create(E.ctx(0), nrow, &dy), "spmv_vec_create");
+    check(spmv_vec_upload(dx, 0, x.size, x.values), "spmv_vec_upload");
+    check(spmv_vec_fill(dy, 0.0), "spmv_vec_fill");
+    double ms = 0.0;
+    check(spmv_apply(E.ctx(0), m, dx, dy), "spmv_apply");  // warm-up
+    check(spmv_vec_fill(dy, 0.0), "spmv_vec_fill");
+    check(spmv_apply_timed(E.ctx(0), m, dx, dy, reps, &ms), "spmv_apply_timed");
+    spmv_mat_info info;
+    check(spmv_mat_get_info(m, &info), "spmv_mat_get_info");
+    printf("### %s GPU-RESIDENT GFLOPS = %.5f   (%.4f ms per product, kernel %d)\n", name, 2.0 * nnz / ms / 1e6, ms, info.kernel);
+    spmv_vec_destroy(dx);
+    spmv_vec_destroy(dy);
+    spmv_mat_destroy(m);
+}
+
+template <class Fn>
+void dropin(const char* name, double nnz, Vector& y, int reps, Fn product)
+{
+    y.Fill(0);
+    product();  // first call uploads the matrix: keep it out of the timing, like the reference keeps construction out
+    y.Fill(0);
+    const double t0 = now_s();
+    for (int i = 0; i < reps; ++i) product();
+    const double dt = now_s() - t0;
+    printf("### %s GPU GFLOPS = %.5f   (drop-in call: x and y cross PCIe every product)\n", name, gflops(nnz, dt, reps));
+}
+
+int usage()
+{
+    printf("Usage: spmv_main <file.mtx> <nshards> [--format coo,csr,csc,ell,dia] [--reps R] [--verify] [--no-dropin] [--no-numa]\n"
+           "       spmv_main --synthetic uniform|band --n N [--k K] [--band W] [--seed S] <nshards> [...]\n");
+    return -1;
+}
+}  // namespace
+
+int main(int argc, char* argv[])
+{
+    Options                  o;
+    std::vector<std::string> pos;
+    for (int i = 1; i < argc; ++i)
+    {
+        std::string a = argv[i];
+        auto        next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
+        if (a == "--format") o.formats = next();
+        else if (a == "--reps") o.reps = atoi(next());
+        else if (a == "--synthetic") o.synthetic = next();
+        else if (a == "--n") o.n = atoi(next());
+        else if (a == "--k") o.k = atoi(next());
+        else if (a == "--band") o.band = atoi(next());
+        else if (a == "--seed") o.seed = strtoull(next(), 0, 10);
+        else if (a == "--verify") o.verify = true;
+        else if (a == "--no-dropin") o.dropin = false;
+        else if (a == "--no-numa") o.numa = false;
+        else pos.push_back(a);
+    }
+    if (o.synthetic.empty())
+    {
+        if (pos.size() < 2) return usage();  // main.cpp:20-24
+        o.file   = pos[0];
+        o.shards = atoi(pos[1].c_str());
+    }
+    else
+    {
+        if (pos.size() < 1 || o.n <= 0) return usage();
+        o.shards = atoi(pos[0].c_str());
+    }
+    if (o.shards < 1) o.shards = 1;
+    if (o.reps < 1) o.reps = 1;
+    spmv_compat_set_numa_reps(o.reps);
+
+    COOMatrix A;
+    if (!o.file.empty())
+        COOMatrixRead(o.file.c_str(), A);
+    else
+    {
+        // synthetic rows drawn on the GPU (spmv_gen_csr_uniform), brought back as a row-sorted COO
+        Engine&   E = Engine::get();
+        spmv_mat* g = nullptr;
+        check(spmv_gen_csr_uniform(E.ctx(0), 0, o.n, o.n, o.k, o.synthetic == "band" ? o.band : 0, o.seed, &g), "spmv_gen_csr_uniform");
+        const size_t     nnz = (size_t)o.n * (size_t)o.k;
+        std::vector<int> rp((size_t)o.n + 1);
+        A.nrow    = o.n;
+        A.ncol    = o.n;
+        A.nnz     = (int)nnz;
+        A.row_ind = new int[nnz];
+        A.col_ind = new int[nnz];
+        A.values  = new double[nnz];
+        check(spmv_mat_download(g, rp.data(), A.col_ind, A.values), "spmv_mat_download");
+        for (int i = 0; i < o.n; ++i)
+            for (int j = rp[(size_t)i]; j < rp[(size_t)i + 1]; ++j) A.row_ind[j] = i;
+        spmv_mat_destroy(g);
+        printf("### ROW=%d, COL=%d, NNZ=%d\n", A.nrow, A.ncol, A.nnz);
+    }
+
+    Vector x, y, y_coo;
+    x.Resize(A.ncol);
+    y.Resize(A.nrow);
+    x.FillRandom();
+    const double nnz = A.nnz;
+
+    // reference result for --verify: the serial COO accumulation of main.cpp:45-51, on the GPU path's COO kernel
+    if (o.verify || o.has("coo"))
+    {
+        if (o.dropin) dropin("COO", nnz, y, o.reps, [&] { COOMatirxMatVector(A, x, y); });
+        resident("COO", nnz, A.nrow, x, o.reps, [&](spmv_ctx* c) {
+            spmv_mat* m = nullptr;
+            check(spmv_coo_upload(c, A.nrow, A.ncol, A.nnz, A.row_ind, A.col_ind, A.values, &m), "spmv_coo_upload");
+            return m;
+        });
+        y.Fill(0);
+        COOMatirxMatVector(A, x, y);
+        y_coo = y;
+    }
+    auto verify = [&](const char* name) {
+        if (!o.verify) return;
+        const double d = rel_diff(y, y_coo);
+        printf("### %s VERIFY max|y - y_coo|/max|y_coo| = %.3e %s\n", name, d, d <= 1e-10 ? "OK" : "FAILED");
+        if (d > 1e-10) exit(2);
+    };
+
+    if (o.has("csr"))
+    {
+        CSRMatrix B(A);
+        if (o.dropin) dropin("CSR", nnz, y, o.reps, [&] { CSRMatrixMatVector(B, x, y); });
+        resident("CSR", nnz, A.nrow, x, o.reps, [&](spmv_ctx* c) {
+            spmv_mat* m = nullptr;
+            check(spmv_csr_upload(c, B.nrow, B.ncol, B.row_ptr, B.col_ind, B.values, &m), "spmv_csr_upload");
+            return m;
+        });
+        y.Fill(0);
+        CSRMatrixMatVector(B, x, y);
+        verify("CSR");
+        if (o.numa)
+        {
+            y.Fill(0);
+            CSRMatrixMatVectorNuma(B, x, y, o.shards);
+            for (int i = 0; i < y.size; ++i) y.values[i] /= o.reps;  // the driver accumulated reps products from 0
+            verify("CSR NUMA");
+        }
+    }
+    if (o.has("csc"))
+    {
+        CSCMatrix C(A);
+        if (o.dropin) dropin("CSC", nnz, y, o.reps, [&] { CSCMatrixMatVector(C, x, y); });
+        y.Fill(0);
+        CSCMatrixMatVector(C, x, y);
+        verify("CSC");
+    }
+    if (o.has("ell"))
+    {
+        ELLMatrix D(A);
+        if (o.dropin) dropin("ELL", nnz, y, o.reps, [&] { ELLMatrixMatVector(D, x, y); });
+        resident("ELL", nnz, A.nrow, x, o.reps, [&](spmv_ctx* c) {
+            spmv_mat* m = nullptr;
+            check(spmv_ell_upload(c, D.nrow, D.ncol, D.nonzeros_in_row, D.nnz, D.col_ind, D.values, &m), "spmv_ell_upload");
+            return m;
+        });
+        y.Fill(0);
+        ELLMatrixMatVector(D, x, y);
+        verify("ELL");
+        if (o.numa)
+        {
+            y.Fill(0);
+            ELLMatrixMatVectorNuma(D, x, y, o.shards);
+            for (int i = 0; i < y.size; ++i) y.values[i] /= o.reps;
+            verify("ELL NUMA");
+        }
+    }
+    if (o.has("dia"))
+    {
+        CSRMatrix B(A);
+        DIAMatrix E(B);
+        printf("### DIA ndiags = %d\n", E.ndiags);
+        if (o.dropin) dropin("DIA", nnz, y, o.reps, [&] { DIAMatrixMatVector(E, x, y); });
+        y.Fill(0);
+        DIAMatrixMatVector(E, x, y);
+        if (A.nrow == A.ncol) verify("DIA");  // the reference's DIA product bounds columns by nrow (src/mat_vec.cpp:140)
+    }
+    if (o.has("coo") && o.numa)
+    {
+        y.Fill(0);
+        COOMatrixMatVectorNuma(A, x, y, o.shards);
+        for (int i = 0; i < y.size; ++i) y.values[i] /= o.reps;
+        verify("COO NUMA");
+    }
+    return 0;
+}
