@@ -543,6 +543,8 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         m->pb_sort = (int32_t)value;
     else if (!strcmp(name, "panel_unroll"))
         m->pb_unroll = (int32_t)value;
+    else if (!strcmp(name, "panel_aos"))
+        m->pb_aos = (int32_t)value;
     else if (!strcmp(name, "panel_skew"))
         m->pb_skew = (int32_t)value;
     else if (!strcmp(name, "panel_two_per_cu"))

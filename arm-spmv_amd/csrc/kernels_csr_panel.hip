@@ -155,7 +155,11 @@ __global__ __launch_bounds__(256) void panel_line_sort_kernel(int G, int W, int 
 // One chunk = UNROLL x 1024 consecutive entries of the group: every lane has UNROLL entries in flight between
 // the streamed loads and the LDS adds (one workgroup per CU = 16 wavefronts is all the thread-level
 // parallelism the LDS footprint allows, so the memory-level parallelism has to come from here).
-template <int UNROLL>
+// LAYOUT 0: three arrays (value fp64, column int32, local row uint16): 14 bytes per entry, three load instructions.
+// LAYOUT 1: one 16-byte record {value, column, local row} per entry: one dwordx4 load instruction, 1 KiB per
+//           wavefront instruction.  The CU's vector-memory pipeline, not HBM, is what the kernel runs out of on
+//           uniform-random columns, so fewer instructions beat fewer bytes there.
+template <int UNROLL, int LAYOUT>
 struct PanelBatch
 {
     int      c[UNROLL];
@@ -167,9 +171,19 @@ struct PanelBatch
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
         {
-            c[u] = load_stream(pcol + e + u * kPanelThreads);
-            r[u] = load_stream(prow + e + u * kPanelThreads);
-            v[u] = load_stream(pval + e + u * kPanelThreads);
+            if constexpr (LAYOUT == 1)
+            {
+                const i32x4 rec = load_stream(reinterpret_cast<const i32x4*>(pval) + e + u * kPanelThreads);
+                v[u]            = __hiloint2double(rec.y, rec.x);
+                c[u]            = rec.z;
+                r[u]            = (unsigned)rec.w;
+            }
+            else
+            {
+                c[u] = load_stream(pcol + e + u * kPanelThreads);
+                r[u] = load_stream(prow + e + u * kPanelThreads);
+                v[u] = load_stream(pval + e + u * kPanelThreads);
+            }
         }
     }
     __device__ __forceinline__ void apply(const double* __restrict__ x, double* acc) const
@@ -180,7 +194,32 @@ struct PanelBatch
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) atomicAdd(&acc[r[u]], v[u] * xv[u]);  // ds_add_f64
     }
+    // single entry (the ragged tail of a group)
+    __device__ static __forceinline__ void one(const int32_t* __restrict__ pcol, const uint16_t* __restrict__ prow,
+                                               const double* __restrict__ pval, int e, const double* __restrict__ x,
+                                               double* acc)
+    {
+        PanelBatch<1, LAYOUT> b;
+        b.load(pcol, prow, pval, e);
+        b.apply(x, acc);
+    }
 };
+
+__global__ __launch_bounds__(256) void panel_pack_kernel(int64_t nnz, const int32_t* __restrict__ col,
+                                                         const uint16_t* __restrict__ row, const double* __restrict__ val,
+                                                         i32x4* __restrict__ rec)
+{
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * 256)
+    {
+        const double v = val[e];
+        i32x4        q;
+        q.x    = __double2loint(v);
+        q.y    = __double2hiint(v);
+        q.z    = col[e];
+        q.w    = (int)row[e];
+        rec[e] = q;
+    }
+}
 
 __global__ void group_nnz_max_kernel(int nrow, int G, int ngroups, const int32_t* __restrict__ row_ptr,
                                      int32_t* __restrict__ out_max)
@@ -245,7 +284,7 @@ __device__ __forceinline__ void gate_wait(GateLds* lds, const unsigned* gate_x, 
     }
 }
 
-template <int UNROLL, bool GATED>
+template <int UNROLL, bool GATED, int LAYOUT>
 __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(int nrow, int G, int ngroups,
                                                                   const int32_t* __restrict__ row_ptr,
                                                                   const int32_t* __restrict__ pcol,
@@ -291,7 +330,7 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(int nrow, int 
             {
                 if (b >= skew && lane == 0) gate_wait(&gl, gate_x, pop_x, (unsigned)(b - skew));
             }
-            PanelBatch<UNROLL> cur;
+            PanelBatch<UNROLL, LAYOUT> cur;
             cur.load(pcol, prow, pval, e);
             cur.apply(x, acc);
             e += STEP;
@@ -313,8 +352,7 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(int nrow, int 
                 for (int b = nfull + lane; b < nchunk; b += kWave)
                     __hip_atomic_fetch_add(gate_x + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        for (; e < end; e += kPanelThreads)
-            atomicAdd(&acc[load_stream(prow + e)], load_stream(pval + e) * x[load_stream(pcol + e)]);
+        for (; e < end; e += kPanelThreads) PanelBatch<1, LAYOUT>::one(pcol, prow, pval, e, x, acc);
         __syncthreads();
         for (int i = threadIdx.x; i < rows; i += kPanelThreads) y[r0 + i] += acc[i];
         __syncthreads();
@@ -327,6 +365,8 @@ void csr_panel_free(spmv_mat* m)
     if (m->pb_col) hipFree(m->pb_col);
     if (m->pb_row) hipFree(m->pb_row);
     if (m->pb_val) hipFree(m->pb_val);
+    if (m->pb_rec) hipFree(m->pb_rec);
+    m->pb_rec = nullptr;
     m->pb_col = nullptr;
     m->pb_row = nullptr;
     m->pb_val = nullptr;
@@ -356,7 +396,9 @@ int csr_panel_build(spmv_mat* m)
     W     = std::max(kLineDoubles, (W / kLineDoubles) * kLineDoubles);
     while (ceil_div(m->ncol, W) > 8192) W *= 2;  // the per-group histogram lives in LDS
     const bool sort = m->pb_sort != 0;
-    if (m->pb_col && m->pb_built_rows == G && m->pb_built_width == W && m->pb_built_sort == (int)sort)
+    const bool aos = m->pb_aos != 0;
+    if ((m->pb_col || m->pb_rec) && m->pb_built_rows == G && m->pb_built_width == W && m->pb_built_sort == (int)sort &&
+        aos == (m->pb_rec != nullptr))
         return SPMV_OK;  // the layout in memory was built with these parameters
     csr_panel_free(m);
     const int ngroups = (int)ceil_div(m->nrow, G);
@@ -424,13 +466,32 @@ int csr_panel_build(spmv_mat* m)
         m->pb_max_group_nnz = h_max;
     }
     m->pb_bytes       = (int64_t)(nnz * 14);
+    if (aos)
+    {
+        // 16-byte records replace the three arrays
+        if (hipMalloc(&m->pb_rec, nnz * 16) != hipSuccess)
+        {
+            csr_panel_free(m);
+            SPMV_FAIL(SPMV_ERR_ALLOC, "panel layout: out of device memory for %zu 16-byte records", nnz);
+        }
+        hipLaunchKernelGGL(panel_pack_kernel, dim3(kMaxGrid), dim3(256), 0, s, (int64_t)nnz, m->pb_col, m->pb_row, m->pb_val,
+                           (i32x4*)m->pb_rec);
+        SPMV_HIP(hipStreamSynchronize(s));
+        hipFree(m->pb_col);
+        hipFree(m->pb_row);
+        hipFree(m->pb_val);
+        m->pb_col   = nullptr;
+        m->pb_row   = nullptr;
+        m->pb_val   = nullptr;
+        m->pb_bytes = (int64_t)(nnz * 16);
+    }
     m->device_bytes += m->pb_bytes;
     return SPMV_OK;
 }
 
 int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
 {
-    if (!A->pb_col) SPMV_FAIL(SPMV_ERR_INVALID, "panel kernel selected but its layout was not built");
+    if (!A->pb_col && !A->pb_rec) SPMV_FAIL(SPMV_ERR_INVALID, "panel kernel selected but its layout was not built");
     const int    G   = A->pb_built_rows;
     const size_t lds = (size_t)G * sizeof(double);
     // two workgroups share a CU when their accumulators fit twice into the 160 KiB LDS
@@ -444,6 +505,7 @@ int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y
     const int nchunk = (int)std::min<int64_t>(A->pb_max_group_nnz / step + 1, 1 << 20);
     unsigned* gate   = nullptr;
     const bool gated = skew > 0 && grid > 1;
+    const int  layout = A->pb_rec ? 1 : 0;
     unsigned* pop = nullptr;
     if (gated)
     {
@@ -454,29 +516,29 @@ int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y
         gate = pop + (size_t)rounds * kNumXcd;
         SPMV_HIP(hipMemsetAsync(pop, 0, words * sizeof(unsigned), ctx->stream));
     }
-#define SPMV_PANEL_CASE(U, GT)                                                                                       \
-    if (unroll == U && gated == GT)                                                                                  \
+#define SPMV_PANEL_CASE(U, GT, LY)                                                                                   \
+    if (unroll == U && gated == GT && layout == LY)                                                                   \
     {                                                                                                                \
         static bool granted = false;                                                                                 \
         if (!granted)                                                                                                \
         {                                                                                                            \
-            SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_kernel<U, GT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                         160000));                                                                   \
+            SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_kernel<U, GT, LY>,                                   \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160000));                       \
             granted = true;                                                                                          \
         }                                                                                                            \
-        hipLaunchKernelGGL((csr_panel_kernel<U, GT>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream, A->nrow, G,   \
-                           A->pb_ngroups, A->a, A->pb_col, A->pb_row, A->pb_val, x, y, gate, pop, nchunk, skew);           \
+        hipLaunchKernelGGL((csr_panel_kernel<U, GT, LY>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream, A->nrow,  \
+                           G, A->pb_ngroups, A->a, A->pb_col, A->pb_row,                  \
+                           layout ? (const double*)A->pb_rec : A->pb_val, x, y, gate, pop, nchunk, skew);   \
         SPMV_HIP(hipGetLastError());                                                                                 \
         return SPMV_OK;                                                                                              \
     }
-    SPMV_PANEL_CASE(2, false)
-    SPMV_PANEL_CASE(4, false)
-    SPMV_PANEL_CASE(8, false)
-    SPMV_PANEL_CASE(16, false)
-    SPMV_PANEL_CASE(2, true)
-    SPMV_PANEL_CASE(4, true)
-    SPMV_PANEL_CASE(8, true)
-    SPMV_PANEL_CASE(16, true)
+#define SPMV_PANEL_CASES(U) \
+    SPMV_PANEL_CASE(U, false, 0) SPMV_PANEL_CASE(U, true, 0) SPMV_PANEL_CASE(U, false, 1) SPMV_PANEL_CASE(U, true, 1)
+    SPMV_PANEL_CASES(2)
+    SPMV_PANEL_CASES(4)
+    SPMV_PANEL_CASES(8)
+    SPMV_PANEL_CASES(16)
+#undef SPMV_PANEL_CASES
 #undef SPMV_PANEL_CASE
     SPMV_FAIL(SPMV_ERR_INVALID, "panel kernel: unroll=%d is not instantiated (2, 4, 8, 16)", unroll);
 }

@@ -31,7 +31,17 @@ __device__ __forceinline__ uint64_t mix(uint64_t z)
     return z ^ (z >> 31);
 }
 
+// MODE 0: plain loads, 1: nontemporal, 2: agent-scope relaxed atomic load (sc1, bypasses L1)
+template <int MODE>
+__device__ __forceinline__ double gload(const double* p)
+{
+    if constexpr (MODE == 1) return __builtin_nontemporal_load(p);
+    if constexpr (MODE == 2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+
 // every lane: G gathers, 4 independent in flight, indices uniform over [0,T)
+template <int MODE>
 __global__ __launch_bounds__(256) void gather_kernel(const double* __restrict__ table, uint32_t T, int G,
                                                      double* __restrict__ out)
 {
@@ -45,7 +55,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const double* __restrict__ 
         const uint32_t i1 = (uint32_t)(((r0 & 0xffffffffu) * (uint64_t)T) >> 32);
         const uint32_t i2 = (uint32_t)(((r1 >> 32) * T) >> 32);
         const uint32_t i3 = (uint32_t)(((r1 & 0xffffffffu) * (uint64_t)T) >> 32);
-        const double   a = table[i0], b = table[i1], c = table[i2], d = table[i3];
+        const double   a = gload<MODE>(table + i0), b = gload<MODE>(table + i1), c = gload<MODE>(table + i2), d = gload<MODE>(table + i3);
         acc += a + b + c + d;
     }
     if (acc == 123.456) out[gid] = acc;  // never true; keeps the loads alive
@@ -106,6 +116,7 @@ struct GArgs
     int           G;
     double*       out;
     int           blocks;
+    int           mode;
 };
 
 int main(int argc, char** argv)
@@ -125,15 +136,21 @@ int main(int argc, char** argv)
             double* table;
             CK(hipMalloc(&table, s * 8));
             CK(hipMemset(table, 0, s * 8));
-            GArgs ga{table, (uint32_t)s, G, out, blocks};
+            for (int mode = 0; mode < 3; ++mode)
+            {
+            GArgs ga{table, (uint32_t)s, G, out, blocks, mode};
             auto  launch = [](void* p) {
                 GArgs* g = (GArgs*)p;
-                hipLaunchKernelGGL(gather_kernel, dim3(g->blocks), dim3(256), 0, 0, g->table, g->T, g->G, g->out);
+                if (g->mode == 0) hipLaunchKernelGGL(gather_kernel<0>, dim3(g->blocks), dim3(256), 0, 0, g->table, g->T, g->G, g->out);
+                if (g->mode == 1) hipLaunchKernelGGL(gather_kernel<1>, dim3(g->blocks), dim3(256), 0, 0, g->table, g->T, g->G, g->out);
+                if (g->mode == 2) hipLaunchKernelGGL(gather_kernel<2>, dim3(g->blocks), dim3(256), 0, 0, g->table, g->T, g->G, g->out);
             };
             float        ms = time_it(launch, &ga, 5);
             const double n  = (double)blocks * 256 * G;
+            printf("mode %d (0 plain 1 nt 2 sc1) ", mode);
             printf("gather table %8.2f MB (%9zu doubles): %8.3f ms  %7.1f Ggather/s  (%6.2f TB/s at 64B, %6.2f TB/s at 128B)\n",
                    s * 8 / 1048576.0, s, ms, n / ms / 1e6, n * 64 / ms / 1e9, n * 128 / ms / 1e9);
+            }
             CK(hipFree(table));
         }
     }

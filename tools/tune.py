@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--full", action="store_true", help="every lanes x flags combination")
+    ap.add_argument("--panel", default="", help="only these panel variants: 'unroll,skew,nt;unroll,skew,nt;...'")
     a = ap.parse_args()
     ctx = capi.Context(0)
     if a.what == "csr":
@@ -64,18 +65,21 @@ def main():
             variants.append(("scalar", lambda A: A.set_kernel(capi.CSR_SCALAR)))
         else:
             variants = [v for v in variants if v[0] in ("vector L=8", "vector L=32", "vector L=8+xcd")]
-        combos = [(0, 0, 1, u, sk, 1) for u in (4, 8, 16) for sk in (0, 2, 4, 8)]
-        combos += [(0, 0, 1, 2, 8, 1), (0, 0, 1, 2, 12, 1)]
-        for rows, width, srt, unroll, skew, two in combos:
-            def setup(A, rows=rows, width=width, srt=srt, unroll=unroll, skew=skew, two=two):
+        if a.panel:
+            variants = []
+            combos = [(0, 0, 1) + tuple(int(t) for t in item.split(",")) for item in a.panel.split(";")]
+        else:
+            combos = [(0, 0, 1, u, sk, 1) for u in (4, 8, 16) for sk in (0, 2, 4, 8)]
+        for rows, width, srt, unroll, skew, nt in combos:
+            def setup(A, rows=rows, width=width, srt=srt, unroll=unroll, skew=skew, nt=nt):
                 A.set_param("panel_rows", rows)
                 A.set_param("panel_width", width)
                 A.set_param("panel_sort", srt)
                 A.set_param("panel_unroll", unroll)
                 A.set_param("panel_skew", skew)
-                A.set_param("panel_two_per_cu", two)
+                A.set_param("panel_aos", nt)  # third field of --panel: 1 = 16-byte records, 0 = three arrays
                 A.set_kernel(capi.CSR_PANEL)  # rebuilds the layout when the parameters changed
-            variants.append((f"panel G={rows or 'auto'} U={unroll} skew={skew}", setup))
+            variants.append((f"panel G={rows or 'auto'} U={unroll} skew={skew} aos={nt}", setup))
         if a.band and a.band <= 8192:
             for lanes in (4, 8, 16):
                 variants.append((f"ldswin L={lanes}", lambda A, lanes=lanes: A.set_kernel(capi.CSR_LDSWIN, lanes)))
