@@ -545,6 +545,8 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         m->pb_unroll = (int32_t)value;
     else if (!strcmp(name, "panel_aos"))
         m->pb_aos = (int32_t)value;
+    else if (!strcmp(name, "panel_pace_ns"))
+        m->pb_pace_ns = (int32_t)value;
     else if (!strcmp(name, "panel_skew"))
         m->pb_skew = (int32_t)value;
     else if (!strcmp(name, "panel_two_per_cu"))

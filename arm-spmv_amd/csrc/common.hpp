@@ -154,7 +154,8 @@ struct spmv_mat
     int32_t   pb_unroll      = 0;        // entries in flight per lane (0 = default)
     int32_t   pb_skew        = 2;        // progress gate: chunks a workgroup may run ahead of the slowest (0 = off)
     void*     pb_rec         = nullptr;  // [nnz] 16-byte records {value, column, local row} (replaces the three arrays)
-    int32_t   pb_aos         = 1;        // build 16-byte records (one load instruction per entry)
+    int32_t   pb_aos         = 0;        // build 16-byte records (one load instruction per entry); measured slower
+    int32_t   pb_pace_ns     = 0;        // pacing throttle: nanoseconds per chunk on the chip clock (0 = off)
     int64_t   pb_max_group_nnz = 0;      // entries of the fullest row group
     int32_t   pb_two_per_cu  = 1;        // allow two workgroups per CU when the accumulators fit twice
     int32_t   pb_ngroups     = 0;

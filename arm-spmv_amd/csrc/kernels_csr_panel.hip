@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(int nrow, int 
                                                                   const double* __restrict__ pval,
                                                                   const double* __restrict__ x, double* __restrict__ y,
                                                                   unsigned* __restrict__ gate, unsigned* __restrict__ pop,
-                                                                  int nchunk, int skew)
+                                                                  int nchunk, int skew, unsigned long long pace_fp)
 {
     extern __shared__ double acc[];  // G accumulators
     __shared__ GateLds       gl;
@@ -324,8 +324,17 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(int nrow, int 
         const int begin = row_ptr[r0], end = row_ptr[r0 + rows];
         const int nfull = (end - begin) / STEP;  // chunks in which every lane has UNROLL valid entries
         int       e     = begin + threadIdx.x;
+        // pacing (alternative throttle without any communication): chunk b does not start before
+        // t0 + b * pace on the chip-wide 100 MHz clock; all workgroups start their round within ~1 us
+        const unsigned long long t0 = pace_fp ? __builtin_amdgcn_s_memrealtime() : 0ull;
         for (int b = 0; b < nfull; ++b)
         {
+            if (pace_fp && lane == 0)
+            {
+                const unsigned long long target = t0 + (((unsigned long long)b * pace_fp) >> 10);
+                int                      spins  = 0;
+                while (__builtin_amdgcn_s_memrealtime() < target && ++spins < (1 << 16)) __builtin_amdgcn_s_sleep(1);
+            }
             if constexpr (GATED)
             {
                 if (b >= skew && lane == 0) gate_wait(&gl, gate_x, pop_x, (unsigned)(b - skew));
@@ -505,6 +514,8 @@ int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y
     const int nchunk = (int)std::min<int64_t>(A->pb_max_group_nnz / step + 1, 1 << 20);
     unsigned* gate   = nullptr;
     const bool gated = skew > 0 && grid > 1;
+    // pace: nanoseconds per chunk -> 10 ns ticks in 22.10 fixed point
+    const unsigned long long pace_fp = A->pb_pace_ns > 0 ? (unsigned long long)((double)A->pb_pace_ns * 102.4) : 0ull;
     const int  layout = A->pb_rec ? 1 : 0;
     unsigned* pop = nullptr;
     if (gated)
@@ -528,7 +539,7 @@ int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y
         }                                                                                                            \
         hipLaunchKernelGGL((csr_panel_kernel<U, GT, LY>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream, A->nrow,  \
                            G, A->pb_ngroups, A->a, A->pb_col, A->pb_row,                  \
-                           layout ? (const double*)A->pb_rec : A->pb_val, x, y, gate, pop, nchunk, skew);   \
+                           layout ? (const double*)A->pb_rec : A->pb_val, x, y, gate, pop, nchunk, skew, pace_fp);   \
         SPMV_HIP(hipGetLastError());                                                                                 \
         return SPMV_OK;                                                                                              \
     }

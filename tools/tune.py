@@ -69,17 +69,17 @@ def main():
             variants = []
             combos = [(0, 0, 1) + tuple(int(t) for t in item.split(",")) for item in a.panel.split(";")]
         else:
-            combos = [(0, 0, 1, u, sk, 1) for u in (4, 8, 16) for sk in (0, 2, 4, 8)]
-        for rows, width, srt, unroll, skew, nt in combos:
-            def setup(A, rows=rows, width=width, srt=srt, unroll=unroll, skew=skew, nt=nt):
+            combos = [(0, 0, 1, u, sk, 0) for u in (4, 8, 16) for sk in (0, 2, 4, 8)]
+        for rows, width, srt, unroll, skew, pace in combos:  # --panel fields: unroll,skew,pace_ns
+            def setup(A, rows=rows, width=width, srt=srt, unroll=unroll, skew=skew, pace=pace):
                 A.set_param("panel_rows", rows)
                 A.set_param("panel_width", width)
                 A.set_param("panel_sort", srt)
                 A.set_param("panel_unroll", unroll)
                 A.set_param("panel_skew", skew)
-                A.set_param("panel_aos", nt)  # third field of --panel: 1 = 16-byte records, 0 = three arrays
+                A.set_param("panel_pace_ns", pace)
                 A.set_kernel(capi.CSR_PANEL)  # rebuilds the layout when the parameters changed
-            variants.append((f"panel G={rows or 'auto'} U={unroll} skew={skew} aos={nt}", setup))
+            variants.append((f"panel G={rows or 'auto'} U={unroll} skew={skew} pace={pace}ns", setup))
         if a.band and a.band <= 8192:
             for lanes in (4, 8, 16):
                 variants.append((f"ldswin L={lanes}", lambda A, lanes=lanes: A.set_kernel(capi.CSR_LDSWIN, lanes)))
