@@ -74,6 +74,7 @@ SIGNATURES = {
     "spmv_mat_set_kernel": (C.c_int, [_vp, C.c_int32, C.c_int32]),
     "spmv_mat_set_flags": (C.c_int, [_vp, C.c_uint32]),
     "spmv_mat_set_param": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
+    "spmv_mat_get_param": (C.c_int, [_vp, C.c_char_p, _i64p]),
     "spmv_mat_download": (C.c_int, [_vp, _vp, _vp, _vp]),
     "spmv_mat_device_ptrs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "spmv_apply": (C.c_int, [_vp, _vp, _vp, _vp]),
@@ -381,6 +382,11 @@ class Matrix:
 
     def set_param(self, name: str, value: int) -> None:
         _check(self.ctx._lib.spmv_mat_set_param(self.h, name.encode(), value))
+
+    def get_param(self, name: str) -> int:
+        v = C.c_int64(0)
+        _check(self.ctx._lib.spmv_mat_get_param(self.h, name.encode(), C.byref(v)))
+        return v.value
 
     def set_flags(self, flags: int) -> None:
         _check(self.ctx._lib.spmv_mat_set_flags(self.h, flags))

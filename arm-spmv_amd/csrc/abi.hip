@@ -546,11 +546,39 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
     else if (!strcmp(name, "panel_aos"))
         m->pb_aos = (int32_t)value;
     else if (!strcmp(name, "panel_pace_ns"))
-        m->pb_pace_ns = (int32_t)value;
+        m->pb_pace_req = (int32_t)value;
     else if (!strcmp(name, "panel_skew"))
         m->pb_skew = (int32_t)value;
     else if (!strcmp(name, "panel_two_per_cu"))
         m->pb_two_per_cu = (int32_t)value;
+    else
+        SPMV_FAIL(SPMV_ERR_INVALID, "unknown parameter '%s'", name);
+    return SPMV_OK;
+}
+
+int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
+{
+    SPMV_REQUIRE(m && name && value, "null argument");
+    if (!strcmp(name, "panel_rows"))
+        *value = m->pb_built_rows;
+    else if (!strcmp(name, "panel_width"))
+        *value = m->pb_built_width;
+    else if (!strcmp(name, "panel_sort"))
+        *value = m->pb_built_sort;
+    else if (!strcmp(name, "panel_groups"))
+        *value = m->pb_ngroups;
+    else if (!strcmp(name, "panel_unroll"))
+        *value = m->pb_unroll > 0 ? m->pb_unroll : 8;
+    else if (!strcmp(name, "panel_pace_ns"))
+        *value = m->pb_pace_ns;
+    else if (!strcmp(name, "panel_skew"))
+        *value = m->pb_skew;
+    else if (!strcmp(name, "panel_bytes"))
+        *value = m->pb_bytes;
+    else if (!strcmp(name, "window_max_span"))
+        *value = m->win_max_span;
+    else if (!strcmp(name, "window_avg_span"))
+        *value = (int64_t)m->win_avg_span;
     else
         SPMV_FAIL(SPMV_ERR_INVALID, "unknown parameter '%s'", name);
     return SPMV_OK;

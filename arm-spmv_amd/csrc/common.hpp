@@ -152,10 +152,12 @@ struct spmv_mat
     int32_t   pb_panel_width = 0;        // W (0 = default)
     int32_t   pb_sort        = 1;        // bucket tile entries by 128-byte line of x
     int32_t   pb_unroll      = 0;        // entries in flight per lane (0 = default)
-    int32_t   pb_skew        = 2;        // progress gate: chunks a workgroup may run ahead of the slowest (0 = off)
+    int32_t   pb_skew        = 0;        // counter gate: chunks a workgroup may run ahead of the slowest (0 = off)
     void*     pb_rec         = nullptr;  // [nnz] 16-byte records {value, column, local row} (replaces the three arrays)
     int32_t   pb_aos         = 0;        // build 16-byte records (one load instruction per entry); measured slower
-    int32_t   pb_pace_ns     = 0;        // pacing throttle: nanoseconds per chunk on the chip clock (0 = off)
+    int32_t   pb_pace_ns     = 0;        // pacing throttle in effect: nanoseconds per chunk on the chip clock (0 = off)
+    int32_t   pb_pace_req    = -1;       // requested pace (-1 = try a few and keep the fastest)
+    int32_t   pb_pace_tuned_unroll = 0;  // chunk size (unroll) the pace in effect was tried for; 0 = not tried
     int64_t   pb_max_group_nnz = 0;      // entries of the fullest row group
     int32_t   pb_two_per_cu  = 1;        // allow two workgroups per CU when the accumulators fit twice
     int32_t   pb_ngroups     = 0;
@@ -172,6 +174,7 @@ int csr_analyse(spmv_mat* m);
 void csr_choose_kernel(spmv_mat* m);
 // kernels_csr_panel.hip
 int  csr_panel_build(spmv_mat* m);
+int  panel_choose_pace(spmv_mat* m);
 void csr_panel_free(spmv_mat* m);
 int  csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 int csr_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);

@@ -380,6 +380,7 @@ void csr_panel_free(spmv_mat* m)
     m->pb_row = nullptr;
     m->pb_val = nullptr;
     m->pb_built_sort = -1;
+    m->pb_pace_tuned_unroll = 0;
     m->device_bytes -= m->pb_bytes;
     m->pb_bytes = 0;
 }
@@ -408,7 +409,7 @@ int csr_panel_build(spmv_mat* m)
     const bool aos = m->pb_aos != 0;
     if ((m->pb_col || m->pb_rec) && m->pb_built_rows == G && m->pb_built_width == W && m->pb_built_sort == (int)sort &&
         aos == (m->pb_rec != nullptr))
-        return SPMV_OK;  // the layout in memory was built with these parameters
+        return panel_choose_pace(m);  // the layout in memory was built with these parameters
     csr_panel_free(m);
     const int ngroups = (int)ceil_div(m->nrow, G);
     const int P       = (int)ceil_div(m->ncol, W);
@@ -495,7 +496,66 @@ int csr_panel_build(spmv_mat* m)
         m->pb_bytes = (int64_t)(nnz * 16);
     }
     m->device_bytes += m->pb_bytes;
-    return SPMV_OK;
+    return panel_choose_pace(m);
+}
+
+// Pick the pace of the clock throttle by trying it: the best value is "just what the CUs sustain", which
+// depends on the matrix (how many x lines a chunk touches) and on the clock the chip holds.  Candidates are
+// multiples of a model value (1.33 ns per entry and CU, measured on L2-resident problems) plus "no throttle";
+// each is timed on scratch vectors (the gather addresses, not the values, set the time).  Part of the
+// one-off analysis, like the reference's shard construction before its timed loop.
+int panel_choose_pace(spmv_mat* m)
+{
+    spmv_ctx* ctx = m->ctx;
+    if (m->pb_pace_req >= 0)
+    {
+        m->pb_pace_ns = m->pb_pace_req;
+        return SPMV_OK;
+    }
+    const int  unroll = m->pb_unroll > 0 ? m->pb_unroll : 8;
+    if (m->pb_pace_tuned_unroll == unroll) return SPMV_OK;  // already tried for this layout and chunk size
+    m->pb_pace_ns     = 0;
+    const bool worth  = (double)m->ncol * 8.0 > 4.0 * 1048576.0 && m->pb_max_group_nnz >= 8LL * unroll * kPanelThreads;
+    if (!worth) return SPMV_OK;  // x fits L2 or the groups are a few chunks long: nothing to keep in step
+    double *x = nullptr, *y = nullptr;
+    if (hipMalloc(&x, sizeof(double) * (size_t)m->ncol) != hipSuccess || hipMalloc(&y, sizeof(double) * (size_t)m->nrow) != hipSuccess)
+    {
+        if (x) hipFree(x);
+        return SPMV_OK;  // no room to try: run unthrottled
+    }
+    hipMemsetAsync(x, 0, sizeof(double) * (size_t)m->ncol, ctx->stream);
+    hipMemsetAsync(y, 0, sizeof(double) * (size_t)m->nrow, ctx->stream);
+    const double base_ns   = 1.33 * unroll * kPanelThreads;
+    const double factors[] = {0.0, 0.90, 1.0, 1.08, 1.16, 1.25, 1.4};
+    double       best_ms   = 1e30;
+    int          best_pace = 0;
+    int          rc        = SPMV_OK;
+    for (double f : factors)
+    {
+        m->pb_pace_ns = (int32_t)(f * base_ns);
+        float ms      = 0.f;
+        if ((rc = csr_panel_apply(ctx, m, x, y)) != SPMV_OK) break;  // warm
+        hipEventRecord(ctx->ev_begin, ctx->stream);
+        for (int i = 0; i < 3 && rc == SPMV_OK; ++i) rc = csr_panel_apply(ctx, m, x, y);
+        hipEventRecord(ctx->ev_end, ctx->stream);
+        if (rc != SPMV_OK || hipEventSynchronize(ctx->ev_end) != hipSuccess ||
+            hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end) != hipSuccess)
+        {
+            if (rc == SPMV_OK) rc = SPMV_ERR_HIP;
+            break;
+        }
+        if (ms < best_ms)
+        {
+            best_ms   = ms;
+            best_pace = m->pb_pace_ns;
+        }
+    }
+    hipStreamSynchronize(ctx->stream);
+    hipFree(x);
+    hipFree(y);
+    m->pb_pace_ns           = rc == SPMV_OK ? best_pace : 0;
+    m->pb_pace_tuned_unroll = rc == SPMV_OK ? unroll : 0;
+    return rc;
 }
 
 int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)

@@ -210,7 +210,10 @@ def main() -> None:
         wl_key = f"csr_n{n}_k{k}_band{args.band}_ncol{ncol}"
         if tfile.exists():
             traffic = json.loads(tfile.read_text()).get(wl_key, {}).get("hbm_bytes_per_launch")
-        kernel_names = {1: "csr_vector_kernel", 2: "csr_ldswin_kernel", 3: "csr_scalar_kernel"}
+        kernel_names = {1: "csr_vector_kernel", 2: "csr_ldswin_kernel", 3: "csr_scalar_kernel", 4: "csr_panel_kernel"}
+        panel = None
+        if int(info.kernel) == 4:
+            panel = {k: A.get_param("panel_" + k) for k in ("rows", "width", "groups", "unroll", "pace_ns", "skew", "bytes")}
         out = {
             "metric": "SpMV GFLOP/s + achieved HBM GB/s (% roofline), fp64 CSR, 1/2/4/8 MI355X",
             "value": round(gflops, 3),
@@ -238,6 +241,7 @@ def main() -> None:
                 "x_exchange": "static replica, all-gathered once before the timed loop (as src/mat_vec.cpp:266 vs :271)",
                 "kernel": kernel_names.get(int(info.kernel), str(info.kernel)),
                 "lanes_per_row": int(info.lanes_per_row),
+                "panel_layout": panel,
             },
             "roofline": {
                 "bound": "hbm",

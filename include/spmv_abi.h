@@ -149,6 +149,9 @@ int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
  *   "panel_width" columns per panel (0 = 131072)
  *   "panel_sort"  1 = bucket the entries of a panel by 128-byte line of x (default), 0 = leave unordered */
 int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value);
+/* What is in effect: "panel_rows", "panel_width", "panel_sort", "panel_groups", "panel_unroll", "panel_pace_ns",
+ * "panel_skew", "panel_bytes", "window_max_span", "window_avg_span". */
+int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value);
 /* Copy the arrays of a handle back to the host (any pointer may be NULL to skip it).
  *   CSR: a=row_ptr[nrow+1]  b=col_ind[nnz]      v=values[nnz]
  *   COO: a=row_ind[nnz]     b=col_ind[nnz]      v=values[nnz]
