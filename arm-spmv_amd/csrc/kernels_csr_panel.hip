@@ -527,7 +527,7 @@ int panel_choose_pace(spmv_mat* m)
     hipMemsetAsync(y, 0, sizeof(double) * (size_t)m->nrow, ctx->stream);
     const double base_ns   = 1.33 * unroll * kPanelThreads;
     const double factors[] = {0.0, 0.90, 1.0, 1.08, 1.16, 1.25, 1.4};
-    double       best_ms   = 1e30;
+    double       best_ms   = 1e30, unthrottled_ms = 1e30;
     int          best_pace = 0;
     int          rc        = SPMV_OK;
     for (double f : factors)
@@ -544,7 +544,10 @@ int panel_choose_pace(spmv_mat* m)
             if (rc == SPMV_OK) rc = SPMV_ERR_HIP;
             break;
         }
-        if (ms < best_ms)
+        // a throttle has to beat the unthrottled run (first candidate) by a clear margin, or timing noise
+        // would switch it on where the columns are local and there is nothing to keep in step
+        if (f == 0.0) unthrottled_ms = ms;
+        if (ms < best_ms && (f == 0.0 || ms < 0.93 * unthrottled_ms))
         {
             best_ms   = ms;
             best_pace = m->pb_pace_ns;

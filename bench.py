@@ -119,6 +119,9 @@ def main() -> None:
 
     pkg = load_package()
     capi, synth = pkg.capi, pkg.synth
+    import importlib
+
+    shard = importlib.import_module("arm_spmv_amd.dist")  # row-range sharding + the x all-gather
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -137,7 +140,7 @@ def main() -> None:
         ctx = capi.Context(local_rank, stream=stream.cuda_stream)
         n, k = args.n, args.k
         ncol = n * world
-        row_begin, row_end = rank * n, (rank + 1) * n  # equal rows per rank (src/mat_vec.cpp:245-246)
+        row_begin, row_end = shard.shard_rows(ncol, world, rank)  # equal rows per rank (src/mat_vec.cpp:245-246)
         A = ctx.gen_csr_uniform(row_begin, row_end, ncol, k, band=args.band, seed=args.seed)
         if args.kernel or args.lanes:
             A.set_kernel(args.kernel, args.lanes)
@@ -153,7 +156,7 @@ def main() -> None:
         allgather_ms = None
         if world > 1:
             x_send = x_own.clone()
-            dist.all_gather_into_tensor(x_full, x_send)
+            shard.allgather_x(x_full, x_send, ncol)
         y = torch.zeros(n, dtype=torch.float64, device=dev)
         vx, vy = ctx.wrap_vector(x_full, ncol), ctx.wrap_vector(y, n)
 
@@ -182,14 +185,14 @@ def main() -> None:
             barrier()
             t1 = time.perf_counter()
             for _ in range(args.steps):
-                dist.all_gather_into_tensor(x_full, x_send)
+                shard.allgather_x(x_full, x_send, ncol)
                 ctx.apply(A, vx, vy)
             barrier()
             exch_s = time.perf_counter() - t1
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
             for _ in range(10):
-                dist.all_gather_into_tensor(x_full, x_send)
+                shard.allgather_x(x_full, x_send, ncol)
             e1.record(stream)
             torch.cuda.synchronize()
             allgather_ms = e0.elapsed_time(e1) / 10
