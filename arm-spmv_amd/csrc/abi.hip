@@ -84,6 +84,7 @@ void mat_free(spmv_mat* m)
     if (m->win_lo) hipFree(m->win_lo);
     if (m->win_span) hipFree(m->win_span);
     csr_panel_free(m);
+    if (m->coo_csr) mat_free(m->coo_csr);
     delete m;
 }
 
@@ -514,6 +515,22 @@ int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
                                         (lanes_per_row & (lanes_per_row - 1)) == 0),
                  "lanes_per_row must be 0 or a power of two in 1..64, got %d", lanes_per_row);
     if (lanes_per_row > 0) m->lanes_per_row = lanes_per_row;
+    if (m->format == SPMV_FMT_COO)
+    {
+        // COO: AUTO = panel layout when it pays, VECTOR = the segmented scan, PANEL = build the panel layout now
+        SPMV_REQUIRE(kernel == SPMV_CSR_AUTO || kernel == SPMV_CSR_VECTOR || kernel == SPMV_CSR_PANEL,
+                     "COO handles take kernel AUTO (0), VECTOR (1: segmented scan) or PANEL (4), got %d", kernel);
+        SPMV_HIP(hipSetDevice(m->ctx->device));
+        m->kernel_forced = kernel != SPMV_CSR_AUTO;
+        if (kernel == SPMV_CSR_VECTOR)
+            m->kernel = SPMV_CSR_VECTOR;
+        else
+        {
+            SPMV_TRY(coo_build_panel(m, /*only_if_worth=*/kernel == SPMV_CSR_AUTO));
+            m->kernel = m->coo_csr ? SPMV_CSR_PANEL : SPMV_CSR_VECTOR;
+        }
+        return SPMV_OK;
+    }
     if (kernel == SPMV_CSR_AUTO)
     {
         m->kernel_forced = false;

@@ -163,6 +163,9 @@ struct spmv_mat
     int32_t   pb_ngroups     = 0;
     int32_t   pb_built_rows = 0, pb_built_width = 0, pb_built_sort = -1;  // parameters of the layout in memory
     int64_t   pb_bytes       = 0;
+
+    // COO: internal row-grouped copy in the panel layout (kernels_coo.hip: coo_build_panel); owns it
+    spmv_mat* coo_csr = nullptr;
 };
 
 namespace spmv
@@ -182,6 +185,7 @@ int csr_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 int ell_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 // kernels_coo.hip
 int coo_analyse(spmv_mat* m);
+int coo_build_panel(spmv_mat* m, bool only_if_worth);
 int coo_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 // kernels_misc.hip (CSC, DIA, BLAS-1, fill)
 int csc_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);

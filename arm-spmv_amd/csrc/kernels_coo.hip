@@ -139,12 +139,50 @@ int coo_analyse(spmv_mat* m)
     SPMV_HIP(hipMemcpyAsync(&unsorted, flag, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     SPMV_HIP(hipStreamSynchronize(ctx->stream));
     m->sorted_rows = unsorted ? 0 : 1;
+    m->kernel      = SPMV_CSR_VECTOR;  // reported for COO as "segmented scan"
+    if (!m->kernel_forced) SPMV_TRY(coo_build_panel(m, /*only_if_worth=*/true));
+    return SPMV_OK;
+}
+
+// Large COO with an x beyond L2 is gather-bound in entry order exactly like CSR (C4: 13 % of roofline with the
+// segmented scan).  Such a handle gets the panel layout too: the entries are grouped by row on the device
+// (spmv_coo_to_csr, duplicates and file order inside a row kept) and re-ordered as in kernels_csr_panel.hip; the
+// product then runs csr_panel_kernel (C4: 0.51 ms instead of 1.81).  Only row_ptr and the panel arrays are kept.
+int coo_build_panel(spmv_mat* m, bool only_if_worth)
+{
+    if (m->coo_csr) return SPMV_OK;
+    const bool worth = m->nnz >= ((int64_t)4 << 20) && (double)m->ncol * 8.0 > 4.0 * 1048576.0;
+    if (only_if_worth && !worth) return SPMV_OK;
+    if (m->nnz == 0 || m->nnz > (int64_t)INT32_MAX - 65536) return SPMV_OK;
+    spmv_mat* csr = nullptr;
+    SPMV_TRY(coo_to_csr(m->ctx, m, &csr));  // csr_analyse inside picks (and builds) the panel layout when x is large
+    if (csr->kernel != SPMV_CSR_PANEL)
+    {
+        csr->kernel_forced = true;
+        csr->kernel        = SPMV_CSR_PANEL;
+        int rc             = csr_panel_build(csr);
+        if (rc != SPMV_OK)
+        {
+            mat_free(csr);
+            return rc;
+        }
+    }
+    // the panel kernel reads row_ptr and its own arrays only: drop the CSR copies of col_ind / values
+    hipFree(const_cast<int32_t*>(csr->b));
+    hipFree(const_cast<double*>(csr->v));
+    csr->device_bytes -= (int64_t)csr->nnz * 12;
+    csr->b     = nullptr;
+    csr->v     = nullptr;
+    m->coo_csr = csr;
+    m->kernel  = SPMV_CSR_PANEL;
+    m->device_bytes += csr->device_bytes;
     return SPMV_OK;
 }
 
 int coo_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
 {
     if (A->nnz == 0) return SPMV_OK;
+    if (A->coo_csr && A->kernel == SPMV_CSR_PANEL) return csr_panel_apply(ctx, A->coo_csr, x, y);
     const unsigned grid = (unsigned)ceil_div(A->nnz, kBlockChunk);
     if (A->sorted_rows)
         hipLaunchKernelGGL(coo_segscan_kernel<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, A->nnz, A->a, A->b, A->v,

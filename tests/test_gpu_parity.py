@@ -110,16 +110,20 @@ def test_ell_odd_row_count_uses_one_row_kernel(ctx, orc):
 
 
 @pytest.mark.parametrize("make", cases.ALL_CASES, ids=lambda f: f.__name__)
-def test_coo_matches_reference_golden(ctx, orc, make):
+def test_coo_matches_reference_golden(ctx, orc, pkg, make):
     c = make()
     g = golden(c["name"])
     scale = _scale(orc, c)
     A = ctx.coo(c["nrow"], c["ncol"], c["row"], c["col"], c["val"])
     sorted_in = bool(np.all(np.diff(c["row"].astype(np.int64)) >= 0))
     assert bool(A.info.sorted_rows) == sorted_in
-    y1, y50 = _apply_n(ctx, A, c["x"], c["nrow"], NUM_TEST)
-    ol.assert_parity(y1, g["y1_coo"], scale, c["name"] + " coo 1 call")
-    ol.assert_parity(y50, g["y50_coo"], scale, c["name"] + " coo 50 calls", reps=NUM_TEST)
+    assert A.info.kernel == pkg.capi.CSR_VECTOR  # small: the segmented scan
+    for kernel in (pkg.capi.CSR_VECTOR, pkg.capi.CSR_PANEL):  # PANEL: grouped by row on the device, panel layout
+        A.set_kernel(kernel)
+        assert A.info.kernel == kernel
+        y1, y50 = _apply_n(ctx, A, c["x"], c["nrow"], NUM_TEST)
+        ol.assert_parity(y1, g["y1_coo"], scale, f"{c['name']} coo kernel={kernel} 1 call")
+        ol.assert_parity(y50, g["y50_coo"], scale, f"{c['name']} coo kernel={kernel} 50 calls", reps=NUM_TEST)
 
 
 def test_coo_ragged_chunk_boundaries(ctx, orc):
@@ -429,3 +433,28 @@ def test_csr_auto_picks_panel_for_large_random_and_agrees_with_vector(ctx, orc, 
         ol.csr_spmv(orc, rp, cc, cv, hx, ref)
         ol.csr_abs_row_sums(orc, rp, cc, cv, hx, scale)
         ol.assert_parity(hp[r0:r0 + 3000], ref, scale, f"panel rows {r0}..")
+
+
+def test_large_coo_takes_the_panel_path_and_matches_oracle(ctx, orc, pkg):
+    """C4-like: power-law rows, x beyond L2 -> AUTO groups the entries by row and uses the panel layout"""
+    synth, capi = pkg.synth, pkg.capi
+    n = 1_000_000
+    A = ctx.gen_coo_powerlaw(n, n, 4096, seed=4)
+    assert A.info.sorted_rows == 1 and A.info.kernel == capi.CSR_PANEL
+    x = ctx.gen_vector(n, seed=4)
+    yp, ys = ctx.vector(n), ctx.vector(n)
+    yp.fill(0.0)
+    ys.fill(0.0)
+    ctx.apply(A, x, yp)
+    A.set_kernel(capi.CSR_VECTOR)  # the segmented scan on the same handle
+    ctx.apply(A, x, ys)
+    ctx.sync()
+    hp, hs = yp.download(), ys.download()
+    row, col, val = synth.coo_powerlaw(n, n, 4096, seed=4)
+    hx = synth.vec_uniform(n, seed=4)
+    rp, cc, cv = ol.coo_to_csr(orc, n, row, col, val)
+    ref, scale = np.zeros(n), np.zeros(n)
+    ol.csr_spmv(orc, rp, cc, cv, hx, ref)
+    ol.csr_abs_row_sums(orc, rp, cc, cv, hx, scale)
+    ol.assert_parity(hp, ref, scale, "large coo, panel path")
+    ol.assert_parity(hs, ref, scale, "large coo, segmented scan")

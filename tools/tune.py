@@ -103,8 +103,15 @@ def main():
         sweep(ctx, A, x, y, [("coo segscan", lambda A: None)], a.rounds, a.reps, algorithmic_bytes("coo", n, n, nnz), nnz)
         csr = ctx.coo_to_csr(A)
         print(f"same matrix as CSR: auto kernel={csr.info.kernel} lanes={csr.info.lanes_per_row} max_row={csr.info.max_row_nnz}")
-        variants = [(f"csr vector L={l}", lambda A, l=l: A.set_kernel(capi.CSR_VECTOR, l)) for l in (8, 16, 32, 64)]
+        variants = [(f"csr vector L={l}", lambda A, l=l: A.set_kernel(capi.CSR_VECTOR, l)) for l in (16, 64)]
+        for unroll, pace in ((8, -1), (8, 0), (4, 0), (16, 0)):
+            def setup(A, unroll=unroll, pace=pace):
+                A.set_param("panel_unroll", unroll)
+                A.set_param("panel_pace_ns", pace)
+                A.set_kernel(capi.CSR_PANEL)
+            variants.append((f"csr panel U={unroll} pace={pace}", setup))
         sweep(ctx, csr, x, y, variants, a.rounds, a.reps, algorithmic_bytes("csr", n, n, nnz), nnz)
+        print("panel layout:", {k: csr.get_param("panel_" + k) for k in ("rows", "groups", "pace_ns")})
 
 
 if __name__ == "__main__":
