@@ -151,7 +151,7 @@ int coo_analyse(spmv_mat* m)
 int coo_build_panel(spmv_mat* m, bool only_if_worth)
 {
     if (m->coo_csr) return SPMV_OK;
-    const bool worth = m->nnz >= ((int64_t)4 << 20) && (double)m->ncol * 8.0 > 4.0 * 1048576.0;
+    const bool worth = m->nnz >= ((int64_t)2 << 20) && m->nrow > 0 && m->nnz / m->nrow >= 2;
     if (only_if_worth && !worth) return SPMV_OK;
     if (m->nnz == 0 || m->nnz > (int64_t)INT32_MAX - 65536) return SPMV_OK;
     spmv_mat* csr = nullptr;

@@ -322,9 +322,10 @@ void csr_choose_kernel(spmv_mat* m)
         // kernel beats the row-parallel one both without column locality (1.70 vs 5.9 ms, uniform columns) and
         // with it (0.76 vs 1.63 ms at a 4096-wide band, 0.76 vs 2.0 ms at 65536), because the column-sorted
         // walk makes neighbouring lanes share x lines.  Small problems stay with the row-parallel kernel.
-        const bool x_beyond_l2 = (double)m->ncol * 8.0 > 4.0 * 1048576.0;
-        const bool big_enough  = m->nnz >= (int64_t)4 << 20 && mean >= 2.0;
-        m->kernel              = (x_beyond_l2 && big_enough) ? SPMV_CSR_PANEL : SPMV_CSR_VECTOR;
+        // It also wins while x still fits L2 (N = 100k..1.5M, 32/row: 1.3x..2.8x, profiles/r01_tune_csr_small.txt);
+        // only matrices too small to occupy 256 workgroups of 1024 lanes stay with the row-parallel kernel.
+        const bool big_enough = m->nnz >= (int64_t)2 << 20 && mean >= 2.0;
+        m->kernel             = big_enough ? SPMV_CSR_PANEL : SPMV_CSR_VECTOR;
     }
 }
 

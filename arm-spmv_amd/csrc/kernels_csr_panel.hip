@@ -526,7 +526,7 @@ int panel_choose_pace(spmv_mat* m)
     hipMemsetAsync(x, 0, sizeof(double) * (size_t)m->ncol, ctx->stream);
     hipMemsetAsync(y, 0, sizeof(double) * (size_t)m->nrow, ctx->stream);
     const double base_ns   = 1.33 * unroll * kPanelThreads;
-    const double factors[] = {0.0, 0.90, 1.0, 1.08, 1.16, 1.25, 1.4};
+    const double factors[] = {0.0, 0.88, 0.94, 0.98, 1.02, 1.06, 1.12, 1.2, 1.32, 1.5};
     double       best_ms   = 1e30, unthrottled_ms = 1e30;
     int          best_pace = 0;
     int          rc        = SPMV_OK;

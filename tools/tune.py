@@ -37,7 +37,7 @@ def sweep(ctx, A, x, y, variants, rounds, reps, bytes_launch, nnz):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["csr", "ell", "coo"])
+    ap.add_argument("what", choices=["csr", "ell", "coo", "blas1", "bandwin"])
     ap.add_argument("--n", type=int, default=0)
     ap.add_argument("--k", type=int, default=0)
     ap.add_argument("--band", type=int, default=0)
@@ -47,6 +47,46 @@ def main():
     ap.add_argument("--panel", default="", help="only these panel variants: 'unroll,skew,nt;unroll,skew,nt;...'")
     a = ap.parse_args()
     ctx = capi.Context(0)
+    if a.what == "blas1":
+        import time
+
+        n = a.n or 50_000_000
+        x, y, w = ctx.gen_vector(n, seed=1), ctx.gen_vector(n, seed=2), ctx.vector(n)
+        for name, (al, be), nbytes in (("axpby general", (0.5, 2.0), 24 * n), ("axpby alpha=1", (1.0, 2.0), 24 * n),
+                                       ("axpby beta=0", (3.0, 0.0), 16 * n)):
+            ctx.axpby(al, x, be, y, w)
+            ctx.sync()
+            t = time.perf_counter()
+            for _ in range(20):
+                ctx.axpby(al, x, be, y, w)
+            ctx.sync()
+            ms = (time.perf_counter() - t) / 20 * 1e3
+            print(f"{name:16s} n={n}: {ms:.4f} ms  {nbytes / ms / 1e6:.1f} GB/s")
+        ctx.dot(x, y)
+        t = time.perf_counter()
+        for _ in range(20):
+            ctx.dot(x, y)  # synchronous (returns the scalar)
+        ms = (time.perf_counter() - t) / 20 * 1e3
+        print(f"{'dot':16s} n={n}: {ms:.4f} ms  {16 * n / ms / 1e6:.1f} GB/s (incl. result read-back)")
+        return
+    if a.what == "bandwin":
+        # non-wrapping band: rows [w, n-w) of the band matrix, so that every row block's window fits LDS
+        import numpy as np
+
+        n, k, band = a.n or 4_000_000, a.k or 32, a.band or 4096
+        full = ctx.gen_csr_uniform(0, n, n, k, band=band, seed=1)
+        rp, cc, cv = full.download()
+        lo, hi = band, n - band
+        A = ctx.csr(hi - lo, n, (rp[lo:hi + 1] - rp[lo]).astype(np.int32), cc[rp[lo]:rp[hi]], cv[rp[lo]:rp[hi]])
+        del full
+        x, y = ctx.gen_vector(n, seed=1), ctx.vector(hi - lo)
+        y.fill(0.0)
+        print(f"band {band}, rows {hi - lo}: auto kernel={A.info.kernel} window max={A.get_param('window_max_span')}")
+        variants = [(f"ldswin L={l}", lambda A, l=l: A.set_kernel(capi.CSR_LDSWIN, l)) for l in (4, 8, 16)]
+        variants += [("vector L=8", lambda A: A.set_kernel(capi.CSR_VECTOR, 8)), ("panel", lambda A: A.set_kernel(capi.CSR_PANEL))]
+        nnz = A.info.nnz
+        sweep(ctx, A, x, y, variants, a.rounds, a.reps, algorithmic_bytes("csr", hi - lo, n, nnz), nnz)
+        return
     if a.what == "csr":
         n, k = a.n or 10_000_000, a.k or 32
         A = ctx.gen_csr_uniform(0, n, n, k, band=a.band, seed=1)
