@@ -307,26 +307,26 @@ int reduce_max_i32(spmv_ctx* ctx, const int32_t* in, int64_t n, int32_t* result)
     return SPMV_OK;
 }
 
-// AUTO policy: stage x in LDS when every row block's column window fits the tile and is re-used
-// (entries per block well above the window length); otherwise gather x through L2.
+// AUTO policy (all measured at 32 entries/row, profiles/r01_tune_*):
+//   * enough entries to occupy 256 workgroups of 1024 lanes -> the panel layout.  It beats the row-parallel kernel
+//     without column locality (N = 10M uniform: 1.63 vs 5.9 ms), with it (0.76 vs 1.63 ms in a 4096-wide band,
+//     0.76 vs 2.0 ms at 65536; the column-sorted walk makes neighbouring lanes share x lines), while x still fits
+//     L2 (N = 100k..1.5M: 1.3x..2.8x), and it beats the LDS-window kernel where that applies (N = 4M band 4096
+//     without wrap-around rows: 0.32 vs 0.43 ms);
+//   * smaller: stage x in LDS when every row block's column window fits the tile and is re-used, else gather
+//     through L1/L2 with the row-parallel kernel.
 void csr_choose_kernel(spmv_mat* m)
 {
-    const double mean  = m->nrow > 0 ? (double)m->nnz / (double)m->nrow : 0.0;
-    const bool   fits  = m->win_max_span > 0 && m->win_max_span <= kWinDoubles;
-    const double reuse = m->win_max_span > 0 ? mean * kWinRows / (double)m->win_max_span : 0.0;
-    if (fits && reuse >= 2.0)
+    const double mean       = m->nrow > 0 ? (double)m->nnz / (double)m->nrow : 0.0;
+    const bool   big_enough = m->nnz >= (int64_t)2 << 20 && mean >= 2.0;
+    const bool   fits       = m->win_max_span > 0 && m->win_max_span <= kWinDoubles;
+    const double reuse      = m->win_max_span > 0 ? mean * kWinRows / (double)m->win_max_span : 0.0;
+    if (big_enough)
+        m->kernel = SPMV_CSR_PANEL;
+    else if (fits && reuse >= 2.0)
         m->kernel = SPMV_CSR_LDSWIN;
     else
-    {
-        // x beyond L2: re-order into row groups x column panels.  Measured at N = 10M, 32 entries/row: the panel
-        // kernel beats the row-parallel one both without column locality (1.70 vs 5.9 ms, uniform columns) and
-        // with it (0.76 vs 1.63 ms at a 4096-wide band, 0.76 vs 2.0 ms at 65536), because the column-sorted
-        // walk makes neighbouring lanes share x lines.  Small problems stay with the row-parallel kernel.
-        // It also wins while x still fits L2 (N = 100k..1.5M, 32/row: 1.3x..2.8x, profiles/r01_tune_csr_small.txt);
-        // only matrices too small to occupy 256 workgroups of 1024 lanes stay with the row-parallel kernel.
-        const bool big_enough = m->nnz >= (int64_t)2 << 20 && mean >= 2.0;
-        m->kernel             = big_enough ? SPMV_CSR_PANEL : SPMV_CSR_VECTOR;
-    }
+        m->kernel = SPMV_CSR_VECTOR;
 }
 
 // Row statistics + kernel choice.  Runs once when a CSR handle is created.

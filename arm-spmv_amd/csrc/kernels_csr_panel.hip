@@ -186,13 +186,22 @@ struct PanelBatch
             }
         }
     }
-    __device__ __forceinline__ void apply(const double* __restrict__ x, double* acc) const
+    // ABLATE (timing experiments only, results are wrong): bit 0 = no LDS adds (products summed in a register),
+    // bit 1 = gathers confined to 8 KiB of x (always L1 hits, one or two lines per instruction)
+    template <int ABLATE = 0>
+    __device__ __forceinline__ void apply(const double* __restrict__ x, double* acc, double* sink = nullptr) const
     {
         double xv[UNROLL];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) xv[u] = x[c[u]];
+        for (int u = 0; u < UNROLL; ++u) xv[u] = x[(ABLATE & 2) ? (c[u] & 1023) : c[u]];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) atomicAdd(&acc[r[u]], v[u] * xv[u]);  // ds_add_f64
+        for (int u = 0; u < UNROLL; ++u)
+        {
+            if constexpr (ABLATE & 1)
+                *sink += v[u] * xv[u] + (double)r[u];
+            else
+                atomicAdd(&acc[r[u]], v[u] * xv[u]);  // ds_add_f64
+        }
     }
     // single entry (the ragged tail of a group)
     __device__ static __forceinline__ void one(const int32_t* __restrict__ pcol, const uint16_t* __restrict__ prow,
@@ -284,7 +293,7 @@ __device__ __forceinline__ void gate_wait(GateLds* lds, const unsigned* gate_x, 
     }
 }
 
-template <int UNROLL, bool GATED, int LAYOUT>
+template <int UNROLL, bool GATED, int LAYOUT, int ABLATE = 0>
 __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(int nrow, int G, int ngroups,
                                                                   const int32_t* __restrict__ row_ptr,
                                                                   const int32_t* __restrict__ pcol,
@@ -296,6 +305,7 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(int nrow, int 
 {
     extern __shared__ double acc[];  // G accumulators
     __shared__ GateLds       gl;
+    double                   sink = 0.0;  // ABLATE only
     constexpr int STEP   = UNROLL * kPanelThreads;
     constexpr int NWAVES = kPanelThreads / kWave;
     const int     lane   = threadIdx.x & 63;
@@ -341,7 +351,7 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(int nrow, int 
             }
             PanelBatch<UNROLL, LAYOUT> cur;
             cur.load(pcol, prow, pval, e);
-            cur.apply(x, acc);
+            cur.template apply<ABLATE>(x, acc, &sink);
             e += STEP;
             if constexpr (GATED)
             {
@@ -366,6 +376,7 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(int nrow, int 
         for (int i = threadIdx.x; i < rows; i += kPanelThreads) y[r0 + i] += acc[i];
         __syncthreads();
     }
+    if (ABLATE && sink == 123.456) y[0] = sink;  // keeps the ablated products alive
 }
 }  // namespace
 
@@ -608,6 +619,25 @@ int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y
     }
 #define SPMV_PANEL_CASES(U) \
     SPMV_PANEL_CASE(U, false, 0) SPMV_PANEL_CASE(U, true, 0) SPMV_PANEL_CASE(U, false, 1) SPMV_PANEL_CASE(U, true, 1)
+    if (A->pb_ablate > 0)
+    {
+        // timing experiments (wrong results by design): UNROLL 8, ungated, three-array layout only
+#define SPMV_PANEL_ABLATE(AB)                                                                                        \
+    if (A->pb_ablate == AB)                                                                                          \
+    {                                                                                                                \
+        SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_kernel<8, false, 0, AB>,                                 \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160000));                           \
+        hipLaunchKernelGGL((csr_panel_kernel<8, false, 0, AB>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream,    \
+                           A->nrow, G, A->pb_ngroups, A->a, A->pb_col, A->pb_row, A->pb_val, x, y, gate, pop, nchunk,  \
+                           skew, pace_fp);                                                                           \
+        SPMV_HIP(hipGetLastError());                                                                                 \
+        return SPMV_OK;                                                                                              \
+    }
+        SPMV_PANEL_ABLATE(1)
+        SPMV_PANEL_ABLATE(2)
+        SPMV_PANEL_ABLATE(3)
+#undef SPMV_PANEL_ABLATE
+    }
     SPMV_PANEL_CASES(2)
     SPMV_PANEL_CASES(4)
     SPMV_PANEL_CASES(8)

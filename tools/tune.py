@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--full", action="store_true", help="every lanes x flags combination")
+    ap.add_argument("--ablate", action="store_true", help="add the ablated (wrong-result) timing variants of the panel kernel")
     ap.add_argument("--panel", default="", help="only these panel variants: 'unroll,skew,nt;unroll,skew,nt;...'")
     a = ap.parse_args()
     ctx = capi.Context(0)
@@ -118,8 +119,16 @@ def main():
                 A.set_param("panel_unroll", unroll)
                 A.set_param("panel_skew", skew)
                 A.set_param("panel_pace_ns", pace)
+                A.set_param("panel_ablate", 0)
                 A.set_kernel(capi.CSR_PANEL)  # rebuilds the layout when the parameters changed
             variants.append((f"panel G={rows or 'auto'} U={unroll} skew={skew} pace={pace}ns", setup))
+        for ab, what in ((1, "no LDS adds"), (2, "gathers always hit L1"), (3, "neither")) if a.ablate else ():
+            def setup(A, ab=ab):
+                for k, v in (("panel_rows", 0), ("panel_width", 0), ("panel_sort", 1), ("panel_unroll", 8), ("panel_skew", 0),
+                             ("panel_pace_ns", 0), ("panel_ablate", ab)):
+                    A.set_param(k, v)
+                A.set_kernel(capi.CSR_PANEL)
+            variants.append((f"panel U=8 ABLATED: {what}", setup))
         if a.band and a.band <= 8192:
             for lanes in (4, 8, 16):
                 variants.append((f"ldswin L={lanes}", lambda A, lanes=lanes: A.set_kernel(capi.CSR_LDSWIN, lanes)))
