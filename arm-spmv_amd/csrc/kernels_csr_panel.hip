@@ -293,7 +293,7 @@ __device__ __forceinline__ void gate_wait(GateLds* lds, const unsigned* gate_x, 
     }
 }
 
-template <int UNROLL, bool GATED, int LAYOUT, int ABLATE = 0>
+template <int UNROLL, bool GATED, int LAYOUT, int ABLATE = 0, bool PIPE = false>
 __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(int nrow, int G, int ngroups,
                                                                   const int32_t* __restrict__ row_ptr,
                                                                   const int32_t* __restrict__ pcol,
@@ -337,6 +337,7 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(int nrow, int 
         // pacing (alternative throttle without any communication): chunk b does not start before
         // t0 + b * pace on the chip-wide 100 MHz clock; all workgroups start their round within ~1 us
         const unsigned long long t0 = pace_fp ? __builtin_amdgcn_s_memrealtime() : 0ull;
+        PanelBatch<UNROLL, LAYOUT> cur, nxt;
         for (int b = 0; b < nfull; ++b)
         {
             if (pace_fp && lane == 0)
@@ -349,9 +350,20 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(int nrow, int 
             {
                 if (b >= skew && lane == 0) gate_wait(&gl, gate_x, pop_x, (unsigned)(b - skew));
             }
-            PanelBatch<UNROLL, LAYOUT> cur;
-            cur.load(pcol, prow, pval, e);
-            cur.template apply<ABLATE>(x, acc, &sink);
+            if constexpr (PIPE)
+            {
+                // the streamed loads of chunk b+1 are issued before the gathers of chunk b: the HBM latency of the
+                // stream and the L1/L2 time of the gathers overlap inside one wavefront instead of adding up
+                if (b == 0) cur.load(pcol, prow, pval, e);
+                if (b + 1 < nfull) nxt.load(pcol, prow, pval, e + STEP);
+                cur.template apply<ABLATE>(x, acc, &sink);
+                cur = nxt;
+            }
+            else
+            {
+                cur.load(pcol, prow, pval, e);
+                cur.template apply<ABLATE>(x, acc, &sink);
+            }
             e += STEP;
             if constexpr (GATED)
             {
@@ -637,6 +649,30 @@ int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y
         SPMV_PANEL_ABLATE(2)
         SPMV_PANEL_ABLATE(3)
 #undef SPMV_PANEL_ABLATE
+    }
+    if (A->pb_pipe && !gated && layout == 0)
+    {
+        // software-pipelined chunks (ungated, three-array layout)
+#define SPMV_PANEL_PIPE(U)                                                                                           \
+    if (unroll == U)                                                                                                 \
+    {                                                                                                                \
+        static bool granted = false;                                                                                 \
+        if (!granted)                                                                                                \
+        {                                                                                                            \
+            SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_kernel<U, false, 0, 0, true>,                        \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160000));                       \
+            granted = true;                                                                                          \
+        }                                                                                                            \
+        hipLaunchKernelGGL((csr_panel_kernel<U, false, 0, 0, true>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream, \
+                           A->nrow, G, A->pb_ngroups, A->a, A->pb_col, A->pb_row, A->pb_val, x, y, gate, pop, nchunk,  \
+                           skew, pace_fp);                                                                           \
+        SPMV_HIP(hipGetLastError());                                                                                 \
+        return SPMV_OK;                                                                                              \
+    }
+        SPMV_PANEL_PIPE(2)
+        SPMV_PANEL_PIPE(4)
+        SPMV_PANEL_PIPE(8)
+#undef SPMV_PANEL_PIPE
     }
     SPMV_PANEL_CASES(2)
     SPMV_PANEL_CASES(4)
