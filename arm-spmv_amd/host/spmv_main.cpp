@@ -6,7 +6,7 @@
 // computes y_ref and never reads it).
 //
 //   spmv_main <file.mtx> <nshards> [options]          nshards plays the role of main.cpp's nthreads (argv[2])
-//   spmv_main --synthetic uniform|band|banded-ell|powerlaw --n N [--k K] [--band W] [--seed S] <nshards> [options]
+//   spmv_main --synthetic uniform|band --n N [--k K] [--band W] [--seed S] <nshards> [options]
 // options: --format coo,csr,csc,ell,dia   (default coo,csr,ell)     --reps R (default 50)
 //          --no-dropin   skip the host-vector timing       --no-numa  skip the sharded drivers
 //          --verify      compare every format's y with the COO result (norm-wise 1e-10)

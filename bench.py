@@ -50,9 +50,15 @@ def cpu_baseline(args, synth, nrow_total: int) -> dict:
     with the full x.  The gather footprint per entry (all of x) is therefore the benchmark's."""
     import numpy as np
 
-    cores = os.cpu_count() or 1
+    # the host share that goes with one GPU of the box is 16 cores; more OpenMP threads than that only
+    # oversubscribe (measured: 256 threads = 0.8 GFLOP/s, slower than 8 threads in the survey container)
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = os.cpu_count() or 1
+    cores = max(1, min(allowed, args.cpu_threads))
     os.environ["OMP_NUM_THREADS"] = str(cores)
-    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    os.environ.setdefault("OMP_PROC_BIND", "close")
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle_lib as ol  # the checker / baseline only — never on the product path
 
@@ -110,6 +116,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the CPU baseline (host share of one GPU)")
     args = ap.parse_args()
 
     import torch

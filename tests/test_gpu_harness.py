@@ -1,0 +1,53 @@
+"""The drop-in layer end to end on the GPU: the engine's harness with --verify, and — where it was built (the
+build container has the reference sources; the binary travels) — the REFERENCE's own main.cpp compiled unchanged
+against include/compat, run on a small Matrix Market file."""
+import re
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from test_host_io import _write_mtx
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+BIN = ROOT / "arm-spmv_amd" / "bin"
+
+
+def _mtx(tmp_path, pkg, n, k, seed):
+    rp, col, val = pkg.synth.csr_uniform(0, n, n, k, seed=seed)
+    c = dict(nrow=n, ncol=n, row=np.repeat(np.arange(n, dtype=np.int32), k), col=col, val=val)
+    p = tmp_path / f"m{n}.mtx"
+    _write_mtx(p, c)
+    return p
+
+
+def test_spmv_main_verifies_every_format_and_the_sharded_drivers(tmp_path, pkg):
+    p = _mtx(tmp_path, pkg, 3000, 12, 17)
+    r = subprocess.run([str(BIN / "spmv_main"), str(p), "8", "--format", "coo,csr,csc,ell,dia", "--verify", "--reps", "50"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout
+    assert "### ROW=3000, COL=3000, NNZ=36000" in out
+    for name in ("CSR", "CSR NUMA", "CSC", "ELL", "ELL NUMA", "DIA", "COO NUMA"):
+        m = re.search(rf"### {name} VERIFY .* = ([0-9.e+-]+) OK", out)
+        assert m and float(m.group(1)) <= 1e-10, (name, out)
+    for name in ("COO", "CSR", "ELL"):
+        assert re.search(rf"### {name} NUMA GFLOPS = [0-9.]+", out) and re.search(rf"### {name} GPU-RESIDENT GFLOPS = [0-9.]+", out)
+
+
+def test_reference_main_cpp_runs_unchanged_on_the_engine(tmp_path, pkg):
+    exe = BIN / "ref_main"
+    if not exe.exists():
+        pytest.skip("ref_main is built only where the reference sources exist (build container)")
+    p = _mtx(tmp_path, pkg, 1500, 8, 23)
+    r = subprocess.run([str(exe), str(p), "4"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "### ROW=1500, COL=1500, NNZ=12000" in r.stdout
+    for fmt in ("COO", "CSR", "CSC", "ELL", "DIA"):  # main.cpp:61,71,81,91,101 and src/mat_vec.cpp:216,285,354,415,470
+        assert re.search(rf"### {fmt} CPU GFLOPS = [0-9.]+", r.stdout), fmt
+        assert re.search(rf"### {fmt} NUMA GFLOPS = [0-9.]+", r.stdout), fmt
+    # main.cpp:20-24: no arguments -> usage, return -1
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 255 and "Usage" in r.stdout

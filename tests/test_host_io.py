@@ -1,0 +1,90 @@
+"""Host logic of the drop-in layer that needs no GPU: the Matrix Market reader (reference src/data_io.cpp:45-105
+behaviour: comments skipped, 1-based -> 0-based, file order kept, size line = rows cols entries), the vector text
+files and the timer.  Called through the C++ symbols of libarmspmv_compat.so (the reference exports C++ names too)."""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import cases
+
+ROOT = Path(__file__).resolve().parent.parent
+LIB = ROOT / "arm-spmv_amd" / "lib" / "libarmspmv_compat.so"
+
+
+class COO(C.Structure):  # include/arm_spmv_compat.hpp == reference include/matrix.h:7-16
+    _fields_ = [("nrow", C.c_int), ("ncol", C.c_int), ("nnz", C.c_int), ("row_ind", C.POINTER(C.c_int)),
+                ("col_ind", C.POINTER(C.c_int)), ("values", C.POINTER(C.c_double))]
+
+
+class Vec(C.Structure):  # reference include/vector.h:7-8
+    _fields_ = [("size", C.c_int), ("values", C.POINTER(C.c_double))]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not LIB.exists():
+        subprocess.run(["make", "host"], cwd=ROOT, check=True, capture_output=True)
+    return C.CDLL(str(LIB))
+
+
+def _write_mtx(path, c, comment=True):
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n")
+        if comment:
+            f.write("% a comment line\n%another\n")
+        f.write(f"{c['nrow']} {c['ncol']} {len(c['val'])}\n")
+        for r, cc, v in zip(c["row"], c["col"], c["val"]):
+            f.write(f"{r + 1} {cc + 1} {v:.17g}\n")
+
+
+@pytest.mark.parametrize("make", cases.SMALL_CASES, ids=lambda f: f.__name__)
+def test_matrix_market_round_trip(lib, tmp_path, make):
+    c = make()
+    p = tmp_path / "m.mtx"
+    _write_mtx(p, c)
+    read = getattr(lib, "_Z13COOMatrixReadPKcR9COOMatrix")
+    read.argtypes = [C.c_char_p, C.POINTER(COO)]
+    A = COO()
+    read(str(p).encode(), C.byref(A))
+    assert (A.nrow, A.ncol, A.nnz) == (c["nrow"], c["ncol"], len(c["val"]))
+    n = A.nnz
+    assert np.array_equal(np.ctypeslib.as_array(A.row_ind, (n,)), c["row"])  # 0-based, file order
+    assert np.array_equal(np.ctypeslib.as_array(A.col_ind, (n,)), c["col"])
+    assert np.array_equal(np.ctypeslib.as_array(A.values, (n,)), c["val"])  # %.17g is round-trip exact
+
+
+def test_vector_files_and_timer(lib, tmp_path):
+    write = getattr(lib, "_Z11VectorWritePKcRK6Vector")
+    read = getattr(lib, "_Z10VectorReadPKcR6Vector")
+    write.argtypes = [C.c_char_p, C.POINTER(Vec)]
+    read.argtypes = [C.c_char_p, C.POINTER(Vec)]
+    x = np.array([0.5, -1.25, 3.0, 1e-3, 0.1])
+    v = Vec(len(x), x.ctypes.data_as(C.POINTER(C.c_double)))
+    p = tmp_path / "v.txt"
+    write(str(p).encode(), C.byref(v))
+    assert p.read_text().split("\n")[0] == "5"
+    back = Vec()
+    read(str(p).encode(), C.byref(back))
+    got = np.ctypeslib.as_array(back.values, (back.size,))
+    assert back.size == 5 and np.allclose(got, x, rtol=1e-15)  # "%20.16g": 16 significant digits (src/data_io.cpp:37)
+    timer = getattr(lib, "_Z7mytimerv")
+    timer.restype = C.c_double
+    assert timer() == 0.0  # the first call returns 0.0 (src/mytime.cpp:10-15)
+    assert timer() >= 0.0
+
+
+def test_reader_rejects_bad_input_like_the_reference(tmp_path):
+    """missing file / bad banner / complex matrices -> message + exit(1) (src/data_io.cpp:53-71); run in a child"""
+    bad = tmp_path / "bad.mtx"
+    bad.write_text("not a banner\n1 1 1\n1 1 1.0\n")
+    cplx = tmp_path / "c.mtx"
+    cplx.write_text("%%MatrixMarket matrix coordinate complex general\n1 1 1\n1 1 1.0 0.0\n")
+    for path, msg in ((tmp_path / "none.mtx", "Failed to open"), (bad, "Could not process Matrix Market banner"),
+                      (cplx, "does not support")):
+        code = ("import ctypes as C; lib=C.CDLL(%r); f=getattr(lib,'_Z13COOMatrixReadPKcR9COOMatrix');"
+                "buf=(C.c_char*64)(); f(%r, buf)") % (str(LIB), str(path).encode())
+        r = subprocess.run(["python3", "-c", code], capture_output=True, text=True)
+        assert r.returncode == 1 and msg in r.stdout, (path, r.stdout, r.stderr)
