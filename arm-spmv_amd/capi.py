@@ -88,6 +88,7 @@ SIGNATURES = {
     "spmv_partition_rows_balanced": (C.c_int, [C.c_int64, _vp, C.c_int32, _vp]),
     "spmv_gen_csr_uniform": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.POINTER(_vp)]),
     "spmv_gen_ell_banded": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.POINTER(_vp)]),
+    "spmv_gen_dia_banded": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_uint64, C.POINTER(_vp)]),
     "spmv_gen_coo_powerlaw": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.POINTER(_vp)]),
     "spmv_gen_vec_uniform": (C.c_int, [_vp, _vp, C.c_int64, C.c_uint64]),
 }
@@ -279,6 +280,11 @@ class Context:
     def gen_ell_banded(self, nrow, ncol, k, seed=1) -> "Matrix":
         h = _vp()
         _check(self._lib.spmv_gen_ell_banded(self.h, nrow, ncol, k, seed, C.byref(h)))
+        return Matrix(self, h)
+
+    def gen_dia_banded(self, nrow, k, seed=1) -> "Matrix":
+        h = _vp()
+        _check(self._lib.spmv_gen_dia_banded(self.h, nrow, k, seed, C.byref(h)))
         return Matrix(self, h)
 
     def gen_coo_powerlaw(self, nrow, ncol, max_len=4096, seed=1) -> "Matrix":

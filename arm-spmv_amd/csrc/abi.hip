@@ -782,6 +782,13 @@ int spmv_gen_ell_banded(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t k, ui
     return gen_ell_banded(ctx, nrow, ncol, k, seed, out);
 }
 
+int spmv_gen_dia_banded(spmv_ctx* ctx, int32_t nrow, int32_t k, uint64_t seed, spmv_mat** out)
+{
+    SPMV_REQUIRE(ctx && out, "spmv_gen_dia_banded: null argument");
+    SPMV_TRY(use_device(ctx));
+    return gen_dia_banded(ctx, nrow, k, seed, out);
+}
+
 int spmv_gen_coo_powerlaw(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t max_len, uint64_t seed, spmv_mat** out)
 {
     SPMV_REQUIRE(ctx && out, "spmv_gen_coo_powerlaw: null argument");

@@ -206,6 +206,7 @@ int gen_csr_uniform(spmv_ctx* ctx, int64_t row_begin, int64_t row_end, int32_t n
                     int32_t band, uint64_t seed, spmv_mat** out);
 int gen_ell_banded(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t k, uint64_t seed,
                    spmv_mat** out);
+int gen_dia_banded(spmv_ctx* ctx, int32_t nrow, int32_t k, uint64_t seed, spmv_mat** out);
 int gen_coo_powerlaw(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t max_len, uint64_t seed,
                      spmv_mat** out);
 int gen_vec_uniform(spmv_ctx* ctx, double* d, int64_t n, int64_t index_offset, uint64_t seed);

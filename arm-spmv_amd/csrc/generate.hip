@@ -213,6 +213,38 @@ int gen_coo_powerlaw(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t max_len,
     return SPMV_OK;
 }
 
+// DIA twin of gen_ell_banded: k diagonals with offsets d - k/2, values (i, d) from the same draw as the ELL
+// generator (index i*k + d), row-major as the reference stores them.  (No wrap-around: entries whose column
+// falls outside [0, nrow) exist in the array but are skipped by the product, src/mat_vec.cpp:140.)
+__global__ __launch_bounds__(kBlock) void gen_dia_banded_kernel(int32_t nrow, int32_t k, uint64_t key_val,
+                                                                int32_t* __restrict__ offsets, double* __restrict__ val)
+{
+    const int64_t total = (int64_t)nrow * k;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock)
+        val[e] = u64_to_sym(splitmix64(key_val + (uint64_t)e));  // e = i*k + d
+    for (int d = blockIdx.x * kBlock + threadIdx.x; d < k; d += gridDim.x * kBlock) offsets[d] = d - k / 2;
+}
+
+int gen_dia_banded(spmv_ctx* ctx, int32_t nrow, int32_t k, uint64_t seed, spmv_mat** out)
+{
+    SPMV_REQUIRE(nrow >= 0 && k >= 0, "bad nrow/k");
+    const size_t total = (size_t)nrow * (size_t)k;
+    spmv_mat*    m     = nullptr;
+    SPMV_TRY(mat_alloc(ctx, SPMV_FMT_DIA, nrow, nrow, (int64_t)total, k, (size_t)k, 0, total, &m));
+    hipLaunchKernelGGL(gen_dia_banded_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(kMaxGrid, ceil_div((int64_t)total, kBlock)))),
+                       dim3(kBlock), 0, ctx->stream, nrow, k, stream_key(seed, kStreamVal), const_cast<int32_t*>(m->a),
+                       const_cast<double*>(m->v));
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess)
+    {
+        mat_free(m);
+        SPMV_FAIL(SPMV_ERR_HIP, "gen_dia_banded: %s", hipGetErrorString(e));
+    }
+    *out = m;
+    return SPMV_OK;
+}
+
 int gen_vec_uniform(spmv_ctx* ctx, double* d, int64_t n, int64_t index_offset, uint64_t seed)
 {
     if (n == 0) return SPMV_OK;

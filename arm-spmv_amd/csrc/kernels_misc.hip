@@ -96,20 +96,39 @@ __global__ __launch_bounds__(kBlock) void csc_kernel(int ncol, const int32_t* __
 
 // ---- DIA: one lane per row, diagonals left to right from y[i] (bit-identical to orc_dia_spmv_fma) ------------
 // The bound check is against nrow, as in the reference (src/mat_vec.cpp:140).
+// The reference stores the diagonals ROW-major (values[i*ndiags + d], src/matrix.cpp:721): a lane walking its own
+// row would make every load instruction touch 64 different lines.  So a workgroup copies a tile of 256 rows x 16
+// diagonals (one 128-byte line per row) into LDS with 16 consecutive lanes per line, and every lane then reads its
+// row from LDS (row stride 17 doubles: conflict-free).  x[i + offset] is contiguous across lanes.
+constexpr int kDiaChunk = 16;
+
 __global__ __launch_bounds__(kBlock) void dia_kernel(int nrow, int ndiags, const int32_t* __restrict__ offsets,
                                                      const double* __restrict__ val, const double* __restrict__ x,
                                                      double* __restrict__ y)
 {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= nrow) return;
-    double        acc = y[i];
-    const double* v   = val + (size_t)i * ndiags;
-    for (int d = 0; d < ndiags; ++d)
+    __shared__ double tile[kBlock * (kDiaChunk + 1)];
+    const int r0 = blockIdx.x * kBlock;
+    const int i  = r0 + threadIdx.x;
+    double    acc = i < nrow ? y[i] : 0.0;
+    for (int d0 = 0; d0 < ndiags; d0 += kDiaChunk)
     {
-        const int j = i + offsets[d];
-        if (j >= 0 && j < nrow) acc = fma(v[d], x[j], acc);
+        const int dn = min(kDiaChunk, ndiags - d0);
+        __syncthreads();  // the previous chunk has been consumed
+        for (int idx = threadIdx.x; idx < kBlock * kDiaChunk; idx += kBlock)
+        {
+            const int r = idx / kDiaChunk, d = idx % kDiaChunk;
+            if (r0 + r < nrow && d < dn)
+                tile[r * (kDiaChunk + 1) + d] = load_stream(val + (size_t)(r0 + r) * ndiags + d0 + d);
+        }
+        __syncthreads();
+        if (i < nrow)
+            for (int d = 0; d < dn; ++d)
+            {
+                const int j = i + offsets[d0 + d];  // wave-uniform address: scalar load
+                if (j >= 0 && j < nrow) acc = fma(tile[threadIdx.x * (kDiaChunk + 1) + d], x[j], acc);
+            }
     }
-    y[i] = acc;
+    if (i < nrow) y[i] = acc;
 }
 
 inline int stream_grid(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(kMaxGrid, ceil_div(n, kBlock))); }

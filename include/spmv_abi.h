@@ -200,6 +200,8 @@ int spmv_gen_csr_uniform(spmv_ctx* ctx, int64_t row_begin, int64_t row_end, int3
 int spmv_gen_ell_banded(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t k, uint64_t seed,
                         spmv_mat** out);
 /* Row-sorted COO with power-law row lengths min(max_len, floor(8/u)), u ~ U(0,1], uniform columns. */
+/* DIA (row-major, reference layout) with k diagonals at offsets d - k/2, same value draws as spmv_gen_ell_banded. */
+int spmv_gen_dia_banded(spmv_ctx* ctx, int32_t nrow, int32_t k, uint64_t seed, spmv_mat** out);
 int spmv_gen_coo_powerlaw(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t max_len, uint64_t seed,
                           spmv_mat** out);
 /* v[i] = U(0,1) drawn from (seed, global index index_offset + i). */

@@ -458,3 +458,21 @@ def test_large_coo_takes_the_panel_path_and_matches_oracle(ctx, orc, pkg):
     ol.csr_abs_row_sums(orc, rp, cc, cv, hx, scale)
     ol.assert_parity(hp, ref, scale, "large coo, panel path")
     ol.assert_parity(hs, ref, scale, "large coo, segmented scan")
+
+
+@pytest.mark.parametrize("nrow,k", [(5000, 64), (1001, 20), (257, 1), (4096, 17)])
+def test_dia_tiled_kernel_is_bitwise_oracle_fma(ctx, orc, pkg, nrow, k):
+    """the LDS-tiled DIA product adds a row's diagonals left to right from y[i], like the reference"""
+    synth = pkg.synth
+    A = ctx.gen_dia_banded(nrow, k, seed=6)
+    off, _, val = A.download()
+    assert np.array_equal(off, np.arange(k) - k // 2)
+    assert np.array_equal(val, synth.to_sym(synth._draw(synth.stream_key(6, synth.STREAM_VAL), np.arange(nrow * k, dtype=np.uint64))))
+    x = synth.vec_uniform(nrow, seed=6)
+    y0 = synth.vec_uniform(nrow, seed=60)
+    dy = ctx.vector_from(y0)
+    ctx.apply(A, ctx.vector_from(x), dy)
+    ctx.sync()
+    ref = y0.copy()
+    ol.dia_spmv(orc, nrow, ol.i32(off), ol.f64(val), x, ref, fma=True)
+    assert np.array_equal(dy.download(), ref)

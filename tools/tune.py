@@ -37,7 +37,7 @@ def sweep(ctx, A, x, y, variants, rounds, reps, bytes_launch, nnz):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["csr", "ell", "coo", "blas1", "bandwin"])
+    ap.add_argument("what", choices=["csr", "ell", "coo", "blas1", "bandwin", "dia"])
     ap.add_argument("--n", type=int, default=0)
     ap.add_argument("--k", type=int, default=0)
     ap.add_argument("--band", type=int, default=0)
@@ -69,6 +69,14 @@ def main():
             ctx.dot(x, y)  # synchronous (returns the scalar)
         ms = (time.perf_counter() - t) / 20 * 1e3
         print(f"{'dot':16s} n={n}: {ms:.4f} ms  {16 * n / ms / 1e6:.1f} GB/s (incl. result read-back)")
+        return
+    if a.what == "dia":
+        n, k = a.n or 4_000_000, a.k or 64
+        A = ctx.gen_dia_banded(n, k, seed=1)
+        x, y = ctx.gen_vector(n, seed=1), ctx.vector(n)
+        y.fill(0.0)
+        # DIA streams 8 bytes per stored entry (no index array): values + x + y read/write
+        sweep(ctx, A, x, y, [("dia tiled", lambda A: None)], a.rounds, a.reps, 8 * n * k + 8 * n + 16 * n, n * k)
         return
     if a.what == "bandwin":
         # non-wrapping band: rows [w, n-w) of the band matrix, so that every row block's window fits LDS
