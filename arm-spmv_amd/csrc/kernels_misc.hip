@@ -110,17 +110,30 @@ __global__ __launch_bounds__(kBlock) void dia_kernel(int nrow, int ndiags, const
     const int r0 = blockIdx.x * kBlock;
     const int i  = r0 + threadIdx.x;
     double    acc = i < nrow ? y[i] : 0.0;
+    // element j of this lane's share of a chunk: tile position (r, d) = ((lane + 256 j) / 16, (lane + 256 j) % 16)
+    const int d_mine = threadIdx.x % kDiaChunk;
+    const int r_mine = threadIdx.x / kDiaChunk;  // + 16 j
+    double    stage[kDiaChunk];
+    auto fetch = [&](int d0) {
+#pragma unroll
+        for (int j = 0; j < kDiaChunk; ++j)
+        {
+            const int r = r_mine + j * (kBlock / kDiaChunk);
+            stage[j]    = (r0 + r < nrow && d0 + d_mine < ndiags)
+                              ? load_stream(val + (size_t)(r0 + r) * ndiags + d0 + d_mine)
+                              : 0.0;
+        }
+    };
+    fetch(0);
     for (int d0 = 0; d0 < ndiags; d0 += kDiaChunk)
     {
         const int dn = min(kDiaChunk, ndiags - d0);
         __syncthreads();  // the previous chunk has been consumed
-        for (int idx = threadIdx.x; idx < kBlock * kDiaChunk; idx += kBlock)
-        {
-            const int r = idx / kDiaChunk, d = idx % kDiaChunk;
-            if (r0 + r < nrow && d < dn)
-                tile[r * (kDiaChunk + 1) + d] = load_stream(val + (size_t)(r0 + r) * ndiags + d0 + d);
-        }
+#pragma unroll
+        for (int j = 0; j < kDiaChunk; ++j)
+            tile[(r_mine + j * (kBlock / kDiaChunk)) * (kDiaChunk + 1) + d_mine] = stage[j];
         __syncthreads();
+        if (d0 + kDiaChunk < ndiags) fetch(d0 + kDiaChunk);  // in flight while this chunk is consumed
         if (i < nrow)
             for (int d = 0; d < dn; ++d)
             {
