@@ -126,6 +126,7 @@ static int finish(spmv_mat* m, spmv_mat** out)
     int rc = SPMV_OK;
     if (m->format == SPMV_FMT_CSR) rc = csr_analyse(m);
     if (m->format == SPMV_FMT_COO) rc = coo_analyse(m);
+    if (m->format == SPMV_FMT_CSC) rc = csc_analyse(m);
     if (rc != SPMV_OK)
     {
         mat_free(m);

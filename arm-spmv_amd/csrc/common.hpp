@@ -191,6 +191,7 @@ int coo_build_panel(spmv_mat* m, bool only_if_worth);
 int coo_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 // kernels_misc.hip (CSC, DIA, BLAS-1, fill)
 int csc_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
+int csc_analyse(spmv_mat* m);
 int dia_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 int vec_fill(spmv_ctx* ctx, double* d, int64_t n, double a);
 int vec_dot(spmv_ctx* ctx, const double* x, const double* y, int64_t n, double* result);

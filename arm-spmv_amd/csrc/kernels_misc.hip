@@ -194,9 +194,57 @@ int vec_axpby(spmv_ctx* ctx, double alpha, const double* x, double beta, const d
     return SPMV_OK;
 }
 
+// Large CSC: one fp64 atomic per entry is an order of magnitude slower than the row-grouped panel product, so the
+// handle is regrouped by row once (expand col_ptr to per-entry columns, then the same device path as a COO handle:
+// spmv_coo_to_csr + panel layout); the scatter kernel stays for small matrices.  Same sums, different order.
+template <int LPC>
+__global__ __launch_bounds__(kBlock) void csc_expand_cols_kernel(int ncol, const int32_t* __restrict__ col_ptr,
+                                                                 int32_t* __restrict__ col_of_entry)
+{
+    const int c = blockIdx.x * (kBlock / LPC) + threadIdx.x / LPC;
+    if (c >= ncol) return;
+    const int end = col_ptr[c + 1];
+    for (int j = col_ptr[c] + threadIdx.x % LPC; j < end; j += LPC) col_of_entry[j] = c;
+}
+
+int csc_analyse(spmv_mat* m)
+{
+    const bool worth = m->nnz >= ((int64_t)2 << 20) && m->nrow > 0 && m->nnz / m->nrow >= 2 &&
+                       m->nnz <= (int64_t)INT32_MAX - 65536;
+    if (!worth || m->coo_csr) return SPMV_OK;
+    spmv_ctx* ctx = m->ctx;
+    int32_t*  cols = nullptr;
+    SPMV_HIP(hipMalloc(&cols, sizeof(int32_t) * (size_t)m->nnz));
+    constexpr int LPC = 8;
+    hipLaunchKernelGGL(csc_expand_cols_kernel<LPC>, dim3((unsigned)ceil_div(m->ncol, kBlock / LPC)), dim3(kBlock), 0,
+                       ctx->stream, m->ncol, m->a, cols);
+    // a borrowed COO view of the same entries: rows = row_ind (column-major order), columns = expanded
+    spmv_mat view;
+    view.ctx    = ctx;
+    view.format = SPMV_FMT_COO;
+    view.nrow   = m->nrow;
+    view.ncol   = m->ncol;
+    view.nnz    = m->nnz;
+    view.a      = m->b;  // CSC row_ind
+    view.b      = cols;
+    view.v      = m->v;
+    view.owned  = false;
+    view.kernel_forced = true;  // no panel build for the temporary view itself
+    int rc = coo_analyse(&view);  // sortedness of the row indices
+    if (rc == SPMV_OK) rc = coo_build_panel(&view, /*only_if_worth=*/false);
+    hipStreamSynchronize(ctx->stream);
+    hipFree(cols);
+    if (rc != SPMV_OK) return rc;
+    m->coo_csr = view.coo_csr;  // adopt; `view` itself owns nothing else
+    m->device_bytes += m->coo_csr->device_bytes;
+    view.coo_csr = nullptr;
+    return SPMV_OK;
+}
+
 int csc_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
 {
     if (A->ncol == 0 || A->nnz == 0) return SPMV_OK;
+    if (A->coo_csr && !A->kernel_forced) return csr_panel_apply(ctx, A->coo_csr, x, y);
     constexpr int LPC = 8;
     hipLaunchKernelGGL(csc_kernel<LPC>, dim3((unsigned)ceil_div(A->ncol, kBlock / LPC)), dim3(kBlock), 0, ctx->stream,
                        A->ncol, A->a, A->b, A->v, x, y);

@@ -476,3 +476,23 @@ def test_dia_tiled_kernel_is_bitwise_oracle_fma(ctx, orc, pkg, nrow, k):
     ref = y0.copy()
     ol.dia_spmv(orc, nrow, ol.i32(off), ol.f64(val), x, ref, fma=True)
     assert np.array_equal(dy.download(), ref)
+
+
+def test_large_csc_is_regrouped_by_row_and_matches_oracle(ctx, orc, pkg):
+    """CSC beyond 2M entries: regrouped by row on the device (panel product); forcing VECTOR keeps the atomic scatter"""
+    synth, capi = pkg.synth, pkg.capi
+    n, k = 300_000, 16
+    rp, col, val = synth.csr_uniform(0, n, n, k, seed=31)
+    row = np.repeat(np.arange(n, dtype=np.int32), k)
+    cp, cr, cw = ol.coo_to_csc(orc, n, row, col, val)
+    x = synth.vec_uniform(n, seed=31)
+    ref, scale = np.zeros(n), np.zeros(n)
+    ol.csc_spmv(orc, cp, cr, cw, x, ref)
+    ol.csr_abs_row_sums(orc, rp, col, val, x, scale)
+    A = ctx.csc(n, n, cp, cr, cw)
+    assert A.info.device_bytes > 12 * n * k + 14 * n * k - 1  # CSC arrays + the panel copy
+    for forced in (False, True):
+        if forced:
+            A.set_kernel(capi.CSR_VECTOR)
+        y1, _ = _apply_n(ctx, A, x, n, 1)
+        ol.assert_parity(y1, ref, scale, f"large csc forced_scatter={forced}")
