@@ -262,12 +262,12 @@ int launch_ldswin(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, 
 #define SPMV_LAUNCH_LPR(L)                                                                                      \
     case L:                                                                                                     \
     {                                                                                                           \
-        static bool granted = false;                                                                            \
-        if (!granted)                                                                                           \
+        static unsigned long long granted = 0; /* bit per device */                                                                            \
+        if (!((granted >> ctx->device) & 1ull))                                                                                         \
         {                                                                                                       \
             SPMV_HIP(hipFuncSetAttribute((const void*)csr_ldswin_kernel<L, false>,                              \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, kWinDoubles * 8));         \
-            granted = true;                                                                                     \
+            granted |= 1ull << ctx->device;                                                                                     \
         }                                                                                                       \
         hipLaunchKernelGGL((csr_ldswin_kernel<L, false>), dim3(nblocks), dim3(kBlock), lds, s, A->nrow, A->a, A->b, \
                            A->v, x, y, A->win_lo, A->win_span);                                                 \

@@ -466,6 +466,8 @@ int csr_panel_build(spmv_mat* m)
         double*   sval = sort ? tval : m->pb_val;
         hipLaunchKernelGGL(panel_scatter_kernel, dim3(ngroups), dim3(256), sizeof(int32_t) * P, s, m->nrow, G, W, P, m->a,
                            m->b, m->v, tile_ptr, scol, srow, sval);
+        if (sort && sizeof(int32_t) * (W / kLineDoubles + 1) > 65536)  // one bin per x line of the panel, in LDS
+            hipFuncSetAttribute((const void*)panel_line_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160000);
         if (sort)
             hipLaunchKernelGGL(panel_line_sort_kernel, dim3((unsigned)ngroups * P), dim3(256),
                                sizeof(int32_t) * (W / kLineDoubles + 1), s, G, W, P, m->nrow, m->a, tile_ptr, tcol, trow,
@@ -616,12 +618,12 @@ int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y
 #define SPMV_PANEL_CASE(U, GT, LY)                                                                                   \
     if (unroll == U && gated == GT && layout == LY)                                                                   \
     {                                                                                                                \
-        static bool granted = false;                                                                                 \
-        if (!granted)                                                                                                \
+        static unsigned long long granted = 0; /* bit per device */                                                                                 \
+        if (!((granted >> ctx->device) & 1ull))                                                                                              \
         {                                                                                                            \
             SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_kernel<U, GT, LY>,                                   \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160000));                       \
-            granted = true;                                                                                          \
+            granted |= 1ull << ctx->device;                                                                                          \
         }                                                                                                            \
         hipLaunchKernelGGL((csr_panel_kernel<U, GT, LY>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream, A->nrow,  \
                            G, A->pb_ngroups, A->a, A->pb_col, A->pb_row,                  \
@@ -656,12 +658,12 @@ int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y
 #define SPMV_PANEL_PIPE(U)                                                                                           \
     if (unroll == U)                                                                                                 \
     {                                                                                                                \
-        static bool granted = false;                                                                                 \
-        if (!granted)                                                                                                \
+        static unsigned long long granted = 0; /* bit per device */                                                                                 \
+        if (!((granted >> ctx->device) & 1ull))                                                                                              \
         {                                                                                                            \
             SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_kernel<U, false, 0, 0, true>,                        \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160000));                       \
-            granted = true;                                                                                          \
+            granted |= 1ull << ctx->device;                                                                                          \
         }                                                                                                            \
         hipLaunchKernelGGL((csr_panel_kernel<U, false, 0, 0, true>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream, \
                            A->nrow, G, A->pb_ngroups, A->a, A->pb_col, A->pb_row, A->pb_val, x, y, gate, pop, nchunk,  \

@@ -7,9 +7,12 @@
 //   * only `matrix coordinate complex` is refused (:66-71); `symmetric` files are NOT expanded and `pattern`
 //     files are read with the same three-field format (a pattern file therefore mis-parses, as it does there)
 //   * entries are read as "%d %d %lg", 1-based -> 0-based (:83-88); failures print and exit(1)
+#include <algorithm>
 #include <cctype>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <vector>
 #include <sys/time.h>
 
 #include "arm_spmv_compat.hpp"
@@ -80,6 +83,99 @@ int mm_size_read(FILE* fp, int* rows, int* cols, int* entries)
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Parallel entry parser (the fscanf loop is the wall-clock bottleneck for real files).
+// Same semantics as `fscanf("%d %d %lg\n")` repeated nz times: the rest of the file is a stream of
+// whitespace-separated tokens, entry k = tokens 3k, 3k+1, 3k+2 (line boundaries do not matter — which is also why a
+// `pattern` file mis-parses exactly as it does in the reference).  The remainder of the file is read in one go, cut
+// into slices at whitespace, tokens are counted per slice, and every thread converts its own tokens in place.
+// Returns false (nothing consumed) when it declines: small files, one thread, or a read problem.
+// ---------------------------------------------------------------------------------------------------------
+static inline bool is_space(char c) { return c == ' ' || c == '\n' || c == '\t' || c == '\r' || c == '\f' || c == '\v'; }
+
+static bool parse_entries_parallel(FILE* fp, int nz, int* ii, int* jj, double* vv)
+{
+    const char* env      = getenv("SPMV_MTX_THREADS");
+    unsigned    nthreads = env ? (unsigned)atoi(env) : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (nthreads <= 1 || nz < (1 << 16)) return false;
+    const long here = ftell(fp);
+    if (here < 0 || fseek(fp, 0, SEEK_END) != 0) return false;
+    const long end = ftell(fp);
+    if (end < here || fseek(fp, here, SEEK_SET) != 0) return false;
+    std::vector<char> buf((size_t)(end - here) + 1);
+    if (fread(buf.data(), 1, (size_t)(end - here), fp) != (size_t)(end - here))
+    {
+        fseek(fp, here, SEEK_SET);
+        return false;
+    }
+    buf.back() = '\0';
+    const size_t len = buf.size() - 1;
+
+    // slice boundaries at the start of a token
+    std::vector<size_t> cut(nthreads + 1, len);
+    cut[0] = 0;
+    for (unsigned t = 1; t < nthreads; ++t)
+    {
+        size_t p = len / nthreads * t;
+        while (p < len && !is_space(buf[p])) ++p;  // finish the token we landed in
+        cut[t] = p;
+    }
+    // pass 1: tokens per slice
+    std::vector<long long> first(nthreads + 1, 0);
+    auto count = [&](unsigned t) {
+        long long n = 0;
+        bool      in = false;
+        for (size_t p = cut[t]; p < cut[t + 1]; ++p)
+        {
+            const bool sp = is_space(buf[p]);
+            if (!sp && !in) ++n;
+            in = !sp;
+        }
+        first[t + 1] = n;
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nthreads; ++t) pool.emplace_back(count, t);
+    for (auto& th : pool) th.join();
+    for (unsigned t = 0; t < nthreads; ++t) first[t + 1] += first[t];
+    if (first[nthreads] < 3LL * nz)
+    {
+        printf("*** Matrix Market file ends after %lld of %d entries ***\n", first[nthreads] / 3, nz);
+        exit(1);
+    }
+    // pass 2: convert
+    std::vector<int> bad(nthreads, 0);
+    auto convert = [&](unsigned t) {
+        long long tok = first[t];
+        size_t    p   = cut[t];
+        while (p < cut[t + 1] && tok < 3LL * nz)
+        {
+            while (p < cut[t + 1] && is_space(buf[p])) ++p;
+            if (p >= cut[t + 1]) break;
+            char*           stop = nullptr;
+            const long long k    = tok / 3;
+            switch (tok % 3)
+            {
+                case 0: ii[k] = (int)strtol(&buf[p], &stop, 10) - 1; break;
+                case 1: jj[k] = (int)strtol(&buf[p], &stop, 10) - 1; break;
+                default: vv[k] = strtod(&buf[p], &stop); break;
+            }
+            if (stop == &buf[p]) bad[t] = 1;  // not a number: fscanf would have stopped here
+            while (p < cut[t + 1] && !is_space(buf[p])) ++p;
+            ++tok;
+        }
+    };
+    pool.clear();
+    for (unsigned t = 0; t < nthreads; ++t) pool.emplace_back(convert, t);
+    for (auto& th : pool) th.join();
+    for (unsigned t = 0; t < nthreads; ++t)
+        if (bad[t])
+        {
+            printf("*** Matrix Market file holds a non-numeric token among its entries ***\n");
+            exit(1);
+        }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // COO / CSR / CSC / ELL readers (include/data_io.h:12-15)
 // ---------------------------------------------------------------------------------------------------------
 void COOMatrixRead(const char* filename, COOMatrix& A)
@@ -114,15 +210,19 @@ void COOMatrixRead(const char* filename, COOMatrix& A)
     double* vv = new double[nz > 0 ? nz : 1];
 
     printf("\tReading matrix entries from file\n");
-    for (int k = 0; k < nz; ++k)
+    if (!parse_entries_parallel(fp, nz, ii, jj, vv))
     {
-        if (fscanf(fp, "%d %d %lg\n", &ii[k], &jj[k], &vv[k]) != 3)
+        // small file, or threads disabled (SPMV_MTX_THREADS=1): the reference's loop (src/data_io.cpp:83-88)
+        for (int k = 0; k < nz; ++k)
         {
-            printf("*** Matrix Market file ends after %d of %d entries ***\n", k, nz);
-            exit(1);
+            if (fscanf(fp, "%d %d %lg\n", &ii[k], &jj[k], &vv[k]) != 3)
+            {
+                printf("*** Matrix Market file ends after %d of %d entries ***\n", k, nz);
+                exit(1);
+            }
+            --ii[k];
+            --jj[k];
         }
-        --ii[k];
-        --jj[k];
     }
     fclose(fp);
     printf("### ROW=%d, COL=%d, NNZ=%d\n", nrow, ncol, nz);

@@ -40,8 +40,11 @@ def _write_mtx(path, c, comment=True):
             f.write(f"{r + 1} {cc + 1} {v:.17g}\n")
 
 
-@pytest.mark.parametrize("make", cases.SMALL_CASES, ids=lambda f: f.__name__)
-def test_matrix_market_round_trip(lib, tmp_path, make):
+@pytest.mark.parametrize("threads", ["1", "5"])
+@pytest.mark.parametrize("make", cases.ALL_CASES, ids=lambda f: f.__name__)
+def test_matrix_market_round_trip(lib, tmp_path, make, threads, monkeypatch):
+    """threads=1: the reference's fscanf loop; threads=5: the parallel token parser (files >= 65536 entries: c1)"""
+    monkeypatch.setenv("SPMV_MTX_THREADS", threads)
     c = make()
     p = tmp_path / "m.mtx"
     _write_mtx(p, c)
