@@ -39,6 +39,12 @@ def allgather_x(x_full: torch.Tensor, x_own: torch.Tensor, nrow: int, group=None
         raise ValueError(f"rank {rank} owns rows [{b},{e}) but passed a slice of {x_own.numel()} entries")
     if x_full.numel() != nrow:
         raise ValueError(f"x_full has {x_full.numel()} entries, expected {nrow}")
+    if x_full.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal only (several ranks sharing one GPU, where RCCL refuses to run): stage through the host
+        host = torch.empty(nrow, dtype=x_full.dtype)
+        allgather_x(host, x_own.cpu(), nrow, group)
+        x_full.copy_(host)
+        return
     if nrow % world == 0:
         dist.all_gather_into_tensor(x_full, x_own.contiguous(), group=group)
         return

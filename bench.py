@@ -137,14 +137,21 @@ def main() -> None:
         sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 through torch.distributed.run (see docstring)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # SPMV_BENCH_BACKEND=gloo rehearses the N>1 control flow with several ranks on ONE GPU (RCCL needs one GPU per
+    # rank); the measured configuration is always the default: nccl (= RCCL on ROCm), rank r on GPU r
+    backend = os.environ.get("SPMV_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
-        ctx = capi.Context(local_rank, stream=stream.cuda_stream)
+        ctx = capi.Context(dev_index, stream=stream.cuda_stream)
         n, k = args.n, args.k
         ncol = n * world
         row_begin, row_end = shard.shard_rows(ncol, world, rank)  # equal rows per rank (src/mat_vec.cpp:245-246)
