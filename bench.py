@@ -106,8 +106,9 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)  # NUM_TEST, main.cpp:16
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=10_000_000, help="rows per GPU")
-    ap.add_argument("--k", type=int, default=32, help="entries per row")
+    # (no short spellings such as --n: torch.distributed.run would claim them as abbreviations of its own options)
+    ap.add_argument("--rows", dest="n", type=int, default=10_000_000, help="rows per GPU")
+    ap.add_argument("--per-row", dest="k", type=int, default=32, help="entries per row")
     ap.add_argument("--band", type=int, default=0, help="0 = uniform columns; >0 = random within a band of this width")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--kernel", type=int, default=0, help="spmv_csr_kernel id (0 = auto)")
