@@ -156,7 +156,7 @@ struct spmv_mat
     void*     pb_rec         = nullptr;  // [nnz] 16-byte records {value, column, local row} (replaces the three arrays)
     int32_t   pb_aos         = 0;        // build 16-byte records (one load instruction per entry); measured slower
     int32_t   pb_pace_ns     = 0;        // pacing throttle in effect: nanoseconds per chunk on the chip clock (0 = off)
-    int32_t   pb_pipe        = 0;        // software-pipeline the chunks (next chunk's stream in flight during the gathers)
+    int32_t   pb_pipe        = 1;       // software-pipeline the chunks (next chunk's stream in flight during the gathers)
     int32_t   pb_ablate      = 0;       // timing experiments only (wrong results): see PanelBatch::apply
     int32_t   pb_pace_req    = -1;       // requested pace (-1 = try a few and keep the fastest)
     int32_t   pb_pace_tuned_unroll = 0;  // chunk size (unroll) the pace in effect was tried for; 0 = not tried

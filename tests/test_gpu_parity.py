@@ -395,8 +395,11 @@ def test_csr_panel_kernel_matches_reference_golden(ctx, orc, pkg, make):
     g = golden(c["name"])
     rp, cc, cv = _csr_of(orc, c)
     scale = _scale(orc, c)
-    for rows, width, srt, aos, unroll, skew in ((0, 0, 1, 1, 8, 2), (0, 0, 0, 0, 4, 0), (37, 16, 1, 1, 2, 1), (1000, 1024, 1, 0, 16, 3),
-                                                (20000, 4096, 0, 1, 4, 12), (5, 48, 1, 0, 8, 2), (3, 16, 1, 1, 2, 2)):
+    # (rows per group, panel width, line sort, 16-byte records, unroll, counter-gate skew, pipelined, pace ns)
+    for rows, width, srt, aos, unroll, skew, pipe, pace in (
+            (0, 0, 1, 1, 8, 2, 0, -1), (0, 0, 0, 0, 4, 0, 1, 0), (37, 16, 1, 1, 2, 1, 0, 0), (1000, 1024, 1, 0, 16, 3, 1, 500),
+            (20000, 4096, 0, 1, 4, 12, 1, 0), (5, 48, 1, 0, 8, 2, 0, 0), (3, 16, 1, 1, 2, 2, 1, 0), (500, 512, 1, 0, 8, 0, 1, 2000),
+            (64, 64, 1, 0, 2, 0, 1, -1), (0, 0, 1, 0, 8, 0, 0, 300)):
         A = ctx.csr(c["nrow"], c["ncol"], rp, cc, cv)
         A.set_param("panel_rows", rows)
         A.set_param("panel_width", width)
@@ -404,9 +407,11 @@ def test_csr_panel_kernel_matches_reference_golden(ctx, orc, pkg, make):
         A.set_param("panel_aos", aos)
         A.set_param("panel_unroll", unroll)
         A.set_param("panel_skew", skew)
+        A.set_param("panel_pipe", pipe)
+        A.set_param("panel_pace_ns", pace)
         A.set_kernel(pkg.capi.CSR_PANEL)
         y1, y50 = _apply_n(ctx, A, c["x"], c["nrow"], NUM_TEST)
-        what = f"{c['name']} panel rows={rows} width={width} sort={srt} aos={aos} unroll={unroll} skew={skew}"
+        what = f"{c['name']} panel rows={rows} width={width} sort={srt} aos={aos} unroll={unroll} skew={skew} pipe={pipe} pace={pace}"
         ol.assert_parity(y1, g["y1_csr"], scale, what + " 1 call")
         ol.assert_parity(y50, g["y50_csr"], scale, what + " 50 calls", reps=NUM_TEST)
 
