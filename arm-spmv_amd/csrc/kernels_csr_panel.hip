@@ -538,8 +538,13 @@ int panel_choose_pace(spmv_mat* m)
         return SPMV_OK;
     }
     const int  unroll = m->pb_unroll > 0 ? m->pb_unroll : 8;
-    if (m->pb_pace_tuned_unroll == unroll) return SPMV_OK;  // already tried for this layout and chunk size
-    m->pb_pace_ns     = 0;
+    if (m->pb_pace_tuned_unroll == unroll)
+    {
+        m->pb_pace_ns = m->pb_pace_tuned_ns;  // already tried for this layout and chunk size
+        return SPMV_OK;
+    }
+    m->pb_pace_ns       = 0;
+    m->pb_pace_tuned_ns = 0;
     const bool worth  = (double)m->ncol * 8.0 > 4.0 * 1048576.0 && m->pb_max_group_nnz >= 8LL * unroll * kPanelThreads;
     if (!worth) return SPMV_OK;  // x fits L2 or the groups are a few chunks long: nothing to keep in step
     double *x = nullptr, *y = nullptr;
@@ -582,6 +587,7 @@ int panel_choose_pace(spmv_mat* m)
     hipFree(x);
     hipFree(y);
     m->pb_pace_ns           = rc == SPMV_OK ? best_pace : 0;
+    m->pb_pace_tuned_ns     = m->pb_pace_ns;
     m->pb_pace_tuned_unroll = rc == SPMV_OK ? unroll : 0;
     return rc;
 }
