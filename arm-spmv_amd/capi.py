@@ -71,6 +71,7 @@ SIGNATURES = {
     "spmv_dia_upload": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, C.POINTER(_vp)]),
     "spmv_mat_destroy": (C.c_int, [_vp]),
     "spmv_mat_get_info": (C.c_int, [_vp, C.POINTER(MatInfo)]),
+    "spmv_mat_validate": (C.c_int, [_vp]),
     "spmv_mat_set_kernel": (C.c_int, [_vp, C.c_int32, C.c_int32]),
     "spmv_mat_set_flags": (C.c_int, [_vp, C.c_uint32]),
     "spmv_mat_set_param": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
@@ -376,6 +377,10 @@ class Matrix:
         except Exception:
             pass
         self.h = None
+
+    def validate(self) -> None:
+        """raise SpmvError if an index is out of range or an offset array is inconsistent"""
+        _check(self.ctx._lib.spmv_mat_validate(self.h))
 
     @property
     def info(self) -> MatInfo:

@@ -123,10 +123,12 @@ static int wrap(spmv_ctx* ctx, int32_t format, int32_t nrow, int32_t ncol, int64
 
 static int finish(spmv_mat* m, spmv_mat** out)
 {
-    int rc = SPMV_OK;
-    if (m->format == SPMV_FMT_CSR) rc = csr_analyse(m);
-    if (m->format == SPMV_FMT_COO) rc = coo_analyse(m);
-    if (m->format == SPMV_FMT_CSC) rc = csc_analyse(m);
+    // The analysis and layout builders index by row and column (histograms in LDS, scatter cursors): a malformed
+    // matrix must be refused before they run — an out-of-bounds access on the GPU can take the whole node down.
+    int rc = mat_validate(m);
+    if (rc == SPMV_OK && m->format == SPMV_FMT_CSR) rc = csr_analyse(m);
+    if (rc == SPMV_OK && m->format == SPMV_FMT_COO) rc = coo_analyse(m);
+    if (rc == SPMV_OK && m->format == SPMV_FMT_CSC) rc = csc_analyse(m);
     if (rc != SPMV_OK)
     {
         mat_free(m);
@@ -489,6 +491,13 @@ int spmv_mat_destroy(spmv_mat* m)
     hipStreamSynchronize(m->ctx->stream);
     mat_free(m);
     return SPMV_OK;
+}
+
+int spmv_mat_validate(const spmv_mat* m)
+{
+    SPMV_REQUIRE(m, "null matrix");
+    SPMV_TRY(use_device(m->ctx));
+    return mat_validate(m);
 }
 
 int spmv_mat_get_info(const spmv_mat* m, spmv_mat_info* info)

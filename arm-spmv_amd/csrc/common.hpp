@@ -198,6 +198,8 @@ int vec_fill(spmv_ctx* ctx, double* d, int64_t n, double a);
 int vec_dot(spmv_ctx* ctx, const double* x, const double* y, int64_t n, double* result);
 int vec_axpby(spmv_ctx* ctx, double alpha, const double* x, double beta, const double* y, double* w,
               int64_t n);
+// validate.hip
+int mat_validate(const spmv_mat* m);
 // convert.hip
 int exclusive_scan_i32(spmv_ctx* ctx, const int32_t* in, int32_t* out, int64_t n);
 int coo_to_csr(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out);

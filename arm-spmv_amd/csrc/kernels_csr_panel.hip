@@ -1,5 +1,6 @@
-// kernels_csr_panel.hip — CSR `y += A*x` for matrices whose x does not fit L2 and whose columns have no
-// locality (BASELINE config 2: N = 10M, 32 uniform-random columns per row).
+// kernels_csr_panel.hip — CSR `y += A*x` through a re-ordered copy of the matrix; the kernel behind BASELINE
+// config 2 (N = 10M, 32 uniform-random columns per row), and — measured — the fastest CSR path for every matrix with
+// enough entries to occupy the chip (banded ones included).  Replaces CSRMatrixMatVector, src/mat_vec.cpp:44-67.
 //
 // Why the plain row-parallel kernel is slow there (measured, profiles/r01_*): every 8-byte gather of x
 // misses the 4 MiB L2 of its XCD and drags a 128-byte line across the fabric — 320M gathers move ~43 GB
@@ -19,7 +20,10 @@
 // round, and every other gather hits L2.  Products are added into the group's accumulators in LDS with
 // ds_add_f64; at the end the accumulators are added to y with coalesced accesses.  Because consecutive
 // entries of a panel are sorted by x line, lanes of one wavefront instruction often share a line, which cuts
-// the number of L1<->L2 line transfers — the next bottleneck (one 128-byte line per ~2 clocks per CU).
+// the number of L2->L1 line transfers — the bound once the fabric traffic is under control: a divergent gather
+// costs one 128-byte line transfer per distinct line (256 Glines/s chip-wide = the L2's ~33 TB/s), whatever the
+// load flavour; ablation: the LDS adds are free, the gathers are 0.83 ms of C2's 1.60 (profiles/r01_ablation_*).
+// Staying "in step" is not automatic: see the throttles below (counter gate, clock pace) and panel_choose_pace.
 //
 // Algorithmic bytes are still counted with CSR's 12 bytes per entry, so the extra 2 bytes and
 // the repeated x sweeps show up as a lower roofline fraction, not as hidden traffic.

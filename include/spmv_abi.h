@@ -141,6 +141,10 @@ int spmv_dia_upload(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t ndiags,
 
 int spmv_mat_destroy(spmv_mat* m);
 int spmv_mat_get_info(const spmv_mat* m, spmv_mat_info* info);
+/* Structural check for untrusted input (the products themselves, like the reference's loops, never check an index):
+ * every row/column index inside its range, offset arrays non-decreasing from 0 to the entry count.
+ * SPMV_ERR_INVALID + message if not.  One pass over the index arrays; synchronous. */
+int spmv_mat_validate(const spmv_mat* m);
 /* Force a CSR kernel (and, for VECTOR, lanes_per_row in {1,2,4,...,64}; 0 = keep auto choice). */
 int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row);
 int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);

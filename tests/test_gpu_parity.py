@@ -501,3 +501,25 @@ def test_large_csc_is_regrouped_by_row_and_matches_oracle(ctx, orc, pkg):
             A.set_kernel(capi.CSR_VECTOR)
         y1, _ = _apply_n(ctx, A, x, n, 1)
         ol.assert_parity(y1, ref, scale, f"large csc forced_scatter={forced}")
+
+
+def test_malformed_matrices_are_refused_before_any_kernel_indexes_with_them(ctx, pkg):
+    """the reference never checks an index; on a GPU an out-of-bounds access can reset the node, so handles are
+    validated when they are created (and on demand: spmv_mat_validate)"""
+    Err = pkg.capi.SpmvError
+    rp = np.array([0, 2, 4], np.int32)
+    val = np.ones(4)
+    with pytest.raises(Err, match="index out of range"):
+        ctx.csr(2, 3, rp, np.array([0, 1, 2, 3], np.int32), val)  # column 3 of 3
+    with pytest.raises(Err, match="index out of range"):
+        ctx.csr(2, 3, rp, np.array([0, -1, 2, 1], np.int32), val)
+    with pytest.raises(Err, match="offsets decrease"):
+        ctx.csr(3, 3, np.array([0, 3, 1, 4], np.int32), np.array([0, 1, 2, 0], np.int32), val)
+    with pytest.raises(Err, match="index out of range"):
+        ctx.coo(2, 3, np.array([0, 2], np.int32), np.array([0, 1], np.int32), np.ones(2))  # row 2 of 2
+    with pytest.raises(Err, match="index out of range"):
+        ctx.ell(2, 3, 2, 4, np.array([0, 1, 5, 2], np.int32), val)
+    with pytest.raises(Err):
+        ctx.csc(2, 3, np.array([0, 1, 1, 2], np.int32), np.array([0, 7], np.int32), np.ones(2))
+    A = ctx.csr(2, 3, rp, np.array([0, 1, 2, 1], np.int32), val)
+    A.validate()  # well-formed
