@@ -148,6 +148,7 @@ struct spmv_mat
     int32_t*  pb_col         = nullptr;  // [nnz] global column
     uint16_t* pb_row         = nullptr;  // [nnz] row inside its group
     double*   pb_val         = nullptr;  // [nnz]
+    int32_t*  pb_gstart      = nullptr;  // [ngroups + 1] first row of every group (entry-balanced unless G was requested)
     int32_t   pb_group_rows  = 0;        // G (0 = choose)
     int32_t   pb_panel_width = 0;        // W (0 = default)
     int32_t   pb_sort        = 1;        // bucket tile entries by 128-byte line of x

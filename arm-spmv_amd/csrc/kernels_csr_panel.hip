@@ -27,6 +27,8 @@
 //
 // Algorithmic bytes are still counted with CSR's 12 bytes per entry, so the extra 2 bytes and
 // the repeated x sweeps show up as a lower roofline fraction, not as hidden traffic.
+#include <vector>
+
 #include "common.hpp"
 #include "wave.hpp"
 
@@ -38,14 +40,14 @@ constexpr int kPanelThreads = 1024;  // 16 wavefronts: one workgroup per CU (LDS
 constexpr int kLineDoubles  = 16;    // 128-byte line of x
 
 // ---- build step 1: entries per (group, panel) + exclusive scan inside the group -----------------------------
-__global__ __launch_bounds__(256) void panel_count_kernel(int nrow, int G, int W, int P,
+__global__ __launch_bounds__(256) void panel_count_kernel(const int32_t* __restrict__ gstart, int W, int P,
                                                           const int32_t* __restrict__ row_ptr,
                                                           const int32_t* __restrict__ col,
                                                           int32_t* __restrict__ tile_ptr /* [ngroups][P+1] */)
 {
     extern __shared__ int32_t hist[];  // P + 1
     const int g  = blockIdx.x;
-    const int r0 = g * G, r1 = min(nrow, r0 + G);
+    const int r0 = gstart[g], r1 = gstart[g + 1];
     for (int i = threadIdx.x; i <= P; i += blockDim.x) hist[i] = 0;
     __syncthreads();
     const int begin = row_ptr[r0], end = row_ptr[r1];
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(256) void panel_count_kernel(int nrow, int G, int W
 }
 
 // ---- build step 2: scatter the group's entries into their panel (order inside a panel: any) ----------------
-__global__ __launch_bounds__(256) void panel_scatter_kernel(int nrow, int G, int W, int P,
+__global__ __launch_bounds__(256) void panel_scatter_kernel(const int32_t* __restrict__ gstart, int W, int P,
                                                             const int32_t* __restrict__ row_ptr,
                                                             const int32_t* __restrict__ col,
                                                             const double* __restrict__ val,
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256) void panel_scatter_kernel(int nrow, int G, int
     extern __shared__ int32_t cursor[];  // P
     constexpr int LPR = 8;
     const int     g   = blockIdx.x;
-    const int     r0 = g * G, r1 = min(nrow, r0 + G);
+    const int     r0 = gstart[g], r1 = gstart[g + 1];
     for (int i = threadIdx.x; i < P; i += blockDim.x) cursor[i] = tile_ptr[(size_t)g * (P + 1) + i];
     __syncthreads();
     const int base = row_ptr[r0];
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void panel_scatter_kernel(int nrow, int G, int
 
 // ---- build step 3: inside each (group, panel) tile, bucket the entries by 128-byte line of x --------------
 // counting sort with one bin per line of the panel (W/16 bins in LDS); src -> dst
-__global__ __launch_bounds__(256) void panel_line_sort_kernel(int G, int W, int P, int nrow,
+__global__ __launch_bounds__(256) void panel_line_sort_kernel(const int32_t* __restrict__ gstart, int W, int P,
                                                               const int32_t* __restrict__ row_ptr,
                                                               const int32_t* __restrict__ tile_ptr,
                                                               const int32_t* __restrict__ src_col,
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void panel_line_sort_kernel(int G, int W, int 
     const int nb   = W / kLineDoubles;
     const int g    = blockIdx.x / P;
     const int p    = blockIdx.x % P;
-    const int base = row_ptr[min(nrow, g * G)];
+    const int base = row_ptr[gstart[g]];
     const int t0   = base + tile_ptr[(size_t)g * (P + 1) + p];
     const int t1   = base + tile_ptr[(size_t)g * (P + 1) + p + 1];
     if (t0 == t1) return;
@@ -234,12 +236,12 @@ __global__ __launch_bounds__(256) void panel_pack_kernel(int64_t nnz, const int3
     }
 }
 
-__global__ void group_nnz_max_kernel(int nrow, int G, int ngroups, const int32_t* __restrict__ row_ptr,
+__global__ void group_nnz_max_kernel(const int32_t* __restrict__ gstart, int ngroups, const int32_t* __restrict__ row_ptr,
                                      int32_t* __restrict__ out_max)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= ngroups) return;
-    const int r0 = g * G, r1 = min(nrow, r0 + G);
+    const int r0 = gstart[g], r1 = gstart[g + 1];
     atomicMax(out_max, row_ptr[r1] - row_ptr[r0]);
 }
 
@@ -298,7 +300,7 @@ __device__ __forceinline__ void gate_wait(GateLds* lds, const unsigned* gate_x, 
 }
 
 template <int UNROLL, bool GATED, int LAYOUT, int ABLATE = 0, bool PIPE = false>
-__global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(int nrow, int G, int ngroups,
+__global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t* __restrict__ gstart, int ngroups,
                                                                   const int32_t* __restrict__ row_ptr,
                                                                   const int32_t* __restrict__ pcol,
                                                                   const uint16_t* __restrict__ prow,
@@ -318,8 +320,8 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(int nrow, int 
     int round = 0;
     for (int g = blockIdx.x; g < ngroups; g += gridDim.x, ++round)
     {
-        const int r0   = g * G;
-        const int rows = min(G, nrow - r0);
+        const int r0   = gstart[g];
+        const int rows = gstart[g + 1] - r0;
         for (int i = threadIdx.x; i < rows; i += kPanelThreads) acc[i] = 0.0;
         unsigned*       gate_x = nullptr;
         const unsigned* pop_x  = nullptr;
@@ -402,6 +404,8 @@ void csr_panel_free(spmv_mat* m)
     if (m->pb_row) hipFree(m->pb_row);
     if (m->pb_val) hipFree(m->pb_val);
     if (m->pb_rec) hipFree(m->pb_rec);
+    if (m->pb_gstart) hipFree(m->pb_gstart);
+    m->pb_gstart = nullptr;
     m->pb_rec = nullptr;
     m->pb_col = nullptr;
     m->pb_row = nullptr;
@@ -438,7 +442,57 @@ int csr_panel_build(spmv_mat* m)
         aos == (m->pb_rec != nullptr))
         return panel_choose_pace(m);  // the layout in memory was built with these parameters
     csr_panel_free(m);
-    const int ngroups = (int)ceil_div(m->nrow, G);
+    // Row groups.  Requested size (panel_rows): equal groups of G rows.  Otherwise the boundaries balance the
+    // ENTRIES per group — a workgroup's time is its group's entry count, and the slowest of a round sets the pace
+    // (C4's power-law rows: equal-row groups differ by 15 %) — under the row cap that LDS imposes.  Smallest bound T
+    // such that a greedy cut (entries <= T, rows <= cap) needs no more groups than equal groups of G rows would.
+    std::vector<int32_t> gstart;
+    {
+        std::vector<int32_t> rp((size_t)m->nrow + 1);
+        SPMV_HIP(hipMemcpyAsync(rp.data(), m->a, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost, ctx->stream));
+        SPMV_HIP(hipStreamSynchronize(ctx->stream));
+        const int want = (int)ceil_div(m->nrow, G);
+        auto cut = [&](int64_t T, std::vector<int32_t>* out) {
+            int groups = 0;
+            int r      = 0;
+            if (out) out->assign(1, 0);
+            while (r < m->nrow)
+            {
+                const int     r_cap = std::min(m->nrow, r + G);
+                const int64_t limit = (int64_t)rp[(size_t)r] + T;
+                // last row index e in (r, r_cap] with rp[e] <= limit; at least one row
+                int e = (int)(std::upper_bound(rp.begin() + r + 1, rp.begin() + r_cap + 1, limit,
+                                               [](int64_t v, int32_t x) { return v < (int64_t)x; }) -
+                              rp.begin()) - 1;
+                if (e <= r) e = r + 1;
+                r = e;
+                ++groups;
+                if (out) out->push_back(r);
+            }
+            return groups;
+        };
+        if (m->pb_group_rows > 0)
+            cut((int64_t)INT32_MAX, &gstart);  // equal groups of G rows
+        else
+        {
+            int64_t lo = ceil_div(m->nnz, want), hi = m->nnz;
+            while (lo < hi)
+            {
+                const int64_t mid = lo + (hi - lo) / 2;
+                if (cut(mid, nullptr) <= want)
+                    hi = mid;
+                else
+                    lo = mid + 1;
+            }
+            cut(lo, &gstart);
+        }
+    }
+    const int ngroups = (int)gstart.size() - 1;
+    int       max_rows = 0;
+    for (int g = 0; g < ngroups; ++g) max_rows = std::max(max_rows, gstart[(size_t)g + 1] - gstart[(size_t)g]);
+    SPMV_HIP(hipMalloc(&m->pb_gstart, sizeof(int32_t) * gstart.size()));
+    SPMV_HIP(hipMemcpyAsync(m->pb_gstart, gstart.data(), sizeof(int32_t) * gstart.size(), hipMemcpyHostToDevice, ctx->stream));
+    SPMV_HIP(hipStreamSynchronize(ctx->stream));  // gstart (host) goes out of use only after the copy
     const int P       = (int)ceil_div(m->ncol, W);
     const size_t nnz  = (size_t)m->nnz;
 
@@ -463,18 +517,18 @@ int csr_panel_build(spmv_mat* m)
             rc = SPMV_ERR_ALLOC;
             break;
         }
-        hipLaunchKernelGGL(panel_count_kernel, dim3(ngroups), dim3(256), sizeof(int32_t) * (P + 1), s, m->nrow, G, W, P,
+        hipLaunchKernelGGL(panel_count_kernel, dim3(ngroups), dim3(256), sizeof(int32_t) * (P + 1), s, m->pb_gstart, W, P,
                            m->a, m->b, tile_ptr);
         int32_t*  scol = sort ? tcol : m->pb_col;
         uint16_t* srow = sort ? trow : m->pb_row;
         double*   sval = sort ? tval : m->pb_val;
-        hipLaunchKernelGGL(panel_scatter_kernel, dim3(ngroups), dim3(256), sizeof(int32_t) * P, s, m->nrow, G, W, P, m->a,
+        hipLaunchKernelGGL(panel_scatter_kernel, dim3(ngroups), dim3(256), sizeof(int32_t) * P, s, m->pb_gstart, W, P, m->a,
                            m->b, m->v, tile_ptr, scol, srow, sval);
         if (sort && sizeof(int32_t) * (W / kLineDoubles + 1) > 65536)  // one bin per x line of the panel, in LDS
             hipFuncSetAttribute((const void*)panel_line_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160000);
         if (sort)
             hipLaunchKernelGGL(panel_line_sort_kernel, dim3((unsigned)ngroups * P), dim3(256),
-                               sizeof(int32_t) * (W / kLineDoubles + 1), s, G, W, P, m->nrow, m->a, tile_ptr, tcol, trow,
+                               sizeof(int32_t) * (W / kLineDoubles + 1), s, m->pb_gstart, W, P, m->a, tile_ptr, tcol, trow,
                                tval, m->pb_col, m->pb_row, m->pb_val);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = SPMV_ERR_HIP;
     } while (0);
@@ -498,7 +552,7 @@ int csr_panel_build(spmv_mat* m)
         int32_t* d_max = (int32_t*)ctx->scratch;
         int32_t  h_max = 0;
         SPMV_HIP(hipMemsetAsync(d_max, 0, sizeof(int32_t), s));
-        hipLaunchKernelGGL(group_nnz_max_kernel, dim3((unsigned)ceil_div(ngroups, 256)), dim3(256), 0, s, m->nrow, G, ngroups,
+        hipLaunchKernelGGL(group_nnz_max_kernel, dim3((unsigned)ceil_div(ngroups, 256)), dim3(256), 0, s, m->pb_gstart, ngroups,
                            m->a, d_max);
         SPMV_HIP(hipMemcpyAsync(&h_max, d_max, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         SPMV_HIP(hipStreamSynchronize(s));
@@ -635,8 +689,8 @@ int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160000));                       \
             granted |= 1ull << ctx->device;                                                                                          \
         }                                                                                                            \
-        hipLaunchKernelGGL((csr_panel_kernel<U, GT, LY>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream, A->nrow,  \
-                           G, A->pb_ngroups, A->a, A->pb_col, A->pb_row,                  \
+        hipLaunchKernelGGL((csr_panel_kernel<U, GT, LY>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream,           \
+                           A->pb_gstart, A->pb_ngroups, A->a, A->pb_col, A->pb_row,                  \
                            layout ? (const double*)A->pb_rec : A->pb_val, x, y, gate, pop, nchunk, skew, pace_fp);   \
         SPMV_HIP(hipGetLastError());                                                                                 \
         return SPMV_OK;                                                                                              \
@@ -652,7 +706,7 @@ int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y
         SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_kernel<8, false, 0, AB>,                                 \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160000));                           \
         hipLaunchKernelGGL((csr_panel_kernel<8, false, 0, AB>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream,    \
-                           A->nrow, G, A->pb_ngroups, A->a, A->pb_col, A->pb_row, A->pb_val, x, y, gate, pop, nchunk,  \
+                           A->pb_gstart, A->pb_ngroups, A->a, A->pb_col, A->pb_row, A->pb_val, x, y, gate, pop, nchunk,  \
                            skew, pace_fp);                                                                           \
         SPMV_HIP(hipGetLastError());                                                                                 \
         return SPMV_OK;                                                                                              \
@@ -676,7 +730,7 @@ int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y
             granted |= 1ull << ctx->device;                                                                                          \
         }                                                                                                            \
         hipLaunchKernelGGL((csr_panel_kernel<U, false, 0, 0, true>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream, \
-                           A->nrow, G, A->pb_ngroups, A->a, A->pb_col, A->pb_row, A->pb_val, x, y, gate, pop, nchunk,  \
+                           A->pb_gstart, A->pb_ngroups, A->a, A->pb_col, A->pb_row, A->pb_val, x, y, gate, pop, nchunk,  \
                            skew, pace_fp);                                                                           \
         SPMV_HIP(hipGetLastError());                                                                                 \
         return SPMV_OK;                                                                                              \
