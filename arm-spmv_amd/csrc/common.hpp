@@ -165,6 +165,7 @@ struct spmv_mat
     int64_t   pb_max_group_nnz = 0;      // entries of the fullest row group
     int32_t   pb_two_per_cu  = 1;        // allow two workgroups per CU when the accumulators fit twice
     int32_t   pb_ngroups     = 0;
+    int32_t   pb_max_rows    = 0;        // rows of the fullest group (sizes the LDS accumulators)
     int32_t   pb_built_rows = 0, pb_built_width = 0, pb_built_sort = -1;  // parameters of the layout in memory
     int64_t   pb_bytes       = 0;
 

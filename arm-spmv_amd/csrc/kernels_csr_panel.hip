@@ -458,7 +458,8 @@ int csr_panel_build(spmv_mat* m)
             if (out) out->assign(1, 0);
             while (r < m->nrow)
             {
-                const int     r_cap = std::min(m->nrow, r + G);
+                // a requested size is exact; otherwise light groups may take up to the LDS cap so heavy ones can shrink
+                const int     r_cap = std::min(m->nrow, r + (m->pb_group_rows > 0 ? G : kCapRows));
                 const int64_t limit = (int64_t)rp[(size_t)r] + T;
                 // last row index e in (r, r_cap] with rp[e] <= limit; at least one row
                 int e = (int)(std::upper_bound(rp.begin() + r + 1, rp.begin() + r_cap + 1, limit,
@@ -543,6 +544,7 @@ int csr_panel_build(spmv_mat* m)
                   W, hipGetErrorString(hipGetLastError()));
     }
     m->pb_built_rows  = G;
+    m->pb_max_rows    = max_rows;
     m->pb_built_width = W;
     m->pb_built_sort  = (int)sort;
     m->pb_ngroups     = ngroups;
@@ -654,7 +656,7 @@ int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y
 {
     if (!A->pb_col && !A->pb_rec) SPMV_FAIL(SPMV_ERR_INVALID, "panel kernel selected but its layout was not built");
     const int    G   = A->pb_built_rows;
-    const size_t lds = (size_t)G * sizeof(double);
+    const size_t lds = (size_t)A->pb_max_rows * sizeof(double);  // the fullest group's accumulators
     // two workgroups share a CU when their accumulators fit twice into the 160 KiB LDS
     const int per_cu = (lds <= 80000 && A->pb_two_per_cu) ? 2 : 1;
     const int grid   = std::min(A->pb_ngroups, kNumCu * per_cu);
