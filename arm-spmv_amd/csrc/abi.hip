@@ -576,6 +576,8 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         m->pb_pace_req = (int32_t)value;
     else if (!strcmp(name, "panel_skew"))
         m->pb_skew = (int32_t)value;
+    else if (!strcmp(name, "panel_pace_slack"))
+        m->pb_pace_slack = (int32_t)value;
     else if (!strcmp(name, "panel_pipe"))
         m->pb_pipe = (int32_t)value;
     else if (!strcmp(name, "panel_ablate"))

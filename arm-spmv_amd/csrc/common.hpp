@@ -159,7 +159,8 @@ struct spmv_mat
     int32_t   pb_pace_ns     = 0;        // pacing throttle in effect: nanoseconds per chunk on the chip clock (0 = off)
     int32_t   pb_pipe        = 1;       // software-pipeline the chunks (next chunk's stream in flight during the gathers)
     int32_t   pb_ablate      = 0;       // timing experiments only (wrong results): see PanelBatch::apply
-    int32_t   pb_pace_req    = -1;       // requested pace (-1 = try a few and keep the fastest)
+    int32_t   pb_pace_slack  = 0;        // chunks a workgroup may run ahead of the paced schedule
+    int32_t   pb_pace_req    = -1;      // requested pace (-1 = try a few and keep the fastest)
     int32_t   pb_pace_tuned_ns = 0;      // the pace found by trying (restored when the request goes back to -1)
     int32_t   pb_pace_tuned_unroll = 0; // chunk size (unroll) the pace in effect was tried for; 0 = not tried
     int64_t   pb_max_group_nnz = 0;      // entries of the fullest row group

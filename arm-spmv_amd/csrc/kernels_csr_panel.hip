@@ -184,6 +184,14 @@ struct PanelBatch
                 c[u]            = rec.z;
                 r[u]            = (unsigned)rec.w;
             }
+            else if constexpr (LAYOUT == 2)
+            {
+                // experiment: system-scope loads (sc0 sc1) for the stream, to see whether they leave the x lines
+                // in L2 alone (profiles/r01_tune_csr_stream_scope.txt)
+                c[u] = __hip_atomic_load(pcol + e + u * kPanelThreads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                r[u] = __hip_atomic_load(prow + e + u * kPanelThreads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                v[u] = __hip_atomic_load(pval + e + u * kPanelThreads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             else
             {
                 c[u] = load_stream(pcol + e + u * kPanelThreads);
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
                                                                   const double* __restrict__ pval,
                                                                   const double* __restrict__ x, double* __restrict__ y,
                                                                   unsigned* __restrict__ gate, unsigned* __restrict__ pop,
-                                                                  int nchunk, int skew, unsigned long long pace_fp)
+                                                                  int nchunk, int skew, unsigned long long pace_fp, int pace_slack)
 {
     extern __shared__ double acc[];  // G accumulators
     __shared__ GateLds       gl;
@@ -346,9 +354,11 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
         PanelBatch<UNROLL, LAYOUT> cur, nxt;
         for (int b = 0; b < nfull; ++b)
         {
-            if (pace_fp && lane == 0)
+            // a workgroup may run up to pace_slack chunks ahead of the clock, so that time lost to a slow stretch
+            // can be made up in a fast one (a hard schedule only ever loses time)
+            if (pace_fp && lane == 0 && b > pace_slack)
             {
-                const unsigned long long target = t0 + (((unsigned long long)b * pace_fp) >> 10);
+                const unsigned long long target = t0 + (((unsigned long long)(b - pace_slack) * pace_fp) >> 10);
                 int                      spins  = 0;
                 while (__builtin_amdgcn_s_memrealtime() < target && ++spins < (1 << 16)) __builtin_amdgcn_s_sleep(1);
             }
@@ -437,7 +447,7 @@ int csr_panel_build(spmv_mat* m)
     W     = std::max(kLineDoubles, (W / kLineDoubles) * kLineDoubles);
     while (ceil_div(m->ncol, W) > 8192) W *= 2;  // the per-group histogram lives in LDS
     const bool sort = m->pb_sort != 0;
-    const bool aos = m->pb_aos != 0;
+    const bool aos = m->pb_aos == 1;  // 2 = three arrays read with system-scope loads (experiment)
     if ((m->pb_col || m->pb_rec) && m->pb_built_rows == G && m->pb_built_width == W && m->pb_built_sort == (int)sort &&
         aos == (m->pb_rec != nullptr))
         return panel_choose_pace(m);  // the layout in memory was built with these parameters
@@ -670,7 +680,11 @@ int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y
     const bool gated = skew > 0 && grid > 1;
     // pace: nanoseconds per chunk -> 10 ns ticks in 22.10 fixed point
     const unsigned long long pace_fp = A->pb_pace_ns > 0 ? (unsigned long long)((double)A->pb_pace_ns * 102.4) : 0ull;
-    const int  layout = A->pb_rec ? 1 : 0;
+    const int  pace_slack = std::max(0, A->pb_pace_slack);
+    const int  layout = A->pb_rec ? 1 : (A->pb_aos == 2 ? 2 : 0);
+    // the kernel dereferences exactly these arrays: refuse on the host rather than fault on the GPU
+    if (!A->pb_gstart || !x || !y || (layout == 1 ? !A->pb_rec : !(A->pb_col && A->pb_row && A->pb_val)))
+        SPMV_FAIL(SPMV_ERR_INVALID, "panel kernel: layout %d is selected but its arrays are not there", layout);
     unsigned* pop = nullptr;
     if (gated)
     {
@@ -693,7 +707,7 @@ int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y
         }                                                                                                            \
         hipLaunchKernelGGL((csr_panel_kernel<U, GT, LY>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream,           \
                            A->pb_gstart, A->pb_ngroups, A->a, A->pb_col, A->pb_row,                  \
-                           layout ? (const double*)A->pb_rec : A->pb_val, x, y, gate, pop, nchunk, skew, pace_fp);   \
+                           layout == 1 ? (const double*)A->pb_rec : A->pb_val, x, y, gate, pop, nchunk, skew, pace_fp, pace_slack);   \
         SPMV_HIP(hipGetLastError());                                                                                 \
         return SPMV_OK;                                                                                              \
     }
@@ -709,7 +723,7 @@ int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160000));                           \
         hipLaunchKernelGGL((csr_panel_kernel<8, false, 0, AB>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream,    \
                            A->pb_gstart, A->pb_ngroups, A->a, A->pb_col, A->pb_row, A->pb_val, x, y, gate, pop, nchunk,  \
-                           skew, pace_fp);                                                                           \
+                           skew, pace_fp, pace_slack);                                                                           \
         SPMV_HIP(hipGetLastError());                                                                                 \
         return SPMV_OK;                                                                                              \
     }
@@ -733,7 +747,7 @@ int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y
         }                                                                                                            \
         hipLaunchKernelGGL((csr_panel_kernel<U, false, 0, 0, true>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream, \
                            A->pb_gstart, A->pb_ngroups, A->a, A->pb_col, A->pb_row, A->pb_val, x, y, gate, pop, nchunk,  \
-                           skew, pace_fp);                                                                           \
+                           skew, pace_fp, pace_slack);                                                                           \
         SPMV_HIP(hipGetLastError());                                                                                 \
         return SPMV_OK;                                                                                              \
     }
@@ -745,6 +759,7 @@ int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y
     SPMV_PANEL_CASES(2)
     SPMV_PANEL_CASES(4)
     SPMV_PANEL_CASES(8)
+    SPMV_PANEL_CASE(8, false, 2)
     SPMV_PANEL_CASES(16)
 #undef SPMV_PANEL_CASES
 #undef SPMV_PANEL_CASE

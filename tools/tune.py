@@ -119,21 +119,25 @@ def main():
             combos = [(0, 0, 1) + tuple(int(t) for t in item.split(",")) for item in a.panel.split(";")]
         else:
             combos = [(0, 0, 1, u, sk, 0) for u in (4, 8, 16) for sk in (0, 2, 4, 8)]
-        for combo in combos:  # --panel fields: unroll,skew,pace_ns[,pipe]
+        for combo in combos:  # --panel fields: unroll,skew,pace_ns[,pipe[,pace_slack]]
             rows, width, srt, unroll, skew, pace = combo[:6]
             pipe = combo[6] if len(combo) > 6 else 0
+            slack = combo[7] if len(combo) > 7 else 0
+            aos = combo[8] if len(combo) > 8 else 0
 
-            def setup(A, rows=rows, width=width, srt=srt, unroll=unroll, skew=skew, pace=pace, pipe=pipe):
+            def setup(A, rows=rows, width=width, srt=srt, unroll=unroll, skew=skew, pace=pace, pipe=pipe, slack=slack, aos=aos):
+                A.set_param("panel_aos", aos)
                 A.set_param("panel_rows", rows)
                 A.set_param("panel_width", width)
                 A.set_param("panel_sort", srt)
                 A.set_param("panel_unroll", unroll)
                 A.set_param("panel_skew", skew)
                 A.set_param("panel_pace_ns", pace)
+                A.set_param("panel_pace_slack", slack)
                 A.set_param("panel_pipe", pipe)
                 A.set_param("panel_ablate", 0)
                 A.set_kernel(capi.CSR_PANEL)  # rebuilds the layout when the parameters changed
-            variants.append((f"panel U={unroll} skew={skew} pace={pace}ns pipe={pipe}", setup))
+            variants.append((f"panel U={unroll} skew={skew} pace={pace}ns pipe={pipe} slack={slack} layout={aos}", setup))
         for ab, what in ((1, "no LDS adds"), (2, "gathers always hit L1"), (3, "neither")) if a.ablate else ():
             def setup(A, ab=ab):
                 for k, v in (("panel_rows", 0), ("panel_width", 0), ("panel_sort", 1), ("panel_unroll", 8), ("panel_skew", 0),
