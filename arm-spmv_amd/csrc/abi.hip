@@ -601,13 +601,15 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
     else if (!strcmp(name, "panel_groups"))
         *value = m->pb_ngroups;
     else if (!strcmp(name, "panel_unroll"))
-        *value = m->pb_unroll > 0 ? m->pb_unroll : 8;
+        *value = m->pb_unroll > 0 ? m->pb_unroll : (m->pb_unroll_tuned > 0 ? m->pb_unroll_tuned : 8);
     else if (!strcmp(name, "panel_pace_ns"))
         *value = m->pb_pace_ns;
     else if (!strcmp(name, "panel_skew"))
         *value = m->pb_skew;
     else if (!strcmp(name, "panel_bytes"))
         *value = m->pb_bytes;
+    else if (!strcmp(name, "panel_layout"))  // layout in memory: 0 three arrays, 1 records, 3 packed 12-byte entries
+        *value = m->pb_pack ? 3 : m->pb_rec ? 1 : 0;
     else if (!strcmp(name, "window_max_span"))
         *value = m->win_max_span;
     else if (!strcmp(name, "window_avg_span"))

@@ -155,14 +155,21 @@ struct spmv_mat
     int32_t   pb_unroll      = 0;        // entries in flight per lane (0 = default)
     int32_t   pb_skew        = 0;        // counter gate: chunks a workgroup may run ahead of the slowest (0 = off)
     void*     pb_rec         = nullptr;  // [nnz] 16-byte records {value, column, local row} (replaces the three arrays)
-    int32_t   pb_aos         = 0;        // build 16-byte records (one load instruction per entry); measured slower
+    int32_t   pb_aos         = 3;        // layout: 0 three arrays, 1 16-byte records (slower), 2 system-scope loads, 3 packed
+    uint32_t* pb_pack        = nullptr;  // [nnz] layout 3: (column - slice base) << rowbits | local row
+    int32_t*  pb_sbase       = nullptr;  // [slices] layout 3: line-aligned first column of every 1024-entry slice
+    int32_t*  pb_soff        = nullptr;  // [ngroups + 1] layout 3: first slice of every group
+    int32_t   pb_rowbits     = 0;
+    int32_t   pb_slices      = 0;        // layout 3: 1024-entry slices in all (padded entries / 1024)
+    int32_t   pb_built_layout = -1;      // pb_aos the layout in memory was built for
     int32_t   pb_pace_ns     = 0;        // pacing throttle in effect: nanoseconds per chunk on the chip clock (0 = off)
     int32_t   pb_pipe        = 1;       // software-pipeline the chunks (next chunk's stream in flight during the gathers)
     int32_t   pb_ablate      = 0;       // timing experiments only (wrong results): see PanelBatch::apply
     int32_t   pb_pace_slack  = 0;        // chunks a workgroup may run ahead of the paced schedule
     int32_t   pb_pace_req    = -1;      // requested pace (-1 = try a few and keep the fastest)
     int32_t   pb_pace_tuned_ns = 0;      // the pace found by trying (restored when the request goes back to -1)
-    int32_t   pb_pace_tuned_unroll = 0; // chunk size (unroll) the pace in effect was tried for; 0 = not tried
+    int32_t   pb_pace_tuned_unroll = 0; // what the trial was made for: requested unroll, -1 = unroll chosen too, 0 = not tried
+    int32_t   pb_unroll_tuned = 0;       // chunk size found by trying (in effect while pb_unroll == 0)
     int64_t   pb_max_group_nnz = 0;      // entries of the fullest row group
     int32_t   pb_two_per_cu  = 1;        // allow two workgroups per CU when the accumulators fit twice
     int32_t   pb_ngroups     = 0;

@@ -165,19 +165,32 @@ __global__ __launch_bounds__(256) void panel_line_sort_kernel(const int32_t* __r
 // LAYOUT 1: one 16-byte record {value, column, local row} per entry: one dwordx4 load instruction, 1 KiB per
 //           wavefront instruction.  The CU's vector-memory pipeline, not HBM, is what the kernel runs out of on
 //           uniform-random columns, so fewer instructions beat fewer bytes there.
+// LAYOUT 3: two arrays (value fp64, one packed 32-bit word): 12 bytes per entry, two load instructions.  The word
+//           holds the local row in its low `rowbits` bits and, above them, the column relative to the base of the
+//           entry's slice (1024 packed entries; the entries are ordered by x line, so a slice spans few
+//           columns; see panel_cut_kernel).  The bases are one int32 per slice, read through the scalar cache.
 template <int UNROLL, int LAYOUT>
 struct PanelBatch
 {
     int      c[UNROLL];
     unsigned r[UNROLL];
     double   v[UNROLL];
+    // sb: (LAYOUT 3) bases of the UNROLL slices this batch reads, uniform over the workgroup
     __device__ __forceinline__ void load(const int32_t* __restrict__ pcol, const uint16_t* __restrict__ prow,
-                                         const double* __restrict__ pval, int e)
+                                         const double* __restrict__ pval, int e, const int32_t* __restrict__ sb = nullptr,
+                                         int rowbits = 0)
     {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
         {
-            if constexpr (LAYOUT == 1)
+            if constexpr (LAYOUT == 3)
+            {
+                const unsigned w = (unsigned)load_stream(pcol + e + u * kPanelThreads);
+                c[u]             = sb[u] + (int)(w >> rowbits);
+                r[u]             = w & ((1u << rowbits) - 1u);
+                v[u]             = load_stream(pval + e + u * kPanelThreads);
+            }
+            else if constexpr (LAYOUT == 1)
             {
                 const i32x4 rec = load_stream(reinterpret_cast<const i32x4*>(pval) + e + u * kPanelThreads);
                 v[u]            = __hiloint2double(rec.y, rec.x);
@@ -220,10 +233,10 @@ struct PanelBatch
     // single entry (the ragged tail of a group)
     __device__ static __forceinline__ void one(const int32_t* __restrict__ pcol, const uint16_t* __restrict__ prow,
                                                const double* __restrict__ pval, int e, const double* __restrict__ x,
-                                               double* acc)
+                                               double* acc, const int32_t* __restrict__ sb = nullptr, int rowbits = 0)
     {
         PanelBatch<1, LAYOUT> b;
-        b.load(pcol, prow, pval, e);
+        b.load(pcol, prow, pval, e, sb, rowbits);
         b.apply(x, acc);
     }
 };
@@ -241,6 +254,90 @@ __global__ __launch_bounds__(256) void panel_pack_kernel(int64_t nnz, const int3
         q.z    = col[e];
         q.w    = (int)row[e];
         rec[e] = q;
+    }
+}
+
+// LAYOUT 3 build.  A group's entries (ordered by x line) are cut into slices of at most 1024 entries that span
+// fewer than 2^colbits columns; every slice is stored as exactly 1024 packed entries (the rest are pads: value 0,
+// column = the slice base, local row = `pad_row`, a spare accumulator past the last row of the fullest group that
+// is never written back: a pad may add 0 * inf = NaN there without touching y), so a group is a whole number of
+// 1024-entry slices and a column gap inside a group (band wrap-around, far couplings) costs at most one partly
+// filled slice.
+struct PanelPacked
+{
+    const int32_t* sbase;    // [slices] first column (line-aligned) of every slice
+    const int32_t* soff;     // [ngroups + 1] first slice of every group
+    int            rowbits;  // low bits of the packed word that hold the local row
+};
+
+// One thread per group walks its entries.  Pass 1 (soff == nullptr) counts the slices, pass 2 records them.
+__global__ void panel_cut_kernel(const int32_t* __restrict__ gstart, int ngroups, const int32_t* __restrict__ row_ptr,
+                                 const int32_t* __restrict__ col, int colbits, const int32_t* __restrict__ soff,
+                                 int32_t* __restrict__ nslices, int32_t* __restrict__ sbase, int32_t* __restrict__ ssrc,
+                                 int32_t* __restrict__ scount)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups) return;
+    const int begin = row_ptr[gstart[g]], end = row_ptr[gstart[g + 1]];
+    int       pos = begin, k = 0;
+    while (pos < end)
+    {
+        const int base_line  = col[pos] / kLineDoubles;
+        const int limit_line = base_line + (1 << (colbits - 4));  // kLineDoubles == 16 columns per line
+        const int most       = min(kPanelThreads, end - pos);
+        int       take       = most;
+        if (col[pos + most - 1] / kLineDoubles >= limit_line)
+        {
+            // lines are non-decreasing along the group: largest take with line(col[pos + take - 1]) < limit_line
+            int lo = 1, hi = most - 1;  // entry pos itself always fits
+            while (lo < hi)
+            {
+                const int mid = (lo + hi + 1) / 2;
+                if (col[pos + mid - 1] / kLineDoubles < limit_line)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            take = lo;
+        }
+        if (soff)
+        {
+            const int idx = soff[g] + k;
+            sbase[idx]    = base_line * kLineDoubles;
+            ssrc[idx]     = pos;
+            scount[idx]   = take;
+        }
+        pos += take;
+        ++k;
+    }
+    if (!soff) nslices[g] = k;
+}
+
+__global__ __launch_bounds__(256) void panel_expand_kernel(int total, const int32_t* __restrict__ sbase,
+                                                           const int32_t* __restrict__ ssrc,
+                                                           const int32_t* __restrict__ scount, const int32_t* __restrict__ col,
+                                                           const uint16_t* __restrict__ row, const double* __restrict__ val,
+                                                           int rowbits, unsigned pad_row,
+                                                           uint32_t* __restrict__ packed, double* __restrict__ pval)
+{
+    const unsigned pad = pad_row;
+    for (int sl = blockIdx.x; sl < total; sl += gridDim.x)
+    {
+        const int base = sbase[sl], src = ssrc[sl], cnt = scount[sl];
+        for (int j = threadIdx.x; j < kPanelThreads; j += 256)
+        {
+            const size_t dst = (size_t)sl * kPanelThreads + j;
+            if (j < cnt)
+            {
+                packed[dst] = ((unsigned)(col[src + j] - base) << rowbits) | (unsigned)row[src + j];
+                pval[dst]   = val[src + j];
+            }
+            else
+            {
+                packed[dst] = pad;
+                pval[dst]   = 0.0;
+            }
+        }
     }
 }
 
@@ -315,7 +412,9 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
                                                                   const double* __restrict__ pval,
                                                                   const double* __restrict__ x, double* __restrict__ y,
                                                                   unsigned* __restrict__ gate, unsigned* __restrict__ pop,
-                                                                  int nchunk, int skew, unsigned long long pace_fp, int pace_slack)
+                                                                  int nchunk, int skew, unsigned long long pace_fp, int pace_slack,
+                                                                  const int32_t* __restrict__ sbase,
+                                                                  const int32_t* __restrict__ soff, int rowbits)
 {
     extern __shared__ double acc[];  // G accumulators
     __shared__ GateLds       gl;
@@ -345,9 +444,12 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
             }
         }
         __syncthreads();
-        const int begin = row_ptr[r0], end = row_ptr[r0 + rows];
+        // LAYOUT 3 keeps its own (padded) entry numbering: whole slices of 1024
+        const int begin = LAYOUT == 3 ? soff[g] * kPanelThreads : row_ptr[r0];
+        const int end   = LAYOUT == 3 ? soff[g + 1] * kPanelThreads : row_ptr[r0 + rows];
         const int nfull = (end - begin) / STEP;  // chunks in which every lane has UNROLL valid entries
         int       e     = begin + threadIdx.x;
+        const int32_t* __restrict__ sb = LAYOUT == 3 ? sbase + soff[g] : pcol;  // slice bases of this group (else unused)
         // pacing (alternative throttle without any communication): chunk b does not start before
         // t0 + b * pace on the chip-wide 100 MHz clock; all workgroups start their round within ~1 us
         const unsigned long long t0 = pace_fp ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -370,14 +472,14 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
             {
                 // the streamed loads of chunk b+1 are issued before the gathers of chunk b: the HBM latency of the
                 // stream and the L1/L2 time of the gathers overlap inside one wavefront instead of adding up
-                if (b == 0) cur.load(pcol, prow, pval, e);
-                if (b + 1 < nfull) nxt.load(pcol, prow, pval, e + STEP);
+                if (b == 0) cur.load(pcol, prow, pval, e, sb, rowbits);
+                if (b + 1 < nfull) nxt.load(pcol, prow, pval, e + STEP, sb + (b + 1) * UNROLL, rowbits);
                 cur.template apply<ABLATE>(x, acc, &sink);
                 cur = nxt;
             }
             else
             {
-                cur.load(pcol, prow, pval, e);
+                cur.load(pcol, prow, pval, e, sb + b * UNROLL, rowbits);
                 cur.template apply<ABLATE>(x, acc, &sink);
             }
             e += STEP;
@@ -399,7 +501,8 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
                 for (int b = nfull + lane; b < nchunk; b += kWave)
                     __hip_atomic_fetch_add(gate_x + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        for (; e < end; e += kPanelThreads) PanelBatch<1, LAYOUT>::one(pcol, prow, pval, e, x, acc);
+        for (int t = nfull * UNROLL; e < end; e += kPanelThreads, ++t)
+            PanelBatch<1, LAYOUT>::one(pcol, prow, pval, e, x, acc, sb + t, rowbits);
         __syncthreads();
         for (int i = threadIdx.x; i < rows; i += kPanelThreads) y[r0 + i] += acc[i];
         __syncthreads();
@@ -414,14 +517,21 @@ void csr_panel_free(spmv_mat* m)
     if (m->pb_row) hipFree(m->pb_row);
     if (m->pb_val) hipFree(m->pb_val);
     if (m->pb_rec) hipFree(m->pb_rec);
+    if (m->pb_pack) hipFree(m->pb_pack);
+    if (m->pb_sbase) hipFree(m->pb_sbase);
+    if (m->pb_soff) hipFree(m->pb_soff);
     if (m->pb_gstart) hipFree(m->pb_gstart);
     m->pb_gstart = nullptr;
+    m->pb_pack   = nullptr;
+    m->pb_sbase  = nullptr;
+    m->pb_soff   = nullptr;
     m->pb_rec = nullptr;
     m->pb_col = nullptr;
     m->pb_row = nullptr;
     m->pb_val = nullptr;
     m->pb_built_sort = -1;
     m->pb_pace_tuned_unroll = 0;
+    m->pb_unroll_tuned = 0;
     m->device_bytes -= m->pb_bytes;
     m->pb_bytes = 0;
 }
@@ -437,6 +547,81 @@ static int pick_group_rows(int nrow, int cap)
     }
 }
 
+// Re-store the (line-ordered) three-array layout as 12-byte packed entries.  Not an error when it does not work
+// out (no memory, or so many column gaps that the padding would outweigh the two bytes saved): the three arrays
+// stay and the product runs from them.
+static void panel_pack(spmv_mat* m, int ngroups, int max_rows)
+{
+    spmv_ctx*   ctx     = m->ctx;
+    hipStream_t s       = ctx->stream;
+    const int   rowbits = 32 - __builtin_clz((unsigned)std::max(1, max_rows));  // local rows 0..max_rows (max_rows = pads)
+    const int   colbits = 32 - rowbits;
+    int32_t *d_n = nullptr, *ssrc = nullptr, *scount = nullptr;
+    uint32_t* pack = nullptr;
+    double*   pval = nullptr;
+    int32_t * sbase = nullptr, *d_soff = nullptr;
+    bool      ok   = false;
+    do
+    {
+        if (rowbits > 16 || hipMalloc(&d_n, sizeof(int32_t) * (size_t)ngroups) != hipSuccess) break;
+        const unsigned gb = (unsigned)ceil_div(ngroups, 64);
+        hipLaunchKernelGGL(panel_cut_kernel, dim3(gb), dim3(64), 0, s, m->pb_gstart, ngroups, m->a, m->pb_col, colbits,
+                           (const int32_t*)nullptr, d_n, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
+        std::vector<int32_t> soff((size_t)ngroups + 1, 0);
+        if (hipMemcpyAsync(soff.data() + 1, d_n, sizeof(int32_t) * (size_t)ngroups, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess)
+            break;
+        int64_t total = 0;
+        for (int g = 1; g <= ngroups; ++g)
+        {
+            total += soff[(size_t)g];
+            if (total > INT32_MAX / kPanelThreads) break;
+            soff[(size_t)g] = (int32_t)total;
+        }
+        // padded entries: whole slices.  Worth it while 12 B x padded < 14 B x stored (with a margin)
+        const int64_t padded = total * kPanelThreads;
+        if (total > INT32_MAX / kPanelThreads || padded * 12 > m->nnz * 13 + (int64_t)ngroups * kPanelThreads * 12) break;
+        if (hipMalloc(&ssrc, sizeof(int32_t) * (size_t)total) != hipSuccess ||
+            hipMalloc(&scount, sizeof(int32_t) * (size_t)total) != hipSuccess ||
+            hipMalloc(&sbase, sizeof(int32_t) * (size_t)total) != hipSuccess ||
+            hipMalloc(&d_soff, sizeof(int32_t) * soff.size()) != hipSuccess ||
+            hipMalloc(&pack, sizeof(uint32_t) * (size_t)padded) != hipSuccess ||
+            hipMalloc(&pval, sizeof(double) * (size_t)padded) != hipSuccess)
+            break;
+        if (hipMemcpyAsync(d_soff, soff.data(), sizeof(int32_t) * soff.size(), hipMemcpyHostToDevice, s) != hipSuccess) break;
+        hipLaunchKernelGGL(panel_cut_kernel, dim3(gb), dim3(64), 0, s, m->pb_gstart, ngroups, m->a, m->pb_col, colbits,
+                           (const int32_t*)d_soff, (int32_t*)nullptr, sbase, ssrc, scount);
+        hipLaunchKernelGGL(panel_expand_kernel, dim3((unsigned)std::min<int64_t>(total, kMaxGrid * 4)), dim3(256), 0, s,
+                           (int)total, sbase, ssrc, scount, m->pb_col, m->pb_row, m->pb_val, rowbits, (unsigned)max_rows, pack, pval);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) break;  // soff (host) is done with
+        ok = true;
+        // the packed words and padded values replace the three arrays
+        hipFree(m->pb_col);
+        hipFree(m->pb_row);
+        hipFree(m->pb_val);
+        m->pb_col     = nullptr;
+        m->pb_row     = nullptr;
+        m->pb_val     = pval;
+        m->pb_pack    = pack;
+        m->pb_sbase   = sbase;
+        m->pb_soff    = d_soff;
+        m->pb_rowbits = rowbits;
+        m->pb_slices  = (int32_t)total;
+        m->pb_bytes   = padded * 12 + (int64_t)sizeof(int32_t) * (total + ngroups + 1);
+    } while (0);
+    if (d_n) hipFree(d_n);
+    if (ssrc) hipFree(ssrc);
+    if (scount) hipFree(scount);
+    if (!ok)
+    {
+        if (pack) hipFree(pack);
+        if (pval) hipFree(pval);
+        if (sbase) hipFree(sbase);
+        if (d_soff) hipFree(d_soff);
+        (void)hipGetLastError();
+    }
+}
+
 int csr_panel_build(spmv_mat* m)
 {
     spmv_ctx* ctx = m->ctx;
@@ -448,8 +633,9 @@ int csr_panel_build(spmv_mat* m)
     while (ceil_div(m->ncol, W) > 8192) W *= 2;  // the per-group histogram lives in LDS
     const bool sort = m->pb_sort != 0;
     const bool aos = m->pb_aos == 1;  // 2 = three arrays read with system-scope loads (experiment)
-    if ((m->pb_col || m->pb_rec) && m->pb_built_rows == G && m->pb_built_width == W && m->pb_built_sort == (int)sort &&
-        aos == (m->pb_rec != nullptr))
+    const bool pack = m->pb_aos == 3 && sort;  // 12-byte entries (needs the line order); kept only if every slice fits
+    if ((m->pb_val || m->pb_rec) && m->pb_built_rows == G && m->pb_built_width == W && m->pb_built_sort == (int)sort &&
+        aos == (m->pb_rec != nullptr) && m->pb_built_layout == m->pb_aos)
         return panel_choose_pace(m);  // the layout in memory was built with these parameters
     csr_panel_free(m);
     // Row groups.  Requested size (panel_rows): equal groups of G rows.  Otherwise the boundaries balance the
@@ -536,7 +722,7 @@ int csr_panel_build(spmv_mat* m)
         hipLaunchKernelGGL(panel_scatter_kernel, dim3(ngroups), dim3(256), sizeof(int32_t) * P, s, m->pb_gstart, W, P, m->a,
                            m->b, m->v, tile_ptr, scol, srow, sval);
         if (sort && sizeof(int32_t) * (W / kLineDoubles + 1) > 65536)  // one bin per x line of the panel, in LDS
-            hipFuncSetAttribute((const void*)panel_line_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160000);
+            hipFuncSetAttribute((const void*)panel_line_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160008);
         if (sort)
             hipLaunchKernelGGL(panel_line_sort_kernel, dim3((unsigned)ngroups * P), dim3(256),
                                sizeof(int32_t) * (W / kLineDoubles + 1), s, m->pb_gstart, W, P, m->a, tile_ptr, tcol, trow,
@@ -571,6 +757,8 @@ int csr_panel_build(spmv_mat* m)
         m->pb_max_group_nnz = h_max;
     }
     m->pb_bytes       = (int64_t)(nnz * 14);
+    m->pb_built_layout = m->pb_aos;
+    if (pack) panel_pack(m, ngroups, max_rows);  // keeps the three arrays when packing does not pay
     if (aos)
     {
         // 16-byte records replace the three arrays
@@ -602,75 +790,114 @@ int csr_panel_build(spmv_mat* m)
 int panel_choose_pace(spmv_mat* m)
 {
     spmv_ctx* ctx = m->ctx;
-    if (m->pb_pace_req >= 0)
+    // what is tried: the chunk size (unless requested) and the pace (unless requested)
+    const int key = m->pb_unroll > 0 ? m->pb_unroll : -1;  // -1: chunk size chosen here as well
+    if (m->pb_pace_tuned_unroll == key)
     {
-        m->pb_pace_ns = m->pb_pace_req;
+        // already tried for this layout; a requested pace only overrides the pace
+        m->pb_pace_ns = m->pb_pace_req >= 0 ? m->pb_pace_req : m->pb_pace_tuned_ns;
         return SPMV_OK;
     }
-    const int  unroll = m->pb_unroll > 0 ? m->pb_unroll : 8;
-    if (m->pb_pace_tuned_unroll == unroll)
-    {
-        m->pb_pace_ns = m->pb_pace_tuned_ns;  // already tried for this layout and chunk size
-        return SPMV_OK;
-    }
-    m->pb_pace_ns       = 0;
+    m->pb_unroll_tuned  = 0;
+    m->pb_pace_ns       = m->pb_pace_req >= 0 ? m->pb_pace_req : 0;
     m->pb_pace_tuned_ns = 0;
-    const bool worth  = (double)m->ncol * 8.0 > 4.0 * 1048576.0 && m->pb_max_group_nnz >= 8LL * unroll * kPanelThreads;
+    if (m->pb_pace_req >= 0 && m->pb_unroll > 0) return SPMV_OK;  // nothing left to choose
+    const int  u_first = m->pb_unroll > 0 ? m->pb_unroll : 8;
+    const bool worth   = (double)m->ncol * 8.0 > 4.0 * 1048576.0 && m->pb_max_group_nnz >= 8LL * u_first * kPanelThreads;
     if (!worth) return SPMV_OK;  // x fits L2 or the groups are a few chunks long: nothing to keep in step
     double *x = nullptr, *y = nullptr;
     if (hipMalloc(&x, sizeof(double) * (size_t)m->ncol) != hipSuccess || hipMalloc(&y, sizeof(double) * (size_t)m->nrow) != hipSuccess)
     {
         if (x) hipFree(x);
+        (void)hipGetLastError();
         return SPMV_OK;  // no room to try: run unthrottled
     }
     hipMemsetAsync(x, 0, sizeof(double) * (size_t)m->ncol, ctx->stream);
     hipMemsetAsync(y, 0, sizeof(double) * (size_t)m->nrow, ctx->stream);
-    const double base_ns   = 1.33 * unroll * kPanelThreads;
-    const double factors[] = {0.0, 0.88, 0.94, 0.98, 1.02, 1.06, 1.12, 1.2, 1.32, 1.5};
-    double       best_ms   = 1e30, unthrottled_ms = 1e30;
-    int          best_pace = 0;
-    int          rc        = SPMV_OK;
-    for (double f : factors)
-    {
-        m->pb_pace_ns = (int32_t)(f * base_ns);
-        float ms      = 0.f;
-        if ((rc = csr_panel_apply(ctx, m, x, y)) != SPMV_OK) break;  // warm
+    int  rc    = SPMV_OK;
+    auto timed = [&](int pace_ns, float* ms) -> int {
+        m->pb_pace_ns = pace_ns;
+        int r         = csr_panel_apply(ctx, m, x, y);  // warm
+        if (r != SPMV_OK) return r;
         hipEventRecord(ctx->ev_begin, ctx->stream);
-        for (int i = 0; i < 3 && rc == SPMV_OK; ++i) rc = csr_panel_apply(ctx, m, x, y);
+        for (int i = 0; i < 3 && r == SPMV_OK; ++i) r = csr_panel_apply(ctx, m, x, y);
         hipEventRecord(ctx->ev_end, ctx->stream);
-        if (rc != SPMV_OK || hipEventSynchronize(ctx->ev_end) != hipSuccess ||
-            hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end) != hipSuccess)
+        if (r == SPMV_OK && (hipEventSynchronize(ctx->ev_end) != hipSuccess ||
+                             hipEventElapsedTime(ms, ctx->ev_begin, ctx->ev_end) != hipSuccess))
+            r = SPMV_ERR_HIP;
+        return r;
+    };
+    double    all_best_ms = 1e30;
+    int       all_best_pace = 0, all_best_unroll = 0;
+    const int unrolls[2] = {u_first, 4};
+    for (int ui = 0; ui < (m->pb_unroll > 0 ? 1 : 2) && rc == SPMV_OK; ++ui)
+    {
+        const int unroll   = unrolls[ui];
+        m->pb_unroll_tuned = unroll;
+        double best_ms = 1e30, unthrottled_ms = 1e30;
+        int    best_pace = 0;
+        if (m->pb_pace_req >= 0)
         {
-            if (rc == SPMV_OK) rc = SPMV_ERR_HIP;
-            break;
-        }
-        // a throttle has to beat the unthrottled run (first candidate) by a clear margin, or timing noise
-        // would switch it on where the columns are local and there is nothing to keep in step
-        if (f == 0.0) unthrottled_ms = ms;
-        if (ms < best_ms && (f == 0.0 || ms < 0.93 * unthrottled_ms))
-        {
+            float ms = 0.f;
+            if ((rc = timed(m->pb_pace_req, &ms)) != SPMV_OK) break;
             best_ms   = ms;
-            best_pace = m->pb_pace_ns;
+            best_pace = m->pb_pace_req;
+        }
+        else
+        {
+            const double base_ns   = 1.33 * unroll * kPanelThreads;
+            const double factors[] = {0.0, 0.76, 0.82, 0.88, 0.94, 1.0, 1.06, 1.12, 1.2, 1.32, 1.5};
+            for (double f : factors)
+            {
+                float ms = 0.f;
+                if ((rc = timed((int32_t)(f * base_ns), &ms)) != SPMV_OK) break;
+                // a throttle has to beat the unthrottled run (first candidate) by a clear margin, or timing noise
+                // would switch it on where the columns are local and there is nothing to keep in step
+                if (f == 0.0) unthrottled_ms = ms;
+                if (ms < best_ms && (f == 0.0 || ms < 0.93 * unthrottled_ms))
+                {
+                    best_ms   = ms;
+                    best_pace = m->pb_pace_ns;
+                }
+            }
+            // the optimum sits right above a cliff (a pace the CUs cannot hold lets them drift apart): refine in
+            // 2 % steps below the coarse winner and stop at the first step that is not faster
+            for (int step = 1; rc == SPMV_OK && best_pace > 0 && step <= 3; ++step)
+            {
+                float     ms   = 0.f;
+                const int cand = (int)(best_pace * 0.98);
+                if ((rc = timed(cand, &ms)) != SPMV_OK || ms >= best_ms) break;
+                best_ms   = ms;
+                best_pace = cand;
+            }
+        }
+        if (rc == SPMV_OK && best_ms < all_best_ms * (ui == 0 ? 1.0 : 0.97))  // a smaller chunk has to win clearly
+        {
+            all_best_ms     = best_ms;
+            all_best_pace   = best_pace;
+            all_best_unroll = unroll;
         }
     }
     hipStreamSynchronize(ctx->stream);
     hipFree(x);
     hipFree(y);
-    m->pb_pace_ns           = rc == SPMV_OK ? best_pace : 0;
-    m->pb_pace_tuned_ns     = m->pb_pace_ns;
-    m->pb_pace_tuned_unroll = rc == SPMV_OK ? unroll : 0;
+    m->pb_unroll_tuned      = rc == SPMV_OK && m->pb_unroll <= 0 ? all_best_unroll : 0;
+    m->pb_pace_tuned_ns     = rc == SPMV_OK ? all_best_pace : 0;
+    m->pb_pace_ns           = m->pb_pace_req >= 0 ? m->pb_pace_req : m->pb_pace_tuned_ns;
+    m->pb_pace_tuned_unroll = rc == SPMV_OK ? key : 0;
     return rc;
 }
 
 int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
 {
-    if (!A->pb_col && !A->pb_rec) SPMV_FAIL(SPMV_ERR_INVALID, "panel kernel selected but its layout was not built");
+    if (!A->pb_val && !A->pb_rec) SPMV_FAIL(SPMV_ERR_INVALID, "panel kernel selected but its layout was not built");
     const int    G   = A->pb_built_rows;
-    const size_t lds = (size_t)A->pb_max_rows * sizeof(double);  // the fullest group's accumulators
+    // the fullest group's accumulators (+ the spare one the pads of the packed layout add into)
+    const size_t lds = ((size_t)A->pb_max_rows + (A->pb_pack ? 1 : 0)) * sizeof(double);
     // two workgroups share a CU when their accumulators fit twice into the 160 KiB LDS
     const int per_cu = (lds <= 80000 && A->pb_two_per_cu) ? 2 : 1;
     const int grid   = std::min(A->pb_ngroups, kNumCu * per_cu);
-    const int unroll = A->pb_unroll > 0 ? A->pb_unroll : 8;
+    const int unroll = A->pb_unroll > 0 ? A->pb_unroll : (A->pb_unroll_tuned > 0 ? A->pb_unroll_tuned : 8);
     const int skew   = std::min(A->pb_skew, 12);  // the per-workgroup completion slots wrap at 16
     const int rounds = (int)ceil_div(A->pb_ngroups, grid);
     // longest group in chunks (uniform bound: the whole matrix in one group)
@@ -681,10 +908,15 @@ int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y
     // pace: nanoseconds per chunk -> 10 ns ticks in 22.10 fixed point
     const unsigned long long pace_fp = A->pb_pace_ns > 0 ? (unsigned long long)((double)A->pb_pace_ns * 102.4) : 0ull;
     const int  pace_slack = std::max(0, A->pb_pace_slack);
-    const int  layout = A->pb_rec ? 1 : (A->pb_aos == 2 ? 2 : 0);
+    const int  layout = A->pb_pack ? 3 : A->pb_rec ? 1 : (A->pb_aos == 2 ? 2 : 0);
     // the kernel dereferences exactly these arrays: refuse on the host rather than fault on the GPU
-    if (!A->pb_gstart || !x || !y || (layout == 1 ? !A->pb_rec : !(A->pb_col && A->pb_row && A->pb_val)))
+    const bool have = layout == 1   ? A->pb_rec != nullptr
+                      : layout == 3 ? (A->pb_pack && A->pb_sbase && A->pb_soff && A->pb_val && A->pb_rowbits > 0 && A->pb_rowbits < 32)
+                                    : (A->pb_col && A->pb_row && A->pb_val);
+    if (!A->pb_gstart || !x || !y || !have)
         SPMV_FAIL(SPMV_ERR_INVALID, "panel kernel: layout %d is selected but its arrays are not there", layout);
+    const PanelPacked pk{A->pb_sbase, A->pb_soff, A->pb_rowbits};
+    const int32_t*    arg_col = layout == 3 ? (const int32_t*)A->pb_pack : A->pb_col;
     unsigned* pop = nullptr;
     if (gated)
     {
@@ -702,12 +934,12 @@ int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y
         if (!((granted >> ctx->device) & 1ull))                                                                                              \
         {                                                                                                            \
             SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_kernel<U, GT, LY>,                                   \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160000));                       \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160008));                       \
             granted |= 1ull << ctx->device;                                                                                          \
         }                                                                                                            \
         hipLaunchKernelGGL((csr_panel_kernel<U, GT, LY>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream,           \
-                           A->pb_gstart, A->pb_ngroups, A->a, A->pb_col, A->pb_row,                  \
-                           layout == 1 ? (const double*)A->pb_rec : A->pb_val, x, y, gate, pop, nchunk, skew, pace_fp, pace_slack);   \
+                           A->pb_gstart, A->pb_ngroups, A->a, arg_col, A->pb_row,                  \
+                           layout == 1 ? (const double*)A->pb_rec : A->pb_val, x, y, gate, pop, nchunk, skew, pace_fp, pace_slack, pk.sbase, pk.soff, pk.rowbits);   \
         SPMV_HIP(hipGetLastError());                                                                                 \
         return SPMV_OK;                                                                                              \
     }
@@ -720,10 +952,10 @@ int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y
     if (A->pb_ablate == AB)                                                                                          \
     {                                                                                                                \
         SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_kernel<8, false, 0, AB>,                                 \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160000));                           \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160008));                           \
         hipLaunchKernelGGL((csr_panel_kernel<8, false, 0, AB>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream,    \
                            A->pb_gstart, A->pb_ngroups, A->a, A->pb_col, A->pb_row, A->pb_val, x, y, gate, pop, nchunk,  \
-                           skew, pace_fp, pace_slack);                                                                           \
+                           skew, pace_fp, pace_slack, pk.sbase, pk.soff, pk.rowbits);                                                                           \
         SPMV_HIP(hipGetLastError());                                                                                 \
         return SPMV_OK;                                                                                              \
     }
@@ -732,34 +964,40 @@ int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y
         SPMV_PANEL_ABLATE(3)
 #undef SPMV_PANEL_ABLATE
     }
-    if (A->pb_pipe && !gated && layout == 0)
+    if (A->pb_pipe && !gated && (layout == 0 || layout == 3))
     {
-        // software-pipelined chunks (ungated, three-array layout)
-#define SPMV_PANEL_PIPE(U)                                                                                           \
-    if (unroll == U)                                                                                                 \
+        // software-pipelined chunks (ungated; three-array and packed layouts)
+#define SPMV_PANEL_PIPE(U, LY)                                                                                       \
+    if (unroll == U && layout == LY)                                                                                 \
     {                                                                                                                \
         static unsigned long long granted = 0; /* bit per device */                                                                                 \
         if (!((granted >> ctx->device) & 1ull))                                                                                              \
         {                                                                                                            \
-            SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_kernel<U, false, 0, 0, true>,                        \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160000));                       \
+            SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_kernel<U, false, LY, 0, true>,                       \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160008));                       \
             granted |= 1ull << ctx->device;                                                                                          \
         }                                                                                                            \
-        hipLaunchKernelGGL((csr_panel_kernel<U, false, 0, 0, true>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream, \
-                           A->pb_gstart, A->pb_ngroups, A->a, A->pb_col, A->pb_row, A->pb_val, x, y, gate, pop, nchunk,  \
-                           skew, pace_fp, pace_slack);                                                                           \
+        hipLaunchKernelGGL((csr_panel_kernel<U, false, LY, 0, true>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream, \
+                           A->pb_gstart, A->pb_ngroups, A->a, arg_col, A->pb_row, A->pb_val, x, y, gate, pop, nchunk,  \
+                           skew, pace_fp, pace_slack, pk.sbase, pk.soff, pk.rowbits);                                                                           \
         SPMV_HIP(hipGetLastError());                                                                                 \
         return SPMV_OK;                                                                                              \
     }
-        SPMV_PANEL_PIPE(2)
-        SPMV_PANEL_PIPE(4)
-        SPMV_PANEL_PIPE(8)
+        SPMV_PANEL_PIPE(2, 0)
+        SPMV_PANEL_PIPE(4, 0)
+        SPMV_PANEL_PIPE(8, 0)
+        SPMV_PANEL_PIPE(4, 3)
+        SPMV_PANEL_PIPE(8, 3)
+        SPMV_PANEL_PIPE(16, 3)
 #undef SPMV_PANEL_PIPE
     }
     SPMV_PANEL_CASES(2)
     SPMV_PANEL_CASES(4)
     SPMV_PANEL_CASES(8)
     SPMV_PANEL_CASE(8, false, 2)
+    SPMV_PANEL_CASE(4, false, 3)
+    SPMV_PANEL_CASE(8, false, 3)
+    SPMV_PANEL_CASE(16, false, 3)
     SPMV_PANEL_CASES(16)
 #undef SPMV_PANEL_CASES
 #undef SPMV_PANEL_CASE

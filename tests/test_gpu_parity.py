@@ -399,7 +399,9 @@ def test_csr_panel_kernel_matches_reference_golden(ctx, orc, pkg, make):
     for rows, width, srt, aos, unroll, skew, pipe, pace in (
             (0, 0, 1, 1, 8, 2, 0, -1), (0, 0, 0, 0, 4, 0, 1, 0), (37, 16, 1, 1, 2, 1, 0, 0), (1000, 1024, 1, 0, 16, 3, 1, 500),
             (20000, 4096, 0, 1, 4, 12, 1, 0), (5, 48, 1, 0, 8, 2, 0, 0), (3, 16, 1, 1, 2, 2, 1, 0), (500, 512, 1, 0, 8, 0, 1, 2000),
-            (64, 64, 1, 0, 2, 0, 1, -1), (0, 0, 1, 0, 8, 0, 0, 300)):
+            (64, 64, 1, 0, 2, 0, 1, -1), (0, 0, 1, 0, 8, 0, 0, 300),
+            # layout 3: 12-byte packed entries (falls back to three arrays when a slice spans too many columns)
+            (0, 0, 1, 3, 8, 0, 1, 0), (37, 16, 1, 3, 4, 0, 0, 0), (5, 48, 1, 3, 16, 0, 1, -1), (1000, 1024, 0, 3, 8, 0, 1, 0)):
         A = ctx.csr(c["nrow"], c["ncol"], rp, cc, cv)
         A.set_param("panel_rows", rows)
         A.set_param("panel_width", width)
@@ -414,6 +416,35 @@ def test_csr_panel_kernel_matches_reference_golden(ctx, orc, pkg, make):
         what = f"{c['name']} panel rows={rows} width={width} sort={srt} aos={aos} unroll={unroll} skew={skew} pipe={pipe} pace={pace}"
         ol.assert_parity(y1, g["y1_csr"], scale, what + " 1 call")
         ol.assert_parity(y50, g["y50_csr"], scale, what + " 50 calls", reps=NUM_TEST)
+
+
+def test_csr_panel_packed_layout_large(ctx, orc, pkg):
+    """12-byte packed entries on matrices big enough for many slices, pipelined chunks and ragged tails; the sparse
+    one (1 entry per row over 8M columns) has slices wider than the packed word and must fall back."""
+    capi = pkg.capi
+    for n, k, band, expect in ((1_500_000, 24, 0, 3), (1_200_000, 16, 4096, 3), (8_000_000, 1, 0, 0)):
+        A = ctx.gen_csr_uniform(0, n, n, k, band=band, seed=5)
+        x = ctx.gen_vector(n, seed=6)
+        yv, yp = ctx.vector(n), ctx.vector(n)
+        yv.fill(0.0)
+        yp.fill(0.0)
+        A.set_kernel(capi.CSR_VECTOR)
+        ctx.apply(A, x, yv)
+        for unroll, pipe in ((8, 1), (4, 0), (16, 1)):
+            A.set_param("panel_aos", 3)
+            A.set_param("panel_unroll", unroll)
+            A.set_param("panel_pipe", pipe)
+            A.set_kernel(capi.CSR_PANEL)
+            # (the wrap-around band has two column clusters in its first and last groups: cut into separate slices)
+            assert A.get_param("panel_layout") == expect, (n, k, band)
+            yp.fill(0.0)
+            ctx.apply(A, x, yp)
+            ctx.sync()
+            hv, hp = yv.download(), yp.download()
+            # same products, different summation order: bound by |A||x| <= k
+            assert np.max(np.abs(hv - hp)) <= ol.REL_TOL * k, (n, k, band, unroll, pipe)
+        if expect == 3:
+            assert A.get_param("panel_bytes") < 12.2 * n * k
 
 
 def test_csr_auto_picks_panel_for_large_random_and_agrees_with_vector(ctx, orc, pkg):
@@ -495,7 +526,7 @@ def test_large_csc_is_regrouped_by_row_and_matches_oracle(ctx, orc, pkg):
     ol.csc_spmv(orc, cp, cr, cw, x, ref)
     ol.csr_abs_row_sums(orc, rp, col, val, x, scale)
     A = ctx.csc(n, n, cp, cr, cw)
-    assert A.info.device_bytes > 12 * n * k + 14 * n * k - 1  # CSC arrays + the panel copy
+    assert A.info.device_bytes > 12 * n * k + 12 * n * k - 1  # CSC arrays + the panel copy (12- or 14-byte entries)
     for forced in (False, True):
         if forced:
             A.set_kernel(capi.CSR_VECTOR)
