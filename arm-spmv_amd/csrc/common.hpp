@@ -163,7 +163,8 @@ struct spmv_mat
     int32_t   pb_slices      = 0;        // layout 3: 1024-entry slices in all (padded entries / 1024)
     int32_t   pb_built_layout = -1;      // pb_aos the layout in memory was built for
     int32_t   pb_pace_ns     = 0;        // pacing throttle in effect: nanoseconds per chunk on the chip clock (0 = off)
-    int32_t   pb_pipe        = 1;       // software-pipeline the chunks (next chunk's stream in flight during the gathers)
+    int32_t   pb_pipe        = -1;      // chunk pipeline: 0 off, 1 stream-first, 2 gather-first, -1 = 1 or 2 by trial
+    int32_t   pb_pipe_tuned  = 0;       // the order found by trying (in effect while pb_pipe == -1; 0 = not tried: 1)
     int32_t   pb_ablate      = 0;       // timing experiments only (wrong results): see PanelBatch::apply
     int32_t   pb_pace_slack  = 0;        // chunks a workgroup may run ahead of the paced schedule
     int32_t   pb_pace_req    = -1;      // requested pace (-1 = try a few and keep the fastest)

@@ -175,20 +175,39 @@ struct PanelBatch
     int      c[UNROLL];
     unsigned r[UNROLL];
     double   v[UNROLL];
-    // sb: (LAYOUT 3) bases of the UNROLL slices this batch reads, uniform over the workgroup
+    // LAYOUT 3: turn the packed words into column and local row.  Kept apart from the loads so that the pipelined
+    // loop can leave the words untouched (and their loads in flight) until the iteration that uses them.
+    // sb: bases of the UNROLL slices this batch reads, uniform over the workgroup
+    __device__ __forceinline__ void unpack(const int32_t* __restrict__ sb, int rowbits)
+    {
+        if constexpr (LAYOUT == 3)
+        {
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+            {
+                const unsigned w = (unsigned)c[u];
+                c[u]             = sb[u] + (int)(w >> rowbits);
+                r[u]             = w & ((1u << rowbits) - 1u);
+            }
+        }
+    }
     __device__ __forceinline__ void load(const int32_t* __restrict__ pcol, const uint16_t* __restrict__ prow,
                                          const double* __restrict__ pval, int e, const int32_t* __restrict__ sb = nullptr,
                                          int rowbits = 0)
+    {
+        load_raw(pcol, prow, pval, e);
+        unpack(sb, rowbits);
+    }
+    __device__ __forceinline__ void load_raw(const int32_t* __restrict__ pcol, const uint16_t* __restrict__ prow,
+                                             const double* __restrict__ pval, int e)
     {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
         {
             if constexpr (LAYOUT == 3)
             {
-                const unsigned w = (unsigned)load_stream(pcol + e + u * kPanelThreads);
-                c[u]             = sb[u] + (int)(w >> rowbits);
-                r[u]             = w & ((1u << rowbits) - 1u);
-                v[u]             = load_stream(pval + e + u * kPanelThreads);
+                c[u] = load_stream(pcol + e + u * kPanelThreads);  // packed word, see unpack()
+                v[u] = load_stream(pval + e + u * kPanelThreads);
             }
             else if constexpr (LAYOUT == 1)
             {
@@ -229,6 +248,17 @@ struct PanelBatch
             else
                 atomicAdd(&acc[r[u]], v[u] * xv[u]);  // ds_add_f64
         }
+    }
+    // the two halves of apply(), for the gather-first pipeline
+    __device__ __forceinline__ void gather(const double* __restrict__ x, double (&xv)[UNROLL]) const
+    {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) xv[u] = x[c[u]];
+    }
+    __device__ __forceinline__ void add(double* acc, const double (&xv)[UNROLL]) const
+    {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) atomicAdd(&acc[r[u]], v[u] * xv[u]);  // ds_add_f64
     }
     // single entry (the ragged tail of a group)
     __device__ static __forceinline__ void one(const int32_t* __restrict__ pcol, const uint16_t* __restrict__ prow,
@@ -404,7 +434,7 @@ __device__ __forceinline__ void gate_wait(GateLds* lds, const unsigned* gate_x, 
     }
 }
 
-template <int UNROLL, bool GATED, int LAYOUT, int ABLATE = 0, bool PIPE = false>
+template <int UNROLL, bool GATED, int LAYOUT, int ABLATE = 0, int PIPE = 0>
 __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t* __restrict__ gstart, int ngroups,
                                                                   const int32_t* __restrict__ row_ptr,
                                                                   const int32_t* __restrict__ pcol,
@@ -468,7 +498,22 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
             {
                 if (b >= skew && lane == 0) gate_wait(&gl, gate_x, pop_x, (unsigned)(b - skew));
             }
-            if constexpr (PIPE)
+            if constexpr (PIPE == 2)
+            {
+                // gather-first order: the gathers of chunk b are issued BEFORE the streamed loads of chunk b+1.
+                // Vector loads return in order, so the adds of chunk b wait for the gathers only, and the HBM
+                // latency of the next chunk's stream runs under them instead of in front of the gathers
+                if (b == 0) cur.load_raw(pcol, prow, pval, e);
+                cur.unpack(sb + b * UNROLL, rowbits);
+                double xv[UNROLL];
+                cur.gather(x, xv);
+                // unconditional (the last chunk re-reads itself): behind a branch, the wait-count bookkeeping of the
+                // compiler would make the adds wait for these loads as well
+                nxt.load_raw(pcol, prow, pval, b + 1 < nfull ? e + STEP : e);
+                cur.add(acc, xv);
+                cur = nxt;
+            }
+            else if constexpr (PIPE == 1)
             {
                 // the streamed loads of chunk b+1 are issued before the gathers of chunk b: the HBM latency of the
                 // stream and the L1/L2 time of the gathers overlap inside one wavefront instead of adding up
@@ -791,17 +836,20 @@ int panel_choose_pace(spmv_mat* m)
 {
     spmv_ctx* ctx = m->ctx;
     // what is tried: the chunk size (unless requested) and the pace (unless requested)
-    const int key = m->pb_unroll > 0 ? m->pb_unroll : -1;  // -1: chunk size chosen here as well
+    // (key: the requests the trial was made under; unroll 0 / pipe -1 = chosen here as well)
+    const int key = 1000 + std::max(m->pb_unroll, 0) * 10 + (m->pb_pipe + 1);
     if (m->pb_pace_tuned_unroll == key)
     {
         // already tried for this layout; a requested pace only overrides the pace
         m->pb_pace_ns = m->pb_pace_req >= 0 ? m->pb_pace_req : m->pb_pace_tuned_ns;
         return SPMV_OK;
     }
+    m->pb_pace_tuned_unroll = 0;  // what was found for other requests no longer applies
     m->pb_unroll_tuned  = 0;
+    m->pb_pipe_tuned    = 0;
     m->pb_pace_ns       = m->pb_pace_req >= 0 ? m->pb_pace_req : 0;
     m->pb_pace_tuned_ns = 0;
-    if (m->pb_pace_req >= 0 && m->pb_unroll > 0) return SPMV_OK;  // nothing left to choose
+    if (m->pb_pace_req >= 0 && m->pb_unroll > 0 && m->pb_pipe >= 0) return SPMV_OK;  // nothing left to choose
     const int  u_first = m->pb_unroll > 0 ? m->pb_unroll : 8;
     const bool worth   = (double)m->ncol * 8.0 > 4.0 * 1048576.0 && m->pb_max_group_nnz >= 8LL * u_first * kPanelThreads;
     if (!worth) return SPMV_OK;  // x fits L2 or the groups are a few chunks long: nothing to keep in step
@@ -828,12 +876,16 @@ int panel_choose_pace(spmv_mat* m)
         return r;
     };
     double    all_best_ms = 1e30;
-    int       all_best_pace = 0, all_best_unroll = 0;
+    int       all_best_pace = 0, all_best_unroll = 0, all_best_pipe = 0;
     const int unrolls[2] = {u_first, 4};
-    for (int ui = 0; ui < (m->pb_unroll > 0 ? 1 : 2) && rc == SPMV_OK; ++ui)
+    const int n_unroll   = m->pb_unroll > 0 ? 1 : 2;
+    const int n_pipe     = m->pb_pipe >= 0 || m->pb_pack == nullptr ? 1 : 2;  // gather-first exists for the packed layout
+    for (int ui = 0; ui < n_unroll * n_pipe && rc == SPMV_OK; ++ui)
     {
-        const int unroll   = unrolls[ui];
+        const int unroll   = unrolls[ui / n_pipe];
+        const int pipe     = n_pipe == 2 ? 1 + ui % 2 : 0;
         m->pb_unroll_tuned = unroll;
+        m->pb_pipe_tuned   = pipe;
         double best_ms = 1e30, unthrottled_ms = 1e30;
         int    best_pace = 0;
         if (m->pb_pace_req >= 0)
@@ -862,7 +914,7 @@ int panel_choose_pace(spmv_mat* m)
             }
             // the optimum sits right above a cliff (a pace the CUs cannot hold lets them drift apart): refine in
             // 2 % steps below the coarse winner and stop at the first step that is not faster
-            for (int step = 1; rc == SPMV_OK && best_pace > 0 && step <= 3; ++step)
+            for (int step = 1; rc == SPMV_OK && best_pace > 0 && step <= 8; ++step)
             {
                 float     ms   = 0.f;
                 const int cand = (int)(best_pace * 0.98);
@@ -871,17 +923,34 @@ int panel_choose_pace(spmv_mat* m)
                 best_pace = cand;
             }
         }
-        if (rc == SPMV_OK && best_ms < all_best_ms * (ui == 0 ? 1.0 : 0.97))  // a smaller chunk has to win clearly
+        if (rc == SPMV_OK && best_ms < all_best_ms * (ui == 0 ? 1.0 : 0.98))  // later candidates have to win clearly
         {
             all_best_ms     = best_ms;
             all_best_pace   = best_pace;
             all_best_unroll = unroll;
+            all_best_pipe   = pipe;
+        }
+    }
+    // The winner sits close to the cliff.  Step back 2 % from it, then check the choice over more launches and
+    // step back further while it does not hold (a pace the chip cannot keep costs 60-80 %, a cautious one 2-3 %).
+    if (rc == SPMV_OK && all_best_pace > 0 && m->pb_pace_req < 0)
+    {
+        m->pb_unroll_tuned = all_best_unroll;
+        m->pb_pipe_tuned   = all_best_pipe;
+        all_best_pace      = (int)(all_best_pace * 1.02);
+        for (int attempt = 0; attempt < 4 && rc == SPMV_OK; ++attempt)
+        {
+            float ms_a = 0.f, ms_b = 0.f;
+            if ((rc = timed(all_best_pace, &ms_a)) != SPMV_OK || (rc = timed(all_best_pace, &ms_b)) != SPMV_OK) break;
+            if (std::max(ms_a, ms_b) <= 1.08 * all_best_ms) break;
+            all_best_pace = (int)(all_best_pace * 1.03);
         }
     }
     hipStreamSynchronize(ctx->stream);
     hipFree(x);
     hipFree(y);
     m->pb_unroll_tuned      = rc == SPMV_OK && m->pb_unroll <= 0 ? all_best_unroll : 0;
+    m->pb_pipe_tuned        = rc == SPMV_OK ? all_best_pipe : 0;
     m->pb_pace_tuned_ns     = rc == SPMV_OK ? all_best_pace : 0;
     m->pb_pace_ns           = m->pb_pace_req >= 0 ? m->pb_pace_req : m->pb_pace_tuned_ns;
     m->pb_pace_tuned_unroll = rc == SPMV_OK ? key : 0;
@@ -964,31 +1033,39 @@ int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y
         SPMV_PANEL_ABLATE(3)
 #undef SPMV_PANEL_ABLATE
     }
-    if (A->pb_pipe && !gated && (layout == 0 || layout == 3))
+    const int pipe = A->pb_pipe >= 0 ? A->pb_pipe : (A->pb_pipe_tuned > 0 ? A->pb_pipe_tuned : 1);
+    // gather-first is instantiated for the chunk sizes that are tried; the others take the stream-first order
+    const int pp = (pipe == 2 && (unroll == 4 || unroll == 8 || (unroll == 16 && layout == 3))) ? 2 : 1;
+    if (pipe && !gated && (layout == 0 || layout == 3))
     {
         // software-pipelined chunks (ungated; three-array and packed layouts)
-#define SPMV_PANEL_PIPE(U, LY)                                                                                       \
-    if (unroll == U && layout == LY)                                                                                 \
+#define SPMV_PANEL_PIPE(U, LY, PP)                                                                                   \
+    if (unroll == U && layout == LY && pp == PP)                                                                 \
     {                                                                                                                \
         static unsigned long long granted = 0; /* bit per device */                                                                                 \
         if (!((granted >> ctx->device) & 1ull))                                                                                              \
         {                                                                                                            \
-            SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_kernel<U, false, LY, 0, true>,                       \
+            SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_kernel<U, false, LY, 0, PP>,                       \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160008));                       \
             granted |= 1ull << ctx->device;                                                                                          \
         }                                                                                                            \
-        hipLaunchKernelGGL((csr_panel_kernel<U, false, LY, 0, true>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream, \
+        hipLaunchKernelGGL((csr_panel_kernel<U, false, LY, 0, PP>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream, \
                            A->pb_gstart, A->pb_ngroups, A->a, arg_col, A->pb_row, A->pb_val, x, y, gate, pop, nchunk,  \
                            skew, pace_fp, pace_slack, pk.sbase, pk.soff, pk.rowbits);                                                                           \
         SPMV_HIP(hipGetLastError());                                                                                 \
         return SPMV_OK;                                                                                              \
     }
-        SPMV_PANEL_PIPE(2, 0)
-        SPMV_PANEL_PIPE(4, 0)
-        SPMV_PANEL_PIPE(8, 0)
-        SPMV_PANEL_PIPE(4, 3)
-        SPMV_PANEL_PIPE(8, 3)
-        SPMV_PANEL_PIPE(16, 3)
+        SPMV_PANEL_PIPE(2, 0, 1)
+        SPMV_PANEL_PIPE(4, 0, 1)
+        SPMV_PANEL_PIPE(8, 0, 1)
+        SPMV_PANEL_PIPE(4, 3, 1)
+        SPMV_PANEL_PIPE(8, 3, 1)
+        SPMV_PANEL_PIPE(16, 3, 1)
+        SPMV_PANEL_PIPE(4, 3, 2)
+        SPMV_PANEL_PIPE(8, 3, 2)
+        SPMV_PANEL_PIPE(16, 3, 2)
+        SPMV_PANEL_PIPE(4, 0, 2)
+        SPMV_PANEL_PIPE(8, 0, 2)
 #undef SPMV_PANEL_PIPE
     }
     SPMV_PANEL_CASES(2)

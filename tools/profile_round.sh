@@ -29,7 +29,7 @@ with open(O + "/timed_region.txt", "w") as out:
 print(open(O + "/timed_region.txt").read())
 PY
 for what in ell coo dia blas1; do timeout -k 10 200 python3 tools/tune.py $what --rounds 3 > "$O/tune_$what.log" 2>&1 || exit 1; done
-timeout -k 10 300 python3 tools/tune.py csr --rounds 3 --reps 10 --panel "8,0,-1,1;8,0,0,1;8,0,-1,0" > "$O/tune_csr_uniform.log" 2>&1 || exit 1
-timeout -k 10 300 python3 tools/tune.py csr --band 4096 --rounds 3 --reps 10 --panel "8,0,-1,1" > "$O/tune_csr_band4096.log" 2>&1 || exit 1
+timeout -k 10 300 python3 tools/tune.py csr --rounds 3 --reps 10 --panel "0,0,-1,-1,0,3;8,0,-1,1,0,3;8,0,0,2,0,3;8,0,-1,1,0,0" > "$O/tune_csr_uniform.log" 2>&1 || exit 1
+timeout -k 10 300 python3 tools/tune.py csr --band 4096 --rounds 3 --reps 10 --panel "0,0,-1,-1,0,3;8,0,-1,1,0,0" > "$O/tune_csr_band4096.log" 2>&1 || exit 1
 for d in pmc_fetch pmc_write pmc_tcc; do python3 tools/pmc_summary.py "$O/$d" csr_panel | tail -3; done
 tail -n 3 "$O"/tune_*.log

@@ -149,6 +149,11 @@ def main():
             for lanes in (4, 8, 16):
                 variants.append((f"ldswin L={lanes}", lambda A, lanes=lanes: A.set_kernel(capi.CSR_LDSWIN, lanes)))
         sweep(ctx, A, x, y, variants, a.rounds, a.reps, algorithmic_bytes("csr", n, n, n * k), n * k)
+        for name, v in (("panel_aos", 3), ("panel_unroll", 0), ("panel_pace_ns", -1), ("panel_pipe", -1), ("panel_skew", 0),
+                        ("panel_pace_slack", 0), ("panel_ablate", 0)):
+            A.set_param(name, v)
+        A.set_kernel(capi.CSR_PANEL)
+        print("chosen by trial:", {k: A.get_param("panel_" + k) for k in ("rows", "groups", "layout", "unroll", "pipe", "pace_ns", "bytes")})
     elif a.what == "ell":
         n, k = a.n or 4_000_000, a.k or 64
         A = ctx.gen_ell_banded(n, n, k, seed=1)
@@ -176,7 +181,7 @@ def main():
                 A.set_kernel(capi.CSR_PANEL)
             variants.append((f"csr panel U={unroll} pace={pace}", setup))
         sweep(ctx, csr, x, y, variants, a.rounds, a.reps, algorithmic_bytes("csr", n, n, nnz), nnz)
-        print("panel layout:", {k: csr.get_param("panel_" + k) for k in ("rows", "groups", "pace_ns")})
+        print("panel layout:", {k: csr.get_param("panel_" + k) for k in ("rows", "groups", "pace_ns", "unroll", "pipe", "layout")})
 
 
 if __name__ == "__main__":
