@@ -190,6 +190,7 @@ static int ctx_create_common(int device, void* borrowed_stream, bool borrow, spm
     hipError_t e = hipEventCreate(&ctx->ev_begin);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_end);
     if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->host_pinned, 64, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->dev_scalars, 64);
     if (e != hipSuccess)
     {
         spmv_ctx_destroy(ctx);
@@ -212,6 +213,7 @@ int spmv_ctx_destroy(spmv_ctx* ctx)
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->host_pinned) hipHostFree(ctx->host_pinned);
+    if (ctx->dev_scalars) hipFree(ctx->dev_scalars);
     if (ctx->ev_begin) hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) hipEventDestroy(ctx->ev_end);
     if (ctx->owns_stream && ctx->stream) hipStreamDestroy(ctx->stream);
@@ -723,6 +725,41 @@ int spmv_axpby(spmv_ctx* ctx, double alpha, const spmv_vec* x, double beta, cons
                  (long long)x->n, (long long)y->n);
     SPMV_TRY(use_device(ctx));
     return vec_axpby(ctx, alpha, x->d, beta, y->d, w->d, w->n);
+}
+
+// ---- solver step (solver.hip) -----------------------------------------------------------------------------
+int spmv_apply_dot(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* x, spmv_vec* y, int32_t overwrite, const spmv_vec* w,
+                   double* dot)
+{
+    SPMV_TRY(check_apply_args(ctx, A, x, y));
+    SPMV_REQUIRE(w && dot, "spmv_apply_dot: null argument");
+    SPMV_REQUIRE(w->n == A->nrow, "spmv_apply_dot: w has %lld entries, matrix has %d rows", (long long)w->n, A->nrow);
+    SPMV_REQUIRE(w->d != y->d || y->n == 0, "spmv_apply_dot: w and y must not alias");
+    SPMV_TRY(use_device(ctx));
+    double* out = ctx->dev_scalars;
+    SPMV_HIP(hipMemsetAsync(out, 0, sizeof(double), ctx->stream));
+    apply_extra ex;
+    ex.overwrite = overwrite != 0;
+    ex.dot_w     = w->d;
+    ex.dot_out   = out;
+    SPMV_TRY(mat_apply_ex(ctx, A, x->d, y->d, ex));
+    SPMV_HIP(hipMemcpyAsync(ctx->host_pinned, out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SPMV_HIP(hipStreamSynchronize(ctx->stream));
+    *dot = ctx->host_pinned[0];
+    return SPMV_OK;
+}
+
+int spmv_cg(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* b, spmv_vec* x, int32_t max_iter, double rel_tol,
+            int32_t check_every, int32_t* iters, double* rel_resid)
+{
+    SPMV_REQUIRE(ctx && A && b && x && iters && rel_resid, "spmv_cg: null argument");
+    SPMV_REQUIRE(A->nrow == A->ncol, "spmv_cg: the matrix is %d x %d, not square", A->nrow, A->ncol);
+    SPMV_REQUIRE(b->n == A->nrow && x->n == A->nrow, "spmv_cg: b has %lld and x %lld entries, the matrix %d rows",
+                 (long long)b->n, (long long)x->n, A->nrow);
+    SPMV_REQUIRE(b->d != x->d || x->n == 0, "spmv_cg: b and x must not alias");
+    SPMV_REQUIRE(max_iter >= 0 && rel_tol >= 0.0, "spmv_cg: max_iter=%d rel_tol=%g", max_iter, rel_tol);
+    SPMV_TRY(use_device(ctx));
+    return cg_solve(ctx, A, b->d, x->d, max_iter, rel_tol, check_every, iters, rel_resid);
 }
 
 // ---- conversions ------------------------------------------------------------------------------------------

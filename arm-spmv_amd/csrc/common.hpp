@@ -101,6 +101,7 @@ struct spmv_ctx
     void*  scratch       = nullptr;
     size_t scratch_bytes = 0;
     double* host_pinned  = nullptr;  // 64 B of pinned host memory for scalar results
+    double* dev_scalars  = nullptr;  // 64 B of device memory for scalar results (never re-allocated, unlike scratch)
 };
 
 struct spmv_vec
@@ -194,6 +195,20 @@ int  csr_panel_build(spmv_mat* m);
 int  panel_choose_pace(spmv_mat* m);
 void csr_panel_free(spmv_mat* m);
 int  csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
+// what a solver step wants on top of y += A*x (solver.hip)
+struct apply_extra
+{
+    bool          overwrite = false;    // y = A*x instead of y += A*x
+    const double* dot_w     = nullptr;  // if set: *dot_out += sum_i dot_w[i] * y_new[i]
+    double*       dot_out   = nullptr;  // device scalar
+};
+int  csr_panel_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, const apply_extra& ex);
+// solver.hip
+int mat_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
+int mat_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, const apply_extra& ex);
+int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int max_iter, double rel_tol, int check_every,
+             int* iters, double* rel_resid);
+int vec_dot_accumulate(spmv_ctx* ctx, const double* x, const double* y, int64_t n, double* device_out);
 int csr_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 // kernels_ell.hip
 int ell_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);

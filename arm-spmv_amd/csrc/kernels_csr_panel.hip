@@ -446,7 +446,9 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
                                                                   unsigned* __restrict__ gate, unsigned* __restrict__ pop,
                                                                   int nchunk, int skew, unsigned long long pace_fp, int pace_slack,
                                                                   const int32_t* __restrict__ sbase,
-                                                                  const int32_t* __restrict__ soff, int rowbits)
+                                                                  const int32_t* __restrict__ soff, int rowbits,
+                                                                  int overwrite, const double* __restrict__ dot_w,
+                                                                  double* __restrict__ dot_out)
 {
     extern __shared__ double acc[];  // G accumulators
     __shared__ GateLds       gl;
@@ -551,7 +553,20 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
         for (int t = nfull * UNROLL; e < end; e += kPanelThreads, ++t)
             PanelBatch<1, LAYOUT>::one(pcol, prow, pval, e, x, acc, sb + t, rowbits);
         __syncthreads();
-        for (int i = threadIdx.x; i < rows; i += kPanelThreads) y[r0 + i] += acc[i];
+        // write-back: y += (or =) the group's sums; optionally the solver's dot product w . y_new rides along
+        // (spmv_apply_dot: saves the separate pass over w and y)
+        double part = 0.0;
+        for (int i = threadIdx.x; i < rows; i += kPanelThreads)
+        {
+            const double yn = overwrite ? acc[i] : y[r0 + i] + acc[i];
+            y[r0 + i]       = yn;
+            if (dot_w) part = fma(dot_w[r0 + i], yn, part);
+        }
+        if (dot_w)
+        {
+            part = wave_sum(part);
+            if (lane == 0) unsafeAtomicAdd(dot_out, part);
+        }
         __syncthreads();
     }
     if (ABLATE && sink == 123.456) y[0] = sink;  // keeps the ablated products alive
@@ -834,7 +849,7 @@ int csr_panel_build(spmv_mat* m)
 // multiples of a model value (1.33 ns per entry and CU, measured on L2-resident problems) plus "no throttle";
 // each is timed on scratch vectors (the gather addresses, not the values, set the time).  Part of the
 // one-off analysis, like the reference's shard construction before its timed loop.
-static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, bool trial);
+static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, bool trial, const apply_extra& ex);
 
 int panel_choose_pace(spmv_mat* m)
 {
@@ -869,10 +884,10 @@ int panel_choose_pace(spmv_mat* m)
     int  rc    = SPMV_OK;
     auto timed = [&](int pace_ns, float* ms) -> int {
         m->pb_pace_ns = pace_ns;
-        int r         = panel_launch(ctx, m, x, y, true);  // warm
+        int r         = panel_launch(ctx, m, x, y, true, apply_extra{});  // warm
         if (r != SPMV_OK) return r;
         hipEventRecord(ctx->ev_begin, ctx->stream);
-        for (int i = 0; i < 3 && r == SPMV_OK; ++i) r = panel_launch(ctx, m, x, y, true);
+        for (int i = 0; i < 3 && r == SPMV_OK; ++i) r = panel_launch(ctx, m, x, y, true, apply_extra{});
         hipEventRecord(ctx->ev_end, ctx->stream);
         if (r == SPMV_OK && (hipEventSynchronize(ctx->ev_end) != hipSuccess ||
                              hipEventElapsedTime(ms, ctx->ev_begin, ctx->ev_end) != hipSuccess))
@@ -961,9 +976,16 @@ int panel_choose_pace(spmv_mat* m)
     return rc;
 }
 
-int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y) { return panel_launch(ctx, A, x, y, false); }
+int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
+{
+    return panel_launch(ctx, A, x, y, false, apply_extra{});
+}
+int csr_panel_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, const apply_extra& ex)
+{
+    return panel_launch(ctx, A, x, y, false, ex);
+}
 
-static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, bool trial)
+static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, bool trial, const apply_extra& ex)
 {
     if (!A->pb_val && !A->pb_rec) SPMV_FAIL(SPMV_ERR_INVALID, "panel kernel selected but its layout was not built");
     const int    G   = A->pb_built_rows;
@@ -1014,7 +1036,7 @@ static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, doubl
         }                                                                                                            \
         hipLaunchKernelGGL((csr_panel_kernel<U, GT, LY>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream,           \
                            A->pb_gstart, A->pb_ngroups, A->a, arg_col, A->pb_row,                  \
-                           layout == 1 ? (const double*)A->pb_rec : A->pb_val, x, y, gate, pop, nchunk, skew, pace_fp, pace_slack, pk.sbase, pk.soff, pk.rowbits);   \
+                           layout == 1 ? (const double*)A->pb_rec : A->pb_val, x, y, gate, pop, nchunk, skew, pace_fp, pace_slack, pk.sbase, pk.soff, pk.rowbits, ex.overwrite ? 1 : 0, ex.dot_w, ex.dot_out);   \
         SPMV_HIP(hipGetLastError());                                                                                 \
         return SPMV_OK;                                                                                              \
     }
@@ -1030,7 +1052,7 @@ static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, doubl
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160008));                           \
         hipLaunchKernelGGL((csr_panel_kernel<8, false, 0, AB>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream,    \
                            A->pb_gstart, A->pb_ngroups, A->a, A->pb_col, A->pb_row, A->pb_val, x, y, gate, pop, nchunk,  \
-                           skew, pace_fp, pace_slack, pk.sbase, pk.soff, pk.rowbits);                                                                           \
+                           skew, pace_fp, pace_slack, pk.sbase, pk.soff, pk.rowbits, ex.overwrite ? 1 : 0, ex.dot_w, ex.dot_out);                                                                           \
         SPMV_HIP(hipGetLastError());                                                                                 \
         return SPMV_OK;                                                                                              \
     }
@@ -1057,7 +1079,7 @@ static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, doubl
         }                                                                                                            \
         hipLaunchKernelGGL((csr_panel_kernel<U, false, LY, 0, PP, TR>), dim3(grid), dim3(kPanelThreads), lds,        \
                            ctx->stream, A->pb_gstart, A->pb_ngroups, A->a, arg_col, A->pb_row, A->pb_val, x, y, gate, \
-                           pop, nchunk, skew, pace_fp, pace_slack, pk.sbase, pk.soff, pk.rowbits);                   \
+                           pop, nchunk, skew, pace_fp, pace_slack, pk.sbase, pk.soff, pk.rowbits, ex.overwrite ? 1 : 0, ex.dot_w, ex.dot_out);                   \
         SPMV_HIP(hipGetLastError());                                                                                 \
         return SPMV_OK;                                                                                              \
     }

@@ -1,0 +1,241 @@
+// solver.hip — the step around the hot path: the consumer the reference's vec_dot / vec_axpby
+// (src/vec_vec.cpp:15-29, :31-94) and the `diagonal // for SymGS` fields (include/matrix.h:36,81) were written for is
+// a Krylov iteration.  The reference never got as far as calling them; here is that loop, device-resident:
+//
+//   mat_apply_ex   y = A*x or y += A*x with the dot product w.y of the updated y riding along (fused into the
+//                  write-back of the panel kernel: saves a pass over w and y; other kernels run a dot pass behind)
+//   cg_solve       conjugate gradients for symmetric positive definite A.  Three launches per iteration
+//                  (product+dot, x/r update+dot, direction update); alpha and beta are computed on the device from
+//                  scalars that never leave it, so iterations queue up without a host round trip; the host looks at
+//                  the residual every `check_every` iterations only.
+//
+// Not part of the reference's API: the results are checked against the oracle's product (residual of the solution)
+// in tests/test_gpu_solver.py.
+#include "common.hpp"
+#include "wave.hpp"
+
+namespace spmv
+{
+namespace
+{
+inline int stream_grid(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(kMaxGrid, ceil_div(n, kBlock))); }
+
+// sum over the workgroup, valid in thread 0
+__device__ __forceinline__ double block_sum(double v)
+{
+    __shared__ double s_part[kBlock / kWave];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double total = 0.0;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < kBlock / kWave; ++w) total += s_part[w];
+    return total;
+}
+
+__global__ __launch_bounds__(kBlock) void dot_accumulate_kernel(const double* __restrict__ x, const double* __restrict__ y,
+                                                                int64_t n, double* __restrict__ out)
+{
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        acc = fma(x[i], y[i], acc);
+    const double total = block_sum(acc);
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, total);
+}
+
+// Scalars of the iteration, on the device.  rr[k & 3] = r_k . r_k, pq[k & 3] = p_k . A p_k; slot k + 2 is cleared
+// during iteration k, long after its last reader and before its next writer.
+struct CgScalars
+{
+    double rr[4];
+    double pq[4];
+    double bb;      // b . b
+    double status;  // != 0: breakdown (p . A p <= 0: the matrix is not positive definite)
+};
+
+// r = b - q (q = A x0), p = r, rr[0] = r.r, bb = b.b
+__global__ __launch_bounds__(kBlock) void cg_init_kernel(int64_t n, const double* __restrict__ b, const double* __restrict__ q,
+                                                         double* __restrict__ r, double* __restrict__ p, CgScalars* __restrict__ s)
+{
+    double rr = 0.0, bb = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    {
+        const double bi = b[i];
+        const double ri = bi - q[i];
+        r[i]            = ri;
+        p[i]            = ri;
+        rr              = fma(ri, ri, rr);
+        bb              = fma(bi, bi, bb);
+    }
+    const double t_rr = block_sum(rr);
+    __syncthreads();
+    const double t_bb = block_sum(bb);
+    if (threadIdx.x == 0)
+    {
+        unsafeAtomicAdd(&s->rr[0], t_rr);
+        unsafeAtomicAdd(&s->bb, t_bb);
+    }
+}
+
+// alpha = rr_k / pq_k;  x += alpha p;  r -= alpha q;  rr_{k+1} += r.r
+__global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, int k, const double* __restrict__ p,
+                                                           const double* __restrict__ q, double* __restrict__ x,
+                                                           double* __restrict__ r, CgScalars* __restrict__ s)
+{
+    const double pq = s->pq[k & 3];
+    if (!(pq > 0.0))
+    {
+        if (blockIdx.x == 0 && threadIdx.x == 0) s->status = 1.0;
+        return;  // uniform over the grid: every thread read the same scalar
+    }
+    const double alpha = s->rr[k & 3] / pq;
+    double       rr    = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    {
+        x[i]            = fma(alpha, p[i], x[i]);
+        const double ri = fma(-alpha, q[i], r[i]);
+        r[i]            = ri;
+        rr              = fma(ri, ri, rr);
+    }
+    const double total = block_sum(rr);
+    if (threadIdx.x == 0) unsafeAtomicAdd(&s->rr[(k + 1) & 3], total);
+}
+
+// beta = rr_{k+1} / rr_k;  p = r + beta p;  clear the slots of iteration k + 2
+__global__ __launch_bounds__(kBlock) void cg_direction_kernel(int64_t n, int k, const double* __restrict__ r,
+                                                              double* __restrict__ p, CgScalars* __restrict__ s)
+{
+    const double rr_k = s->rr[k & 3];
+    const double beta = rr_k > 0.0 ? s->rr[(k + 1) & 3] / rr_k : 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        p[i] = fma(beta, p[i], r[i]);
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+    {
+        s->rr[(k + 2) & 3] = 0.0;
+        s->pq[(k + 2) & 3] = 0.0;
+    }
+}
+}  // namespace
+
+int vec_dot_accumulate(spmv_ctx* ctx, const double* x, const double* y, int64_t n, double* device_out)
+{
+    if (n == 0) return SPMV_OK;
+    hipLaunchKernelGGL(dot_accumulate_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, x, y, n, device_out);
+    SPMV_HIP(hipGetLastError());
+    return SPMV_OK;
+}
+
+int mat_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
+{
+    switch (A->format)
+    {
+        case SPMV_FMT_CSR: return csr_apply(ctx, A, x, y);
+        case SPMV_FMT_ELL: return ell_apply(ctx, A, x, y);
+        case SPMV_FMT_COO: return coo_apply(ctx, A, x, y);
+        case SPMV_FMT_CSC: return csc_apply(ctx, A, x, y);
+        case SPMV_FMT_DIA: return dia_apply(ctx, A, x, y);
+        default: SPMV_FAIL(SPMV_ERR_INVALID, "unknown format %d", A->format);
+    }
+}
+
+int mat_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, const apply_extra& ex)
+{
+    // the panel kernel (CSR, and COO / CSC through their row-grouped copies) does all of it in its write-back
+    const spmv_mat* panel = nullptr;
+    if (A->format == SPMV_FMT_CSR && A->kernel == SPMV_CSR_PANEL && A->nrow > 0 && A->nnz > 0) panel = A;
+    if (A->format == SPMV_FMT_COO && A->coo_csr && A->kernel == SPMV_CSR_PANEL && A->nnz > 0) panel = A->coo_csr;
+    if (A->format == SPMV_FMT_CSC && A->coo_csr && !A->kernel_forced && A->nnz > 0 && A->ncol > 0) panel = A->coo_csr;
+    if (panel) return csr_panel_apply_ex(ctx, panel, x, y, ex);
+    if (ex.overwrite) SPMV_TRY(vec_fill(ctx, y, A->nrow, 0.0));
+    SPMV_TRY(mat_apply(ctx, A, x, y));
+    if (ex.dot_w) SPMV_TRY(vec_dot_accumulate(ctx, ex.dot_w, y, A->nrow, ex.dot_out));
+    return SPMV_OK;
+}
+
+int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int max_iter, double rel_tol, int check_every,
+             int* iters, double* rel_resid)
+{
+    const int64_t n = A->nrow;
+    *iters          = 0;
+    *rel_resid      = 0.0;
+    if (n == 0) return SPMV_OK;
+    hipStream_t st = ctx->stream;
+    double *    r = nullptr, *p = nullptr, *q = nullptr;
+    CgScalars*  s = nullptr;
+    auto        release = [&]() {
+        if (r) hipFree(r);
+        if (p) hipFree(p);
+        if (q) hipFree(q);
+        if (s) hipFree(s);
+    };
+    if (hipMalloc(&r, sizeof(double) * (size_t)n) != hipSuccess || hipMalloc(&p, sizeof(double) * (size_t)n) != hipSuccess ||
+        hipMalloc(&q, sizeof(double) * (size_t)n) != hipSuccess || hipMalloc(&s, sizeof(CgScalars)) != hipSuccess)
+    {
+        release();
+        SPMV_FAIL(SPMV_ERR_ALLOC, "spmv_cg: out of device memory for three work vectors of %lld entries", (long long)n);
+    }
+    const int grid = stream_grid(n);
+    int       rc   = SPMV_OK;
+    CgScalars h{};
+    auto      fetch = [&]() -> int {
+        if (hipMemcpyAsync(&h, s, sizeof(CgScalars), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        {
+            set_error("spmv_cg: reading the iteration scalars failed: %s", hipGetErrorString(hipGetLastError()));
+            return SPMV_ERR_HIP;
+        }
+        return SPMV_OK;
+    };
+    do
+    {
+        if (hipMemsetAsync(s, 0, sizeof(CgScalars), st) != hipSuccess)
+        {
+            rc = SPMV_ERR_HIP;
+            break;
+        }
+        apply_extra first;
+        first.overwrite = true;
+        if ((rc = mat_apply_ex(ctx, A, x, q, first)) != SPMV_OK) break;  // q = A x0
+        hipLaunchKernelGGL(cg_init_kernel, dim3(grid), dim3(kBlock), 0, st, n, b, q, r, p, s);
+        if ((rc = fetch()) != SPMV_OK) break;
+        const double bb    = h.bb;
+        const double limit = rel_tol * rel_tol * bb;  // compare squared norms
+        double       rr    = h.rr[0];
+        int          k     = 0;
+        if (!(bb > 0.0) || rr <= limit)
+        {
+            *rel_resid = bb > 0.0 ? sqrt(rr / bb) : 0.0;  // b = 0: x0 solves it if r = 0 (else the caller sees iters = 0)
+            break;
+        }
+        const int every = std::max(1, check_every);
+        while (k < max_iter)
+        {
+            apply_extra ex;
+            ex.overwrite = true;
+            ex.dot_w     = p;
+            ex.dot_out   = &s->pq[k & 3];
+            if ((rc = mat_apply_ex(ctx, A, p, q, ex)) != SPMV_OK) break;  // q = A p, pq_k = p . q
+            hipLaunchKernelGGL(cg_update_kernel, dim3(grid), dim3(kBlock), 0, st, n, k, p, q, x, r, s);
+            hipLaunchKernelGGL(cg_direction_kernel, dim3(grid), dim3(kBlock), 0, st, n, k, r, p, s);
+            ++k;
+            if (k % every == 0 || k == max_iter)
+            {
+                if ((rc = fetch()) != SPMV_OK) break;
+                rr = h.rr[k & 3];
+                if (h.status != 0.0)
+                {
+                    set_error("spmv_cg: p.Ap <= 0 at or before iteration %d: the matrix is not positive definite", k);
+                    rc = SPMV_ERR_INVALID;
+                    break;
+                }
+                if (rr <= limit) break;
+            }
+        }
+        if (rc == SPMV_OK && hipGetLastError() != hipSuccess) rc = SPMV_ERR_HIP;
+        *iters     = k;
+        *rel_resid = sqrt(rr / bb);
+    } while (0);
+    hipStreamSynchronize(st);
+    release();
+    return rc;
+}
+}  // namespace spmv

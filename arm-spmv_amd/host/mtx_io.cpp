@@ -7,6 +7,11 @@
 //   * only `matrix coordinate complex` is refused (:66-71); `symmetric` files are NOT expanded and `pattern`
 //     files are read with the same three-field format (a pattern file therefore mis-parses, as it does there)
 //   * entries are read as "%d %d %lg", 1-based -> 0-based (:83-88); failures print and exit(1)
+// Opt-in (off by default so that the default output equals the reference's):
+//   SPMV_MTX_PATTERN=1    a `pattern` file is read as "%d %d" per entry with value 1.0
+//   SPMV_MTX_SYMMETRIC=1  `symmetric` / `hermitian` / `skew-symmetric` files are expanded: every off-diagonal entry
+//                         (i, j, v) is followed by its mirror (j, i, v) (skew: -v); NNZ in the `###` line is the
+//                         expanded count
 #include <algorithm>
 #include <cctype>
 #include <cstring>
@@ -92,7 +97,14 @@ int mm_size_read(FILE* fp, int* rows, int* cols, int* entries)
 // ---------------------------------------------------------------------------------------------------------
 static inline bool is_space(char c) { return c == ' ' || c == '\n' || c == '\t' || c == '\r' || c == '\f' || c == '\v'; }
 
-static bool parse_entries_parallel(FILE* fp, int nz, int* ii, int* jj, double* vv)
+static bool env_on(const char* name)
+{
+    const char* e = getenv(name);
+    return e && *e && strcmp(e, "0") != 0;
+}
+
+// fields: tokens per entry (3, or 2 for a pattern file read with SPMV_MTX_PATTERN=1: the value is 1.0)
+static bool parse_entries_parallel(FILE* fp, int nz, int* ii, int* jj, double* vv, int fields)
 {
     const char* env      = getenv("SPMV_MTX_THREADS");
     unsigned    nthreads = env ? (unsigned)atoi(env) : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
@@ -136,9 +148,9 @@ static bool parse_entries_parallel(FILE* fp, int nz, int* ii, int* jj, double* v
     for (unsigned t = 0; t < nthreads; ++t) pool.emplace_back(count, t);
     for (auto& th : pool) th.join();
     for (unsigned t = 0; t < nthreads; ++t) first[t + 1] += first[t];
-    if (first[nthreads] < 3LL * nz)
+    if (first[nthreads] < (long long)fields * nz)
     {
-        printf("*** Matrix Market file ends after %lld of %d entries ***\n", first[nthreads] / 3, nz);
+        printf("*** Matrix Market file ends after %lld of %d entries ***\n", first[nthreads] / fields, nz);
         exit(1);
     }
     // pass 2: convert
@@ -146,16 +158,19 @@ static bool parse_entries_parallel(FILE* fp, int nz, int* ii, int* jj, double* v
     auto convert = [&](unsigned t) {
         long long tok = first[t];
         size_t    p   = cut[t];
-        while (p < cut[t + 1] && tok < 3LL * nz)
+        while (p < cut[t + 1] && tok < (long long)fields * nz)
         {
             while (p < cut[t + 1] && is_space(buf[p])) ++p;
             if (p >= cut[t + 1]) break;
             char*           stop = nullptr;
-            const long long k    = tok / 3;
-            switch (tok % 3)
+            const long long k    = tok / fields;
+            switch (tok % fields)
             {
                 case 0: ii[k] = (int)strtol(&buf[p], &stop, 10) - 1; break;
-                case 1: jj[k] = (int)strtol(&buf[p], &stop, 10) - 1; break;
+                case 1:
+                    jj[k] = (int)strtol(&buf[p], &stop, 10) - 1;
+                    if (fields == 2) vv[k] = 1.0;
+                    break;
                 default: vv[k] = strtod(&buf[p], &stop); break;
             }
             if (stop == &buf[p]) bad[t] = 1;  // not a number: fscanf would have stopped here
@@ -204,18 +219,28 @@ void COOMatrixRead(const char* filename, COOMatrix& A)
     int nrow, ncol, nz;
     if (mm_size_read(fp, &nrow, &ncol, &nz) != 0) exit(1);
 
+    const bool pattern = banner.field == 'P' && env_on("SPMV_MTX_PATTERN");
+    const bool expand  = banner.symmetry != 'G' && env_on("SPMV_MTX_SYMMETRIC");
+    if (nz < 0 || (expand && nz > INT32_MAX / 2))
+    {
+        printf("*** Matrix Market size line: %d entries cannot be held ***\n", nz);
+        exit(1);
+    }
     printf("\tAllocating memory for matrix\n");
-    int*    ii = new int[nz > 0 ? nz : 1];
-    int*    jj = new int[nz > 0 ? nz : 1];
-    double* vv = new double[nz > 0 ? nz : 1];
+    const size_t room = (size_t)(nz > 0 ? nz : 1) * (expand ? 2 : 1);  // mirrors of a symmetric file
+    int*    ii = new int[room];
+    int*    jj = new int[room];
+    double* vv = new double[room];
 
     printf("\tReading matrix entries from file\n");
-    if (!parse_entries_parallel(fp, nz, ii, jj, vv))
+    if (!parse_entries_parallel(fp, nz, ii, jj, vv, pattern ? 2 : 3))
     {
         // small file, or threads disabled (SPMV_MTX_THREADS=1): the reference's loop (src/data_io.cpp:83-88)
         for (int k = 0; k < nz; ++k)
         {
-            if (fscanf(fp, "%d %d %lg\n", &ii[k], &jj[k], &vv[k]) != 3)
+            vv[k]        = 1.0;
+            const int got = pattern ? fscanf(fp, "%d %d\n", &ii[k], &jj[k]) + 1 : fscanf(fp, "%d %d %lg\n", &ii[k], &jj[k], &vv[k]);
+            if (got != 3)
             {
                 printf("*** Matrix Market file ends after %d of %d entries ***\n", k, nz);
                 exit(1);
@@ -225,6 +250,31 @@ void COOMatrixRead(const char* filename, COOMatrix& A)
         }
     }
     fclose(fp);
+    if (expand)
+    {
+        // in place, back to front: entry k lands at k + (off-diagonal entries before k), its mirror right after it
+        int off = 0;
+        for (int k = 0; k < nz; ++k) off += ii[k] != jj[k];
+        const double sign = banner.symmetry == 'K' ? -1.0 : 1.0;
+        int          w    = nz + off;
+        for (int k = nz - 1; k >= 0; --k)
+        {
+            const int    i = ii[k], j = jj[k];
+            const double v = vv[k];
+            if (i != j)
+            {
+                --w;
+                ii[w] = j;
+                jj[w] = i;
+                vv[w] = sign * v;
+            }
+            --w;
+            ii[w] = i;
+            jj[w] = j;
+            vv[w] = v;
+        }
+        nz += off;
+    }
     printf("### ROW=%d, COL=%d, NNZ=%d\n", nrow, ncol, nz);
 
     A.Free();

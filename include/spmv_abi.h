@@ -179,6 +179,23 @@ int spmv_dot(spmv_ctx* ctx, const spmv_vec* x, const spmv_vec* y, double* result
 int spmv_axpby(spmv_ctx* ctx, double alpha, const spmv_vec* x, double beta, const spmv_vec* y,
                spmv_vec* w);
 
+/* ---- the solver step around the product ------------------------------------ */
+/* The reference ships vec_dot / vec_axpby (src/vec_vec.cpp) and `diagonal // for SymGS` fields
+ * (include/matrix.h:36,81) for a Krylov loop it never calls; these two entry points are that loop,
+ * device-resident.  Not present in the reference's API.
+ *
+ * spmv_apply_dot: y = A*x (overwrite != 0) or y += A*x, and *dot = sum_i w_i * y_i over the UPDATED y,
+ *   computed in the product's own write-back where the kernel supports it (panel kernel), else by a
+ *   pass behind it.  w has nrow entries and may be x itself (square A).  Synchronous (returns the scalar).
+ * spmv_cg: conjugate gradients for symmetric positive definite A (square): solves A*x = b starting from
+ *   the x passed in, until ||r|| <= rel_tol * ||b|| or max_iter iterations.  alpha/beta stay on the
+ *   device; the host reads the residual every check_every iterations (>= 1).  *iters = iterations run,
+ *   *rel_resid = ||r|| / ||b|| of the recurrence at the last check.  SPMV_ERR_INVALID if p.Ap <= 0. */
+int spmv_apply_dot(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* x, spmv_vec* y, int32_t overwrite,
+                   const spmv_vec* w, double* dot);
+int spmv_cg(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* b, spmv_vec* x, int32_t max_iter,
+            double rel_tol, int32_t check_every, int32_t* iters, double* rel_resid);
+
 /* ---- format conversion on the device (src/matrix.cpp:115-154, :450-500) -------------------------- */
 /* Both keep the COO order of the entries inside each row (stable), like the reference's backward
  * scatter, so the result is identical to the reference's arrays, not merely equivalent. */

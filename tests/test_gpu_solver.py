@@ -1,0 +1,143 @@
+"""GPU tests of the solver step around the product (spmv_apply_dot, spmv_cg).
+
+The reference has no solver (its vec_dot / vec_axpby are never called), so there is no reference output to pin these
+against ("parity unpinned" for the iteration itself).  What IS pinned: the y of apply_dot against the reference's golden
+y (same gate as the product), its dot against the dot of that y, and the solution of CG through the oracle's product:
+||b - A x|| / ||b|| computed on the CPU with oracle/spmv_oracle.c.
+"""
+import numpy as np
+import pytest
+
+import cases
+import oracle_lib as ol
+from conftest import golden
+from test_gpu_parity import _csr_of, _scale
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("make", cases.ALL_CASES, ids=lambda f: f.__name__)
+def test_apply_dot_matches_golden_y_and_its_dot(ctx, orc, pkg, make):
+    capi = pkg.capi
+    c = make()
+    g = golden(c["name"])
+    rp, cc, cv = _csr_of(orc, c)
+    scale = _scale(orc, c)
+    w_host = np.random.default_rng(11).uniform(-1, 1, c["nrow"])
+    mats = []
+    for kernel in (capi.CSR_AUTO, capi.CSR_PANEL, capi.CSR_VECTOR, capi.CSR_SCALAR):
+        A = ctx.csr(c["nrow"], c["ncol"], rp, cc, cv)
+        A.set_kernel(kernel)
+        mats.append((f"csr kernel={kernel}", A, "y1_csr"))
+    mats.append(("coo", ctx.coo(c["nrow"], c["ncol"], ol.i32(c["row"]), ol.i32(c["col"]), ol.f64(c["val"])), "y1_coo"))
+    mats.append(("ell", ctx.coo_to_ell(mats[-1][1]), "y1_ell"))
+    x, w = ctx.vector_from(c["x"]), ctx.vector_from(w_host)
+    for name, A, key in mats:
+        for overwrite in (True, False):
+            y = ctx.vector(c["nrow"])
+            y.fill(123.0 if overwrite else 0.0)  # overwrite must not see what was there
+            d = ctx.apply_dot(A, x, y, w, overwrite=overwrite)
+            got = y.download()
+            ol.assert_parity(got, g[key], scale, f"{c['name']} apply_dot {name} overwrite={overwrite}")
+            ref = float(np.dot(w_host, got))
+            assert abs(d - ref) <= 1e-12 * float(np.dot(np.abs(w_host), np.abs(got))) + 1e-300, (name, overwrite, d, ref)
+
+
+def _laplacian_2d(m):
+    """5-point Laplacian on an m x m grid, CSR (symmetric positive definite)"""
+    n = m * m
+    idx = np.arange(n).reshape(m, m)
+    rows, cols, vals = [idx.ravel()], [idx.ravel()], [np.full(n, 4.0)]
+    for a, b in ((idx[:, :-1], idx[:, 1:]), (idx[:-1, :], idx[1:, :])):
+        rows += [a.ravel(), b.ravel()]
+        cols += [b.ravel(), a.ravel()]
+        vals += [np.full(a.size, -1.0)] * 2
+    r, c, v = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    o = np.lexsort((c, r))
+    r, c, v = r[o], c[o], v[o]
+    rp = np.zeros(n + 1, np.int32)
+    np.add.at(rp, r + 1, 1)
+    return n, np.cumsum(rp).astype(np.int32), c.astype(np.int32), v
+
+
+def _spd_random(n, k, seed):
+    """B + B^T with a dominant diagonal: symmetric, strictly diagonally dominant -> positive definite"""
+    rng = np.random.default_rng(seed)
+    r = np.repeat(np.arange(n), k)
+    c = rng.integers(0, n, n * k)
+    v = rng.uniform(-1, 1, n * k)
+    keep = r != c
+    r, c, v = r[keep], c[keep], v[keep]
+    rr, cc, vv = np.concatenate([r, c]), np.concatenate([c, r]), np.concatenate([v, v])
+    diag = np.zeros(n)
+    np.add.at(diag, rr, np.abs(vv))
+    rr, cc, vv = np.concatenate([rr, np.arange(n)]), np.concatenate([cc, np.arange(n)]), np.concatenate([vv, diag + 1.0])
+    o = np.lexsort((cc, rr))
+    rr, cc, vv = rr[o], cc[o], vv[o]
+    rp = np.zeros(n + 1, np.int64)
+    np.add.at(rp, rr + 1, 1)
+    return n, np.cumsum(rp).astype(np.int32), cc.astype(np.int32), vv
+
+
+def _cg_numpy_iters(orc, rp, cc, cv, b, tol, max_iter):
+    """the same recurrence on the CPU with the oracle's product, for the iteration count"""
+    n = len(b)
+    x, r = np.zeros(n), b.copy()
+    p, rr = r.copy(), float(r @ r)
+    bb = float(b @ b)
+    for k in range(1, max_iter + 1):
+        q = np.zeros(n)
+        ol.csr_spmv(orc, rp, cc, cv, p, q)
+        alpha = rr / float(p @ q)
+        x += alpha * p
+        r -= alpha * q
+        rr_new = float(r @ r)
+        if rr_new <= tol * tol * bb:
+            return k
+        p = r + (rr_new / rr) * p
+        rr = rr_new
+    return max_iter
+
+
+@pytest.mark.parametrize("problem", ["laplacian", "random_spd", "random_spd_panel"])
+def test_cg_solves_spd_systems(ctx, orc, pkg, problem):
+    capi = pkg.capi
+    if problem == "laplacian":
+        n, rp, cc, cv = _laplacian_2d(96)
+    elif problem == "random_spd":
+        n, rp, cc, cv = _spd_random(20_000, 6, 5)
+    else:
+        n, rp, cc, cv = _spd_random(300_000, 5, 6)  # > 2M entries: the panel kernel with the fused dot
+    A = ctx.csr(n, n, rp, cc, cv)
+    if problem == "random_spd_panel":
+        assert A.info.kernel == capi.CSR_PANEL
+    b_host = np.random.default_rng(2).uniform(-1, 1, n)
+    b, x = ctx.vector_from(b_host), ctx.vector(n)
+    tol = 1e-9
+    for check_every in (1, 7):
+        x.fill(0.0)
+        iters, relres = ctx.cg(A, b, x, max_iter=2000, rel_tol=tol, check_every=check_every)
+        sol = x.download()
+        ax = np.zeros(n)
+        ol.csr_spmv(orc, rp, cc, cv, sol, ax)
+        true_res = np.linalg.norm(b_host - ax) / np.linalg.norm(b_host)
+        assert relres <= tol and true_res <= 20 * tol, (problem, check_every, iters, relres, true_res)
+        if n <= 20_000:
+            want = _cg_numpy_iters(orc, rp, cc, cv, b_host, tol, 2000)
+            assert abs(iters - want) <= max(2, check_every), (problem, check_every, iters, want)
+    # warm start from the solution: nothing left to do
+    iters, relres = ctx.cg(A, b, x, max_iter=50, rel_tol=1e-6)
+    assert iters == 0 and relres <= 1e-6
+
+
+def test_cg_reports_a_matrix_that_is_not_positive_definite(ctx, pkg):
+    n = 1000
+    rp = np.arange(n + 1, dtype=np.int32)
+    A = ctx.csr(n, n, rp, np.arange(n, dtype=np.int32), np.full(n, -1.0))  # -I
+    b, x = ctx.vector_from(np.ones(n)), ctx.vector(n)
+    x.fill(0.0)
+    with pytest.raises(pkg.capi.SpmvError, match="not positive definite"):
+        ctx.cg(A, b, x, max_iter=10, rel_tol=1e-8)
+    rect = ctx.csr(n, n + 1, rp, np.arange(n, dtype=np.int32), np.ones(n))
+    with pytest.raises(pkg.capi.SpmvError, match="not square"):
+        ctx.cg(rect, b, x, max_iter=10, rel_tol=1e-8)

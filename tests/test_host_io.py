@@ -91,3 +91,56 @@ def test_reader_rejects_bad_input_like_the_reference(tmp_path):
                 "buf=(C.c_char*64)(); f(%r, buf)") % (str(LIB), str(path).encode())
         r = subprocess.run(["python3", "-c", code], capture_output=True, text=True)
         assert r.returncode == 1 and msg in r.stdout, (path, r.stdout, r.stderr)
+
+
+@pytest.mark.parametrize("threads", ["1", "4"])
+def test_opt_in_pattern_and_symmetric_expansion(lib, tmp_path, threads, monkeypatch):
+    """SURVEY 8f rank 2: by default a symmetric file is NOT expanded (as in the reference, src/data_io.cpp:83-88);
+    SPMV_MTX_SYMMETRIC=1 adds the mirrored entries, SPMV_MTX_PATTERN=1 reads `pattern` files as (i, j) pairs of 1.0"""
+    monkeypatch.setenv("SPMV_MTX_THREADS", threads)
+    rng = np.random.default_rng(3)
+    n, nz = 700, 70_000  # >= 65536 entries: the parallel parser takes the file when threads > 1
+    i = rng.integers(0, n, nz)
+    j = rng.integers(0, n, nz)
+    i, j = np.maximum(i, j), np.minimum(i, j)  # lower triangle, diagonal included
+    v = rng.uniform(-1, 1, nz)
+    read = getattr(lib, "_Z13COOMatrixReadPKcR9COOMatrix")
+    read.argtypes = [C.c_char_p, C.POINTER(COO)]
+
+    def load(path):
+        A = COO()
+        read(str(path).encode(), C.byref(A))
+        k = A.nnz
+        return (A.nrow, A.ncol, np.ctypeslib.as_array(A.row_ind, (k,)).copy(), np.ctypeslib.as_array(A.col_ind, (k,)).copy(),
+                np.ctypeslib.as_array(A.values, (k,)).copy())
+
+    for sym, sign in (("symmetric", 1.0), ("skew-symmetric", -1.0)):
+        p = tmp_path / f"{sym}.mtx"
+        with open(p, "w") as f:
+            f.write(f"%%MatrixMarket matrix coordinate real {sym}\n{n} {n} {nz}\n")
+            for a, b, c in zip(i, j, v):
+                f.write(f"{a + 1} {b + 1} {c:.17g}\n")
+        monkeypatch.delenv("SPMV_MTX_SYMMETRIC", raising=False)
+        _, _, r, c, w = load(p)
+        assert len(w) == nz and np.array_equal(r, i) and np.array_equal(c, j)  # default: as the reference
+        monkeypatch.setenv("SPMV_MTX_SYMMETRIC", "1")
+        _, _, r, c, w = load(p)
+        off = i != j
+        assert len(w) == nz + off.sum()
+        # every stored entry keeps its place in file order, followed by its mirror
+        er = np.empty(len(w), np.int64)
+        ec = np.empty(len(w), np.int64)
+        ev = np.empty(len(w))
+        pos = np.arange(nz) + np.concatenate(([0], np.cumsum(off)[:-1]))
+        er[pos], ec[pos], ev[pos] = i, j, v
+        er[pos[off] + 1], ec[pos[off] + 1], ev[pos[off] + 1] = j[off], i[off], sign * v[off]
+        assert np.array_equal(r, er) and np.array_equal(c, ec) and np.array_equal(w, ev)
+    monkeypatch.delenv("SPMV_MTX_SYMMETRIC", raising=False)
+    p = tmp_path / "pattern.mtx"
+    with open(p, "w") as f:
+        f.write(f"%%MatrixMarket matrix coordinate pattern general\n{n} {n} {nz}\n")
+        for a, b in zip(i, j):
+            f.write(f"{a + 1} {b + 1}\n")
+    monkeypatch.setenv("SPMV_MTX_PATTERN", "1")
+    _, _, r, c, w = load(p)
+    assert len(w) == nz and np.array_equal(r, i) and np.array_equal(c, j) and np.all(w == 1.0)
