@@ -67,3 +67,83 @@ def max_over_ranks(value: float, device, group=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+# ---- solver step across shards ----------------------------------------------------------
+def sum_over_ranks(value: float, device, group=None) -> float:
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return float(t.item())
+
+
+class HipShardOps:
+    """What one rank does locally in cg_sharded, on its GPU through the engine (no torch arithmetic):
+    the shard product with the fused dot (spmv_apply_dot) and the reference's BLAS-1 (spmv_axpby, spmv_dot)."""
+
+    def __init__(self, ctx: "capi.Context", A_shard: "capi.Matrix"):
+        self.ctx, self.A = ctx, A_shard
+        self._views: dict = {}
+
+    def _v(self, t: torch.Tensor) -> "capi.Vector":
+        key = (t.data_ptr(), t.numel())
+        if key not in self._views:
+            self._views[key] = self.ctx.wrap_vector(t)
+        return self._views[key]
+
+    def product_dot(self, p_full, w_own, q_own) -> float:  # q = A_shard p ; returns w_own . q
+        return self.ctx.apply_dot(self.A, self._v(p_full), self._v(q_own), self._v(w_own), overwrite=True)
+
+    def axpby(self, alpha, x, beta, y, w) -> None:  # w = alpha x + beta y (w may be x or y)
+        self.ctx.axpby(alpha, self._v(x), beta, self._v(y), self._v(w))
+
+    def dot(self, a, b) -> float:
+        return self.ctx.dot(self._v(a), self._v(b))
+
+    def sync(self) -> None:
+        self.ctx.sync()
+
+
+def cg_sharded(ops, b_own: torch.Tensor, x_own: torch.Tensor, nrow: int, max_iter: int = 1000, rel_tol: float = 1e-8,
+               group=None) -> tuple[int, float]:
+    """Conjugate gradients over row shards (A symmetric positive definite, x0 = x_own on entry, overwritten).
+
+    Per iteration: ONE all-gather (the search direction p, which every shard needs in full — the x exchange of
+    SURVEY.md 8e) and two scalar all-reduces (p.Ap and r.r).  Vectors stay sharded by rows and device-resident;
+    `ops` does the local work (HipShardOps on a GPU; the CPU tests plug the oracle in).  Every rank returns the same
+    (iterations, ||r|| / ||b||)."""
+    dev = b_own.device
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lo, hi = all_bounds(nrow, world)[rank]
+    p_full = torch.empty(nrow, dtype=torch.float64, device=dev)
+    q_own, r_own, p_own = torch.empty_like(b_own), torch.empty_like(b_own), torch.empty_like(b_own)
+    # r = b - A x0, p = r
+    allgather_x(p_full, x_own, nrow, group)
+    if dev.type == "cuda":
+        torch.cuda.current_stream(dev).synchronize()
+    ops.product_dot(p_full, b_own, q_own)
+    ops.axpby(1.0, b_own, -1.0, q_own, r_own)
+    ops.axpby(1.0, r_own, 0.0, r_own, p_own)
+    bb = sum_over_ranks(ops.dot(b_own, b_own), dev, group)
+    rr = sum_over_ranks(ops.dot(r_own, r_own), dev, group)
+    if bb == 0.0 or rr <= rel_tol * rel_tol * bb:
+        return 0, (rr / bb) ** 0.5 if bb > 0.0 else 0.0
+    k = 0
+    while k < max_iter:
+        ops.sync()  # the collective runs on torch's stream: p_own must be complete
+        allgather_x(p_full, p_own, nrow, group)
+        if dev.type == "cuda":
+            torch.cuda.current_stream(dev).synchronize()  # ... and p_full before the engine's stream reads it
+        pq = sum_over_ranks(ops.product_dot(p_full, p_own, q_own), dev, group)
+        if not pq > 0.0:
+            raise ArithmeticError(f"cg_sharded: p.Ap = {pq} at iteration {k}: the matrix is not positive definite")
+        alpha = rr / pq
+        ops.axpby(alpha, p_own, 1.0, x_own, x_own)
+        ops.axpby(-alpha, q_own, 1.0, r_own, r_own)
+        rr_new = sum_over_ranks(ops.dot(r_own, r_own), dev, group)
+        k += 1
+        if rr_new <= rel_tol * rel_tol * bb:
+            rr = rr_new
+            break
+        ops.axpby(1.0, r_own, rr_new / rr, p_own, p_own)
+        rr = rr_new
+    return k, (rr / bb) ** 0.5

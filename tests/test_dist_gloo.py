@@ -73,3 +73,81 @@ def test_row_sharded_product_over_gloo(world, nrow):
     assert sorted(r[0] for r in results) == list(range(world))
     assert all(r[1] for r in results), "assembled y differs from the unsharded product"
     assert all(r[2] == float(world) for r in results)
+
+
+class _OracleOps:
+    """CPU stand-in for dist.HipShardOps in the gloo tests: the oracle's product and numpy BLAS-1"""
+
+    def __init__(self, orc, ol, srp, scol, sval):
+        self.orc, self.ol, self.m = orc, ol, (srp, scol, sval)
+
+    def product_dot(self, p_full, w_own, q_own):
+        q = q_own.numpy()
+        q[:] = 0.0
+        self.ol.csr_spmv(self.orc, *self.m, p_full.numpy(), q)
+        return float(np.dot(w_own.numpy(), q))
+
+    def axpby(self, alpha, x, beta, y, w):
+        w.numpy()[:] = alpha * x.numpy() + beta * y.numpy()
+
+    def dot(self, a, b):
+        return float(np.dot(a.numpy(), b.numpy()))
+
+    def sync(self):
+        pass
+
+
+def _cg_worker(rank, world, port, m, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    sys.path[:0] = [str(root), str(root / "tests")]
+    from __graft_entry__ import load_package
+    import importlib
+
+    load_package()
+    dmod = importlib.import_module("arm_spmv_amd.dist")
+    import oracle_lib as ol
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        orc = ol.load_oracle()
+        # 1-D Laplacian plus a wrap-around coupling: symmetric positive definite, rows reach into other shards
+        n = m
+        rows = np.repeat(np.arange(n), 3)
+        cols = np.stack([(np.arange(n) - 1) % n, np.arange(n), (np.arange(n) + 1) % n], 1).ravel()
+        vals = np.tile(np.array([-1.0, 2.5, -1.0]), n)
+        rp = np.arange(0, 3 * n + 1, 3, dtype=np.int32)
+        col, val = cols.astype(np.int32), vals
+        bvec = np.random.default_rng(4).uniform(-1, 1, n)
+        b, e = dmod.shard_rows(n, world, rank)
+        srp = ol.csr_shard_row_ptr(orc, rp, b, e)
+        ops = _OracleOps(orc, ol, srp, np.ascontiguousarray(col[rp[b]:rp[e]]), np.ascontiguousarray(val[rp[b]:rp[e]]))
+        x_own = torch.zeros(e - b, dtype=torch.float64)
+        iters, relres = dmod.cg_sharded(ops, torch.from_numpy(bvec[b:e].copy()), x_own, n, max_iter=500, rel_tol=1e-10)
+        x_full = dmod.concatenate_y(x_own, n).numpy()
+        ax = np.zeros(n)
+        ol.csr_spmv(orc, rp, col, val, x_full, ax)
+        true_res = float(np.linalg.norm(bvec - ax) / np.linalg.norm(bvec))
+        q.put((rank, iters, relres, true_res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,m", [(2, 600), (3, 601)])
+def test_sharded_cg_over_gloo(world, m):
+    """dist.cg_sharded: one all-gather of the direction + two scalar all-reduces per iteration"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cg_worker, args=(r, world, port, m, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len({(r[1], r[2]) for r in results}) == 1, "ranks disagree on iterations / residual"
+    assert all(0 < r[1] < 500 and r[2] <= 1e-10 and r[3] <= 1e-9 for r in results), results
