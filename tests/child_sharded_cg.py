@@ -1,0 +1,58 @@
+"""Child process of tests/test_gpu_solver.py::test_sharded_cg_with_the_engine_as_local_ops (GPU box only)."""
+import importlib
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "tests")]
+
+
+def main():
+    torch.cuda.init()  # torch's HIP runtime first, then the engine (same order as bench.py)
+    dev = torch.device("cuda", 0)
+    from __graft_entry__ import load_package
+
+    import oracle_lib as ol
+    from test_gpu_solver import _spd_random
+
+    pkg = load_package()
+    dmod = importlib.import_module("arm_spmv_amd.dist")
+    orc = ol.load_oracle()
+    ctx = pkg.capi.Context(0)
+    n, rp, cc, cv = _spd_random(50_000, 6, 9)
+    A = ctx.csr(n, n, rp, cc, cv)
+    b_host = np.random.default_rng(3).uniform(-1, 1, n)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        b_t = torch.from_numpy(b_host).to(dev)
+        x_t = torch.zeros(n, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        iters, relres = dmod.cg_sharded(dmod.HipShardOps(ctx, A), b_t, x_t, n, max_iter=500, rel_tol=1e-9)
+        ctx.sync()
+        sol = x_t.cpu().numpy()
+    finally:
+        dist.destroy_process_group()
+    ax = np.zeros(n)
+    ol.csr_spmv(orc, rp, cc, cv, sol, ax)
+    true_res = np.linalg.norm(b_host - ax) / np.linalg.norm(b_host)
+    assert relres <= 1e-9 and true_res <= 2e-8, (relres, true_res)
+    x2 = ctx.vector(n)
+    x2.fill(0.0)
+    iters2, _ = ctx.cg(A, ctx.vector_from(b_host), x2, max_iter=500, rel_tol=1e-9)
+    assert abs(iters - iters2) <= 2, (iters, iters2)
+    assert np.max(np.abs(x2.download() - sol)) <= 1e-7 * np.max(np.abs(sol))
+    print(f"SHARDED_CG_OK iters={iters} single_device_iters={iters2} true_residual={true_res:.3e}")
+
+
+if __name__ == "__main__":
+    main()

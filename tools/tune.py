@@ -37,7 +37,7 @@ def sweep(ctx, A, x, y, variants, rounds, reps, bytes_launch, nnz):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["csr", "ell", "coo", "blas1", "bandwin", "dia"])
+    ap.add_argument("what", choices=["csr", "ell", "coo", "blas1", "bandwin", "dia", "cg"])
     ap.add_argument("--n", type=int, default=0)
     ap.add_argument("--k", type=int, default=0)
     ap.add_argument("--band", type=int, default=0)
@@ -69,6 +69,38 @@ def main():
             ctx.dot(x, y)  # synchronous (returns the scalar)
         ms = (time.perf_counter() - t) / 20 * 1e3
         print(f"{'dot':16s} n={n}: {ms:.4f} ms  {16 * n / ms / 1e6:.1f} GB/s (incl. result read-back)")
+        return
+    if a.what == "cg":
+        # device-resident conjugate gradients (spmv_cg) on the 5-point Laplacian of an m x m grid
+        import time
+
+        import numpy as np
+
+        m = a.n or 2048
+        n = m * m
+        idx = np.arange(n, dtype=np.int64).reshape(m, m)
+        rows, cols, vals = [idx.ravel()], [idx.ravel()], [np.full(n, 4.0)]
+        for u, v in ((idx[:, :-1], idx[:, 1:]), (idx[:-1, :], idx[1:, :])):
+            rows += [u.ravel(), v.ravel()]
+            cols += [v.ravel(), u.ravel()]
+            vals += [np.full(u.size, -1.0)] * 2
+        r, c, v = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+        o = np.lexsort((c, r))
+        rp = np.zeros(n + 1, np.int64)
+        np.add.at(rp, r + 1, 1)
+        A = ctx.csr(n, n, np.cumsum(rp).astype(np.int32), c[o].astype(np.int32), v[o])
+        nnz = len(v)
+        b, x = ctx.gen_vector(n, seed=3), ctx.vector(n)
+        print(f"CG, 5-point Laplacian {m} x {m}: n={n} nnz={nnz} kernel={A.info.kernel}")
+        for iters_cap, every in ((200, 1), (200, 50)):
+            x.fill(0.0)
+            ctx.sync()
+            t = time.perf_counter()
+            it, res = ctx.cg(A, b, x, max_iter=iters_cap, rel_tol=0.0, check_every=every)
+            dt = time.perf_counter() - t
+            bytes_it = 12 * nnz + 4 * n + 16 * n + 48 * n + 24 * n  # product (A, p, q) + x/r update + direction
+            print(f"  check_every={every:3d}: {it} iterations in {dt*1e3:.2f} ms = {dt/it*1e6:.1f} us/iteration, "
+                  f"{bytes_it/(dt/it)/1e9:.0f} GB/s algorithmic, residual {res:.3e}")
         return
     if a.what == "dia":
         n, k = a.n or 4_000_000, a.k or 64
