@@ -57,9 +57,9 @@ int mat_alloc(spmv_ctx* ctx, int32_t format, int32_t nrow, int32_t ncol, int64_t
     if (e == hipSuccess) e = hipMalloc(&v, std::max<size_t>(v_count, 1) * sizeof(double));
     if (e != hipSuccess)
     {
-        if (a) hipFree(a);
-        if (b) hipFree(b);
-        if (v) hipFree(v);
+        if (a) (void)hipFree(a);
+        if (b) (void)hipFree(b);
+        if (v) (void)hipFree(v);
         delete m;
         SPMV_FAIL(SPMV_ERR_ALLOC, "device allocation of %zu+%zu int32 and %zu fp64 failed: %s", a_count, b_count,
                   v_count, hipGetErrorString(e));
@@ -77,12 +77,12 @@ void mat_free(spmv_mat* m)
     if (!m) return;
     if (m->owned)
     {
-        if (m->a) hipFree(const_cast<int32_t*>(m->a));
-        if (m->b) hipFree(const_cast<int32_t*>(m->b));
-        if (m->v) hipFree(const_cast<double*>(m->v));
+        if (m->a) (void)hipFree(const_cast<int32_t*>(m->a));
+        if (m->b) (void)hipFree(const_cast<int32_t*>(m->b));
+        if (m->v) (void)hipFree(const_cast<double*>(m->v));
     }
-    if (m->win_lo) hipFree(m->win_lo);
-    if (m->win_span) hipFree(m->win_span);
+    if (m->win_lo) (void)hipFree(m->win_lo);
+    if (m->win_span) (void)hipFree(m->win_span);
     csr_panel_free(m);
     if (m->coo_csr) mat_free(m->coo_csr);
     delete m;
@@ -209,14 +209,14 @@ int spmv_ctx_create_on_stream(int device, void* hip_stream, spmv_ctx** out)
 int spmv_ctx_destroy(spmv_ctx* ctx)
 {
     if (!ctx) return SPMV_OK;
-    hipSetDevice(ctx->device);
-    if (ctx->stream) hipStreamSynchronize(ctx->stream);
-    if (ctx->scratch) hipFree(ctx->scratch);
-    if (ctx->host_pinned) hipHostFree(ctx->host_pinned);
-    if (ctx->dev_scalars) hipFree(ctx->dev_scalars);
-    if (ctx->ev_begin) hipEventDestroy(ctx->ev_begin);
-    if (ctx->ev_end) hipEventDestroy(ctx->ev_end);
-    if (ctx->owns_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
+    if (ctx->dev_scalars) (void)hipFree(ctx->dev_scalars);
+    if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
+    if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return SPMV_OK;
 }
@@ -273,8 +273,8 @@ int spmv_vec_destroy(spmv_vec* v)
     if (!v) return SPMV_OK;
     if (v->owned && v->d)
     {
-        hipSetDevice(v->ctx->device);
-        hipFree(v->d);
+        (void)hipSetDevice(v->ctx->device);
+        (void)hipFree(v->d);
     }
     delete v;
     return SPMV_OK;
@@ -489,8 +489,8 @@ int spmv_dia_upload(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t ndiags, c
 int spmv_mat_destroy(spmv_mat* m)
 {
     if (!m) return SPMV_OK;
-    hipSetDevice(m->ctx->device);
-    hipStreamSynchronize(m->ctx->stream);
+    (void)hipSetDevice(m->ctx->device);
+    (void)hipStreamSynchronize(m->ctx->stream);
     mat_free(m);
     return SPMV_OK;
 }

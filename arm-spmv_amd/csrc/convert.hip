@@ -149,8 +149,8 @@ int exclusive_scan_i32(spmv_ctx* ctx, const int32_t* in, int32_t* out, int64_t n
         hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, ctx->stream, out, n, tile_sum);
         if (hipGetLastError() != hipSuccess) rc = SPMV_ERR_HIP;
     }
-    hipStreamSynchronize(ctx->stream);
-    hipFree(tile_sum);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tile_sum);
     if (rc != SPMV_OK) SPMV_FAIL(rc, "exclusive_scan_i32 failed");
     return SPMV_OK;
 }
@@ -173,7 +173,7 @@ int coo_to_csr(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out)
     do
     {
         if (hipMalloc(&count, sizeof(int32_t) * ((size_t)nrow + 1)) != hipSuccess) { rc = SPMV_ERR_ALLOC; break; }
-        hipMemsetAsync(count, 0, sizeof(int32_t) * ((size_t)nrow + 1), s);
+        (void)hipMemsetAsync(count, 0, sizeof(int32_t) * ((size_t)nrow + 1), s);
         if (nnz > 0)
             hipLaunchKernelGGL(row_histogram_kernel, dim3((unsigned)std::min<int64_t>(kMaxGrid, ceil_div(nnz, kBlock))),
                                dim3(kBlock), 0, s, nnz, coo->a, count);
@@ -182,13 +182,13 @@ int coo_to_csr(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out)
         if (coo->sorted_rows)
         {
             // row-sorted COO is already in CSR order
-            hipMemcpyAsync(out_col, coo->b, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToDevice, s);
-            hipMemcpyAsync(out_val, coo->v, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToDevice, s);
+            (void)hipMemcpyAsync(out_col, coo->b, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToDevice, s);
+            (void)hipMemcpyAsync(out_val, coo->v, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToDevice, s);
         }
         else
         {
             if (hipMalloc(&perm, sizeof(int32_t) * (size_t)nnz) != hipSuccess) { rc = SPMV_ERR_ALLOC; break; }
-            hipMemsetAsync(count, 0, sizeof(int32_t) * ((size_t)nrow + 1), s);  // reuse as per-row cursor
+            (void)hipMemsetAsync(count, 0, sizeof(int32_t) * ((size_t)nrow + 1), s);  // reuse as per-row cursor
             hipLaunchKernelGGL(claim_slot_kernel, dim3((unsigned)std::min<int64_t>(kMaxGrid, ceil_div(nnz, kBlock))),
                                dim3(kBlock), 0, s, nnz, coo->a, row_ptr, count, perm);
             constexpr int LPR = 8;
@@ -197,9 +197,9 @@ int coo_to_csr(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out)
         }
         if (hipGetLastError() != hipSuccess) rc = SPMV_ERR_HIP;
     } while (0);
-    hipStreamSynchronize(s);
-    if (count) hipFree(count);
-    if (perm) hipFree(perm);
+    (void)hipStreamSynchronize(s);
+    if (count) (void)hipFree(count);
+    if (perm) (void)hipFree(perm);
     if (rc != SPMV_OK)
     {
         mat_free(csr);
@@ -223,8 +223,8 @@ int csr_to_ell(spmv_ctx* ctx, const spmv_mat* csr, spmv_mat** out)
     if (total > 0)
     {
         // padding: col 0, val +0.0 (src/matrix.cpp:473-474, value-initialised new[])
-        hipMemsetAsync(const_cast<int32_t*>(ell->b), 0, sizeof(int32_t) * total, ctx->stream);
-        hipMemsetAsync(const_cast<double*>(ell->v), 0, sizeof(double) * total, ctx->stream);
+        (void)hipMemsetAsync(const_cast<int32_t*>(ell->b), 0, sizeof(int32_t) * total, ctx->stream);
+        (void)hipMemsetAsync(const_cast<double*>(ell->v), 0, sizeof(double) * total, ctx->stream);
         constexpr int LPR = 8;
         hipLaunchKernelGGL(csr_to_ell_kernel<LPR>, dim3((unsigned)ceil_div(nrow, kBlock / LPR)), dim3(kBlock), 0,
                            ctx->stream, nrow, csr->a, csr->b, csr->v, const_cast<int32_t*>(ell->b),

@@ -165,7 +165,7 @@ int gen_coo_powerlaw(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t max_len,
     SPMV_HIP(hipMalloc(&len, sizeof(int32_t) * ((size_t)nrow + 1)));
     if (hipMalloc(&row_ptr, sizeof(int32_t) * ((size_t)nrow + 1)) != hipSuccess)
     {
-        hipFree(len);
+        (void)hipFree(len);
         SPMV_FAIL(SPMV_ERR_ALLOC, "gen_coo_powerlaw: out of device memory");
     }
     spmv_mat* m  = nullptr;
@@ -197,8 +197,8 @@ int gen_coo_powerlaw(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t max_len,
                                const_cast<int32_t*>(m->b), const_cast<double*>(m->v));
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) rc = SPMV_ERR_HIP;
     } while (0);
-    hipFree(len);
-    hipFree(row_ptr);
+    (void)hipFree(len);
+    (void)hipFree(row_ptr);
     if (rc != SPMV_OK)
     {
         if (m) mat_free(m);

@@ -168,8 +168,8 @@ int coo_build_panel(spmv_mat* m, bool only_if_worth)
         }
     }
     // the panel kernel reads row_ptr and its own arrays only: drop the CSR copies of col_ind / values
-    hipFree(const_cast<int32_t*>(csr->b));
-    hipFree(const_cast<double*>(csr->v));
+    (void)hipFree(const_cast<int32_t*>(csr->b));
+    (void)hipFree(const_cast<double*>(csr->v));
     csr->device_bytes -= (int64_t)csr->nnz * 12;
     csr->b     = nullptr;
     csr->v     = nullptr;

@@ -575,14 +575,14 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
 
 void csr_panel_free(spmv_mat* m)
 {
-    if (m->pb_col) hipFree(m->pb_col);
-    if (m->pb_row) hipFree(m->pb_row);
-    if (m->pb_val) hipFree(m->pb_val);
-    if (m->pb_rec) hipFree(m->pb_rec);
-    if (m->pb_pack) hipFree(m->pb_pack);
-    if (m->pb_sbase) hipFree(m->pb_sbase);
-    if (m->pb_soff) hipFree(m->pb_soff);
-    if (m->pb_gstart) hipFree(m->pb_gstart);
+    if (m->pb_col) (void)hipFree(m->pb_col);
+    if (m->pb_row) (void)hipFree(m->pb_row);
+    if (m->pb_val) (void)hipFree(m->pb_val);
+    if (m->pb_rec) (void)hipFree(m->pb_rec);
+    if (m->pb_pack) (void)hipFree(m->pb_pack);
+    if (m->pb_sbase) (void)hipFree(m->pb_sbase);
+    if (m->pb_soff) (void)hipFree(m->pb_soff);
+    if (m->pb_gstart) (void)hipFree(m->pb_gstart);
     m->pb_gstart = nullptr;
     m->pb_pack   = nullptr;
     m->pb_sbase  = nullptr;
@@ -658,9 +658,9 @@ static void panel_pack(spmv_mat* m, int ngroups, int max_rows)
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) break;  // soff (host) is done with
         ok = true;
         // the packed words and padded values replace the three arrays
-        hipFree(m->pb_col);
-        hipFree(m->pb_row);
-        hipFree(m->pb_val);
+        (void)hipFree(m->pb_col);
+        (void)hipFree(m->pb_row);
+        (void)hipFree(m->pb_val);
         m->pb_col     = nullptr;
         m->pb_row     = nullptr;
         m->pb_val     = pval;
@@ -671,15 +671,15 @@ static void panel_pack(spmv_mat* m, int ngroups, int max_rows)
         m->pb_slices  = (int32_t)total;
         m->pb_bytes   = padded * 12 + (int64_t)sizeof(int32_t) * (total + ngroups + 1);
     } while (0);
-    if (d_n) hipFree(d_n);
-    if (ssrc) hipFree(ssrc);
-    if (scount) hipFree(scount);
+    if (d_n) (void)hipFree(d_n);
+    if (ssrc) (void)hipFree(ssrc);
+    if (scount) (void)hipFree(scount);
     if (!ok)
     {
-        if (pack) hipFree(pack);
-        if (pval) hipFree(pval);
-        if (sbase) hipFree(sbase);
-        if (d_soff) hipFree(d_soff);
+        if (pack) (void)hipFree(pack);
+        if (pval) (void)hipFree(pval);
+        if (sbase) (void)hipFree(sbase);
+        if (d_soff) (void)hipFree(d_soff);
         (void)hipGetLastError();
     }
 }
@@ -784,17 +784,17 @@ int csr_panel_build(spmv_mat* m)
         hipLaunchKernelGGL(panel_scatter_kernel, dim3(ngroups), dim3(256), sizeof(int32_t) * P, s, m->pb_gstart, W, P, m->a,
                            m->b, m->v, tile_ptr, scol, srow, sval);
         if (sort && sizeof(int32_t) * (W / kLineDoubles + 1) > 65536)  // one bin per x line of the panel, in LDS
-            hipFuncSetAttribute((const void*)panel_line_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160008);
+            (void)hipFuncSetAttribute((const void*)panel_line_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160008);
         if (sort)
             hipLaunchKernelGGL(panel_line_sort_kernel, dim3((unsigned)ngroups * P), dim3(256),
                                sizeof(int32_t) * (W / kLineDoubles + 1), s, m->pb_gstart, W, P, m->a, tile_ptr, tcol, trow,
                                tval, m->pb_col, m->pb_row, m->pb_val);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = SPMV_ERR_HIP;
     } while (0);
-    if (tile_ptr) hipFree(tile_ptr);
-    if (tcol) hipFree(tcol);
-    if (trow) hipFree(trow);
-    if (tval) hipFree(tval);
+    if (tile_ptr) (void)hipFree(tile_ptr);
+    if (tcol) (void)hipFree(tcol);
+    if (trow) (void)hipFree(trow);
+    if (tval) (void)hipFree(tval);
     if (rc != SPMV_OK)
     {
         csr_panel_free(m);
@@ -832,9 +832,9 @@ int csr_panel_build(spmv_mat* m)
         hipLaunchKernelGGL(panel_pack_kernel, dim3(kMaxGrid), dim3(256), 0, s, (int64_t)nnz, m->pb_col, m->pb_row, m->pb_val,
                            (i32x4*)m->pb_rec);
         SPMV_HIP(hipStreamSynchronize(s));
-        hipFree(m->pb_col);
-        hipFree(m->pb_row);
-        hipFree(m->pb_val);
+        (void)hipFree(m->pb_col);
+        (void)hipFree(m->pb_row);
+        (void)hipFree(m->pb_val);
         m->pb_col   = nullptr;
         m->pb_row   = nullptr;
         m->pb_val   = nullptr;
@@ -875,20 +875,20 @@ int panel_choose_pace(spmv_mat* m)
     double *x = nullptr, *y = nullptr;
     if (hipMalloc(&x, sizeof(double) * (size_t)m->ncol) != hipSuccess || hipMalloc(&y, sizeof(double) * (size_t)m->nrow) != hipSuccess)
     {
-        if (x) hipFree(x);
+        if (x) (void)hipFree(x);
         (void)hipGetLastError();
         return SPMV_OK;  // no room to try: run unthrottled
     }
-    hipMemsetAsync(x, 0, sizeof(double) * (size_t)m->ncol, ctx->stream);
-    hipMemsetAsync(y, 0, sizeof(double) * (size_t)m->nrow, ctx->stream);
+    (void)hipMemsetAsync(x, 0, sizeof(double) * (size_t)m->ncol, ctx->stream);
+    (void)hipMemsetAsync(y, 0, sizeof(double) * (size_t)m->nrow, ctx->stream);
     int  rc    = SPMV_OK;
     auto timed = [&](int pace_ns, float* ms) -> int {
         m->pb_pace_ns = pace_ns;
         int r         = panel_launch(ctx, m, x, y, true, apply_extra{});  // warm
         if (r != SPMV_OK) return r;
-        hipEventRecord(ctx->ev_begin, ctx->stream);
+        (void)hipEventRecord(ctx->ev_begin, ctx->stream);
         for (int i = 0; i < 3 && r == SPMV_OK; ++i) r = panel_launch(ctx, m, x, y, true, apply_extra{});
-        hipEventRecord(ctx->ev_end, ctx->stream);
+        (void)hipEventRecord(ctx->ev_end, ctx->stream);
         if (r == SPMV_OK && (hipEventSynchronize(ctx->ev_end) != hipSuccess ||
                              hipEventElapsedTime(ms, ctx->ev_begin, ctx->ev_end) != hipSuccess))
             r = SPMV_ERR_HIP;
@@ -965,9 +965,9 @@ int panel_choose_pace(spmv_mat* m)
             all_best_pace = (int)(all_best_pace * 1.03);
         }
     }
-    hipStreamSynchronize(ctx->stream);
-    hipFree(x);
-    hipFree(y);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(x);
+    (void)hipFree(y);
     m->pb_unroll_tuned      = rc == SPMV_OK && m->pb_unroll <= 0 ? all_best_unroll : 0;
     m->pb_pipe_tuned        = rc == SPMV_OK ? all_best_pipe : 0;
     m->pb_pace_tuned_ns     = rc == SPMV_OK ? all_best_pace : 0;
@@ -988,7 +988,6 @@ int csr_panel_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, double
 static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, bool trial, const apply_extra& ex)
 {
     if (!A->pb_val && !A->pb_rec) SPMV_FAIL(SPMV_ERR_INVALID, "panel kernel selected but its layout was not built");
-    const int    G   = A->pb_built_rows;
     // the fullest group's accumulators (+ the spare one the pads of the packed layout add into)
     const size_t lds = ((size_t)A->pb_max_rows + (A->pb_pack ? 1 : 0)) * sizeof(double);
     // two workgroups share a CU when their accumulators fit twice into the 160 KiB LDS
@@ -1001,7 +1000,8 @@ static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, doubl
     const int step   = unroll * kPanelThreads;
     const int nchunk = (int)std::min<int64_t>(A->pb_max_group_nnz / step + 1, 1 << 20);
     unsigned* gate   = nullptr;
-    const bool gated = skew > 0 && grid > 1;
+    // the counter gate (an experiment kept for the record) exists for the three-array and record layouts only
+    const bool gated = skew > 0 && grid > 1 && !A->pb_pack;
     // pace: nanoseconds per chunk -> 10 ns ticks in 22.10 fixed point
     const unsigned long long pace_fp = A->pb_pace_ns > 0 ? (unsigned long long)((double)A->pb_pace_ns * 102.4) : 0ull;
     const int  pace_slack = std::max(0, A->pb_pace_slack);
@@ -1102,6 +1102,7 @@ static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, doubl
     SPMV_PANEL_CASES(4)
     SPMV_PANEL_CASES(8)
     SPMV_PANEL_CASE(8, false, 2)
+    SPMV_PANEL_CASE(2, false, 3)
     SPMV_PANEL_CASE(4, false, 3)
     SPMV_PANEL_CASE(8, false, 3)
     SPMV_PANEL_CASE(16, false, 3)

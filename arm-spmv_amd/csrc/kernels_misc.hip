@@ -232,8 +232,8 @@ int csc_analyse(spmv_mat* m)
     view.kernel_forced = true;  // no panel build for the temporary view itself
     int rc = coo_analyse(&view);  // sortedness of the row indices
     if (rc == SPMV_OK) rc = coo_build_panel(&view, /*only_if_worth=*/false);
-    hipStreamSynchronize(ctx->stream);
-    hipFree(cols);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(cols);
     if (rc != SPMV_OK) return rc;
     m->coo_csr = view.coo_csr;  // adopt; `view` itself owns nothing else
     m->device_bytes += m->coo_csr->device_bytes;

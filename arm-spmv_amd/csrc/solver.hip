@@ -163,10 +163,10 @@ int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int m
     double *    r = nullptr, *p = nullptr, *q = nullptr;
     CgScalars*  s = nullptr;
     auto        release = [&]() {
-        if (r) hipFree(r);
-        if (p) hipFree(p);
-        if (q) hipFree(q);
-        if (s) hipFree(s);
+        if (r) (void)hipFree(r);
+        if (p) (void)hipFree(p);
+        if (q) (void)hipFree(q);
+        if (s) (void)hipFree(s);
     };
     if (hipMalloc(&r, sizeof(double) * (size_t)n) != hipSuccess || hipMalloc(&p, sizeof(double) * (size_t)n) != hipSuccess ||
         hipMalloc(&q, sizeof(double) * (size_t)n) != hipSuccess || hipMalloc(&s, sizeof(CgScalars)) != hipSuccess)
@@ -234,7 +234,7 @@ int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int m
         *iters     = k;
         *rel_resid = sqrt(rr / bb);
     } while (0);
-    hipStreamSynchronize(st);
+    (void)hipStreamSynchronize(st);
     release();
     return rc;
 }

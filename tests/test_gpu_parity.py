@@ -401,7 +401,8 @@ def test_csr_panel_kernel_matches_reference_golden(ctx, orc, pkg, make):
             (20000, 4096, 0, 1, 4, 12, 1, 0), (5, 48, 1, 0, 8, 2, 0, 0), (3, 16, 1, 1, 2, 2, 1, 0), (500, 512, 1, 0, 8, 0, 1, 2000),
             (64, 64, 1, 0, 2, 0, 1, -1), (0, 0, 1, 0, 8, 0, 0, 300),
             # layout 3: 12-byte packed entries (falls back to three arrays when a slice spans too many columns)
-            (0, 0, 1, 3, 8, 0, 1, 0), (37, 16, 1, 3, 4, 0, 0, 0), (5, 48, 1, 3, 16, 0, 1, -1), (1000, 1024, 0, 3, 8, 0, 1, 0)):
+            (0, 0, 1, 3, 8, 0, 1, 0), (37, 16, 1, 3, 4, 0, 0, 0), (5, 48, 1, 3, 16, 0, 1, -1), (1000, 1024, 0, 3, 8, 0, 1, 0),
+            (0, 0, 1, 3, 8, 0, 2, 0), (64, 64, 1, 3, 4, 0, 2, -1), (3, 16, 1, 3, 2, 3, 2, 0), (0, 0, 1, 3, 0, 2, -1, -1), (500, 512, 1, 0, 8, 0, 2, 0)):
         A = ctx.csr(c["nrow"], c["ncol"], rp, cc, cv)
         A.set_param("panel_rows", rows)
         A.set_param("panel_width", width)

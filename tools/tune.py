@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--n", type=int, default=0)
     ap.add_argument("--k", type=int, default=0)
     ap.add_argument("--band", type=int, default=0)
+    ap.add_argument("--ncol", type=int, default=0, help="csr: columns (default n); n x 8 = the shard shape of one rank of 8")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--full", action="store_true", help="every lanes x flags combination")
@@ -130,11 +131,12 @@ def main():
         return
     if a.what == "csr":
         n, k = a.n or 10_000_000, a.k or 32
-        A = ctx.gen_csr_uniform(0, n, n, k, band=a.band, seed=1)
-        x, y = ctx.gen_vector(n, seed=1), ctx.vector(n)
+        ncol = a.ncol or n
+        A = ctx.gen_csr_uniform(0, n, ncol, k, band=a.band, seed=1)
+        x, y = ctx.gen_vector(ncol, seed=1), ctx.vector(n)
         y.fill(0.0)
         info = A.info
-        print(f"CSR n={n} k={k} band={a.band} auto: kernel={info.kernel} lanes={info.lanes_per_row}")
+        print(f"CSR n={n} ncol={ncol} k={k} band={a.band} auto: kernel={info.kernel} lanes={info.lanes_per_row}")
         variants = []
         for lanes in (2, 4, 8, 16, 32):
             for fl, tag in ((0, ""), (1, "+dpp"), (2, "+xcd"), (3, "+dpp+xcd")):
@@ -180,7 +182,7 @@ def main():
         if a.band and a.band <= 8192:
             for lanes in (4, 8, 16):
                 variants.append((f"ldswin L={lanes}", lambda A, lanes=lanes: A.set_kernel(capi.CSR_LDSWIN, lanes)))
-        sweep(ctx, A, x, y, variants, a.rounds, a.reps, algorithmic_bytes("csr", n, n, n * k), n * k)
+        sweep(ctx, A, x, y, variants, a.rounds, a.reps, algorithmic_bytes("csr", n, ncol, n * k), n * k)
         for name, v in (("panel_aos", 3), ("panel_unroll", 0), ("panel_pace_ns", -1), ("panel_pipe", -1), ("panel_skew", 0),
                         ("panel_pace_slack", 0), ("panel_ablate", 0)):
             A.set_param(name, v)
