@@ -917,7 +917,7 @@ int panel_choose_pace(spmv_mat* m)
         else
         {
             const double base_ns   = 1.33 * unroll * kPanelThreads;
-            const double factors[] = {0.0, 0.76, 0.82, 0.88, 0.94, 1.0, 1.06, 1.12, 1.2, 1.32, 1.5};
+            const double factors[] = {0.0, 0.76, 0.82, 0.88, 0.94, 1.0, 1.06, 1.12, 1.2, 1.32, 1.5, 1.7, 1.95, 2.25, 2.6};
             for (double f : factors)
             {
                 float ms = 0.f;
