@@ -896,13 +896,14 @@ int panel_choose_pace(spmv_mat* m)
     };
     double    all_best_ms = 1e30;
     int       all_best_pace = 0, all_best_unroll = 0, all_best_pipe = 0;
-    const int unrolls[2] = {u_first, 4};
-    const int n_unroll   = m->pb_unroll > 0 ? 1 : 2;
+    const int unrolls[3] = {u_first, 4, 2};
+    const int n_unroll   = m->pb_unroll > 0 ? 1 : 3;
     const int n_pipe     = m->pb_pipe >= 0 || m->pb_pack == nullptr ? 1 : 2;  // gather-first exists for the packed layout
     for (int ui = 0; ui < n_unroll * n_pipe && rc == SPMV_OK; ++ui)
     {
         const int unroll   = unrolls[ui / n_pipe];
         const int pipe     = n_pipe == 2 ? 1 + ui % 2 : 0;
+        if (pipe == 2 && unroll == 2) continue;  // gather-first is not instantiated for U = 2
         m->pb_unroll_tuned = unroll;
         m->pb_pipe_tuned   = pipe;
         double best_ms = 1e30, unthrottled_ms = 1e30;
@@ -1087,6 +1088,7 @@ static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, doubl
         SPMV_PANEL_PIPE(2, 0, 1)
         SPMV_PANEL_PIPE(4, 0, 1)
         SPMV_PANEL_PIPE(8, 0, 1)
+        SPMV_PANEL_PIPE(2, 3, 1)
         SPMV_PANEL_PIPE(4, 3, 1)
         SPMV_PANEL_PIPE(8, 3, 1)
         SPMV_PANEL_PIPE(16, 3, 1)
