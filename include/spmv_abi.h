@@ -148,13 +148,22 @@ int spmv_mat_validate(const spmv_mat* m);
 /* Force a CSR kernel (and, for VECTOR, lanes_per_row in {1,2,4,...,64}; 0 = keep auto choice). */
 int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row);
 int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
-/* Named tuning parameters, applied by the next spmv_mat_set_kernel:
- *   "panel_rows"  rows per group of the panel kernel (0 = choose; at most 20000)
- *   "panel_width" columns per panel (0 = 131072)
- *   "panel_sort"  1 = bucket the entries of a panel by 128-byte line of x (default), 0 = leave unordered */
+/* Named tuning parameters of the panel kernel, applied by the next spmv_mat_set_kernel (none is needed in normal use:
+ * what is left at its default is chosen by timing a few candidates when the layout is built):
+ *   "panel_rows"    rows per group (0 = choose, entry-balanced; at most 20000)
+ *   "panel_width"   columns per panel (0 = 131072)
+ *   "panel_sort"    1 = bucket the entries of a panel by 128-byte line of x (default), 0 = leave unordered
+ *   "panel_aos"     entry layout: 3 = 12-byte packed entries (default; falls back to 0 where padding would outweigh it),
+ *                   0 = three arrays (14 bytes), 1 = 16-byte records, 2 = three arrays read with system-scope loads
+ *   "panel_unroll"  chunk = unroll x 1024 entries: 2, 4, 8 or 16 (0 = by trial among 8, 4, 2)
+ *   "panel_pipe"    order of the memory instructions of a chunk: 0 = no pipelining, 1 = next chunk's stream first,
+ *                   2 = this chunk's gathers first (-1 = by trial)
+ *   "panel_pace_ns" clock throttle, nanoseconds per chunk (0 = off, -1 = by trial)
+ *   "panel_skew", "panel_pace_slack", "panel_two_per_cu", "panel_ablate"   experiments kept for the record
+ *                   (DESIGN.md 4.2); "panel_ablate" > 0 gives WRONG results by design (timing only) */
 int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value);
-/* What is in effect: "panel_rows", "panel_width", "panel_sort", "panel_groups", "panel_unroll", "panel_pace_ns",
- * "panel_skew", "panel_bytes", "window_max_span", "window_avg_span". */
+/* What is in effect: "panel_rows", "panel_width", "panel_sort", "panel_groups", "panel_layout", "panel_unroll",
+ * "panel_pipe", "panel_pace_ns", "panel_skew", "panel_bytes", "window_max_span", "window_avg_span". */
 int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value);
 /* Copy the arrays of a handle back to the host (any pointer may be NULL to skip it).
  *   CSR: a=row_ptr[nrow+1]  b=col_ind[nnz]      v=values[nnz]
