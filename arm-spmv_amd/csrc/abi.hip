@@ -582,6 +582,8 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         m->pb_pace_slack = (int32_t)value;
     else if (!strcmp(name, "panel_pipe"))
         m->pb_pipe = (int32_t)value;
+    else if (!strcmp(name, "panel_stagger"))
+        m->pb_stagger = (int32_t)value;
     else if (!strcmp(name, "panel_ablate"))
         m->pb_ablate = (int32_t)value;
     else if (!strcmp(name, "panel_two_per_cu"))

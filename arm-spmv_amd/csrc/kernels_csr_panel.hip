@@ -490,13 +490,21 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
         PanelBatch<UNROLL, LAYOUT> cur, nxt;
         for (int b = 0; b < nfull; ++b)
         {
-            // a workgroup may run up to pace_slack chunks ahead of the clock, so that time lost to a slow stretch
-            // can be made up in a fast one (a hard schedule only ever loses time)
-            if (pace_fp && lane == 0 && b > pace_slack)
+            // Pace.  A workgroup may run up to `slack` chunks ahead of the clock (experiment: any slack loses).  With
+            // `stagger` the 16 wavefronts of the workgroup enter a chunk 1/16 of the pace apart instead of together:
+            // in lockstep every CU of the chip streams at the same moment and gathers at the same moment, so HBM
+            // idles while the L2->L1 path is busy and vice versa; staggered, both are in use all the time.
+            if (pace_fp && lane == 0)
             {
-                const unsigned long long target = t0 + (((unsigned long long)(b - pace_slack) * pace_fp) >> 10);
-                int                      spins  = 0;
-                while (__builtin_amdgcn_s_memrealtime() < target && ++spins < (1 << 16)) __builtin_amdgcn_s_sleep(1);
+                const int                slack = pace_slack & 0xFFFF;
+                const unsigned long long phase = (pace_slack >> 16) ? ((unsigned long long)(threadIdx.x >> 6) * pace_fp) / NWAVES : 0ull;
+                if (b > slack || phase)
+                {
+                    const unsigned long long ahead  = b > slack ? (unsigned long long)(b - slack) * pace_fp : 0ull;
+                    const unsigned long long target = t0 + ((ahead + phase) >> 10);
+                    int                      spins  = 0;
+                    while (__builtin_amdgcn_s_memrealtime() < target && ++spins < (1 << 16)) __builtin_amdgcn_s_sleep(1);
+                }
             }
             if constexpr (GATED)
             {
@@ -856,7 +864,7 @@ int panel_choose_pace(spmv_mat* m)
     spmv_ctx* ctx = m->ctx;
     // what is tried: the chunk size (unless requested) and the pace (unless requested)
     // (key: the requests the trial was made under; unroll 0 / pipe -1 = chosen here as well)
-    const int key = 1000 + std::max(m->pb_unroll, 0) * 10 + (m->pb_pipe + 1);
+    const int key = 1000 + std::max(m->pb_unroll, 0) * 10 + (m->pb_pipe + 1) + (m->pb_stagger ? 100000 : 0);
     if (m->pb_pace_tuned_unroll == key)
     {
         // already tried for this layout; a requested pace only overrides the pace
@@ -1005,7 +1013,7 @@ static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, doubl
     const bool gated = skew > 0 && grid > 1 && !A->pb_pack;
     // pace: nanoseconds per chunk -> 10 ns ticks in 22.10 fixed point
     const unsigned long long pace_fp = A->pb_pace_ns > 0 ? (unsigned long long)((double)A->pb_pace_ns * 102.4) : 0ull;
-    const int  pace_slack = std::max(0, A->pb_pace_slack);
+    const int  pace_slack = std::min(std::max(0, A->pb_pace_slack), 0xFFFF) | (A->pb_stagger ? 1 << 16 : 0);
     const int  layout = A->pb_pack ? 3 : A->pb_rec ? 1 : (A->pb_aos == 2 ? 2 : 0);
     // the kernel dereferences exactly these arrays: refuse on the host rather than fault on the GPU
     const bool have = layout == 1   ? A->pb_rec != nullptr

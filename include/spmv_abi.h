@@ -159,7 +159,7 @@ int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
  *   "panel_pipe"    order of the memory instructions of a chunk: 0 = no pipelining, 1 = next chunk's stream first,
  *                   2 = this chunk's gathers first (-1 = by trial)
  *   "panel_pace_ns" clock throttle, nanoseconds per chunk (0 = off, -1 = by trial)
- *   "panel_skew", "panel_pace_slack", "panel_two_per_cu", "panel_ablate"   experiments kept for the record
+ *   "panel_skew", "panel_pace_slack", "panel_stagger", "panel_two_per_cu", "panel_ablate"   experiments kept for the record
  *                   (DESIGN.md 4.2); "panel_ablate" > 0 gives WRONG results by design (timing only) */
 int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value);
 /* What is in effect: "panel_rows", "panel_width", "panel_sort", "panel_groups", "panel_layout", "panel_unroll",

@@ -158,9 +158,11 @@ def main():
             pipe = combo[6] if len(combo) > 6 else 0
             slack = combo[7] if len(combo) > 7 else 0
             aos = combo[8] if len(combo) > 8 else 0
+            stagger = combo[9] if len(combo) > 9 else 0
 
-            def setup(A, rows=rows, width=width, srt=srt, unroll=unroll, skew=skew, pace=pace, pipe=pipe, slack=slack, aos=aos):
+            def setup(A, rows=rows, width=width, srt=srt, unroll=unroll, skew=skew, pace=pace, pipe=pipe, slack=slack, aos=aos, stagger=stagger):
                 A.set_param("panel_aos", aos)
+                A.set_param("panel_stagger", stagger)
                 A.set_param("panel_rows", rows)
                 A.set_param("panel_width", width)
                 A.set_param("panel_sort", srt)
@@ -171,7 +173,7 @@ def main():
                 A.set_param("panel_pipe", pipe)
                 A.set_param("panel_ablate", 0)
                 A.set_kernel(capi.CSR_PANEL)  # rebuilds the layout when the parameters changed
-            variants.append((f"panel U={unroll} skew={skew} pace={pace}ns pipe={pipe} slack={slack} layout={aos}", setup))
+            variants.append((f"panel U={unroll} skew={skew} pace={pace}ns pipe={pipe} slack={slack} layout={aos} stagger={stagger}", setup))
         for ab, what in ((1, "no LDS adds"), (2, "gathers always hit L1"), (3, "neither")) if a.ablate else ():
             def setup(A, ab=ab):
                 for k, v in (("panel_rows", 0), ("panel_width", 0), ("panel_sort", 1), ("panel_unroll", 8), ("panel_skew", 0),
@@ -184,7 +186,7 @@ def main():
                 variants.append((f"ldswin L={lanes}", lambda A, lanes=lanes: A.set_kernel(capi.CSR_LDSWIN, lanes)))
         sweep(ctx, A, x, y, variants, a.rounds, a.reps, algorithmic_bytes("csr", n, ncol, n * k), n * k)
         for name, v in (("panel_aos", 3), ("panel_unroll", 0), ("panel_pace_ns", -1), ("panel_pipe", -1), ("panel_skew", 0),
-                        ("panel_pace_slack", 0), ("panel_ablate", 0)):
+                        ("panel_pace_slack", 0), ("panel_ablate", 0), ("panel_stagger", 0)):
             A.set_param(name, v)
         A.set_kernel(capi.CSR_PANEL)
         print("chosen by trial:", {k: A.get_param("panel_" + k) for k in ("rows", "groups", "layout", "unroll", "pipe", "pace_ns", "bytes")})
