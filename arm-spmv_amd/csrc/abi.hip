@@ -614,6 +614,8 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         *value = m->pb_bytes;
     else if (!strcmp(name, "panel_pipe"))
         *value = m->pb_pipe >= 0 ? m->pb_pipe : (m->pb_pipe_tuned > 0 ? m->pb_pipe_tuned : 1);
+    else if (!strcmp(name, "panel_stagger"))
+        *value = m->pb_stagger_tuned >= 0 ? m->pb_stagger_tuned : m->pb_stagger;
     else if (!strcmp(name, "panel_layout"))  // layout in memory: 0 three arrays, 1 records, 3 packed 12-byte entries
         *value = m->pb_pack ? 3 : m->pb_rec ? 1 : 0;
     else if (!strcmp(name, "window_max_span"))

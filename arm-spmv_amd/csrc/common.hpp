@@ -168,7 +168,8 @@ struct spmv_mat
     int32_t   pb_pipe_tuned  = 0;       // the order found by trying (in effect while pb_pipe == -1; 0 = not tried: 1)
     int32_t   pb_ablate      = 0;       // timing experiments only (wrong results): see PanelBatch::apply
     int32_t   pb_pace_slack  = 0;        // chunks a workgroup may run ahead of the paced schedule
-    int32_t   pb_stagger     = 0;        // wavefronts of a workgroup enter a chunk 1/16 of the pace apart
+    int32_t   pb_stagger_tuned = -1;     // schedule offsets found by trial (-1: use pb_stagger)
+    int32_t   pb_stagger     = 2;        // paced schedule offsets: 0 none, 1 wavefronts 1/16 of the pace apart (loses), 2 XCDs 1/8 apart
     int32_t   pb_pace_req    = -1;      // requested pace (-1 = try a few and keep the fastest)
     int32_t   pb_pace_tuned_ns = 0;      // the pace found by trying (restored when the request goes back to -1)
     int32_t   pb_pace_tuned_unroll = 0; // what the trial was made for: requested unroll, -1 = unroll chosen too, 0 = not tried

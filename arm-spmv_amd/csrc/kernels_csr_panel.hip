@@ -490,14 +490,18 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
         PanelBatch<UNROLL, LAYOUT> cur, nxt;
         for (int b = 0; b < nfull; ++b)
         {
-            // Pace.  A workgroup may run up to `slack` chunks ahead of the clock (experiment: any slack loses).  With
-            // `stagger` the 16 wavefronts of the workgroup enter a chunk 1/16 of the pace apart instead of together:
-            // in lockstep every CU of the chip streams at the same moment and gathers at the same moment, so HBM
-            // idles while the L2->L1 path is busy and vice versa; staggered, both are in use all the time.
+            // Pace.  A workgroup may run up to `slack` chunks ahead of the clock (experiment: any slack loses).
+            // In lockstep every CU of the chip streams at the same moment and gathers at the same moment, so HBM idles
+            // while the L2->L1 path is busy and vice versa.  Offsetting the wavefronts of a workgroup against each other
+            // (mode 1) loses: the x window in use doubles and drops out of L2.  Offsetting whole XCDs against each other
+            // (mode 2, the default) keeps the lockstep where it matters — inside an L2 — and evens out the HBM demand.
             if (pace_fp && lane == 0)
             {
                 const int                slack = pace_slack & 0xFFFF;
-                const unsigned long long phase = (pace_slack >> 16) ? ((unsigned long long)(threadIdx.x >> 6) * pace_fp) / NWAVES : 0ull;
+                const int                mode  = pace_slack >> 16;  // 1: wavefronts apart, 2: XCDs apart (L2s are per XCD)
+                const unsigned long long phase = mode == 1   ? ((unsigned long long)(threadIdx.x >> 6) * pace_fp) / NWAVES
+                                                 : mode == 2 ? ((unsigned long long)xcd_id() * pace_fp) / kNumXcd
+                                                             : 0ull;
                 if (b > slack || phase)
                 {
                     const unsigned long long ahead  = b > slack ? (unsigned long long)(b - slack) * pace_fp : 0ull;
@@ -602,6 +606,7 @@ void csr_panel_free(spmv_mat* m)
     m->pb_built_sort = -1;
     m->pb_pace_tuned_unroll = 0;
     m->pb_unroll_tuned = 0;
+    m->pb_stagger_tuned = -1;
     m->device_bytes -= m->pb_bytes;
     m->pb_bytes = 0;
 }
@@ -864,7 +869,7 @@ int panel_choose_pace(spmv_mat* m)
     spmv_ctx* ctx = m->ctx;
     // what is tried: the chunk size (unless requested) and the pace (unless requested)
     // (key: the requests the trial was made under; unroll 0 / pipe -1 = chosen here as well)
-    const int key = 1000 + std::max(m->pb_unroll, 0) * 10 + (m->pb_pipe + 1) + (m->pb_stagger ? 100000 : 0);
+    const int key = 1000 + std::max(m->pb_unroll, 0) * 10 + (m->pb_pipe + 1) + (m->pb_stagger & 3) * 100000;
     if (m->pb_pace_tuned_unroll == key)
     {
         // already tried for this layout; a requested pace only overrides the pace
@@ -872,6 +877,7 @@ int panel_choose_pace(spmv_mat* m)
         return SPMV_OK;
     }
     m->pb_pace_tuned_unroll = 0;  // what was found for other requests no longer applies
+    m->pb_stagger_tuned = -1;
     m->pb_unroll_tuned  = 0;
     m->pb_pipe_tuned    = 0;
     m->pb_pace_ns       = m->pb_pace_req >= 0 ? m->pb_pace_req : 0;
@@ -890,90 +896,121 @@ int panel_choose_pace(spmv_mat* m)
     (void)hipMemsetAsync(x, 0, sizeof(double) * (size_t)m->ncol, ctx->stream);
     (void)hipMemsetAsync(y, 0, sizeof(double) * (size_t)m->nrow, ctx->stream);
     int  rc    = SPMV_OK;
-    auto timed = [&](int pace_ns, float* ms) -> int {
+    auto timed = [&](int pace_ns, int launches, float* ms) -> int {
         m->pb_pace_ns = pace_ns;
         int r         = panel_launch(ctx, m, x, y, true, apply_extra{});  // warm
         if (r != SPMV_OK) return r;
         (void)hipEventRecord(ctx->ev_begin, ctx->stream);
-        for (int i = 0; i < 3 && r == SPMV_OK; ++i) r = panel_launch(ctx, m, x, y, true, apply_extra{});
+        for (int i = 0; i < launches && r == SPMV_OK; ++i) r = panel_launch(ctx, m, x, y, true, apply_extra{});
         (void)hipEventRecord(ctx->ev_end, ctx->stream);
         if (r == SPMV_OK && (hipEventSynchronize(ctx->ev_end) != hipSuccess ||
                              hipEventElapsedTime(ms, ctx->ev_begin, ctx->ev_end) != hipSuccess))
             r = SPMV_ERR_HIP;
+        *ms /= (float)launches;
         return r;
     };
-    double    all_best_ms = 1e30;
-    int       all_best_pace = 0, all_best_unroll = 0, all_best_pipe = 0;
-    const int unrolls[3] = {u_first, 4, 2};
-    const int n_unroll   = m->pb_unroll > 0 ? 1 : 3;
-    const int n_pipe     = m->pb_pipe >= 0 || m->pb_pack == nullptr ? 1 : 2;  // gather-first exists for the packed layout
-    for (int ui = 0; ui < n_unroll * n_pipe && rc == SPMV_OK; ++ui)
+    struct Config
     {
-        const int unroll   = unrolls[ui / n_pipe];
-        const int pipe     = n_pipe == 2 ? 1 + ui % 2 : 0;
-        if (pipe == 2 && unroll == 2) continue;  // gather-first is not instantiated for U = 2
-        m->pb_unroll_tuned = unroll;
-        m->pb_pipe_tuned   = pipe;
-        double best_ms = 1e30, unthrottled_ms = 1e30;
-        int    best_pace = 0;
+        int    unroll, pipe, stagger, pace;
+        double ms;  // per launch
+    };
+    // best pace of one configuration: coarse candidates, then 2 % steps down from the coarse winner
+    auto search = [&](Config& c) -> int {
+        m->pb_unroll_tuned = c.unroll;
+        m->pb_pipe_tuned   = c.pipe;
+        m->pb_stagger      = c.stagger;
+        c.ms               = 1e30;
+        c.pace             = 0;
+        float ms           = 0.f;
         if (m->pb_pace_req >= 0)
         {
-            float ms = 0.f;
-            if ((rc = timed(m->pb_pace_req, &ms)) != SPMV_OK) break;
-            best_ms   = ms;
-            best_pace = m->pb_pace_req;
+            SPMV_TRY(timed(m->pb_pace_req, 3, &ms));
+            c.ms   = ms;
+            c.pace = m->pb_pace_req;
+            return SPMV_OK;
         }
-        else
+        const double base_ns   = 1.33 * c.unroll * kPanelThreads;
+        const double factors[] = {0.0, 0.76, 0.82, 0.88, 0.94, 1.0, 1.06, 1.12, 1.2, 1.32, 1.5, 1.7, 1.95, 2.25, 2.6};
+        double       unthrottled_ms = 1e30;
+        for (double f : factors)
         {
-            const double base_ns   = 1.33 * unroll * kPanelThreads;
-            const double factors[] = {0.0, 0.76, 0.82, 0.88, 0.94, 1.0, 1.06, 1.12, 1.2, 1.32, 1.5, 1.7, 1.95, 2.25, 2.6};
-            for (double f : factors)
+            SPMV_TRY(timed((int32_t)(f * base_ns), 3, &ms));
+            // a throttle has to beat the unthrottled run (first candidate) by a clear margin, or timing noise
+            // would switch it on where the columns are local and there is nothing to keep in step
+            if (f == 0.0) unthrottled_ms = ms;
+            if (ms < c.ms && (f == 0.0 || ms < 0.93 * unthrottled_ms))
             {
-                float ms = 0.f;
-                if ((rc = timed((int32_t)(f * base_ns), &ms)) != SPMV_OK) break;
-                // a throttle has to beat the unthrottled run (first candidate) by a clear margin, or timing noise
-                // would switch it on where the columns are local and there is nothing to keep in step
-                if (f == 0.0) unthrottled_ms = ms;
-                if (ms < best_ms && (f == 0.0 || ms < 0.93 * unthrottled_ms))
-                {
-                    best_ms   = ms;
-                    best_pace = m->pb_pace_ns;
-                }
-            }
-            // the optimum sits right above a cliff (a pace the CUs cannot hold lets them drift apart): refine in
-            // 2 % steps below the coarse winner and stop at the first step that is not faster
-            for (int step = 1; rc == SPMV_OK && best_pace > 0 && step <= 8; ++step)
-            {
-                float     ms   = 0.f;
-                const int cand = (int)(best_pace * 0.98);
-                if ((rc = timed(cand, &ms)) != SPMV_OK || ms >= best_ms) break;
-                best_ms   = ms;
-                best_pace = cand;
+                c.ms   = ms;
+                c.pace = m->pb_pace_ns;
             }
         }
-        if (rc == SPMV_OK && best_ms < all_best_ms * (ui == 0 ? 1.0 : 0.98))  // later candidates have to win clearly
+        // the optimum sits right above a cliff (a pace the CUs cannot hold lets them drift apart)
+        for (int step = 1; c.pace > 0 && step <= 8; ++step)
         {
-            all_best_ms     = best_ms;
-            all_best_pace   = best_pace;
-            all_best_unroll = unroll;
-            all_best_pipe   = pipe;
+            const int cand = (int)(c.pace * 0.98);
+            SPMV_TRY(timed(cand, 3, &ms));
+            if (ms >= c.ms) break;
+            c.ms   = ms;
+            c.pace = cand;
+        }
+        return SPMV_OK;
+    };
+    const int stagger_req = m->pb_stagger;
+    const int unrolls[3]  = {u_first, 4, 2};
+    const int n_unroll    = m->pb_unroll > 0 ? 1 : 3;
+    const int n_pipe      = m->pb_pipe >= 0 || m->pb_pack == nullptr ? 1 : 2;  // gather-first: packed layout
+    Config    cand[8];
+    int       ncand = 0;
+    for (int ui = 0; ui < n_unroll * n_pipe && rc == SPMV_OK; ++ui)
+    {
+        Config c{unrolls[ui / n_pipe], n_pipe == 2 ? 1 + ui % 2 : 0, stagger_req, 0, 1e30};
+        if (c.pipe == 2 && c.unroll == 2) continue;  // gather-first is not instantiated for U = 2
+        if ((rc = search(c)) == SPMV_OK) cand[ncand++] = c;
+    }
+    // The configurations are often within a few per cent of each other: decide among them (and, for the winner,
+    // between XCD-offset and plain lockstep schedules) over more launches than the search used.
+    Config best{u_first, 0, stagger_req, 0, 1e30};
+    for (int i = 0; i < ncand && rc == SPMV_OK; ++i)
+    {
+        Config& c = cand[i];
+        m->pb_unroll_tuned = c.unroll;
+        m->pb_pipe_tuned   = c.pipe;
+        m->pb_stagger      = c.stagger;
+        float a = 0.f, b = 0.f;
+        if ((rc = timed(c.pace, 6, &a)) != SPMV_OK || (rc = timed(c.pace, 6, &b)) != SPMV_OK) break;
+        c.ms = std::min(a, b);
+        if (c.ms < best.ms * (i == 0 ? 1.0 : 0.99)) best = c;
+    }
+    if (rc == SPMV_OK && ncand > 0 && best.pace > 0 && m->pb_pace_req < 0 && stagger_req == 2)
+    {
+        Config alt = best;
+        alt.stagger = 0;
+        float a = 0.f, b = 0.f;
+        if ((rc = search(alt)) == SPMV_OK && (rc = timed(alt.pace, 6, &a)) == SPMV_OK && (rc = timed(alt.pace, 6, &b)) == SPMV_OK)
+        {
+            alt.ms = std::min(a, b);
+            if (alt.ms < 0.99 * best.ms) best = alt;
         }
     }
     // The winner sits close to the cliff.  Step back 2 % from it, then check the choice over more launches and
     // step back further while it does not hold (a pace the chip cannot keep costs 60-80 %, a cautious one 2-3 %).
-    if (rc == SPMV_OK && all_best_pace > 0 && m->pb_pace_req < 0)
+    m->pb_unroll_tuned = best.unroll;
+    m->pb_pipe_tuned   = best.pipe;
+    m->pb_stagger      = best.stagger;
+    if (rc == SPMV_OK && best.pace > 0 && m->pb_pace_req < 0)
     {
-        m->pb_unroll_tuned = all_best_unroll;
-        m->pb_pipe_tuned   = all_best_pipe;
-        all_best_pace      = (int)(all_best_pace * 1.02);
+        best.pace = (int)(best.pace * 1.02);
         for (int attempt = 0; attempt < 4 && rc == SPMV_OK; ++attempt)
         {
             float ms_a = 0.f, ms_b = 0.f;
-            if ((rc = timed(all_best_pace, &ms_a)) != SPMV_OK || (rc = timed(all_best_pace, &ms_b)) != SPMV_OK) break;
-            if (std::max(ms_a, ms_b) <= 1.08 * all_best_ms) break;
-            all_best_pace = (int)(all_best_pace * 1.03);
+            if ((rc = timed(best.pace, 3, &ms_a)) != SPMV_OK || (rc = timed(best.pace, 3, &ms_b)) != SPMV_OK) break;
+            if (std::max(ms_a, ms_b) <= 1.08 * best.ms) break;
+            best.pace = (int)(best.pace * 1.03);
         }
     }
+    const int all_best_pace = best.pace, all_best_unroll = best.unroll, all_best_pipe = best.pipe;
+    m->pb_stagger_tuned = rc == SPMV_OK ? best.stagger : stagger_req;
+    m->pb_stagger       = stagger_req;  // the request stays what the caller set; the launch uses the tuned value
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(x);
     (void)hipFree(y);
@@ -1013,7 +1050,7 @@ static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, doubl
     const bool gated = skew > 0 && grid > 1 && !A->pb_pack;
     // pace: nanoseconds per chunk -> 10 ns ticks in 22.10 fixed point
     const unsigned long long pace_fp = A->pb_pace_ns > 0 ? (unsigned long long)((double)A->pb_pace_ns * 102.4) : 0ull;
-    const int  pace_slack = std::min(std::max(0, A->pb_pace_slack), 0xFFFF) | (A->pb_stagger ? 1 << 16 : 0);
+    const int  pace_slack = std::min(std::max(0, A->pb_pace_slack), 0xFFFF) | (((A->pb_stagger_tuned >= 0 ? A->pb_stagger_tuned : A->pb_stagger) & 3) << 16);
     const int  layout = A->pb_pack ? 3 : A->pb_rec ? 1 : (A->pb_aos == 2 ? 2 : 0);
     // the kernel dereferences exactly these arrays: refuse on the host rather than fault on the GPU
     const bool have = layout == 1   ? A->pb_rec != nullptr

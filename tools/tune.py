@@ -158,7 +158,7 @@ def main():
             pipe = combo[6] if len(combo) > 6 else 0
             slack = combo[7] if len(combo) > 7 else 0
             aos = combo[8] if len(combo) > 8 else 0
-            stagger = combo[9] if len(combo) > 9 else 0
+            stagger = combo[9] if len(combo) > 9 else 2
 
             def setup(A, rows=rows, width=width, srt=srt, unroll=unroll, skew=skew, pace=pace, pipe=pipe, slack=slack, aos=aos, stagger=stagger):
                 A.set_param("panel_aos", aos)
@@ -186,10 +186,10 @@ def main():
                 variants.append((f"ldswin L={lanes}", lambda A, lanes=lanes: A.set_kernel(capi.CSR_LDSWIN, lanes)))
         sweep(ctx, A, x, y, variants, a.rounds, a.reps, algorithmic_bytes("csr", n, ncol, n * k), n * k)
         for name, v in (("panel_aos", 3), ("panel_unroll", 0), ("panel_pace_ns", -1), ("panel_pipe", -1), ("panel_skew", 0),
-                        ("panel_pace_slack", 0), ("panel_ablate", 0), ("panel_stagger", 0)):
+                        ("panel_pace_slack", 0), ("panel_ablate", 0), ("panel_stagger", 2)):
             A.set_param(name, v)
         A.set_kernel(capi.CSR_PANEL)
-        print("chosen by trial:", {k: A.get_param("panel_" + k) for k in ("rows", "groups", "layout", "unroll", "pipe", "pace_ns", "bytes")})
+        print("chosen by trial:", {k: A.get_param("panel_" + k) for k in ("rows", "groups", "layout", "unroll", "pipe", "stagger", "pace_ns", "bytes")})
     elif a.what == "ell":
         n, k = a.n or 4_000_000, a.k or 64
         A = ctx.gen_ell_banded(n, n, k, seed=1)
