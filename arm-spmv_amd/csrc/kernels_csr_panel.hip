@@ -501,7 +501,9 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
                 const int                mode  = pace_slack >> 16;  // 1: wavefronts apart, 2: XCDs apart (L2s are per XCD)
                 const unsigned long long phase = mode == 1   ? ((unsigned long long)(threadIdx.x >> 6) * pace_fp) / NWAVES
                                                  : mode == 2 ? ((unsigned long long)xcd_id() * pace_fp) / kNumXcd
-                                                             : 0ull;
+                                                 : mode == 3 ? ((unsigned long long)((blockIdx.x >> 3) & 1) * pace_fp) / 2 +
+                                                                   ((unsigned long long)xcd_id() * pace_fp) / (2 * kNumXcd)
+                                                             : 0ull;  // 3: halves of an XCD in antiphase (experiment)
                 if (b > slack || phase)
                 {
                     const unsigned long long ahead  = b > slack ? (unsigned long long)(b - slack) * pace_fp : 0ull;

@@ -101,6 +101,71 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, int k, con
     if (threadIdx.x == 0) unsafeAtomicAdd(&s->rr[(k + 1) & 3], total);
 }
 
+// The same two kernels with two elements per lane and 16-byte accesses (used when the vectors are 16-byte aligned);
+// an odd last element is handled by one extra lane.
+typedef double f64x2_t __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(kBlock) void cg_update2_kernel(int64_t n, int k, const double* __restrict__ p,
+                                                            const double* __restrict__ q, double* __restrict__ x,
+                                                            double* __restrict__ r, CgScalars* __restrict__ s)
+{
+    const double pq = s->pq[k & 3];
+    if (!(pq > 0.0))
+    {
+        if (blockIdx.x == 0 && threadIdx.x == 0) s->status = 1.0;
+        return;
+    }
+    const double  alpha  = s->rr[k & 3] / pq;
+    const int64_t npairs = n / 2;
+    double        rr     = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < npairs; i += (int64_t)gridDim.x * kBlock)
+    {
+        const f64x2_t pv = ((const f64x2_t*)p)[i], qv = ((const f64x2_t*)q)[i];
+        f64x2_t       xv = ((f64x2_t*)x)[i], rv = ((f64x2_t*)r)[i];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+        {
+            xv[e] = fma(alpha, pv[e], xv[e]);
+            rv[e] = fma(-alpha, qv[e], rv[e]);
+            rr    = fma(rv[e], rv[e], rr);
+        }
+        ((f64x2_t*)x)[i] = xv;
+        ((f64x2_t*)r)[i] = rv;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+    {
+        const int64_t i  = n - 1;
+        x[i]             = fma(alpha, p[i], x[i]);
+        const double ri  = fma(-alpha, q[i], r[i]);
+        r[i]             = ri;
+        rr               = fma(ri, ri, rr);
+    }
+    const double total = block_sum(rr);
+    if (threadIdx.x == 0) unsafeAtomicAdd(&s->rr[(k + 1) & 3], total);
+}
+
+__global__ __launch_bounds__(kBlock) void cg_direction2_kernel(int64_t n, int k, const double* __restrict__ r,
+                                                               double* __restrict__ p, CgScalars* __restrict__ s)
+{
+    const double  rr_k   = s->rr[k & 3];
+    const double  beta   = rr_k > 0.0 ? s->rr[(k + 1) & 3] / rr_k : 0.0;
+    const int64_t npairs = n / 2;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < npairs; i += (int64_t)gridDim.x * kBlock)
+    {
+        const f64x2_t rv = ((const f64x2_t*)r)[i];
+        f64x2_t       pv = ((f64x2_t*)p)[i];
+        pv[0]            = fma(beta, pv[0], rv[0]);
+        pv[1]            = fma(beta, pv[1], rv[1]);
+        ((f64x2_t*)p)[i] = pv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+    {
+        if (n & 1) p[n - 1] = fma(beta, p[n - 1], r[n - 1]);
+        s->rr[(k + 2) & 3] = 0.0;
+        s->pq[(k + 2) & 3] = 0.0;
+    }
+}
+
 // beta = rr_{k+1} / rr_k;  p = r + beta p;  clear the slots of iteration k + 2
 __global__ __launch_bounds__(kBlock) void cg_direction_kernel(int64_t n, int k, const double* __restrict__ r,
                                                               double* __restrict__ p, CgScalars* __restrict__ s)
@@ -174,8 +239,10 @@ int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int m
         release();
         SPMV_FAIL(SPMV_ERR_ALLOC, "spmv_cg: out of device memory for three work vectors of %lld entries", (long long)n);
     }
-    const int grid = stream_grid(n);
-    int       rc   = SPMV_OK;
+    const int  grid  = stream_grid(n);
+    const int  grid2 = stream_grid(std::max<int64_t>(1, n / 2));
+    const bool wide  = (((uintptr_t)x) & 15) == 0 && n >= 2;  // r, p, q are fresh allocations (256-byte aligned)
+    int        rc    = SPMV_OK;
     CgScalars h{};
     auto      fetch = [&]() -> int {
         if (hipMemcpyAsync(&h, s, sizeof(CgScalars), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
@@ -214,8 +281,16 @@ int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int m
             ex.dot_w     = p;
             ex.dot_out   = &s->pq[k & 3];
             if ((rc = mat_apply_ex(ctx, A, p, q, ex)) != SPMV_OK) break;  // q = A p, pq_k = p . q
-            hipLaunchKernelGGL(cg_update_kernel, dim3(grid), dim3(kBlock), 0, st, n, k, p, q, x, r, s);
-            hipLaunchKernelGGL(cg_direction_kernel, dim3(grid), dim3(kBlock), 0, st, n, k, r, p, s);
+            if (wide)
+            {
+                hipLaunchKernelGGL(cg_update2_kernel, dim3(grid2), dim3(kBlock), 0, st, n, k, p, q, x, r, s);
+                hipLaunchKernelGGL(cg_direction2_kernel, dim3(grid2), dim3(kBlock), 0, st, n, k, r, p, s);
+            }
+            else
+            {
+                hipLaunchKernelGGL(cg_update_kernel, dim3(grid), dim3(kBlock), 0, st, n, k, p, q, x, r, s);
+                hipLaunchKernelGGL(cg_direction_kernel, dim3(grid), dim3(kBlock), 0, st, n, k, r, p, s);
+            }
             ++k;
             if (k % every == 0 || k == max_iter)
             {
