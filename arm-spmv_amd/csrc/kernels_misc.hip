@@ -11,6 +11,7 @@ namespace spmv
 {
 namespace
 {
+typedef double f64x2_t __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(kBlock) void fill_kernel(double* __restrict__ d, int64_t n, double a)
 {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) d[i] = a;
@@ -83,8 +84,6 @@ __global__ __launch_bounds__(kBlock) void axpby_kernel(int64_t n, double alpha, 
 // Two elements per lane with 16-byte accesses (the streaming width that reaches HBM speed on this chip); the same
 // element-wise arithmetic, so the results are bit-identical to the one-element kernel.  NT: nontemporal loads and
 // stores for vectors far beyond the caches.
-typedef double f64x2_t __attribute__((ext_vector_type(2)));
-
 template <int MODE, bool NT>
 __global__ __launch_bounds__(kBlock) void axpby2_kernel(int64_t npairs, double alpha, const f64x2_t* __restrict__ x,
                                                         double beta, const f64x2_t* __restrict__ y, f64x2_t* __restrict__ w)
@@ -134,26 +133,40 @@ __global__ __launch_bounds__(kBlock) void csc_kernel(int ncol, const int32_t* __
 // row from LDS (row stride 17 doubles: conflict-free).  x[i + offset] is contiguous across lanes.
 constexpr int kDiaChunk = 16;
 
+// WIDE: 16-byte loads (two adjacent diagonals per lane, 8 lanes per 128-byte line); needs an even ndiags so that every
+// pair is 16-byte aligned.  8-byte accesses reach only ~0.65x of the streaming rate on this chip.
+template <bool WIDE>
 __global__ __launch_bounds__(kBlock) void dia_kernel(int nrow, int ndiags, const int32_t* __restrict__ offsets,
                                                      const double* __restrict__ val, const double* __restrict__ x,
                                                      double* __restrict__ y)
 {
     __shared__ double tile[kBlock * (kDiaChunk + 1)];
+    constexpr int PER   = WIDE ? 2 : 1;                  // diagonals per lane and load
+    constexpr int LPR   = kDiaChunk / PER;               // lanes per row of the tile
+    constexpr int RPP   = kBlock / LPR;                  // rows per pass of the workgroup
+    constexpr int NPASS = kBlock / RPP;                  // passes per tile
     const int r0 = blockIdx.x * kBlock;
     const int i  = r0 + threadIdx.x;
     double    acc = i < nrow ? y[i] : 0.0;
-    // element j of this lane's share of a chunk: tile position (r, d) = ((lane + 256 j) / 16, (lane + 256 j) % 16)
-    const int d_mine = threadIdx.x % kDiaChunk;
-    const int r_mine = threadIdx.x / kDiaChunk;  // + 16 j
-    double    stage[kDiaChunk];
+    // element j of this lane's share of a chunk: tile position (r, d) = (r_mine + RPP j, d_mine [+ 1])
+    const int d_mine = (threadIdx.x % LPR) * PER;
+    const int r_mine = threadIdx.x / LPR;
+    double    stage[NPASS * PER];
     auto fetch = [&](int d0) {
 #pragma unroll
-        for (int j = 0; j < kDiaChunk; ++j)
+        for (int j = 0; j < NPASS; ++j)
         {
-            const int r = r_mine + j * (kBlock / kDiaChunk);
-            stage[j]    = (r0 + r < nrow && d0 + d_mine < ndiags)
-                              ? load_stream(val + (size_t)(r0 + r) * ndiags + d0 + d_mine)
-                              : 0.0;
+            const int     r = r_mine + j * RPP;
+            const double* p = val + (size_t)(r0 + r) * ndiags + d0 + d_mine;
+            if constexpr (WIDE)
+            {
+                f64x2_t v = {0.0, 0.0};
+                if (r0 + r < nrow && d0 + d_mine < ndiags) v = __builtin_nontemporal_load((const f64x2_t*)p);  // ndiags even
+                stage[2 * j]     = v[0];
+                stage[2 * j + 1] = v[1];
+            }
+            else
+                stage[j] = (r0 + r < nrow && d0 + d_mine < ndiags) ? load_stream(p) : 0.0;
         }
     };
     fetch(0);
@@ -162,8 +175,9 @@ __global__ __launch_bounds__(kBlock) void dia_kernel(int nrow, int ndiags, const
         const int dn = min(kDiaChunk, ndiags - d0);
         __syncthreads();  // the previous chunk has been consumed
 #pragma unroll
-        for (int j = 0; j < kDiaChunk; ++j)
-            tile[(r_mine + j * (kBlock / kDiaChunk)) * (kDiaChunk + 1) + d_mine] = stage[j];
+        for (int j = 0; j < NPASS; ++j)
+#pragma unroll
+            for (int e = 0; e < PER; ++e) tile[(r_mine + j * RPP) * (kDiaChunk + 1) + d_mine + e] = stage[PER * j + e];
         __syncthreads();
         if (d0 + kDiaChunk < ndiags) fetch(d0 + kDiaChunk);  // in flight while this chunk is consumed
         if (i < nrow)
@@ -308,8 +322,11 @@ int csc_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
 int dia_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
 {
     if (A->nrow == 0 || A->k == 0) return SPMV_OK;
-    hipLaunchKernelGGL(dia_kernel, dim3((unsigned)ceil_div(A->nrow, kBlock)), dim3(kBlock), 0, ctx->stream, A->nrow,
-                       A->k, A->a, A->v, x, y);
+    const dim3 grid((unsigned)ceil_div(A->nrow, kBlock));
+    if (A->k % 2 == 0 && (((uintptr_t)A->v) & 15) == 0)
+        hipLaunchKernelGGL(dia_kernel<true>, grid, dim3(kBlock), 0, ctx->stream, A->nrow, A->k, A->a, A->v, x, y);
+    else
+        hipLaunchKernelGGL(dia_kernel<false>, grid, dim3(kBlock), 0, ctx->stream, A->nrow, A->k, A->a, A->v, x, y);
     SPMV_HIP(hipGetLastError());
     return SPMV_OK;
 }
