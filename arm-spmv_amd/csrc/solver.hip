@@ -7,10 +7,13 @@
 //   cg_solve       conjugate gradients for symmetric positive definite A.  Three launches per iteration
 //                  (product+dot, x/r update+dot, direction update); alpha and beta are computed on the device from
 //                  scalars that never leave it, so iterations queue up without a host round trip; the host looks at
-//                  the residual every `check_every` iterations only.
+//                  the residual every `check_every` iterations only.  (A hipGraph replay of the iterations in
+//                  between was built and measured slower than plain launches: kept behind SPMV_CG_GRAPH=1.)
 //
 // Not part of the reference's API: the results are checked against the oracle's product (residual of the solution)
 // in tests/test_gpu_solver.py.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "wave.hpp"
 
@@ -274,24 +277,63 @@ int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int m
             break;
         }
         const int every = std::max(1, check_every);
-        while (k < max_iter)
-        {
+        // one iteration = three launches on the stream (k enters the kernels only through k & 3)
+        auto iteration = [&](int kk) -> int {
             apply_extra ex;
             ex.overwrite = true;
             ex.dot_w     = p;
-            ex.dot_out   = &s->pq[k & 3];
-            if ((rc = mat_apply_ex(ctx, A, p, q, ex)) != SPMV_OK) break;  // q = A p, pq_k = p . q
+            ex.dot_out   = &s->pq[kk & 3];
+            SPMV_TRY(mat_apply_ex(ctx, A, p, q, ex));  // q = A p, pq_k = p . q
             if (wide)
             {
-                hipLaunchKernelGGL(cg_update2_kernel, dim3(grid2), dim3(kBlock), 0, st, n, k, p, q, x, r, s);
-                hipLaunchKernelGGL(cg_direction2_kernel, dim3(grid2), dim3(kBlock), 0, st, n, k, r, p, s);
+                hipLaunchKernelGGL(cg_update2_kernel, dim3(grid2), dim3(kBlock), 0, st, n, kk, p, q, x, r, s);
+                hipLaunchKernelGGL(cg_direction2_kernel, dim3(grid2), dim3(kBlock), 0, st, n, kk, r, p, s);
             }
             else
             {
-                hipLaunchKernelGGL(cg_update_kernel, dim3(grid), dim3(kBlock), 0, st, n, k, p, q, x, r, s);
-                hipLaunchKernelGGL(cg_direction_kernel, dim3(grid), dim3(kBlock), 0, st, n, k, r, p, s);
+                hipLaunchKernelGGL(cg_update_kernel, dim3(grid), dim3(kBlock), 0, st, n, kk, p, q, x, r, s);
+                hipLaunchKernelGGL(cg_direction_kernel, dim3(grid), dim3(kBlock), 0, st, n, kk, r, p, s);
             }
-            ++k;
+            return SPMV_OK;
+        };
+        // Between two looks at the residual nothing depends on the host, and the scalar slots repeat with period 4, so
+        // four iterations can be captured once into a hipGraph and replayed with one launch.  MEASURED SLOWER than the
+        // plain stream of launches on ROCm 7.2 (profiles/r01_tune_cg_graph.txt: 61 vs 23 us per iteration at n = 10^4,
+        // 214 vs 168 us at n = 4M), so it is off unless SPMV_CG_GRAPH=1 asks for it.
+        hipGraph_t     graph = nullptr;
+        hipGraphExec_t exec  = nullptr;
+        const char*    want_graph = getenv("SPMV_CG_GRAPH");
+        if (want_graph && want_graph[0] == '1' && every >= 4 && max_iter >= 4 &&
+            hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess)
+        {
+            int crc = SPMV_OK;
+            for (int kk = 0; kk < 4 && crc == SPMV_OK; ++kk) crc = iteration(kk);
+            const hipError_t e_end = hipStreamEndCapture(st, &graph);
+            if (crc != SPMV_OK || e_end != hipSuccess || graph == nullptr ||
+                hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess)
+            {
+                exec = nullptr;
+                (void)hipGetLastError();
+            }
+        }
+        while (k < max_iter)
+        {
+            const int until = std::min(max_iter, (k / every + 1) * every);  // the next look at the residual
+            if (exec && (k & 3) == 0 && k + 4 <= until)
+            {
+                if (hipGraphLaunch(exec, st) != hipSuccess)
+                {
+                    rc = SPMV_ERR_HIP;
+                    set_error("spmv_cg: hipGraphLaunch failed: %s", hipGetErrorString(hipGetLastError()));
+                    break;
+                }
+                k += 4;
+            }
+            else
+            {
+                if ((rc = iteration(k)) != SPMV_OK) break;
+                ++k;
+            }
             if (k % every == 0 || k == max_iter)
             {
                 if ((rc = fetch()) != SPMV_OK) break;
@@ -305,6 +347,8 @@ int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int m
                 if (rr <= limit) break;
             }
         }
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
         if (rc == SPMV_OK && hipGetLastError() != hipSuccess) rc = SPMV_ERR_HIP;
         *iters     = k;
         *rel_resid = sqrt(rr / bb);
