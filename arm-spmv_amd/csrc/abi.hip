@@ -190,7 +190,7 @@ static int ctx_create_common(int device, void* borrowed_stream, bool borrow, spm
     hipError_t e = hipEventCreate(&ctx->ev_begin);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_end);
     if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->host_pinned, 64, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipMalloc((void**)&ctx->dev_scalars, 64);
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->dev_scalars, sizeof(double) * kDotDoubles);
     if (e != hipSuccess)
     {
         spmv_ctx_destroy(ctx);
@@ -741,15 +741,18 @@ int spmv_apply_dot(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* x, spmv_vec
     SPMV_REQUIRE(w->d != y->d || y->n == 0, "spmv_apply_dot: w and y must not alias");
     SPMV_TRY(use_device(ctx));
     double* out = ctx->dev_scalars;
-    SPMV_HIP(hipMemsetAsync(out, 0, sizeof(double), ctx->stream));
+    SPMV_HIP(hipMemsetAsync(out, 0, sizeof(double) * kDotDoubles, ctx->stream));
     apply_extra ex;
     ex.overwrite = overwrite != 0;
     ex.dot_w     = w->d;
     ex.dot_out   = out;
     SPMV_TRY(mat_apply_ex(ctx, A, x->d, y->d, ex));
-    SPMV_HIP(hipMemcpyAsync(ctx->host_pinned, out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<double> slots(kDotDoubles);
+    SPMV_HIP(hipMemcpyAsync(slots.data(), out, sizeof(double) * kDotDoubles, hipMemcpyDeviceToHost, ctx->stream));
     SPMV_HIP(hipStreamSynchronize(ctx->stream));
-    *dot = ctx->host_pinned[0];
+    double total = 0.0;
+    for (int i = 0; i < kDotSlots; ++i) total += slots[(size_t)i * kDotStride];
+    *dot = total;
     return SPMV_OK;
 }
 

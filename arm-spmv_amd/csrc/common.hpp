@@ -101,7 +101,7 @@ struct spmv_ctx
     void*  scratch       = nullptr;
     size_t scratch_bytes = 0;
     double* host_pinned  = nullptr;  // 64 B of pinned host memory for scalar results
-    double* dev_scalars  = nullptr;  // 64 B of device memory for scalar results (never re-allocated, unlike scratch)
+    double* dev_scalars  = nullptr;  // one slotted accumulator (kDotDoubles) for scalar results; never re-allocated
 };
 
 struct spmv_vec
@@ -197,14 +197,21 @@ int  csr_panel_build(spmv_mat* m);
 int  panel_choose_pace(spmv_mat* m);
 void csr_panel_free(spmv_mat* m);
 int  csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
+// A sum that thousands of wavefronts add into is kept as kDotSlots partial sums on different 128-byte lines (an
+// atomic on ONE word costs ~12 ns each at the L2, serialised: 8192 of them are 100 us); readers add the slots up.
+constexpr int kDotSlots   = 32;
+constexpr int kDotStride  = 16;                       // doubles between slots: one 128-byte line each
+constexpr int kDotDoubles = kDotSlots * kDotStride;   // size of one slotted accumulator
+
 // what a solver step wants on top of y += A*x (solver.hip)
 struct apply_extra
 {
     bool          overwrite = false;    // y = A*x instead of y += A*x
-    const double* dot_w     = nullptr;  // if set: *dot_out += sum_i dot_w[i] * y_new[i]
-    double*       dot_out   = nullptr;  // device scalar
+    const double* dot_w     = nullptr;  // if set: accumulate sum_i dot_w[i] * y_new[i] into dot_out
+    double*       dot_out   = nullptr;  // slotted accumulator on the device (kDotDoubles doubles)
 };
 int  csr_panel_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, const apply_extra& ex);
+bool csr_vector_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, const apply_extra& ex, int* rc);
 // solver.hip
 int mat_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 int mat_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, const apply_extra& ex);

@@ -38,7 +38,8 @@ __device__ __forceinline__ int remap_block(int bid, int nblocks)
 template <int LPR, bool USE_DPP, bool XCD_REMAP>
 __global__ __launch_bounds__(kBlock) void csr_vector_kernel(
     int nrow, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
-    const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y)
+    const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y, int overwrite,
+    const double* __restrict__ dot_w, double* __restrict__ dot_out)
 {
     constexpr int ROWS = kBlock / LPR;
     int bid = blockIdx.x;
@@ -74,7 +75,19 @@ __global__ __launch_bounds__(kBlock) void csr_vector_kernel(
     }
     // every lane of the wave takes part in the cross-lane step (no early exit above)
     sum = group_sum<LPR, USE_DPP>(sum);
-    if (row < nrow && sub == 0) y[row] += sum;
+    // y += sum (the reference's op), or y = sum; the solver's dot product w . y_new rides along (spmv_apply_dot)
+    double part = 0.0;
+    if (row < nrow && sub == 0)
+    {
+        const double yn = overwrite ? sum : y[row] + sum;
+        y[row]          = yn;
+        if (dot_w) part = dot_w[row] * yn;
+    }
+    if (dot_w)  // uniform over the grid
+    {
+        part = wave_sum(part);
+        if ((threadIdx.x & 63) == 0) slot_add(dot_out, part);
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void csr_scalar_kernel(
@@ -228,14 +241,15 @@ int pick_lanes(double mean_row)
 }
 
 template <bool USE_DPP, bool XCD_REMAP>
-int launch_vector(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, int lanes)
+int launch_vector(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, int lanes, const apply_extra& ex = apply_extra{})
 {
     const int   nrow = A->nrow;
     hipStream_t s    = ctx->stream;
 #define SPMV_LAUNCH_LPR(L)                                                                              \
     case L:                                                                                             \
         hipLaunchKernelGGL((csr_vector_kernel<L, USE_DPP, XCD_REMAP>), dim3((unsigned)ceil_div(nrow, kBlock / L)), \
-                           dim3(kBlock), 0, s, nrow, A->a, A->b, A->v, x, y);                           \
+                           dim3(kBlock), 0, s, nrow, A->a, A->b, A->v, x, y, ex.overwrite ? 1 : 0,      \
+                           ex.dot_w, ex.dot_out);                                                       \
         break;
     switch (lanes)
     {
@@ -375,6 +389,23 @@ int csr_analyse(spmv_mat* m)
     if (!m->kernel_forced) csr_choose_kernel(m);
     if (m->kernel == SPMV_CSR_PANEL) SPMV_TRY(csr_panel_build(m));
     return SPMV_OK;
+}
+
+// the row-parallel kernel with the solver's extras fused into its write-back; false if another kernel is selected
+bool csr_vector_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, const apply_extra& ex, int* rc)
+{
+    if (A->nrow == 0 || (A->kernel != SPMV_CSR_VECTOR && A->kernel != SPMV_CSR_AUTO)) return false;
+    const int  lanes = A->lanes_per_row > 0 ? A->lanes_per_row : 8;
+    const bool dpp = A->flags & SPMV_FLAG_DPP_REDUCE, remap = A->flags & SPMV_FLAG_XCD_REMAP;
+    if (dpp && remap)
+        *rc = launch_vector<true, true>(ctx, A, x, y, lanes, ex);
+    else if (dpp)
+        *rc = launch_vector<true, false>(ctx, A, x, y, lanes, ex);
+    else if (remap)
+        *rc = launch_vector<false, true>(ctx, A, x, y, lanes, ex);
+    else
+        *rc = launch_vector<false, false>(ctx, A, x, y, lanes, ex);
+    return true;
 }
 
 int csr_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)

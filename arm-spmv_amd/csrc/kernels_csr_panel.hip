@@ -579,7 +579,7 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
         if (dot_w)
         {
             part = wave_sum(part);
-            if (lane == 0) unsafeAtomicAdd(dot_out, part);
+            if (lane == 0) slot_add(dot_out, part);
         }
         __syncthreads();
     }

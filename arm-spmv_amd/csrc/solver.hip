@@ -13,6 +13,7 @@
 // Not part of the reference's API: the results are checked against the oracle's product (residual of the solution)
 // in tests/test_gpu_solver.py.
 #include <cstdlib>
+#include <vector>
 
 #include "common.hpp"
 #include "wave.hpp"
@@ -36,6 +37,25 @@ __device__ __forceinline__ double block_sum(double v)
     return total;
 }
 
+// Totals of two slotted accumulators, for every thread of the workgroup: lanes 0-31 of the first wavefront read the
+// slots of `a`, lanes 32-63 those of `b` (one load latency instead of a chain of 32), halves are summed, LDS broadcast.
+__device__ __forceinline__ void slot_sum2_block(const double* a, const double* b, double* ta, double* tb)
+{
+    static_assert(kDotSlots == 32, "one slot per lane of a 32-lane half");
+    __shared__ double s_tot[2];
+    if (threadIdx.x < kWave)
+    {
+        const int    lane = threadIdx.x;
+        const double v    = (lane < 32 ? a : b)[(lane & 31) * kDotStride];
+        const double t    = group_sum_swizzle<32>(v);
+        if ((lane & 31) == 0) s_tot[lane >> 5] = t;
+    }
+    __syncthreads();
+    *ta = s_tot[0];
+    *tb = s_tot[1];
+    __syncthreads();  // s_tot may be reused (block_sum has its own array)
+}
+
 __global__ __launch_bounds__(kBlock) void dot_accumulate_kernel(const double* __restrict__ x, const double* __restrict__ y,
                                                                 int64_t n, double* __restrict__ out)
 {
@@ -43,17 +63,18 @@ __global__ __launch_bounds__(kBlock) void dot_accumulate_kernel(const double* __
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
         acc = fma(x[i], y[i], acc);
     const double total = block_sum(acc);
-    if (threadIdx.x == 0) unsafeAtomicAdd(out, total);
+    if (threadIdx.x == 0) slot_add(out, total);
 }
 
-// Scalars of the iteration, on the device.  rr[k & 3] = r_k . r_k, pq[k & 3] = p_k . A p_k; slot k + 2 is cleared
-// during iteration k, long after its last reader and before its next writer.
+// Scalars of the iteration, on the device, each a slotted accumulator (common.hpp: kDotSlots partial sums).
+// rr[k & 3] = r_k . r_k, pq[k & 3] = p_k . A p_k; ring slot k + 2 is cleared during iteration k, long after its last
+// reader and before its next writer.
 struct CgScalars
 {
-    double rr[4];
-    double pq[4];
-    double bb;      // b . b
-    double status;  // != 0: breakdown (p . A p <= 0: the matrix is not positive definite)
+    double rr[4][kDotDoubles];
+    double pq[4][kDotDoubles];
+    double bb[kDotDoubles];  // b . b
+    double status;           // != 0: breakdown (p . A p <= 0: the matrix is not positive definite)
 };
 
 // r = b - q (q = A x0), p = r, rr[0] = r.r, bb = b.b
@@ -75,8 +96,8 @@ __global__ __launch_bounds__(kBlock) void cg_init_kernel(int64_t n, const double
     const double t_bb = block_sum(bb);
     if (threadIdx.x == 0)
     {
-        unsafeAtomicAdd(&s->rr[0], t_rr);
-        unsafeAtomicAdd(&s->bb, t_bb);
+        slot_add(s->rr[0], t_rr);
+        slot_add(s->bb, t_bb);
     }
 }
 
@@ -85,13 +106,14 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, int k, con
                                                            const double* __restrict__ q, double* __restrict__ x,
                                                            double* __restrict__ r, CgScalars* __restrict__ s)
 {
-    const double pq = s->pq[k & 3];
+    double pq, rr_k;
+    slot_sum2_block(s->pq[k & 3], s->rr[k & 3], &pq, &rr_k);
     if (!(pq > 0.0))
     {
         if (blockIdx.x == 0 && threadIdx.x == 0) s->status = 1.0;
         return;  // uniform over the grid: every thread read the same scalar
     }
-    const double alpha = s->rr[k & 3] / pq;
+    const double alpha = rr_k / pq;
     double       rr    = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
     {
@@ -101,7 +123,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, int k, con
         rr              = fma(ri, ri, rr);
     }
     const double total = block_sum(rr);
-    if (threadIdx.x == 0) unsafeAtomicAdd(&s->rr[(k + 1) & 3], total);
+    if (threadIdx.x == 0) slot_add(s->rr[(k + 1) & 3], total);
 }
 
 // The same two kernels with two elements per lane and 16-byte accesses (used when the vectors are 16-byte aligned);
@@ -112,13 +134,14 @@ __global__ __launch_bounds__(kBlock) void cg_update2_kernel(int64_t n, int k, co
                                                             const double* __restrict__ q, double* __restrict__ x,
                                                             double* __restrict__ r, CgScalars* __restrict__ s)
 {
-    const double pq = s->pq[k & 3];
+    double pq, rr_k;
+    slot_sum2_block(s->pq[k & 3], s->rr[k & 3], &pq, &rr_k);
     if (!(pq > 0.0))
     {
         if (blockIdx.x == 0 && threadIdx.x == 0) s->status = 1.0;
         return;
     }
-    const double  alpha  = s->rr[k & 3] / pq;
+    const double  alpha  = rr_k / pq;
     const int64_t npairs = n / 2;
     double        rr     = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < npairs; i += (int64_t)gridDim.x * kBlock)
@@ -144,14 +167,15 @@ __global__ __launch_bounds__(kBlock) void cg_update2_kernel(int64_t n, int k, co
         rr               = fma(ri, ri, rr);
     }
     const double total = block_sum(rr);
-    if (threadIdx.x == 0) unsafeAtomicAdd(&s->rr[(k + 1) & 3], total);
+    if (threadIdx.x == 0) slot_add(s->rr[(k + 1) & 3], total);
 }
 
 __global__ __launch_bounds__(kBlock) void cg_direction2_kernel(int64_t n, int k, const double* __restrict__ r,
                                                                double* __restrict__ p, CgScalars* __restrict__ s)
 {
-    const double  rr_k   = s->rr[k & 3];
-    const double  beta   = rr_k > 0.0 ? s->rr[(k + 1) & 3] / rr_k : 0.0;
+    double rr_k, rr_next;
+    slot_sum2_block(s->rr[k & 3], s->rr[(k + 1) & 3], &rr_k, &rr_next);
+    const double  beta   = rr_k > 0.0 ? rr_next / rr_k : 0.0;
     const int64_t npairs = n / 2;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < npairs; i += (int64_t)gridDim.x * kBlock)
     {
@@ -161,11 +185,11 @@ __global__ __launch_bounds__(kBlock) void cg_direction2_kernel(int64_t n, int k,
         pv[1]            = fma(beta, pv[1], rv[1]);
         ((f64x2_t*)p)[i] = pv;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) p[n - 1] = fma(beta, p[n - 1], r[n - 1]);
+    if (blockIdx.x == 0 && threadIdx.x < kDotSlots)
     {
-        if (n & 1) p[n - 1] = fma(beta, p[n - 1], r[n - 1]);
-        s->rr[(k + 2) & 3] = 0.0;
-        s->pq[(k + 2) & 3] = 0.0;
+        s->rr[(k + 2) & 3][threadIdx.x * kDotStride] = 0.0;
+        s->pq[(k + 2) & 3][threadIdx.x * kDotStride] = 0.0;
     }
 }
 
@@ -173,14 +197,15 @@ __global__ __launch_bounds__(kBlock) void cg_direction2_kernel(int64_t n, int k,
 __global__ __launch_bounds__(kBlock) void cg_direction_kernel(int64_t n, int k, const double* __restrict__ r,
                                                               double* __restrict__ p, CgScalars* __restrict__ s)
 {
-    const double rr_k = s->rr[k & 3];
-    const double beta = rr_k > 0.0 ? s->rr[(k + 1) & 3] / rr_k : 0.0;
+    double rr_k, rr_next;
+    slot_sum2_block(s->rr[k & 3], s->rr[(k + 1) & 3], &rr_k, &rr_next);
+    const double beta = rr_k > 0.0 ? rr_next / rr_k : 0.0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
         p[i] = fma(beta, p[i], r[i]);
-    if (blockIdx.x == 0 && threadIdx.x == 0)
+    if (blockIdx.x == 0 && threadIdx.x < kDotSlots)
     {
-        s->rr[(k + 2) & 3] = 0.0;
-        s->pq[(k + 2) & 3] = 0.0;
+        s->rr[(k + 2) & 3][threadIdx.x * kDotStride] = 0.0;
+        s->pq[(k + 2) & 3][threadIdx.x * kDotStride] = 0.0;
     }
 }
 }  // namespace
@@ -214,6 +239,8 @@ int mat_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, c
     if (A->format == SPMV_FMT_COO && A->coo_csr && A->kernel == SPMV_CSR_PANEL && A->nnz > 0) panel = A->coo_csr;
     if (A->format == SPMV_FMT_CSC && A->coo_csr && !A->kernel_forced && A->nnz > 0 && A->ncol > 0) panel = A->coo_csr;
     if (panel) return csr_panel_apply_ex(ctx, panel, x, y, ex);
+    int rc = SPMV_OK;
+    if (A->format == SPMV_FMT_CSR && csr_vector_apply_ex(ctx, A, x, y, ex, &rc)) return rc;  // row-parallel kernel: fused too
     if (ex.overwrite) SPMV_TRY(vec_fill(ctx, y, A->nrow, 0.0));
     SPMV_TRY(mat_apply(ctx, A, x, y));
     if (ex.dot_w) SPMV_TRY(vec_dot_accumulate(ctx, ex.dot_w, y, A->nrow, ex.dot_out));
@@ -246,9 +273,24 @@ int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int m
     const int  grid2 = stream_grid(std::max<int64_t>(1, n / 2));
     const bool wide  = (((uintptr_t)x) & 15) == 0 && n >= 2;  // r, p, q are fresh allocations (256-byte aligned)
     int        rc    = SPMV_OK;
-    CgScalars h{};
-    auto      fetch = [&]() -> int {
-        if (hipMemcpyAsync(&h, s, sizeof(CgScalars), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+    std::vector<double> hbuf(sizeof(CgScalars) / sizeof(double));
+    CgScalars&          h = *reinterpret_cast<CgScalars*>(hbuf.data());
+    auto                host_sum = [](const double* acc) {
+        double t = 0.0;
+        for (int i = 0; i < kDotSlots; ++i) t += acc[i * kDotStride];
+        return t;
+    };
+    // ring < 0: everything (once, after the set-up); else the r.r accumulator of that ring slot and the status word
+    auto      fetch = [&](int ring) -> int {
+        hipError_t e = hipSuccess;
+        if (ring < 0)
+            e = hipMemcpyAsync(&h, s, sizeof(CgScalars), hipMemcpyDeviceToHost, st);
+        else
+        {
+            e = hipMemcpyAsync(h.rr[ring], s->rr[ring], sizeof(double) * kDotDoubles, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(&h.status, &s->status, sizeof(double), hipMemcpyDeviceToHost, st);
+        }
+        if (e != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
         {
             set_error("spmv_cg: reading the iteration scalars failed: %s", hipGetErrorString(hipGetLastError()));
             return SPMV_ERR_HIP;
@@ -266,10 +308,10 @@ int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int m
         first.overwrite = true;
         if ((rc = mat_apply_ex(ctx, A, x, q, first)) != SPMV_OK) break;  // q = A x0
         hipLaunchKernelGGL(cg_init_kernel, dim3(grid), dim3(kBlock), 0, st, n, b, q, r, p, s);
-        if ((rc = fetch()) != SPMV_OK) break;
-        const double bb    = h.bb;
+        if ((rc = fetch(-1)) != SPMV_OK) break;
+        const double bb    = host_sum(h.bb);
         const double limit = rel_tol * rel_tol * bb;  // compare squared norms
-        double       rr    = h.rr[0];
+        double       rr    = host_sum(h.rr[0]);
         int          k     = 0;
         if (!(bb > 0.0) || rr <= limit)
         {
@@ -282,7 +324,7 @@ int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int m
             apply_extra ex;
             ex.overwrite = true;
             ex.dot_w     = p;
-            ex.dot_out   = &s->pq[kk & 3];
+            ex.dot_out   = s->pq[kk & 3];
             SPMV_TRY(mat_apply_ex(ctx, A, p, q, ex));  // q = A p, pq_k = p . q
             if (wide)
             {
@@ -336,8 +378,8 @@ int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int m
             }
             if (k % every == 0 || k == max_iter)
             {
-                if ((rc = fetch()) != SPMV_OK) break;
-                rr = h.rr[k & 3];
+                if ((rc = fetch(k & 3)) != SPMV_OK) break;
+                rr = host_sum(h.rr[k & 3]);
                 if (h.status != 0.0)
                 {
                     set_error("spmv_cg: p.Ap <= 0 at or before iteration %d: the matrix is not positive definite", k);

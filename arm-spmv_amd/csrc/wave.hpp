@@ -108,6 +108,19 @@ __device__ __forceinline__ double group_sum(double v)
 // full-wave sum, valid in every lane
 __device__ __forceinline__ double wave_sum(double v) { return group_sum_swizzle<64>(v); }
 
+// ---- slotted accumulators (common.hpp: kDotSlots) -----------------------------------------------------------
+__device__ __forceinline__ void slot_add(double* acc, double v)
+{
+    unsafeAtomicAdd(acc + (blockIdx.x & (kDotSlots - 1)) * kDotStride, v);
+}
+__device__ __forceinline__ double slot_sum(const double* acc)
+{
+    double t = 0.0;
+#pragma unroll 8
+    for (int i = 0; i < kDotSlots; ++i) t += acc[i * kDotStride];
+    return t;
+}
+
 // ---- streaming (read-once) loads: nontemporal so the matrix stream does not displace x in L2/MALL -------
 template <typename T>
 __device__ __forceinline__ T load_stream(const T* p)

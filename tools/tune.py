@@ -93,7 +93,7 @@ def main():
         nnz = len(v)
         b, x = ctx.gen_vector(n, seed=3), ctx.vector(n)
         print(f"CG, 5-point Laplacian {m} x {m}: n={n} nnz={nnz} kernel={A.info.kernel}")
-        for iters_cap, every in ((200, 1), (200, 3), (200, 50)):  # 3: no host round trip, plain launches; 50: hipGraph replay
+        for iters_cap, every in ((200, 1), (200, 3), (200, 50), (200, 1), (200, 3), (200, 50)):  # twice: run-to-run spread
             x.fill(0.0)
             ctx.sync()
             t = time.perf_counter()
