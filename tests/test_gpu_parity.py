@@ -555,3 +555,96 @@ def test_malformed_matrices_are_refused_before_any_kernel_indexes_with_them(ctx,
         ctx.csc(2, 3, np.array([0, 1, 1, 2], np.int32), np.array([0, 7], np.int32), np.ones(2))
     A = ctx.csr(2, 3, rp, np.array([0, 1, 2, 1], np.int32), val)
     A.validate()  # well-formed
+
+
+def _nasty_shapes():
+    """(name, nrow, ncol, row lengths, column sampler) — shapes that stress the panel layout: one huge row, many empty
+    rows, a single column, columns at both ends of a wide range (slices must be cut at the gap), more rows than one
+    row group holds with almost nothing in them, duplicates"""
+    rng = np.random.RandomState(123)
+    out = []
+    lens = np.zeros(50, np.int64)
+    lens[17] = 300_000
+    out.append(("one huge row", 50, 70_000, lens, lambda n: rng.randint(0, 70_000, n)))
+    lens = np.zeros(60_000, np.int64)
+    lens[rng.choice(60_000, 400, replace=False)] = rng.randint(1, 2000, 400)
+    out.append(("mostly empty rows", 60_000, 5_000, lens, lambda n: rng.randint(0, 5_000, n)))
+    out.append(("single column", 30_000, 1, rng.randint(0, 4, 30_000), lambda n: np.zeros(n, np.int64)))
+    out.append(("two far column clusters", 25_000, 40_000_000, rng.randint(8, 24, 25_000),
+                lambda n: np.where(rng.rand(n) < 0.5, rng.randint(0, 3000, n), 40_000_000 - 1 - rng.randint(0, 3000, n))))
+    out.append(("sparse wide rows", 45_000, 30_000_000, rng.randint(0, 3, 45_000), lambda n: rng.randint(0, 30_000_000, n)))
+    out.append(("duplicates in a few columns", 5_000, 8, rng.randint(0, 200, 5_000), lambda n: rng.randint(0, 8, n)))
+    return out
+
+
+def test_panel_kernel_on_nasty_shapes(ctx, orc, pkg):
+    capi = pkg.capi
+    for name, nrow, ncol, lens, cols in _nasty_shapes():
+        lens = np.asarray(lens, np.int64)
+        rp = np.zeros(nrow + 1, np.int32)
+        rp[1:] = np.cumsum(lens)
+        nnz = int(rp[-1])
+        cc = np.asarray(cols(nnz), np.int64).astype(np.int32)
+        rng = np.random.RandomState(nnz % 9973)
+        cv = rng.uniform(-1, 1, nnz)
+        x = rng.uniform(0, 1, ncol) if ncol <= 1_000_000 else None
+        if x is None:  # wide x: generate on the device, fetch back for the oracle
+            xv = ctx.gen_vector(ncol, seed=5)
+            x = xv.download()
+        else:
+            xv = ctx.vector_from(x)
+        ref, scale = np.zeros(nrow), np.zeros(nrow)
+        ol.csr_spmv(orc, rp, cc, cv, x, ref)
+        ol.csr_abs_row_sums(orc, rp, cc, cv, x, scale)
+        ref2 = ref.copy()
+        ol.csr_spmv(orc, rp, cc, cv, x, ref2)
+        for layout, unroll, pipe, rows in ((3, 0, -1, 0), (3, 8, 2, 0), (3, 4, 1, 7), (3, 2, 0, 20000), (0, 8, 1, 0), (0, 8, 2, 333), (1, 4, 0, 0)):
+            A = ctx.csr(nrow, ncol, rp, cc, cv)
+            for k, v in (("panel_aos", layout), ("panel_unroll", unroll), ("panel_pipe", pipe), ("panel_rows", rows)):
+                A.set_param(k, v)
+            A.set_kernel(capi.CSR_PANEL)
+            y = ctx.vector(nrow)
+            y.fill(0.0)
+            ctx.apply(A, xv, y)
+            ctx.sync()
+            what = f"{name}: layout={layout} (in memory {A.get_param('panel_layout')}) unroll={unroll} pipe={pipe} rows={rows}"
+            ol.assert_parity(y.download(), ref, scale, what + " 1 call")
+            ctx.apply(A, xv, y)
+            ctx.sync()
+            ol.assert_parity(y.download(), ref2, scale, what + " 2 calls", reps=2)
+
+
+def test_packed_layout_pads_do_not_leak_non_finite_x(ctx, orc, pkg):
+    """The pads of the 12-byte layout multiply 0.0 by x[slice base]; that product (NaN when x there is inf) goes into
+    a spare accumulator that is never written back.  Entries only use columns = 5 mod 16, x is inf on every multiple
+    of 16 (all possible slice bases), so any leak would show up as NaN/inf in y."""
+    capi = pkg.capi
+    rng = np.random.RandomState(77)
+    nrow, ncol = 30_000, 20_000_000
+    lens = rng.randint(4, 12, nrow)
+    rp = np.zeros(nrow + 1, np.int32)
+    rp[1:] = np.cumsum(lens)
+    nnz = int(rp[-1])
+    near = rng.rand(nnz) < 0.5  # two far clusters: slices are cut at the gap and padded
+    cc = (np.where(near, rng.randint(0, 2000, nnz), (ncol // 16 - 1) - rng.randint(0, 2000, nnz)) * 16 + 5).astype(np.int32)
+    cv = rng.uniform(-1, 1, nnz)
+    x = rng.uniform(0, 1, ncol)
+    x[::16] = np.inf
+    ref, scale = np.zeros(nrow), np.zeros(nrow)
+    ol.csr_spmv(orc, rp, cc, cv, x, ref)
+    assert np.all(np.isfinite(ref))
+    xs = x.copy()
+    xs[::16] = 0.0
+    ol.csr_abs_row_sums(orc, rp, cc, cv, xs, scale)
+    A = ctx.csr(nrow, ncol, rp, cc, cv)
+    A.set_param("panel_aos", 3)
+    A.set_kernel(capi.CSR_PANEL)
+    assert A.get_param("panel_layout") == 3
+    assert A.get_param("panel_bytes") > 12 * nnz  # there are pads
+    y = ctx.vector(nrow)
+    y.fill(0.0)
+    ctx.apply(A, ctx.vector_from(x), y)
+    ctx.sync()
+    got = y.download()
+    assert np.all(np.isfinite(got))
+    ol.assert_parity(got, ref, scale, "packed layout, inf at every slice base")
