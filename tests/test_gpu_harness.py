@@ -54,3 +54,37 @@ def test_reference_main_cpp_runs_unchanged_on_the_engine(tmp_path, pkg):
     # main.cpp:20-24: no arguments -> usage, return -1
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert r.returncode == 255 and "Usage" in r.stdout
+
+
+def test_bench_contract_one_rank_and_two_rank_rehearsal(tmp_path):
+    """bench.py end to end on small shards: the single-rank line carries roofline + cpu_baseline; the two-rank run
+    (both ranks on this one GPU, gloo standing in for RCCL: SPMV_BENCH_BACKEND=gloo) exercises sharding, the x
+    all-gather and the max-over-ranks timing of the N > 1 path.  Parity of the shards themselves is covered by
+    test_row_shards_concatenate_to_unsharded_result."""
+    import json
+    import os
+    import socket
+    import sys
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--rows", "400000", "--steps", "4", "--warmup", "1",
+                        "--cpu-sample-rows", "100000", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 4 and line["unit"] == "GFLOP/s" and line["value"] > 0
+    assert line["dtype"] == "f64" and line["scaling"] == "weak" and line["vs_baseline"] is None
+    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1.2
+    assert line["cpu_baseline"]["kind"] in ("reference", "port") and line["cpu_baseline"]["value"] > 0
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env["SPMV_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--rows", "400000",
+                        "--steps", "4", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["ncol"] == 800000 and line["config"]["nnz_total"] == 2 * 400000 * 32
+    assert line["value"] > 0 and "with_x_allgather_each_step" in line
