@@ -156,12 +156,15 @@ def main() -> None:
         n, k = args.n, args.k
         ncol = n * world
         row_begin, row_end = shard.shard_rows(ncol, world, rank)  # equal rows per rank (src/mat_vec.cpp:245-246)
+        t_setup = time.perf_counter()
         A = ctx.gen_csr_uniform(row_begin, row_end, ncol, k, band=args.band, seed=args.seed)
         if args.kernel or args.lanes:
             A.set_kernel(args.kernel, args.lanes)
         if args.flags:
             A.set_flags(args.flags)
         info = A.info
+        ctx.sync()
+        setup_s = time.perf_counter() - t_setup  # generation + analysis + layout + trials: one-off, outside the timed region
 
         # x: every rank draws its own slice; the replica is assembled by an RCCL all-gather over xGMI
         x_full = torch.empty(ncol, dtype=torch.float64, device=dev)
@@ -259,6 +262,7 @@ def main() -> None:
                 "x_exchange": "static replica, all-gathered once before the timed loop (as src/mat_vec.cpp:266 vs :271)",
                 "kernel": kernel_names.get(int(info.kernel), str(info.kernel)),
                 "lanes_per_row": int(info.lanes_per_row),
+                "setup_seconds": round(setup_s, 3),
                 "panel_layout": panel,
             },
             "roofline": {
