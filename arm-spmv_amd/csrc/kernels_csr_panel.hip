@@ -10,23 +10,28 @@
 //
 // Layout built here once per matrix (the reference does the same kind of work before its timed loop when it
 // builds the per-node sub-matrices, src/mat_vec.cpp:240-268):
-//   * rows are cut into GROUPS of G consecutive rows (G*8 bytes = the group's y accumulators fit the
-//     160 KiB LDS of one CU);
-//   * inside a group the entries are re-ordered by column PANEL (W columns, W*8 bytes << L2) and, inside a
-//     panel, by 128-byte line of x — entries keep their value, their global column and a 16-bit row index
-//     local to the group (14 bytes per entry instead of CSR's 12).
+//   * rows are cut into GROUPS of consecutive rows (at most 20000: the group's y accumulators fill the 160 KiB
+//     LDS of one CU), with cuts that balance the entries per group;
+//   * inside a group the entries are re-ordered by column PANEL (W columns) and, inside a panel, by 128-byte
+//     line of x;
+//   * the ordered entries are stored packed, 12 bytes each (fp64 value + one word: local row | column relative to
+//     the base of the entry's 1024-entry slice) — see panel_cut_kernel / panel_expand_kernel; where that does not
+//     pay, as three arrays (value, int32 column, uint16 local row: 14 bytes).
 // Kernel: one 1024-thread workgroup per CU walks its group's entries front to back, so at any moment all
 // 256 workgroups gather from the same few panels of x: the lines are fetched from HBM/MALL once per XCD and
 // round, and every other gather hits L2.  Products are added into the group's accumulators in LDS with
 // ds_add_f64; at the end the accumulators are added to y with coalesced accesses.  Because consecutive
 // entries of a panel are sorted by x line, lanes of one wavefront instruction often share a line, which cuts
 // the number of L2->L1 line transfers — the bound once the fabric traffic is under control: a divergent gather
-// costs one 128-byte line transfer per distinct line (256 Glines/s chip-wide = the L2's ~33 TB/s), whatever the
-// load flavour; ablation: the LDS adds are free, the gathers are 0.83 ms of C2's 1.60 (profiles/r01_ablation_*).
-// Staying "in step" is not automatic: see the throttles below (counter gate, clock pace) and panel_choose_pace.
+// costs one 128-byte line transfer per distinct line (~258 Glines/s chip-wide = the L2's ~33 TB/s), whatever the
+// load flavour.
+// Staying "in step" is not automatic: see the throttles below (counter gate, clock pace with per-XCD offsets), the
+// two pipeline orders of a chunk, and panel_choose_pace, which picks chunk size, order, offsets and pace by trial.
+// Several experiments that lost are still selectable (spmv_mat_set_param) so that the logs in profiles/ can be
+// reproduced: 16-byte records, system-scope stream loads, pace slack, wavefront stagger, the counter gate.
 //
-// Algorithmic bytes are still counted with CSR's 12 bytes per entry, so the extra 2 bytes and
-// the repeated x sweeps show up as a lower roofline fraction, not as hidden traffic.
+// Algorithmic bytes are counted with CSR's 12 bytes per entry; the packed layout streams exactly
+// that, so what is left between achieved and roofline is the x traffic and the gather path, not layout overhead.
 #include <vector>
 
 #include "common.hpp"
