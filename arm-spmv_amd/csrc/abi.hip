@@ -584,6 +584,8 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         m->pb_pipe = (int32_t)value;
     else if (!strcmp(name, "panel_stagger"))
         m->pb_stagger = (int32_t)value;
+    else if (!strcmp(name, "panel_guard"))
+        m->pb_guard = (int32_t)value;
     else if (!strcmp(name, "panel_ablate"))
         m->pb_ablate = (int32_t)value;
     else if (!strcmp(name, "panel_two_per_cu"))
@@ -616,6 +618,18 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         *value = m->pb_pipe >= 0 ? m->pb_pipe : (m->pb_pipe_tuned > 0 ? m->pb_pipe_tuned : 1);
     else if (!strcmp(name, "panel_stagger"))
         *value = m->pb_stagger_tuned >= 0 ? m->pb_stagger_tuned : m->pb_stagger;
+    else if (!strcmp(name, "panel_pace_scale") || !strcmp(name, "panel_pace_bumps"))
+    {
+        // the run-time guard's state: pace stretch in 1/1024 and how often it was stretched (synchronous read)
+        unsigned h[4] = {1024u, 0u, 0u, 0u};
+        if (m->pb_ctl)
+        {
+            SPMV_HIP(hipSetDevice(m->ctx->device));
+            SPMV_HIP(hipMemcpyAsync(h, m->pb_ctl, sizeof(h), hipMemcpyDeviceToHost, m->ctx->stream));
+            SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
+        }
+        *value = !strcmp(name, "panel_pace_scale") ? h[0] : h[3];
+    }
     else if (!strcmp(name, "panel_layout"))  // layout in memory: 0 three arrays, 1 records, 3 packed 12-byte entries
         *value = m->pb_pack ? 3 : m->pb_rec ? 1 : 0;
     else if (!strcmp(name, "window_max_span"))

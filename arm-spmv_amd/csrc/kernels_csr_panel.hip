@@ -453,7 +453,7 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
                                                                   const int32_t* __restrict__ sbase,
                                                                   const int32_t* __restrict__ soff, int rowbits,
                                                                   int overwrite, const double* __restrict__ dot_w,
-                                                                  double* __restrict__ dot_out)
+                                                                  double* __restrict__ dot_out, unsigned* __restrict__ ctl)
 {
     extern __shared__ double acc[];  // G accumulators
     __shared__ GateLds       gl;
@@ -463,6 +463,13 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
     const int     lane   = threadIdx.x & 63;
     const int     xcd    = GATED ? xcd_id() : 0;
     if (GATED && threadIdx.x < 16) gl.wave_done[threadIdx.x] = 0;
+    // Run-time guard of the pace (ctl: {scale in 1/1024, worst lag of this launch, workgroups done, bumps}).  The pace
+    // found at build time sits a few per cent above the cliff; if the chip later slows down (clocks, a neighbour on
+    // the fabric) the workgroups fall behind the schedule, drift apart and the product takes twice as long.  Every
+    // workgroup reports how far behind the schedule it got; the last one to finish stretches the pace by 5 % for the
+    // following launches when that was more than two chunks.  Never shrinks: the next build measures afresh.
+    if (ctl && pace_fp) pace_fp = (pace_fp * __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 10;
+    unsigned lag_max = 0;
     int round = 0;
     for (int g = blockIdx.x; g < ngroups; g += gridDim.x, ++round)
     {
@@ -513,6 +520,8 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
                 {
                     const unsigned long long ahead  = b > slack ? (unsigned long long)(b - slack) * pace_fp : 0ull;
                     const unsigned long long target = t0 + ((ahead + phase) >> 10);
+                    const unsigned long long now    = __builtin_amdgcn_s_memrealtime();
+                    if (now > target) lag_max = max(lag_max, (unsigned)min(now - target, 0xFFFFFFFFull));
                     int                      spins  = 0;
                     while (__builtin_amdgcn_s_memrealtime() < target && ++spins < (1 << 16)) __builtin_amdgcn_s_sleep(1);
                 }
@@ -588,6 +597,22 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
         }
         __syncthreads();
     }
+    if (ctl && pace_fp && threadIdx.x == 0)
+    {
+        __hip_atomic_fetch_max(ctl + 1, lag_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        if (__hip_atomic_fetch_add(ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1)
+        {
+            const unsigned worst = __hip_atomic_exchange(ctl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ctl + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (worst > 2u * (unsigned)(pace_fp >> 10))  // ticks of 10 ns
+            {
+                const unsigned scale = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ctl, min(scale + scale / 20u, 2048u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(ctl + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
     if (ABLATE && sink == 123.456) y[0] = sink;  // keeps the ablated products alive
 }
 }  // namespace
@@ -602,6 +627,8 @@ void csr_panel_free(spmv_mat* m)
     if (m->pb_sbase) (void)hipFree(m->pb_sbase);
     if (m->pb_soff) (void)hipFree(m->pb_soff);
     if (m->pb_gstart) (void)hipFree(m->pb_gstart);
+    if (m->pb_ctl) (void)hipFree(m->pb_ctl);
+    m->pb_ctl    = nullptr;
     m->pb_gstart = nullptr;
     m->pb_pack   = nullptr;
     m->pb_sbase  = nullptr;
@@ -770,6 +797,7 @@ int csr_panel_build(spmv_mat* m)
     int       max_rows = 0;
     for (int g = 0; g < ngroups; ++g) max_rows = std::max(max_rows, gstart[(size_t)g + 1] - gstart[(size_t)g]);
     SPMV_HIP(hipMalloc(&m->pb_gstart, sizeof(int32_t) * gstart.size()));
+    SPMV_HIP(hipMalloc(&m->pb_ctl, 4 * sizeof(unsigned)));
     SPMV_HIP(hipMemcpyAsync(m->pb_gstart, gstart.data(), sizeof(int32_t) * gstart.size(), hipMemcpyHostToDevice, ctx->stream));
     SPMV_HIP(hipStreamSynchronize(ctx->stream));  // gstart (host) goes out of use only after the copy
     const int P       = (int)ceil_div(m->ncol, W);
@@ -871,9 +899,20 @@ int csr_panel_build(spmv_mat* m)
 // one-off analysis, like the reference's shard construction before its timed loop.
 static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, bool trial, const apply_extra& ex);
 
+static void panel_guard_reset(spmv_mat* m)
+{
+    const unsigned init[4] = {1024u, 0u, 0u, 0u};
+    if (m->pb_ctl)
+    {
+        (void)hipMemcpyAsync(m->pb_ctl, init, sizeof(init), hipMemcpyHostToDevice, m->ctx->stream);
+        (void)hipStreamSynchronize(m->ctx->stream);  // `init` is on the stack
+    }
+}
+
 int panel_choose_pace(spmv_mat* m)
 {
     spmv_ctx* ctx = m->ctx;
+    panel_guard_reset(m);  // whatever is chosen below starts with an unstretched pace
     // what is tried: the chunk size (unless requested) and the pace (unless requested)
     // (key: the requests the trial was made under; unroll 0 / pipe -1 = chosen here as well)
     const int key = 1000 + std::max(m->pb_unroll, 0) * 10 + (m->pb_pipe + 1) + (m->pb_stagger & 3) * 100000;
@@ -1066,6 +1105,7 @@ static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, doubl
     if (!A->pb_gstart || !x || !y || !have)
         SPMV_FAIL(SPMV_ERR_INVALID, "panel kernel: layout %d is selected but its arrays are not there", layout);
     const PanelPacked pk{A->pb_sbase, A->pb_soff, A->pb_rowbits};
+    unsigned*         ctl = (trial || !A->pb_guard) ? nullptr : A->pb_ctl;  // the trials must not train the guard
     const int32_t*    arg_col = layout == 3 ? (const int32_t*)A->pb_pack : A->pb_col;
     unsigned* pop = nullptr;
     if (gated)
@@ -1089,7 +1129,7 @@ static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, doubl
         }                                                                                                            \
         hipLaunchKernelGGL((csr_panel_kernel<U, GT, LY>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream,           \
                            A->pb_gstart, A->pb_ngroups, A->a, arg_col, A->pb_row,                  \
-                           layout == 1 ? (const double*)A->pb_rec : A->pb_val, x, y, gate, pop, nchunk, skew, pace_fp, pace_slack, pk.sbase, pk.soff, pk.rowbits, ex.overwrite ? 1 : 0, ex.dot_w, ex.dot_out);   \
+                           layout == 1 ? (const double*)A->pb_rec : A->pb_val, x, y, gate, pop, nchunk, skew, pace_fp, pace_slack, pk.sbase, pk.soff, pk.rowbits, ex.overwrite ? 1 : 0, ex.dot_w, ex.dot_out, ctl);   \
         SPMV_HIP(hipGetLastError());                                                                                 \
         return SPMV_OK;                                                                                              \
     }
@@ -1105,7 +1145,7 @@ static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, doubl
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160008));                           \
         hipLaunchKernelGGL((csr_panel_kernel<8, false, 0, AB>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream,    \
                            A->pb_gstart, A->pb_ngroups, A->a, A->pb_col, A->pb_row, A->pb_val, x, y, gate, pop, nchunk,  \
-                           skew, pace_fp, pace_slack, pk.sbase, pk.soff, pk.rowbits, ex.overwrite ? 1 : 0, ex.dot_w, ex.dot_out);                                                                           \
+                           skew, pace_fp, pace_slack, pk.sbase, pk.soff, pk.rowbits, ex.overwrite ? 1 : 0, ex.dot_w, ex.dot_out, ctl);                                                                           \
         SPMV_HIP(hipGetLastError());                                                                                 \
         return SPMV_OK;                                                                                              \
     }
@@ -1132,7 +1172,7 @@ static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, doubl
         }                                                                                                            \
         hipLaunchKernelGGL((csr_panel_kernel<U, false, LY, 0, PP, TR>), dim3(grid), dim3(kPanelThreads), lds,        \
                            ctx->stream, A->pb_gstart, A->pb_ngroups, A->a, arg_col, A->pb_row, A->pb_val, x, y, gate, \
-                           pop, nchunk, skew, pace_fp, pace_slack, pk.sbase, pk.soff, pk.rowbits, ex.overwrite ? 1 : 0, ex.dot_w, ex.dot_out);                   \
+                           pop, nchunk, skew, pace_fp, pace_slack, pk.sbase, pk.soff, pk.rowbits, ex.overwrite ? 1 : 0, ex.dot_w, ex.dot_out, ctl);                   \
         SPMV_HIP(hipGetLastError());                                                                                 \
         return SPMV_OK;                                                                                              \
     }

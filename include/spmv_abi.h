@@ -159,13 +159,16 @@ int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
  *   "panel_pipe"    order of the memory instructions of a chunk: 0 = no pipelining, 1 = next chunk's stream first,
  *                   2 = this chunk's gathers first (-1 = by trial)
  *   "panel_pace_ns" clock throttle, nanoseconds per chunk (0 = off, -1 = by trial)
+ *   "panel_guard"   1 = stretch the pace by 5 % for the following launches whenever the workgroups of a launch fell more
+ *                   than two chunks behind it (default; get "panel_pace_scale" / "panel_pace_bumps" to see), 0 = off
  *   "panel_stagger" offsets of the paced schedule: 2 = XCDs 1/8 of the pace apart unless plain lockstep wins the
  *                   trial (default), 0 = none, 1 = wavefronts of a workgroup apart (experiment: loses)
  *   "panel_skew", "panel_pace_slack", "panel_two_per_cu", "panel_ablate"   experiments kept for the record
  *                   (DESIGN.md 4.2); "panel_ablate" > 0 gives WRONG results by design (timing only) */
 int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value);
 /* What is in effect: "panel_rows", "panel_width", "panel_sort", "panel_groups", "panel_layout", "panel_unroll",
- * "panel_pipe", "panel_stagger", "panel_pace_ns", "panel_skew", "panel_bytes", "window_max_span", "window_avg_span". */
+ * "panel_pipe", "panel_stagger", "panel_pace_ns", "panel_pace_scale", "panel_pace_bumps", "panel_skew", "panel_bytes",
+ * "window_max_span", "window_avg_span". */
 int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value);
 /* Copy the arrays of a handle back to the host (any pointer may be NULL to skip it).
  *   CSR: a=row_ptr[nrow+1]  b=col_ind[nnz]      v=values[nnz]

@@ -648,3 +648,36 @@ def test_packed_layout_pads_do_not_leak_non_finite_x(ctx, orc, pkg):
     got = y.download()
     assert np.all(np.isfinite(got))
     ol.assert_parity(got, ref, scale, "packed layout, inf at every slice base")
+
+
+def test_panel_pace_guard_stretches_a_pace_the_chip_cannot_hold(ctx, pkg):
+    """run-time guard of the clock throttle: with a pace far below what the CUs sustain the workgroups fall behind, the
+    last one to finish stretches the pace for the next launches; the products stay correct throughout"""
+    capi = pkg.capi
+    n, k = 4_000_000, 32
+    A = ctx.gen_csr_uniform(0, n, n, k, seed=21)
+    x = ctx.gen_vector(n, seed=22)
+    yv, yp = ctx.vector(n), ctx.vector(n)
+    yv.fill(0.0)
+    A.set_kernel(capi.CSR_VECTOR)
+    ctx.apply(A, x, yv)
+    ctx.sync()
+    ref = yv.download()
+    A.set_param("panel_unroll", 8)
+    A.set_param("panel_pipe", 2)
+    A.set_param("panel_pace_ns", 2000)  # a quarter of what a chunk of 8192 entries takes
+    A.set_kernel(capi.CSR_PANEL)
+    assert A.get_param("panel_pace_scale") == 1024 and A.get_param("panel_pace_bumps") == 0
+    for _ in range(6):
+        yp.fill(0.0)
+        ctx.apply(A, x, yp)
+        ctx.sync()
+        assert np.max(np.abs(yp.download() - ref)) <= ol.REL_TOL * k
+    assert A.get_param("panel_pace_bumps") >= 3 and A.get_param("panel_pace_scale") > 1024
+    A.set_param("panel_guard", 0)
+    A.set_kernel(capi.CSR_PANEL)  # re-selecting resets the guard
+    assert A.get_param("panel_pace_scale") == 1024
+    yp.fill(0.0)
+    ctx.apply(A, x, yp)
+    ctx.sync()
+    assert A.get_param("panel_pace_bumps") == 0 and np.max(np.abs(yp.download() - ref)) <= ol.REL_TOL * k

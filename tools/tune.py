@@ -189,7 +189,18 @@ def main():
                         ("panel_pace_slack", 0), ("panel_ablate", 0), ("panel_stagger", 2)):
             A.set_param(name, v)
         A.set_kernel(capi.CSR_PANEL)
-        print("chosen by trial:", {k: A.get_param("panel_" + k) for k in ("rows", "groups", "layout", "unroll", "pipe", "stagger", "pace_ns", "bytes")})
+        chosen = {k: A.get_param("panel_" + k) for k in ("rows", "groups", "layout", "unroll", "pipe", "stagger", "pace_ns", "bytes")}
+        print("chosen by trial:", chosen)
+        if chosen["pace_ns"] > 0:
+            # the run-time guard: start from a pace the chip cannot hold and watch it stretch back
+            A.set_param("panel_unroll", chosen["unroll"])
+            A.set_param("panel_pipe", chosen["pipe"])
+            A.set_param("panel_pace_ns", int(chosen["pace_ns"] * 0.8))
+            A.set_kernel(capi.CSR_PANEL)
+            for i in range(8):
+                ms = ctx.apply_timed(A, x, y, 3)
+                print(f"guard: pace {int(chosen['pace_ns'] * 0.8)} ns x {A.get_param('panel_pace_scale') / 1024:.3f} "
+                      f"(bumps {A.get_param('panel_pace_bumps')}): {ms:.4f} ms per product over 3 launches")
     elif a.what == "ell":
         n, k = a.n or 4_000_000, a.k or 64
         A = ctx.gen_ell_banded(n, n, k, seed=1)
