@@ -289,6 +289,12 @@ def test_device_generators_equal_numpy_twin(ctx, pkg):
     assert np.array_equal(r, er) and np.array_equal(c, ec) and np.array_equal(v, ev)
     assert P.info.sorted_rows == 1
     assert np.array_equal(ctx.gen_vector(10_000, index_offset=77, seed=8).download(), synth.vec_uniform(10_000, 77, 8))
+    # the last rows of the last of 8 shards of C5 (global row and entry indices beyond 2^31)
+    A = ctx.gen_csr_uniform(79_997_000, 80_000_000, 80_000_000, 32, seed=1)
+    rp, cc, cv = A.download()
+    erp, ec, ev = synth.csr_uniform(79_997_000, 80_000_000, 80_000_000, 32, seed=1)
+    assert np.array_equal(rp, erp) and np.array_equal(cc, ec) and np.array_equal(cv, ev) and int(cc.max()) > 2**26
+    assert np.array_equal(ctx.gen_vector(5_000, index_offset=79_995_000, seed=1).download(), synth.vec_uniform(5_000, 79_995_000, 1))
 
 
 # ---------------------------------------------------------------------------------- LDS-window kernel (banded)

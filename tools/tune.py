@@ -159,6 +159,7 @@ def main():
             slack = combo[7] if len(combo) > 7 else 0
             aos = combo[8] if len(combo) > 8 else 0
             stagger = combo[9] if len(combo) > 9 else 2
+            rows = combo[10] if len(combo) > 10 else rows
 
             def setup(A, rows=rows, width=width, srt=srt, unroll=unroll, skew=skew, pace=pace, pipe=pipe, slack=slack, aos=aos, stagger=stagger):
                 A.set_param("panel_aos", aos)
@@ -173,7 +174,7 @@ def main():
                 A.set_param("panel_pipe", pipe)
                 A.set_param("panel_ablate", 0)
                 A.set_kernel(capi.CSR_PANEL)  # rebuilds the layout when the parameters changed
-            variants.append((f"panel U={unroll} skew={skew} pace={pace}ns pipe={pipe} slack={slack} layout={aos} stagger={stagger}", setup))
+            variants.append((f"panel U={unroll} skew={skew} pace={pace}ns pipe={pipe} slack={slack} layout={aos} stagger={stagger} rows={rows}", setup))
         for ab, what in ((1, "no LDS adds"), (2, "gathers always hit L1"), (3, "neither")) if a.ablate else ():
             def setup(A, ab=ab):
                 for k, v in (("panel_rows", 0), ("panel_width", 0), ("panel_sort", 1), ("panel_unroll", 8), ("panel_skew", 0),
