@@ -10,6 +10,7 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this
 from __future__ import annotations
 
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 
@@ -35,9 +36,13 @@ def f64(a):
 
 
 def load_oracle() -> C.CDLL:
-    if not ORACLE_SO.exists():
-        subprocess.run(["make", "-C", str(ROOT / "oracle")], check=True, capture_output=True)
-    lib = C.CDLL(str(ORACLE_SO))
+    override = os.environ.get("SPMV_ORACLE_SO")  # e.g. an AddressSanitizer build of the same sources (CPU only)
+    if override:
+        lib = C.CDLL(override)
+    else:
+        if not ORACLE_SO.exists():
+            subprocess.run(["make", "-C", str(ROOT / "oracle")], check=True, capture_output=True)
+        lib = C.CDLL(str(ORACLE_SO))
     lib.orc_dot.restype = C.c_double
     lib.orc_dot_fma.restype = C.c_double
     for name in ("orc_coo_to_csr", "orc_coo_max_row_nnz", "orc_csr_count_diags"):

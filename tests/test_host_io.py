@@ -2,6 +2,7 @@
 behaviour: comments skipped, 1-based -> 0-based, file order kept, size line = rows cols entries), the vector text
 files and the timer.  Called through the C++ symbols of libarmspmv_compat.so (the reference exports C++ names too)."""
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 
@@ -11,7 +12,7 @@ import pytest
 import cases
 
 ROOT = Path(__file__).resolve().parent.parent
-LIB = ROOT / "arm-spmv_amd" / "lib" / "libarmspmv_compat.so"
+LIB = Path(os.environ.get("SPMV_COMPAT_SO") or ROOT / "arm-spmv_amd" / "lib" / "libarmspmv_compat.so")  # override: sanitizer build
 
 
 class COO(C.Structure):  # include/arm_spmv_compat.hpp == reference include/matrix.h:7-16
