@@ -129,6 +129,7 @@ static int finish(spmv_mat* m, spmv_mat** out)
     if (rc == SPMV_OK && m->format == SPMV_FMT_CSR) rc = csr_analyse(m);
     if (rc == SPMV_OK && m->format == SPMV_FMT_COO) rc = coo_analyse(m);
     if (rc == SPMV_OK && m->format == SPMV_FMT_CSC) rc = csc_analyse(m);
+    if (rc == SPMV_OK && m->format == SPMV_FMT_ELL) rc = ell_analyse(m);
     if (rc != SPMV_OK)
     {
         mat_free(m);
@@ -543,6 +544,22 @@ int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
         }
         return SPMV_OK;
     }
+    if (m->format == SPMV_FMT_ELL)
+    {
+        // ELL: AUTO = panel layout when the columns are scattered, VECTOR = one lane per row, PANEL = build it now
+        SPMV_REQUIRE(kernel == SPMV_CSR_AUTO || kernel == SPMV_CSR_VECTOR || kernel == SPMV_CSR_PANEL,
+                     "ELL handles take kernel AUTO (0), VECTOR (1: one lane per row) or PANEL (4), got %d", kernel);
+        SPMV_HIP(hipSetDevice(m->ctx->device));
+        m->kernel_forced = kernel != SPMV_CSR_AUTO;
+        if (kernel == SPMV_CSR_VECTOR)
+            m->kernel = SPMV_CSR_VECTOR;
+        else
+        {
+            SPMV_TRY(ell_build_panel(m, /*only_if_worth=*/kernel == SPMV_CSR_AUTO));
+            m->kernel = m->coo_csr ? SPMV_CSR_PANEL : SPMV_CSR_VECTOR;
+        }
+        return SPMV_OK;
+    }
     if (kernel == SPMV_CSR_AUTO)
     {
         m->kernel_forced = false;
@@ -784,6 +801,18 @@ int spmv_cg(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* b, spmv_vec* x, in
 }
 
 // ---- conversions ------------------------------------------------------------------------------------------
+// a converted ELL handle gets the same analysis as an uploaded one (kernel choice, regrouped copy when it pays)
+static int analyse_new_ell(spmv_mat** out)
+{
+    const int rc = ell_analyse(*out);
+    if (rc != SPMV_OK)
+    {
+        mat_free(*out);
+        *out = nullptr;
+    }
+    return rc;
+}
+
 int spmv_coo_to_csr(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out_csr)
 {
     SPMV_REQUIRE(ctx && coo && out_csr, "spmv_coo_to_csr: null argument");
@@ -795,7 +824,8 @@ int spmv_csr_to_ell(spmv_ctx* ctx, const spmv_mat* csr, spmv_mat** out_ell)
 {
     SPMV_REQUIRE(ctx && csr && out_ell, "spmv_csr_to_ell: null argument");
     SPMV_TRY(use_device(ctx));
-    return csr_to_ell(ctx, csr, out_ell);
+    SPMV_TRY(csr_to_ell(ctx, csr, out_ell));
+    return analyse_new_ell(out_ell);
 }
 
 int spmv_coo_to_ell(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out_ell)
@@ -806,7 +836,7 @@ int spmv_coo_to_ell(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out_ell)
     SPMV_TRY(coo_to_csr(ctx, coo, &csr));
     int rc = csr_to_ell(ctx, csr, out_ell);
     mat_free(csr);
-    return rc;
+    return rc == SPMV_OK ? analyse_new_ell(out_ell) : rc;
 }
 
 // ---- sharding ---------------------------------------------------------------------------------------------
@@ -853,7 +883,8 @@ int spmv_gen_ell_banded(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t k, ui
 {
     SPMV_REQUIRE(ctx && out, "spmv_gen_ell_banded: null argument");
     SPMV_TRY(use_device(ctx));
-    return gen_ell_banded(ctx, nrow, ncol, k, seed, out);
+    SPMV_TRY(gen_ell_banded(ctx, nrow, ncol, k, seed, out));
+    return analyse_new_ell(out);
 }
 
 int spmv_gen_dia_banded(spmv_ctx* ctx, int32_t nrow, int32_t k, uint64_t seed, spmv_mat** out)

@@ -183,7 +183,7 @@ struct spmv_mat
     int32_t   pb_built_rows = 0, pb_built_width = 0, pb_built_sort = -1;  // parameters of the layout in memory
     int64_t   pb_bytes       = 0;
 
-    // COO: internal row-grouped copy in the panel layout (kernels_coo.hip: coo_build_panel); owns it
+    // COO / CSC / ELL: internal row-grouped copy in the panel layout (coo_build_panel, csc_analyse, ell_build_panel); owned
     spmv_mat* coo_csr = nullptr;
 };
 
@@ -223,6 +223,8 @@ int vec_dot_accumulate(spmv_ctx* ctx, const double* x, const double* y, int64_t 
 int csr_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 // kernels_ell.hip
 int ell_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
+int ell_analyse(spmv_mat* m);
+int ell_build_panel(spmv_mat* m, bool only_if_worth);
 // kernels_coo.hip
 int coo_analyse(spmv_mat* m);
 int coo_build_panel(spmv_mat* m, bool only_if_worth);

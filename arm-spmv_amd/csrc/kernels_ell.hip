@@ -103,11 +103,125 @@ __global__ __launch_bounds__(kBlock) void ell_kernel_x2(int nrow, int k, const i
     }
     *reinterpret_cast<f64x2*>(y + i) = acc;
 }
+// ---- large ELL with non-local columns ----------------------------------------------------------------------
+// One lane per row is the right kernel when neighbouring rows touch neighbouring columns (C3's band: the x window of
+// a row block sits in L2).  With scattered columns every gather misses L2 exactly as in the row-parallel CSR kernel.
+// Such a handle gets the panel layout too (kernels_csr_panel.hip): the slots are copied row by row — ALL of them,
+// padding included, so that the sums are the reference's (its loop multiplies the padding's 0.0 by x[0] as well,
+// src/mat_vec.cpp:108-117) — and only row_ptr and the panel arrays are kept.
+__global__ __launch_bounds__(kBlock) void ell_window_scan_kernel(int nrow, int k, const int32_t* __restrict__ col,
+                                                                 const double* __restrict__ val,
+                                                                 unsigned long long* __restrict__ span_sum)
+{
+    __shared__ int s_lo, s_hi;
+    if (threadIdx.x == 0)
+    {
+        s_lo = INT32_MAX;
+        s_hi = -1;
+    }
+    __syncthreads();
+    const int i  = blockIdx.x * kBlock + threadIdx.x;
+    int       lo = INT32_MAX, hi = -1;
+    if (i < nrow)
+        for (int s = 0; s < k; ++s)
+        {
+            const size_t e = (size_t)i + (size_t)s * nrow;
+            if (val[e] != 0.0)  // padding (col 0, val 0.0) says nothing about where the row's columns are
+            {
+                const int c = col[e];
+                lo          = min(lo, c);
+                hi          = max(hi, c);
+            }
+        }
+    if (hi >= 0)
+    {
+        atomicMin(&s_lo, lo);
+        atomicMax(&s_hi, hi);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_hi >= 0) atomicAdd(span_sum, (unsigned long long)(s_hi - s_lo + 1));
+}
+
+__global__ __launch_bounds__(kBlock) void ell_to_csr_kernel(int nrow, int k, const int32_t* __restrict__ ecol,
+                                                            const double* __restrict__ eval, int32_t* __restrict__ row_ptr,
+                                                            int32_t* __restrict__ ccol, double* __restrict__ cval)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i > nrow) return;
+    row_ptr[i] = i * k;
+    if (i == nrow) return;
+    for (int s = 0; s < k; ++s)
+    {
+        const size_t e           = (size_t)i + (size_t)s * nrow;
+        ccol[(size_t)i * k + s] = ecol[e];
+        cval[(size_t)i * k + s] = eval[e];
+    }
+}
 }  // namespace
+
+int ell_build_panel(spmv_mat* m, bool only_if_worth)
+{
+    if (m->coo_csr) return SPMV_OK;
+    spmv_ctx*     ctx   = m->ctx;
+    const int64_t slots = (int64_t)m->nrow * m->k;
+    if (slots == 0 || slots > (int64_t)INT32_MAX - 65536) return SPMV_OK;
+    if (only_if_worth)
+    {
+        if (slots < ((int64_t)2 << 20) || m->k < 2 || (double)m->ncol * 8.0 <= 4.0 * 1048576.0) return SPMV_OK;
+        // how far apart are the columns of 256 consecutive rows, on average?
+        SPMV_TRY(ensure_scratch(ctx, 64));
+        unsigned long long* d_sum = (unsigned long long*)ctx->scratch;
+        unsigned long long  h_sum = 0;
+        const unsigned      nblk  = (unsigned)ceil_div(m->nrow, kBlock);
+        SPMV_HIP(hipMemsetAsync(d_sum, 0, sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(ell_window_scan_kernel, dim3(nblk), dim3(kBlock), 0, ctx->stream, m->nrow, m->k, m->b, m->v, d_sum);
+        SPMV_HIP(hipMemcpyAsync(&h_sum, d_sum, sizeof(h_sum), hipMemcpyDeviceToHost, ctx->stream));
+        SPMV_HIP(hipStreamSynchronize(ctx->stream));
+        if ((double)h_sum / nblk <= 131072.0) return SPMV_OK;  // a row block's x window is at most 1 MiB: stays in L2
+    }
+    spmv_mat* csr = nullptr;
+    SPMV_TRY(mat_alloc(ctx, SPMV_FMT_CSR, m->nrow, m->ncol, slots, 0, (size_t)m->nrow + 1, (size_t)slots, (size_t)slots, &csr));
+    hipLaunchKernelGGL(ell_to_csr_kernel, dim3((unsigned)ceil_div((int64_t)m->nrow + 1, kBlock)), dim3(kBlock), 0, ctx->stream,
+                       m->nrow, m->k, m->b, m->v, const_cast<int32_t*>(csr->a), const_cast<int32_t*>(csr->b),
+                       const_cast<double*>(csr->v));
+    int rc = hipGetLastError() == hipSuccess ? SPMV_OK : SPMV_ERR_HIP;
+    if (rc == SPMV_OK)
+    {
+        csr->max_row_nnz   = m->k;
+        csr->lanes_per_row = 8;
+        csr->kernel_forced = true;
+        csr->kernel        = SPMV_CSR_PANEL;
+        rc                 = csr_panel_build(csr);
+    }
+    if (rc != SPMV_OK)
+    {
+        mat_free(csr);
+        if (rc == SPMV_ERR_HIP) set_error("building the row-grouped copy of an ELL handle failed");
+        return rc;
+    }
+    // the panel kernel reads row_ptr and its own arrays only
+    (void)hipFree(const_cast<int32_t*>(csr->b));
+    (void)hipFree(const_cast<double*>(csr->v));
+    csr->device_bytes -= slots * 12;
+    csr->b     = nullptr;
+    csr->v     = nullptr;
+    m->coo_csr = csr;
+    m->kernel  = SPMV_CSR_PANEL;
+    m->device_bytes += csr->device_bytes;
+    return SPMV_OK;
+}
+
+int ell_analyse(spmv_mat* m)
+{
+    m->kernel = SPMV_CSR_VECTOR;  // reported for ELL as "one lane per row"
+    if (!m->kernel_forced) SPMV_TRY(ell_build_panel(m, /*only_if_worth=*/true));
+    return SPMV_OK;
+}
 
 int ell_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
 {
     if (A->nrow == 0) return SPMV_OK;
+    if (A->coo_csr && A->kernel == SPMV_CSR_PANEL) return csr_panel_apply(ctx, A->coo_csr, x, y);
     const bool aligned = (A->nrow % 2 == 0) && (((uintptr_t)A->b % 8) == 0) && (((uintptr_t)A->v % 16) == 0) &&
                          (((uintptr_t)y % 16) == 0);
     const bool x2 = aligned && !(A->lanes_per_row == 1);  // lanes_per_row==1 forces the one-row kernel

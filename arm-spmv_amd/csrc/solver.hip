@@ -236,7 +236,8 @@ int mat_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, c
     // the panel kernel (CSR, and COO / CSC through their row-grouped copies) does all of it in its write-back
     const spmv_mat* panel = nullptr;
     if (A->format == SPMV_FMT_CSR && A->kernel == SPMV_CSR_PANEL && A->nrow > 0 && A->nnz > 0) panel = A;
-    if (A->format == SPMV_FMT_COO && A->coo_csr && A->kernel == SPMV_CSR_PANEL && A->nnz > 0) panel = A->coo_csr;
+    if ((A->format == SPMV_FMT_COO || A->format == SPMV_FMT_ELL) && A->coo_csr && A->kernel == SPMV_CSR_PANEL && A->nnz > 0 && A->nrow > 0)
+        panel = A->coo_csr;
     if (A->format == SPMV_FMT_CSC && A->coo_csr && !A->kernel_forced && A->nnz > 0 && A->ncol > 0) panel = A->coo_csr;
     if (panel) return csr_panel_apply_ex(ctx, panel, x, y, ex);
     int rc = SPMV_OK;

@@ -687,3 +687,52 @@ def test_panel_pace_guard_stretches_a_pace_the_chip_cannot_hold(ctx, pkg):
     ctx.apply(A, x, yp)
     ctx.sync()
     assert A.get_param("panel_pace_bumps") == 0 and np.max(np.abs(yp.download() - ref)) <= ol.REL_TOL * k
+
+
+def test_large_ell_with_scattered_columns_runs_the_panel_product(ctx, pkg):
+    """ELL whose rows touch columns all over x is gather-bound with one lane per row; such handles are regrouped
+    (every slot, padding included) and run the panel kernel.  Banded ELL (C3's shape) keeps the ELL kernel."""
+    capi = pkg.capi
+    n, k = 1_500_000, 24
+    csr = ctx.gen_csr_uniform(0, n, n, k, seed=9)
+    E = ctx.csr_to_ell(csr)
+    assert E.info.kernel == capi.CSR_PANEL
+    x = ctx.gen_vector(n, seed=10)
+    y_csr, y_pan, y_ell = ctx.vector(n), ctx.vector(n), ctx.vector(n)
+    for v in (y_csr, y_pan, y_ell):
+        v.fill(0.0)
+    csr.set_kernel(capi.CSR_VECTOR)
+    ctx.apply(csr, x, y_csr)
+    ctx.apply(E, x, y_pan)
+    E.set_kernel(capi.CSR_VECTOR)  # one lane per row
+    assert E.info.kernel == capi.CSR_VECTOR
+    ctx.apply(E, x, y_ell)
+    ctx.sync()
+    ref = y_ell.download()  # the ELL kernel adds in the reference's order (bit-identical to the fma oracle, tested above)
+    assert np.max(np.abs(y_pan.download() - ref)) <= ol.REL_TOL * k
+    assert np.max(np.abs(y_csr.download() - ref)) <= ol.REL_TOL * k
+    E.set_kernel(capi.CSR_AUTO)
+    assert E.info.kernel == capi.CSR_PANEL
+    B = ctx.gen_ell_banded(1_000_000, 1_000_000, 16, seed=2)
+    assert B.info.kernel == capi.CSR_VECTOR
+    # ragged rows: padding slots (col 0, val 0.0) are kept, so x[0] = inf poisons every padded row as in the reference
+    rp = np.zeros(4001, np.int32)
+    lens = np.random.RandomState(3).randint(0, 600, 4000)
+    rp[1:] = np.cumsum(lens)
+    cc = np.random.RandomState(4).randint(1, 3_000_000, rp[-1]).astype(np.int32)
+    cv = np.random.RandomState(5).uniform(0.5, 1.0, rp[-1])
+    R = ctx.csr_to_ell(ctx.csr(4000, 3_000_000, rp, cc, cv))
+    R.set_kernel(capi.CSR_PANEL)
+    xs = np.ones(3_000_000)
+    xs[0] = np.inf
+    yp, ye = ctx.vector(4000), ctx.vector(4000)
+    yp.fill(0.0)
+    ye.fill(0.0)
+    ctx.apply(R, ctx.vector_from(xs), yp)
+    R.set_kernel(capi.CSR_VECTOR)
+    ctx.apply(R, ctx.vector_from(xs), ye)
+    ctx.sync()
+    a, b = yp.download(), ye.download()
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.isnan(a).sum() > 0
+    ok = ~np.isnan(a)
+    assert np.max(np.abs(a[ok] - b[ok])) <= ol.REL_TOL * 600

@@ -204,12 +204,15 @@ def main():
                       f"(bumps {A.get_param('panel_pace_bumps')}): {ms:.4f} ms per product over 3 launches")
     elif a.what == "ell":
         n, k = a.n or 4_000_000, a.k or 64
-        A = ctx.gen_ell_banded(n, n, k, seed=1)
+        if a.band < 0:  # uniform-random columns: ELL made from the CSR generator
+            A = ctx.csr_to_ell(ctx.gen_csr_uniform(0, n, n, k, seed=1))
+        else:
+            A = ctx.gen_ell_banded(n, n, k, seed=1)
+        print(f"ELL n={n} k={k} {'uniform columns' if a.band < 0 else 'circulant band'}: auto kernel={A.info.kernel} (4 = panel copy, 1 = one lane per row)")
         x, y = ctx.gen_vector(n, seed=1), ctx.vector(n)
         y.fill(0.0)
-        variants = [("ell x2 (16B loads)", lambda A: A.set_kernel(0, 0)), ("ell x1", lambda A: A.set_kernel(0, 1))]
-        # lanes_per_row == 1 forces the one-row-per-lane kernel; restore with a fresh handle is not needed (x2 needs lanes != 1)
-        variants[0] = ("ell x2 (16B loads)", lambda A: A.set_kernel(0, 2))
+        variants = [("ell x2 (16B loads)", lambda A: A.set_kernel(capi.CSR_VECTOR, 2)), ("ell x1", lambda A: A.set_kernel(capi.CSR_VECTOR, 1)),
+                    ("auto", lambda A: A.set_kernel(capi.CSR_AUTO, 2))]
         sweep(ctx, A, x, y, variants, a.rounds, a.reps, algorithmic_bytes("ell", n, n, n * k, k), n * k)
     else:
         n = a.n or 2_000_000
