@@ -145,7 +145,10 @@ int spmv_mat_get_info(const spmv_mat* m, spmv_mat_info* info);
  * every row/column index inside its range, offset arrays non-decreasing from 0 to the entry count.
  * SPMV_ERR_INVALID + message if not.  One pass over the index arrays; synchronous. */
 int spmv_mat_validate(const spmv_mat* m);
-/* Force a CSR kernel (and, for VECTOR, lanes_per_row in {1,2,4,...,64}; 0 = keep auto choice). */
+/* Force a CSR kernel (and, for VECTOR, lanes_per_row in {1,2,4,...,64}; 0 = keep auto choice).
+ * COO, CSC and ELL handles take AUTO (regroup by row and run the panel product when the handle is large and its
+ * columns are scattered), VECTOR (the format's own kernel: segmented scan / atomic scatter / one lane per row;
+ * for ELL lanes_per_row 1 or 2 picks the one- or two-rows-per-lane variant) or PANEL (regroup now). */
 int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row);
 int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
 /* Named tuning parameters of the panel kernel, applied by the next spmv_mat_set_kernel (none is needed in normal use:
