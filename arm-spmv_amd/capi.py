@@ -83,7 +83,7 @@ SIGNATURES = {
     "spmv_dot": (C.c_int, [_vp, _vp, _vp, _f64p]),
     "spmv_axpby": (C.c_int, [_vp, C.c_double, _vp, C.c_double, _vp, _vp]),
     "spmv_apply_dot": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, _vp, _f64p]),
-    "spmv_cg": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_double, C.c_int32, C.POINTER(C.c_int32), _f64p]),
+    "spmv_cg": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _f64p]),
     "spmv_coo_to_csr": (C.c_int, [_vp, _vp, C.POINTER(_vp)]),
     "spmv_coo_to_ell": (C.c_int, [_vp, _vp, C.POINTER(_vp)]),
     "spmv_csr_to_ell": (C.c_int, [_vp, _vp, C.POINTER(_vp)]),
@@ -324,10 +324,13 @@ class Context:
         _check(self._lib.spmv_apply_dot(self.h, A.h, x.h, y.h, 1 if overwrite else 0, w.h, C.byref(d)))
         return d.value
 
-    def cg(self, A: "Matrix", b: "Vector", x: "Vector", max_iter: int = 1000, rel_tol: float = 1e-8, check_every: int = 1):
-        """conjugate gradients on the device from the x passed in; returns (iterations, ||r|| / ||b||)"""
+    def cg(self, A: "Matrix", b: "Vector", x: "Vector", max_iter: int = 1000, rel_tol: float = 1e-8, check_every: int = 1,
+           jacobi: bool = False):
+        """conjugate gradients on the device from the x passed in (jacobi: diagonal preconditioner, CSR handles);
+        returns (iterations, ||r|| / ||b||)"""
         it, res = C.c_int32(0), C.c_double(0.0)
-        _check(self._lib.spmv_cg(self.h, A.h, b.h, x.h, max_iter, rel_tol, check_every, C.byref(it), C.byref(res)))
+        _check(self._lib.spmv_cg(self.h, A.h, b.h, x.h, max_iter, rel_tol, check_every, 1 if jacobi else 0, C.byref(it),
+                                 C.byref(res)))
         return it.value, res.value
 
     def coo_to_csr(self, coo: "Matrix") -> "Matrix":

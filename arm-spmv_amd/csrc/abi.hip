@@ -788,7 +788,7 @@ int spmv_apply_dot(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* x, spmv_vec
 }
 
 int spmv_cg(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* b, spmv_vec* x, int32_t max_iter, double rel_tol,
-            int32_t check_every, int32_t* iters, double* rel_resid)
+            int32_t check_every, int32_t precond, int32_t* iters, double* rel_resid)
 {
     SPMV_REQUIRE(ctx && A && b && x && iters && rel_resid, "spmv_cg: null argument");
     SPMV_REQUIRE(A->nrow == A->ncol, "spmv_cg: the matrix is %d x %d, not square", A->nrow, A->ncol);
@@ -796,8 +796,9 @@ int spmv_cg(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* b, spmv_vec* x, in
                  (long long)b->n, (long long)x->n, A->nrow);
     SPMV_REQUIRE(b->d != x->d || x->n == 0, "spmv_cg: b and x must not alias");
     SPMV_REQUIRE(max_iter >= 0 && rel_tol >= 0.0, "spmv_cg: max_iter=%d rel_tol=%g", max_iter, rel_tol);
+    SPMV_REQUIRE(precond == SPMV_PRECOND_NONE || precond == SPMV_PRECOND_JACOBI, "spmv_cg: unknown preconditioner %d", precond);
     SPMV_TRY(use_device(ctx));
-    return cg_solve(ctx, A, b->d, x->d, max_iter, rel_tol, check_every, iters, rel_resid);
+    return cg_solve(ctx, A, b->d, x->d, max_iter, rel_tol, check_every, precond, iters, rel_resid);
 }
 
 // ---- conversions ------------------------------------------------------------------------------------------

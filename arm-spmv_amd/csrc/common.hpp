@@ -218,7 +218,7 @@ bool csr_vector_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, doub
 int mat_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 int mat_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, const apply_extra& ex);
 int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int max_iter, double rel_tol, int check_every,
-             int* iters, double* rel_resid);
+             int precond, int* iters, double* rel_resid);
 int vec_dot_accumulate(spmv_ctx* ctx, const double* x, const double* y, int64_t n, double* device_out);
 int csr_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 // kernels_ell.hip

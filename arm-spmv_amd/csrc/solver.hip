@@ -73,32 +73,111 @@ struct CgScalars
 {
     double rr[4][kDotDoubles];
     double pq[4][kDotDoubles];
+    double rz[4][kDotDoubles];  // Jacobi-preconditioned runs: r_k . z_k with z = D^-1 r (else unused: z = r, r.z = r.r)
     double bb[kDotDoubles];  // b . b
     double status;           // != 0: breakdown (p . A p <= 0: the matrix is not positive definite)
 };
 
-// r = b - q (q = A x0), p = r, rr[0] = r.r, bb = b.b
+// r = b - q (q = A x0), p = z = r (PRE: D^-1 r), rr[0] = r.r, rz[0] = r.z, bb = b.b
+template <bool PRE>
 __global__ __launch_bounds__(kBlock) void cg_init_kernel(int64_t n, const double* __restrict__ b, const double* __restrict__ q,
-                                                         double* __restrict__ r, double* __restrict__ p, CgScalars* __restrict__ s)
+                                                         double* __restrict__ r, double* __restrict__ p, CgScalars* __restrict__ s,
+                                                         const double* __restrict__ dinv)
 {
-    double rr = 0.0, bb = 0.0;
+    double rr = 0.0, bb = 0.0, rz = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
     {
         const double bi = b[i];
         const double ri = bi - q[i];
+        const double zi = PRE ? ri * dinv[i] : ri;
         r[i]            = ri;
-        p[i]            = ri;
+        p[i]            = zi;
         rr              = fma(ri, ri, rr);
         bb              = fma(bi, bi, bb);
+        if (PRE) rz = fma(ri, zi, rz);
     }
     const double t_rr = block_sum(rr);
     __syncthreads();
     const double t_bb = block_sum(bb);
+    __syncthreads();
+    const double t_rz = PRE ? block_sum(rz) : 0.0;
     if (threadIdx.x == 0)
     {
         slot_add(s->rr[0], t_rr);
         slot_add(s->bb, t_bb);
+        if (PRE) slot_add(s->rz[0], t_rz);
     }
+}
+
+// Jacobi-preconditioned pair (scalar width): alpha = rz_k / pq_k; x += alpha p; r -= alpha q; rr_{k+1} += r.r;
+// rz_{k+1} += r . D^-1 r   and   beta = rz_{k+1} / rz_k; p = D^-1 r + beta p
+__global__ __launch_bounds__(kBlock) void pcg_update_kernel(int64_t n, int k, const double* __restrict__ p,
+                                                            const double* __restrict__ q, double* __restrict__ x,
+                                                            double* __restrict__ r, CgScalars* __restrict__ s,
+                                                            const double* __restrict__ dinv)
+{
+    double pq, rz_k;
+    slot_sum2_block(s->pq[k & 3], s->rz[k & 3], &pq, &rz_k);
+    if (!(pq > 0.0))
+    {
+        if (blockIdx.x == 0 && threadIdx.x == 0) s->status = 1.0;
+        return;
+    }
+    const double alpha = rz_k / pq;
+    double       rr = 0.0, rz = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    {
+        x[i]            = fma(alpha, p[i], x[i]);
+        const double ri = fma(-alpha, q[i], r[i]);
+        r[i]            = ri;
+        rr              = fma(ri, ri, rr);
+        rz              = fma(ri * dinv[i], ri, rz);
+    }
+    const double t_rr = block_sum(rr);
+    __syncthreads();
+    const double t_rz = block_sum(rz);
+    if (threadIdx.x == 0)
+    {
+        slot_add(s->rr[(k + 1) & 3], t_rr);
+        slot_add(s->rz[(k + 1) & 3], t_rz);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void pcg_direction_kernel(int64_t n, int k, const double* __restrict__ r,
+                                                               double* __restrict__ p, CgScalars* __restrict__ s,
+                                                               const double* __restrict__ dinv)
+{
+    double rz_k, rz_next;
+    slot_sum2_block(s->rz[k & 3], s->rz[(k + 1) & 3], &rz_k, &rz_next);
+    const double beta = rz_k > 0.0 ? rz_next / rz_k : 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        p[i] = fma(beta, p[i], r[i] * dinv[i]);
+    if (blockIdx.x == 0 && threadIdx.x < kDotSlots)
+    {
+        s->rr[(k + 2) & 3][threadIdx.x * kDotStride] = 0.0;
+        s->rz[(k + 2) & 3][threadIdx.x * kDotStride] = 0.0;
+        s->pq[(k + 2) & 3][threadIdx.x * kDotStride] = 0.0;
+    }
+}
+
+// 1 / a_ii of a CSR handle (duplicates of the diagonal entry are summed, as the product would); flag != 0: a zero or
+// missing diagonal entry
+__global__ __launch_bounds__(kBlock) void csr_inv_diag_kernel(int nrow, int64_t row_begin, const int32_t* __restrict__ row_ptr,
+                                                              const int32_t* __restrict__ col, const double* __restrict__ val,
+                                                              double* __restrict__ dinv, int* __restrict__ flag)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nrow) return;
+    double    d   = 0.0;
+    const int end = row_ptr[i + 1];
+    for (int j = row_ptr[i]; j < end; ++j)
+        if ((int64_t)col[j] == row_begin + i) d += val[j];
+    if (d == 0.0)
+    {
+        atomicOr(flag, 1);
+        d = 1.0;
+    }
+    dinv[i] = 1.0 / d;
 }
 
 // alpha = rr_k / pq_k;  x += alpha p;  r -= alpha q;  rr_{k+1} += r.r
@@ -249,21 +328,42 @@ int mat_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, c
 }
 
 int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int max_iter, double rel_tol, int check_every,
-             int* iters, double* rel_resid)
+             int precond, int* iters, double* rel_resid)
 {
     const int64_t n = A->nrow;
     *iters          = 0;
     *rel_resid      = 0.0;
     if (n == 0) return SPMV_OK;
     hipStream_t st = ctx->stream;
-    double *    r = nullptr, *p = nullptr, *q = nullptr;
+    double *    r = nullptr, *p = nullptr, *q = nullptr, *dinv = nullptr;
     CgScalars*  s = nullptr;
     auto        release = [&]() {
         if (r) (void)hipFree(r);
         if (p) (void)hipFree(p);
         if (q) (void)hipFree(q);
         if (s) (void)hipFree(s);
+        if (dinv) (void)hipFree(dinv);
     };
+    if (precond)
+    {
+        // Jacobi: the diagonal the reference's containers carry "for SymGS" (include/matrix.h:36); taken from the CSR arrays
+        if (A->format != SPMV_FMT_CSR || !A->b || !A->v)
+            SPMV_FAIL(SPMV_ERR_UNSUPPORTED, "spmv_cg: the Jacobi preconditioner reads the diagonal of a CSR handle");
+        SPMV_TRY(ensure_scratch(ctx, 64));
+        int* flag   = (int*)ctx->scratch;
+        int  h_flag = 0;
+        if (hipMalloc(&dinv, sizeof(double) * (size_t)n) != hipSuccess)
+            SPMV_FAIL(SPMV_ERR_ALLOC, "spmv_cg: out of device memory for the diagonal (%lld entries)", (long long)n);
+        (void)hipMemsetAsync(flag, 0, sizeof(int), st);
+        hipLaunchKernelGGL(csr_inv_diag_kernel, dim3((unsigned)ceil_div(n, kBlock)), dim3(kBlock), 0, st, (int)n, A->row_begin,
+                           A->a, A->b, A->v, dinv, flag);
+        if (hipMemcpyAsync(&h_flag, flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
+            h_flag != 0)
+        {
+            release();
+            SPMV_FAIL(SPMV_ERR_INVALID, "spmv_cg: the matrix has a zero or missing diagonal entry (Jacobi preconditioner)");
+        }
+    }
     if (hipMalloc(&r, sizeof(double) * (size_t)n) != hipSuccess || hipMalloc(&p, sizeof(double) * (size_t)n) != hipSuccess ||
         hipMalloc(&q, sizeof(double) * (size_t)n) != hipSuccess || hipMalloc(&s, sizeof(CgScalars)) != hipSuccess)
     {
@@ -308,7 +408,10 @@ int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int m
         apply_extra first;
         first.overwrite = true;
         if ((rc = mat_apply_ex(ctx, A, x, q, first)) != SPMV_OK) break;  // q = A x0
-        hipLaunchKernelGGL(cg_init_kernel, dim3(grid), dim3(kBlock), 0, st, n, b, q, r, p, s);
+        if (dinv)
+            hipLaunchKernelGGL(cg_init_kernel<true>, dim3(grid), dim3(kBlock), 0, st, n, b, q, r, p, s, dinv);
+        else
+            hipLaunchKernelGGL(cg_init_kernel<false>, dim3(grid), dim3(kBlock), 0, st, n, b, q, r, p, s, dinv);
         if ((rc = fetch(-1)) != SPMV_OK) break;
         const double bb    = host_sum(h.bb);
         const double limit = rel_tol * rel_tol * bb;  // compare squared norms
@@ -327,7 +430,12 @@ int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int m
             ex.dot_w     = p;
             ex.dot_out   = s->pq[kk & 3];
             SPMV_TRY(mat_apply_ex(ctx, A, p, q, ex));  // q = A p, pq_k = p . q
-            if (wide)
+            if (dinv)
+            {
+                hipLaunchKernelGGL(pcg_update_kernel, dim3(grid), dim3(kBlock), 0, st, n, kk, p, q, x, r, s, dinv);
+                hipLaunchKernelGGL(pcg_direction_kernel, dim3(grid), dim3(kBlock), 0, st, n, kk, r, p, s, dinv);
+            }
+            else if (wide)
             {
                 hipLaunchKernelGGL(cg_update2_kernel, dim3(grid2), dim3(kBlock), 0, st, n, kk, p, q, x, r, s);
                 hipLaunchKernelGGL(cg_direction2_kernel, dim3(grid2), dim3(kBlock), 0, st, n, kk, r, p, s);

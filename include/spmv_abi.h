@@ -207,11 +207,17 @@ int spmv_axpby(spmv_ctx* ctx, double alpha, const spmv_vec* x, double beta, cons
  * spmv_cg: conjugate gradients for symmetric positive definite A (square): solves A*x = b starting from
  *   the x passed in, until ||r|| <= rel_tol * ||b|| or max_iter iterations.  alpha/beta stay on the
  *   device; the host reads the residual every check_every iterations (>= 1).  *iters = iterations run,
- *   *rel_resid = ||r|| / ||b|| of the recurrence at the last check.  SPMV_ERR_INVALID if p.Ap <= 0. */
+ *   *rel_resid = ||r|| / ||b|| of the recurrence at the last check.  SPMV_ERR_INVALID if p.Ap <= 0.
+ *   precond: spmv_precond (Jacobi uses the diagonal the reference's containers carry "for SymGS", matrix.h:36). */
 int spmv_apply_dot(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* x, spmv_vec* y, int32_t overwrite,
                    const spmv_vec* w, double* dot);
+enum spmv_precond
+{
+    SPMV_PRECOND_NONE   = 0,
+    SPMV_PRECOND_JACOBI = 1 /* z = D^-1 r, D = diag(A) read from a CSR handle (zero diagonal: SPMV_ERR_INVALID) */
+};
 int spmv_cg(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* b, spmv_vec* x, int32_t max_iter,
-            double rel_tol, int32_t check_every, int32_t* iters, double* rel_resid);
+            double rel_tol, int32_t check_every, int32_t precond, int32_t* iters, double* rel_resid);
 
 /* ---- format conversion on the device (src/matrix.cpp:115-154, :450-500) -------------------------- */
 /* Both keep the COO order of the entries inside each row (stable), like the reference's backward

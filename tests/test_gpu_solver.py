@@ -155,3 +155,33 @@ def test_sharded_cg_with_the_engine_as_local_ops():
     child = Path(__file__).with_name("child_sharded_cg.py")
     r = subprocess.run([sys.executable, str(child)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SHARDED_CG_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_jacobi_preconditioned_cg(ctx, orc, pkg):
+    """badly scaled SPD system S L S (L = 2-D Laplacian, S = diag of scales over six decades): plain CG crawls, the
+    diagonal preconditioner undoes the scaling; both answers are checked through the oracle's product"""
+    n, rp, cc, cv = _laplacian_2d(64)
+    scale = 10.0 ** np.random.default_rng(8).uniform(-3, 3, n)
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    cv = cv * scale[rows] * scale[cc]
+    A = ctx.csr(n, n, rp, cc, cv)
+    b_host = np.random.default_rng(9).uniform(-1, 1, n) * scale
+    b, x = ctx.vector_from(b_host), ctx.vector(n)
+    res = {}
+    for jacobi in (False, True):
+        x.fill(0.0)
+        iters, relres = ctx.cg(A, b, x, max_iter=3000, rel_tol=1e-8, check_every=5, jacobi=jacobi)
+        ax = np.zeros(n)
+        ol.csr_spmv(orc, rp, cc, cv, x.download(), ax)
+        res[jacobi] = (iters, relres, np.linalg.norm(b_host - ax) / np.linalg.norm(b_host))
+    assert res[True][1] <= 1e-8 and res[True][2] <= 1e-6, res
+    assert res[True][0] < 400 and res[True][0] * 3 < res[False][0], res  # ~the unscaled Laplacian's count vs thousands
+    # error paths
+    Err = pkg.capi.SpmvError
+    rp0 = np.arange(4, dtype=np.int32)
+    Z = ctx.csr(3, 3, rp0, np.array([1, 2, 0], np.int32), np.ones(3))  # no diagonal entries
+    with pytest.raises(Err, match="diagonal"):
+        ctx.cg(Z, ctx.vector_from(np.ones(3)), ctx.vector(3), jacobi=True)
+    E = ctx.csr_to_ell(A)
+    with pytest.raises(Err, match="CSR"):
+        ctx.cg(E, b, x, jacobi=True)
