@@ -12,12 +12,16 @@
 //   SPMV_MTX_SYMMETRIC=1  `symmetric` / `hermitian` / `skew-symmetric` files are expanded: every off-diagonal entry
 //                         (i, j, v) is followed by its mirror (j, i, v) (skew: -v); NNZ in the `###` line is the
 //                         expanded count
+//   SPMV_MTX_CACHE=1      binary cache beside the file (`<file>.spmvbin`: header + the three arrays as parsed, i.e.
+//                         after the two options above); used when its recorded size / mtime of the .mtx and the
+//                         options match, rewritten otherwise.  Same output lines either way.
 #include <algorithm>
 #include <cctype>
 #include <cstring>
 #include <string>
 #include <thread>
 #include <vector>
+#include <sys/stat.h>
 #include <sys/time.h>
 
 #include "arm_spmv_compat.hpp"
@@ -191,6 +195,66 @@ static bool parse_entries_parallel(FILE* fp, int nz, int* ii, int* jj, double* v
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Binary cache (SPMV_MTX_CACHE=1)
+// ---------------------------------------------------------------------------------------------------------
+struct CacheHeader
+{
+    char      magic[8];  // "SPMVBIN1"
+    long long src_size, src_mtime;
+    int       nrow, ncol, nz, options;  // options: bit 0 pattern read as pairs, bit 1 symmetric expanded
+};
+
+static bool cache_load(const std::string& path, const struct stat& src, int options, int* nrow, int* ncol, int* nz, int** ii,
+                       int** jj, double** vv)
+{
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    CacheHeader h;
+    bool        ok = fread(&h, sizeof(h), 1, f) == 1 && memcmp(h.magic, "SPMVBIN1", 8) == 0 && h.src_size == (long long)src.st_size &&
+              h.src_mtime == (long long)src.st_mtime && h.options == options && h.nz >= 0 && h.nrow >= 0 && h.ncol >= 0;
+    if (ok)
+    {
+        const size_t n = (size_t)(h.nz > 0 ? h.nz : 1);
+        *ii            = new int[n];
+        *jj            = new int[n];
+        *vv            = new double[n];
+        ok = fread(*ii, sizeof(int), (size_t)h.nz, f) == (size_t)h.nz && fread(*jj, sizeof(int), (size_t)h.nz, f) == (size_t)h.nz &&
+             fread(*vv, sizeof(double), (size_t)h.nz, f) == (size_t)h.nz;
+        if (!ok)
+        {
+            delete[] *ii;
+            delete[] *jj;
+            delete[] *vv;
+        }
+        *nrow = h.nrow;
+        *ncol = h.ncol;
+        *nz   = h.nz;
+    }
+    fclose(f);
+    return ok;
+}
+
+static void cache_store(const std::string& path, const struct stat& src, int options, int nrow, int ncol, int nz, const int* ii,
+                        const int* jj, const double* vv)
+{
+    const std::string tmp = path + ".tmp";
+    FILE*             f   = fopen(tmp.c_str(), "wb");
+    if (!f) return;  // read-only directory: no cache, no complaint
+    CacheHeader h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, "SPMVBIN1", 8);
+    h.src_size  = (long long)src.st_size;
+    h.src_mtime = (long long)src.st_mtime;
+    h.nrow      = nrow;
+    h.ncol      = ncol;
+    h.nz        = nz;
+    h.options   = options;
+    const bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(ii, sizeof(int), (size_t)nz, f) == (size_t)nz &&
+                    fwrite(jj, sizeof(int), (size_t)nz, f) == (size_t)nz && fwrite(vv, sizeof(double), (size_t)nz, f) == (size_t)nz;
+    if (fclose(f) != 0 || !ok || rename(tmp.c_str(), path.c_str()) != 0) remove(tmp.c_str());
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // COO / CSR / CSC / ELL readers (include/data_io.h:12-15)
 // ---------------------------------------------------------------------------------------------------------
 void COOMatrixRead(const char* filename, COOMatrix& A)
@@ -221,6 +285,30 @@ void COOMatrixRead(const char* filename, COOMatrix& A)
 
     const bool pattern = banner.field == 'P' && env_on("SPMV_MTX_PATTERN");
     const bool expand  = banner.symmetry != 'G' && env_on("SPMV_MTX_SYMMETRIC");
+    const int  options = (pattern ? 1 : 0) | (expand ? 2 : 0);
+    struct stat src;
+    const bool        use_cache  = env_on("SPMV_MTX_CACHE") && stat(filename, &src) == 0;
+    const std::string cache_path = std::string(filename) + ".spmvbin";
+    if (use_cache)
+    {
+        int *   ci = nullptr, *cj = nullptr, cn = 0, cm = 0, cz = 0;
+        double* cv = nullptr;
+        if (cache_load(cache_path, src, options, &cn, &cm, &cz, &ci, &cj, &cv))
+        {
+            fclose(fp);
+            printf("\tAllocating memory for matrix\n");
+            printf("\tReading matrix entries from file\n");
+            printf("### ROW=%d, COL=%d, NNZ=%d\n", cn, cm, cz);
+            A.Free();
+            A.nrow    = cn;
+            A.ncol    = cm;
+            A.nnz     = cz;
+            A.row_ind = ci;
+            A.col_ind = cj;
+            A.values  = cv;
+            return;
+        }
+    }
     if (nz < 0 || (expand && nz > INT32_MAX / 2))
     {
         printf("*** Matrix Market size line: %d entries cannot be held ***\n", nz);
@@ -276,6 +364,7 @@ void COOMatrixRead(const char* filename, COOMatrix& A)
         nz += off;
     }
     printf("### ROW=%d, COL=%d, NNZ=%d\n", nrow, ncol, nz);
+    if (use_cache) cache_store(cache_path, src, options, nrow, ncol, nz, ii, jj, vv);
 
     A.Free();
     A.nrow    = nrow;

@@ -145,3 +145,41 @@ def test_opt_in_pattern_and_symmetric_expansion(lib, tmp_path, threads, monkeypa
     monkeypatch.setenv("SPMV_MTX_PATTERN", "1")
     _, _, r, c, w = load(p)
     assert len(w) == nz and np.array_equal(r, i) and np.array_equal(c, j) and np.all(w == 1.0)
+
+
+def test_binary_cache_round_trip(lib, tmp_path, monkeypatch):
+    """SPMV_MTX_CACHE=1: the second read comes from `<file>.spmvbin` and equals the first; a changed .mtx or changed
+    options invalidate it"""
+    import time
+
+    c = cases.case_c1() if hasattr(cases, "case_c1") else cases.ALL_CASES[-1]()
+    p = tmp_path / "m.mtx"
+    _write_mtx(p, c)
+    read = getattr(lib, "_Z13COOMatrixReadPKcR9COOMatrix")
+    read.argtypes = [C.c_char_p, C.POINTER(COO)]
+
+    def load():
+        A = COO()
+        read(str(p).encode(), C.byref(A))
+        n = A.nnz
+        return (A.nrow, A.ncol, np.ctypeslib.as_array(A.row_ind, (n,)).copy(), np.ctypeslib.as_array(A.col_ind, (n,)).copy(),
+                np.ctypeslib.as_array(A.values, (n,)).copy())
+
+    monkeypatch.delenv("SPMV_MTX_CACHE", raising=False)
+    first = load()
+    assert not (tmp_path / "m.mtx.spmvbin").exists()
+    monkeypatch.setenv("SPMV_MTX_CACHE", "1")
+    second = load()
+    cache = tmp_path / "m.mtx.spmvbin"
+    assert cache.exists()
+    stamp = cache.stat().st_mtime_ns
+    third = load()  # from the cache
+    assert cache.stat().st_mtime_ns == stamp
+    for a, b in ((first, second), (first, third)):
+        assert a[0] == b[0] and a[1] == b[1] and all(np.array_equal(x, y) for x, y in zip(a[2:], b[2:]))
+    # the source changes (one more entry): the cache no longer matches and is rewritten
+    time.sleep(1.1)
+    c2 = dict(c, row=np.append(c["row"], 0), col=np.append(c["col"], 0), val=np.append(c["val"], 2.5))
+    _write_mtx(p, c2)
+    fourth = load()
+    assert len(fourth[4]) == len(first[4]) + 1 and fourth[4][-1] == 2.5
