@@ -87,6 +87,7 @@ SIGNATURES = {
     "spmv_coo_to_csr": (C.c_int, [_vp, _vp, C.POINTER(_vp)]),
     "spmv_coo_to_ell": (C.c_int, [_vp, _vp, C.POINTER(_vp)]),
     "spmv_csr_to_ell": (C.c_int, [_vp, _vp, C.POINTER(_vp)]),
+    "spmv_csr_split_columns": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.POINTER(_vp), C.POINTER(_vp)]),
     "spmv_partition_rows": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, _i64p, _i64p]),
     "spmv_partition_rows_balanced": (C.c_int, [C.c_int64, _vp, C.c_int32, _vp]),
     "spmv_gen_csr_uniform": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.POINTER(_vp)]),
@@ -337,6 +338,12 @@ class Context:
         h = _vp()
         _check(self._lib.spmv_coo_to_csr(self.h, coo.h, C.byref(h)))
         return Matrix(self, h)
+
+    def csr_split_columns(self, csr: "Matrix", col_begin: int, col_end: int):
+        """(inside, outside): entries with a column in [col_begin, col_end) rebased to 0, and the rest with global columns"""
+        a, b = _vp(), _vp()
+        _check(self._lib.spmv_csr_split_columns(self.h, csr.h, col_begin, col_end, C.byref(a), C.byref(b)))
+        return Matrix(self, a), Matrix(self, b)
 
     def coo_to_ell(self, coo: "Matrix") -> "Matrix":
         h = _vp()

@@ -829,6 +829,28 @@ int spmv_csr_to_ell(spmv_ctx* ctx, const spmv_mat* csr, spmv_mat** out_ell)
     return analyse_new_ell(out_ell);
 }
 
+int spmv_csr_split_columns(spmv_ctx* ctx, const spmv_mat* csr, int32_t col_begin, int32_t col_end, spmv_mat** out_inside,
+                           spmv_mat** out_outside)
+{
+    SPMV_REQUIRE(ctx && csr && out_inside && out_outside, "spmv_csr_split_columns: null argument");
+    SPMV_TRY(use_device(ctx));
+    spmv_mat *in = nullptr, *outm = nullptr;
+    SPMV_TRY(csr_split_columns(ctx, csr, col_begin, col_end, &in, &outm));
+    int rc = finish(in, out_inside);  // validates and analyses like an uploaded handle (frees on failure)
+    if (rc != SPMV_OK)
+    {
+        mat_free(outm);
+        return rc;
+    }
+    rc = finish(outm, out_outside);
+    if (rc != SPMV_OK)
+    {
+        mat_free(*out_inside);
+        *out_inside = nullptr;
+    }
+    return rc;
+}
+
 int spmv_coo_to_ell(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out_ell)
 {
     SPMV_REQUIRE(ctx && coo && out_ell, "spmv_coo_to_ell: null argument");

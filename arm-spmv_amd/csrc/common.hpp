@@ -243,6 +243,7 @@ int mat_validate(const spmv_mat* m);
 int exclusive_scan_i32(spmv_ctx* ctx, const int32_t* in, int32_t* out, int64_t n);
 int coo_to_csr(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out);
 int csr_to_ell(spmv_ctx* ctx, const spmv_mat* csr, spmv_mat** out);
+int csr_split_columns(spmv_ctx* ctx, const spmv_mat* csr, int32_t c0, int32_t c1, spmv_mat** out_in, spmv_mat** out_out);
 int reduce_max_i32(spmv_ctx* ctx, const int32_t* in, int64_t n, int32_t* result);
 // generate.hip
 int gen_csr_uniform(spmv_ctx* ctx, int64_t row_begin, int64_t row_end, int32_t ncol, int32_t k,

@@ -242,4 +242,114 @@ int csr_to_ell(spmv_ctx* ctx, const spmv_mat* csr, spmv_mat** out)
     *out             = ell;
     return SPMV_OK;
 }
+// ---- CSR split by column range (sharded solver step: local columns first, the rest after the exchange) -----------
+namespace
+{
+// per row: entries with a column inside [c0, c1)
+__global__ __launch_bounds__(kBlock) void split_count_kernel(int nrow, const int32_t* __restrict__ row_ptr,
+                                                             const int32_t* __restrict__ col, int c0, int c1,
+                                                             int32_t* __restrict__ n_in, int32_t* __restrict__ n_out)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i > nrow) return;
+    int inside = 0, total = 0;
+    if (i < nrow)
+    {
+        const int end = row_ptr[i + 1];
+        total         = end - row_ptr[i];
+        for (int j = row_ptr[i]; j < end; ++j)
+        {
+            const int c = col[j];
+            inside += (c >= c0 && c < c1);
+        }
+    }
+    n_in[i]  = inside;  // entry nrow = 0: the scans run over nrow + 1 values
+    n_out[i] = total - inside;
+}
+
+__global__ __launch_bounds__(kBlock) void split_fill_kernel(int nrow, const int32_t* __restrict__ row_ptr,
+                                                            const int32_t* __restrict__ col, const double* __restrict__ val,
+                                                            int c0, int c1, const int32_t* __restrict__ rp_in,
+                                                            int32_t* __restrict__ col_in, double* __restrict__ val_in,
+                                                            const int32_t* __restrict__ rp_out, int32_t* __restrict__ col_out,
+                                                            double* __restrict__ val_out)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nrow) return;
+    int       a = rp_in[i], b = rp_out[i];
+    const int end = row_ptr[i + 1];
+    for (int j = row_ptr[i]; j < end; ++j)  // the order inside a row is kept in both parts
+    {
+        const int    c = col[j];
+        const double v = val[j];
+        if (c >= c0 && c < c1)
+        {
+            col_in[a] = c - c0;  // rebased: the inside part multiplies the caller's own slice of x
+            val_in[a] = v;
+            ++a;
+        }
+        else
+        {
+            col_out[b] = c;
+            val_out[b] = v;
+            ++b;
+        }
+    }
+}
+}  // namespace
+
+int csr_split_columns(spmv_ctx* ctx, const spmv_mat* csr, int32_t c0, int32_t c1, spmv_mat** out_in, spmv_mat** out_out)
+{
+    SPMV_REQUIRE(csr->format == SPMV_FMT_CSR && csr->b && csr->v, "spmv_csr_split_columns: input is not a CSR handle with its arrays");
+    SPMV_REQUIRE(c0 >= 0 && c0 <= c1 && c1 <= csr->ncol, "spmv_csr_split_columns: column range [%d, %d) outside [0, %d)", c0, c1,
+                 csr->ncol);
+    const int   nrow = csr->nrow;
+    hipStream_t s    = ctx->stream;
+    int32_t *   n_in = nullptr, *n_out = nullptr;
+    spmv_mat *  A_in = nullptr, *A_out = nullptr;
+    int         rc   = SPMV_OK;
+    do
+    {
+        if (hipMalloc(&n_in, sizeof(int32_t) * ((size_t)nrow + 1)) != hipSuccess ||
+            hipMalloc(&n_out, sizeof(int32_t) * ((size_t)nrow + 1)) != hipSuccess)
+        {
+            rc = SPMV_ERR_ALLOC;
+            break;
+        }
+        const unsigned grid = (unsigned)ceil_div((int64_t)nrow + 1, kBlock);
+        hipLaunchKernelGGL(split_count_kernel, dim3(grid), dim3(kBlock), 0, s, nrow, csr->a, csr->b, c0, c1, n_in, n_out);
+        // totals first (sizes of the two parts), then the offsets
+        int32_t last_in = 0, last_out = 0;
+        if ((rc = exclusive_scan_i32(ctx, n_in, n_in, (int64_t)nrow + 1)) != SPMV_OK) break;
+        if ((rc = exclusive_scan_i32(ctx, n_out, n_out, (int64_t)nrow + 1)) != SPMV_OK) break;
+        if (hipMemcpyAsync(&last_in, n_in + nrow, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipMemcpyAsync(&last_out, n_out + nrow, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess)
+        {
+            rc = SPMV_ERR_HIP;
+            break;
+        }
+        if ((rc = mat_alloc(ctx, SPMV_FMT_CSR, nrow, c1 - c0, last_in, 0, (size_t)nrow + 1, (size_t)last_in, (size_t)last_in, &A_in)) != SPMV_OK) break;
+        if ((rc = mat_alloc(ctx, SPMV_FMT_CSR, nrow, csr->ncol, last_out, 0, (size_t)nrow + 1, (size_t)last_out, (size_t)last_out, &A_out)) != SPMV_OK) break;
+        (void)hipMemcpyAsync(const_cast<int32_t*>(A_in->a), n_in, sizeof(int32_t) * ((size_t)nrow + 1), hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(const_cast<int32_t*>(A_out->a), n_out, sizeof(int32_t) * ((size_t)nrow + 1), hipMemcpyDeviceToDevice, s);
+        if (nrow > 0)
+            hipLaunchKernelGGL(split_fill_kernel, dim3((unsigned)ceil_div(nrow, kBlock)), dim3(kBlock), 0, s, nrow, csr->a, csr->b,
+                               csr->v, c0, c1, A_in->a, const_cast<int32_t*>(A_in->b), const_cast<double*>(A_in->v), A_out->a,
+                               const_cast<int32_t*>(A_out->b), const_cast<double*>(A_out->v));
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = SPMV_ERR_HIP;
+    } while (0);
+    if (n_in) (void)hipFree(n_in);
+    if (n_out) (void)hipFree(n_out);
+    if (rc != SPMV_OK)
+    {
+        if (A_in) mat_free(A_in);
+        if (A_out) mat_free(A_out);
+        SPMV_FAIL(rc, "spmv_csr_split_columns failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    A_in->row_begin = A_out->row_begin = csr->row_begin;
+    *out_in  = A_in;
+    *out_out = A_out;
+    return SPMV_OK;
+}
 }  // namespace spmv

@@ -93,6 +93,23 @@ class HipShardOps:
     def product_dot(self, p_full, w_own, q_own) -> float:  # q = A_shard p ; returns w_own . q
         return self.ctx.apply_dot(self.A, self._v(p_full), self._v(q_own), self._v(w_own), overwrite=True)
 
+    # ---- the same product in two halves, for overlapping the exchange (enable_overlap) -------------------------
+    def enable_overlap(self, col_begin: int, col_end: int) -> None:
+        """split the shard by column range on the device: the part inside [col_begin, col_end) multiplies the rank's
+        OWN slice of the direction and needs no exchange (spmv_csr_split_columns)"""
+        self.A_in, self.A_out = self.ctx.csr_split_columns(self.A, col_begin, col_end)
+
+    def begin_local(self, p_own, q_own) -> None:  # q = A_in p_own, queued on the engine's stream; returns at once
+        self.ctx.apply(self.A_in, self._v(p_own), self._fill0(q_own))
+
+    def finish_remote_dot(self, p_full, w_own, q_own) -> float:  # q += A_out p_full ; returns w_own . q
+        return self.ctx.apply_dot(self.A_out, self._v(p_full), self._v(q_own), self._v(w_own), overwrite=False)
+
+    def _fill0(self, t):
+        v = self._v(t)
+        v.fill(0.0)
+        return v
+
     def axpby(self, alpha, x, beta, y, w) -> None:  # w = alpha x + beta y (w may be x or y)
         self.ctx.axpby(alpha, self._v(x), beta, self._v(y), self._v(w))
 
@@ -108,7 +125,9 @@ def cg_sharded(ops, b_own: torch.Tensor, x_own: torch.Tensor, nrow: int, max_ite
     """Conjugate gradients over row shards (A symmetric positive definite, x0 = x_own on entry, overwritten).
 
     Per iteration: ONE all-gather (the search direction p, which every shard needs in full — the x exchange of
-    SURVEY.md 8e) and two scalar all-reduces (p.Ap and r.r).  Vectors stay sharded by rows and device-resident;
+    SURVEY.md 8e) and two scalar all-reduces (p.Ap and r.r).  When `ops` was split by column range
+    (HipShardOps.enable_overlap), the product of the rank's own columns is queued on the engine's stream BEFORE the
+    all-gather is issued on torch's, so the two run side by side; the remaining columns follow the exchange.  Vectors stay sharded by rows and device-resident;
     `ops` does the local work (HipShardOps on a GPU; the CPU tests plug the oracle in).  Every rank returns the same
     (iterations, ||r|| / ||b||)."""
     dev = b_own.device
@@ -128,12 +147,21 @@ def cg_sharded(ops, b_own: torch.Tensor, x_own: torch.Tensor, nrow: int, max_ite
     if bb == 0.0 or rr <= rel_tol * rel_tol * bb:
         return 0, (rr / bb) ** 0.5 if bb > 0.0 else 0.0
     k = 0
+    overlap = hasattr(ops, "A_in") or getattr(ops, "overlap", False)
     while k < max_iter:
         ops.sync()  # the collective runs on torch's stream: p_own must be complete
-        allgather_x(p_full, p_own, nrow, group)
-        if dev.type == "cuda":
-            torch.cuda.current_stream(dev).synchronize()  # ... and p_full before the engine's stream reads it
-        pq = sum_over_ranks(ops.product_dot(p_full, p_own, q_own), dev, group)
+        if overlap:
+            # the product of the rank's own column range runs on the engine's stream while the exchange is in flight
+            ops.begin_local(p_own, q_own)
+            allgather_x(p_full, p_own, nrow, group)
+            if dev.type == "cuda":
+                torch.cuda.current_stream(dev).synchronize()
+            pq = sum_over_ranks(ops.finish_remote_dot(p_full, p_own, q_own), dev, group)
+        else:
+            allgather_x(p_full, p_own, nrow, group)
+            if dev.type == "cuda":
+                torch.cuda.current_stream(dev).synchronize()  # ... and p_full before the engine's stream reads it
+            pq = sum_over_ranks(ops.product_dot(p_full, p_own, q_own), dev, group)
         if not pq > 0.0:
             raise ArithmeticError(f"cg_sharded: p.Ap = {pq} at iteration {k}: the matrix is not positive definite")
         alpha = rr / pq

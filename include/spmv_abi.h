@@ -225,6 +225,13 @@ int spmv_cg(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* b, spmv_vec* x, in
 int spmv_coo_to_csr(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out_csr);
 int spmv_coo_to_ell(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out_ell);
 int spmv_csr_to_ell(spmv_ctx* ctx, const spmv_mat* csr, spmv_mat** out_ell);
+/* Split a CSR handle (a row shard) by column range, on the device: `inside` holds the entries with a column in
+ * [col_begin, col_end), REBASED to 0 (it multiplies the caller's own slice of x: ncol = col_end - col_begin);
+ * `outside` holds the others with their global columns.  A*x = inside*x[col_begin:col_end] + outside*x, rows and the
+ * order inside each row kept.  For the sharded solver step: the inside product needs no exchange and can run while
+ * the x all-gather is in flight (no counterpart in the reference). */
+int spmv_csr_split_columns(spmv_ctx* ctx, const spmv_mat* csr, int32_t col_begin, int32_t col_end,
+                           spmv_mat** out_inside, spmv_mat** out_outside);
 
 /* ---- row-range sharding (src/mat_vec.cpp:233,245-246) ------------------------------------------- */
 /* Equal rows per part, the last part takes the remainder.  Pure host arithmetic. */

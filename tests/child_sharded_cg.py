@@ -40,6 +40,14 @@ def main():
         iters, relres = dmod.cg_sharded(dmod.HipShardOps(ctx, A), b_t, x_t, n, max_iter=500, rel_tol=1e-9)
         ctx.sync()
         sol = x_t.cpu().numpy()
+        # the overlapped variant: at world 1 every column is the rank's own (the outside part is empty)
+        ops2 = dmod.HipShardOps(ctx, A)
+        ops2.enable_overlap(0, n)
+        x2_t = torch.zeros(n, dtype=torch.float64, device=dev)
+        iters_o, relres_o = dmod.cg_sharded(ops2, b_t, x2_t, n, max_iter=500, rel_tol=1e-9)
+        ctx.sync()
+        assert abs(iters_o - iters) <= 2 and relres_o <= 1e-9, (iters_o, iters, relres_o)
+        assert float((x2_t - x_t).abs().max()) <= 1e-7 * float(x_t.abs().max())
     finally:
         dist.destroy_process_group()
     ax = np.zeros(n)

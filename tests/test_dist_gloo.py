@@ -90,6 +90,31 @@ class _OracleOps:
     def axpby(self, alpha, x, beta, y, w):
         w.numpy()[:] = alpha * x.numpy() + beta * y.numpy()
 
+    # overlap variant (dist.HipShardOps.enable_overlap): the shard split by column range with numpy
+    def enable_overlap(self, c0, c1):
+        srp, scol, sval = self.m
+        rows = np.repeat(np.arange(len(srp) - 1), np.diff(srp))
+        inside = (scol >= c0) & (scol < c1)
+
+        def part(mask, rebase):
+            rp = np.zeros(len(srp), np.int64)
+            np.add.at(rp, rows[mask] + 1, 1)
+            return (np.cumsum(rp).astype(np.int32), np.ascontiguousarray(scol[mask] - rebase, dtype=np.int32),
+                    np.ascontiguousarray(sval[mask]))
+
+        self.m_in, self.m_out = part(inside, c0), part(~inside, 0)
+        self.overlap = True
+
+    def begin_local(self, p_own, q_own):
+        q = q_own.numpy()
+        q[:] = 0.0
+        self.ol.csr_spmv(self.orc, *self.m_in, p_own.numpy(), q)
+
+    def finish_remote_dot(self, p_full, w_own, q_own):
+        q = q_own.numpy()
+        self.ol.csr_spmv(self.orc, *self.m_out, p_full.numpy(), q)
+        return float(np.dot(w_own.numpy(), q))
+
     def dot(self, a, b):
         return float(np.dot(a.numpy(), b.numpy()))
 
@@ -97,7 +122,7 @@ class _OracleOps:
         pass
 
 
-def _cg_worker(rank, world, port, m, q):
+def _cg_worker(rank, world, port, m, q, overlap=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import sys
     from pathlib import Path
@@ -125,6 +150,8 @@ def _cg_worker(rank, world, port, m, q):
         b, e = dmod.shard_rows(n, world, rank)
         srp = ol.csr_shard_row_ptr(orc, rp, b, e)
         ops = _OracleOps(orc, ol, srp, np.ascontiguousarray(col[rp[b]:rp[e]]), np.ascontiguousarray(val[rp[b]:rp[e]]))
+        if overlap:
+            ops.enable_overlap(b, e)
         x_own = torch.zeros(e - b, dtype=torch.float64)
         iters, relres = dmod.cg_sharded(ops, torch.from_numpy(bvec[b:e].copy()), x_own, n, max_iter=500, rel_tol=1e-10)
         x_full = dmod.concatenate_y(x_own, n).numpy()
@@ -136,13 +163,13 @@ def _cg_worker(rank, world, port, m, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,m", [(2, 600), (3, 601)])
-def test_sharded_cg_over_gloo(world, m):
+@pytest.mark.parametrize("world,m,overlap", [(2, 600, False), (3, 601, False), (2, 600, True), (3, 601, True)])
+def test_sharded_cg_over_gloo(world, m, overlap):
     """dist.cg_sharded: one all-gather of the direction + two scalar all-reduces per iteration"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_cg_worker, args=(r, world, port, m, q)) for r in range(world)]
+    procs = [ctx.Process(target=_cg_worker, args=(r, world, port, m, q, overlap)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=180) for _ in range(world)]

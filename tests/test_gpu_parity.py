@@ -736,3 +736,34 @@ def test_large_ell_with_scattered_columns_runs_the_panel_product(ctx, pkg):
     assert np.array_equal(np.isnan(a), np.isnan(b)) and np.isnan(a).sum() > 0
     ok = ~np.isnan(a)
     assert np.max(np.abs(a[ok] - b[ok])) <= ol.REL_TOL * 600
+
+
+def test_csr_split_columns_is_exact_and_the_parts_add_up(ctx, orc, pkg):
+    """spmv_csr_split_columns (sharded solver step): arrays equal a numpy split (order inside rows kept, inside part
+    rebased), and inside * x[c0:c1] + outside * x equals the unsplit product within the parity gate"""
+    synth = pkg.synth
+    n, k = 120_000, 12
+    rp, cc, cv = synth.csr_uniform(0, n, n, k, seed=14)
+    x = synth.vec_uniform(n, seed=14)
+    A = ctx.csr(n, n, rp, cc, cv)
+    ref, scale = np.zeros(n), np.zeros(n)
+    ol.csr_spmv(orc, rp, cc, cv, x, ref)
+    ol.csr_abs_row_sums(orc, rp, cc, cv, x, scale)
+    for c0, c1 in ((30_000, 75_000), (0, n), (0, 0), (n - 7, n)):
+        A_in, A_out = ctx.csr_split_columns(A, c0, c1)
+        inside = (cc >= c0) & (cc < c1)
+        rows = np.repeat(np.arange(n), np.diff(rp))
+        for part, mask, rebase in ((A_in, inside, c0), (A_out, ~inside, 0)):
+            prp, pcc, pcv = part.download()
+            erp = np.zeros(n + 1, np.int64)
+            np.add.at(erp, rows[mask] + 1, 1)
+            assert np.array_equal(prp, np.cumsum(erp)) and np.array_equal(pcc, cc[mask] - rebase) and np.array_equal(pcv, cv[mask])
+        assert A_in.info.ncol == c1 - c0 and A_out.info.ncol == n
+        y = ctx.vector(n)
+        y.fill(0.0)
+        ctx.apply(A_in, ctx.vector_from(x[c0:c1]), y)
+        ctx.apply(A_out, ctx.vector_from(x), y)
+        ctx.sync()
+        ol.assert_parity(y.download(), ref, scale, f"split [{c0},{c1})")
+    with pytest.raises(pkg.capi.SpmvError):
+        ctx.csr_split_columns(A, 5, n + 1)
