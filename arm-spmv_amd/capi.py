@@ -51,6 +51,7 @@ SIGNATURES = {
     "spmv_ctx_create_on_stream": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
     "spmv_ctx_destroy": (C.c_int, [_vp]),
     "spmv_sync": (C.c_int, [_vp]),
+    "spmv_ctx_mem_info": (C.c_int, [_vp, _i64p, _i64p]),
     "spmv_ctx_device": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "spmv_vec_create": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp)]),
     "spmv_vec_wrap_device": (C.c_int, [_vp, C.c_int64, _vp, C.POINTER(_vp)]),
@@ -318,6 +319,12 @@ class Context:
 
     def axpby(self, alpha: float, x: "Vector", beta: float, y: "Vector", w: "Vector") -> None:
         _check(self._lib.spmv_axpby(self.h, alpha, x.h, beta, y.h, w.h))
+
+    def mem_info(self) -> tuple[int, int]:
+        """(free, total) device memory in bytes"""
+        f, t = C.c_int64(0), C.c_int64(0)
+        _check(self._lib.spmv_ctx_mem_info(self.h, C.byref(f), C.byref(t)))
+        return f.value, t.value
 
     def apply_dot(self, A: "Matrix", x: "Vector", y: "Vector", w: "Vector", overwrite: bool = False) -> float:
         """y = A*x (overwrite) or y += A*x; returns w . y of the updated y (fused into the product where possible)"""

@@ -222,6 +222,17 @@ int spmv_ctx_destroy(spmv_ctx* ctx)
     return SPMV_OK;
 }
 
+int spmv_ctx_mem_info(spmv_ctx* ctx, int64_t* free_bytes, int64_t* total_bytes)
+{
+    SPMV_REQUIRE(ctx && free_bytes && total_bytes, "spmv_ctx_mem_info: null argument");
+    SPMV_HIP(hipSetDevice(ctx->device));
+    size_t f = 0, t = 0;
+    SPMV_HIP(hipMemGetInfo(&f, &t));
+    *free_bytes  = (int64_t)f;
+    *total_bytes = (int64_t)t;
+    return SPMV_OK;
+}
+
 int spmv_sync(spmv_ctx* ctx)
 {
     SPMV_REQUIRE(ctx, "ctx is null");

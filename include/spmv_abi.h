@@ -97,6 +97,8 @@ int spmv_ctx_create_on_stream(int device, void* hip_stream, spmv_ctx** out);
 int spmv_ctx_destroy(spmv_ctx* ctx);
 int spmv_sync(spmv_ctx* ctx);
 int spmv_ctx_device(const spmv_ctx* ctx, int* device);
+/* free and total device memory in bytes (sizing shards for 288 GB of HBM; checking that handles give memory back) */
+int spmv_ctx_mem_info(spmv_ctx* ctx, int64_t* free_bytes, int64_t* total_bytes);
 
 /* ---- vectors  (reference: include/vector.h:4-26 {int size; double* values}) --------------------- */
 int spmv_vec_create(spmv_ctx* ctx, int64_t n, spmv_vec** out);

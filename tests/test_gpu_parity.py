@@ -767,3 +767,34 @@ def test_csr_split_columns_is_exact_and_the_parts_add_up(ctx, orc, pkg):
         ol.assert_parity(y.download(), ref, scale, f"split [{c0},{c1})")
     with pytest.raises(pkg.capi.SpmvError):
         ctx.csr_split_columns(A, 5, n + 1)
+
+
+def test_handles_give_their_device_memory_back(ctx, pkg):
+    """every layout a handle builds (CSR arrays, panel copy, packed words, slice tables, guard words, the regrouped
+    copies of COO / ELL handles, solver work vectors) is released with it"""
+    import gc
+
+    capi = pkg.capi
+    gc.collect()
+    ctx.sync()
+    free0, total = ctx.mem_info()
+    assert 0 < free0 <= total
+    for _ in range(3):
+        A = ctx.gen_csr_uniform(0, 1_500_000, 1_500_000, 16, seed=4)  # panel layout + trials
+        for layout in (0, 1, 3):
+            A.set_param("panel_aos", layout)
+            A.set_kernel(capi.CSR_PANEL)
+        E = ctx.csr_to_ell(A)  # scattered columns: regrouped copy
+        P = ctx.gen_coo_powerlaw(300_000, 300_000, 2048, seed=2)  # COO with its row-grouped copy
+        a_in, a_out = ctx.csr_split_columns(A, 100, 700_000)
+        x, b = ctx.vector(1_500_000), ctx.gen_vector(1_500_000, seed=1)
+        x.fill(0.0)
+        try:
+            ctx.cg(A, b, x, max_iter=3, rel_tol=0.0)  # not SPD: may stop with an error after allocating its vectors
+        except capi.SpmvError:
+            pass
+        del A, E, P, a_in, a_out, x, b
+        gc.collect()
+    ctx.sync()
+    free1, _ = ctx.mem_info()
+    assert free0 - free1 < 256 << 20, f"{(free0 - free1) >> 20} MiB of device memory not returned"
