@@ -614,6 +614,8 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         m->pb_stagger = (int32_t)value;
     else if (!strcmp(name, "panel_guard"))
         m->pb_guard = (int32_t)value;
+    else if (!strcmp(name, "panel_uncached"))
+        m->pb_uncached = (int32_t)value;
     else if (!strcmp(name, "panel_ablate"))
         m->pb_ablate = (int32_t)value;
     else if (!strcmp(name, "panel_two_per_cu"))

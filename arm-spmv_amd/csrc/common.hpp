@@ -169,6 +169,7 @@ struct spmv_mat
     int32_t   pb_ablate      = 0;       // timing experiments only (wrong results): see PanelBatch::apply
     int32_t   pb_pace_slack  = 0;        // chunks a workgroup may run ahead of the paced schedule
     unsigned* pb_ctl         = nullptr;  // device: {pace scale in 1/1024, worst lag, workgroups done, bumps} (run-time guard)
+    int32_t   pb_uncached    = 0;        // experiment: packed arrays in uncached (1) / fine-grained (2) device memory
     int32_t   pb_guard       = 1;        // stretch the pace at run time when the workgroups fall behind it
     int32_t   pb_stagger_tuned = -1;     // schedule offsets found by trial (-1: use pb_stagger)
     int32_t   pb_stagger     = 2;        // paced schedule offsets: 0 none, 1 wavefronts 1/16 of the pace apart (loses), 2 XCDs 1/8 apart

@@ -659,6 +659,15 @@ static int pick_group_rows(int nrow, int cap)
 // Re-store the (line-ordered) three-array layout as 12-byte packed entries.  Not an error when it does not work
 // out (no memory, or so many column gaps that the padding would outweigh the two bytes saved): the three arrays
 // stay and the product runs from them.
+// experiment (panel_uncached): the streamed arrays in uncached / fine-grained device memory, so that the read-once
+// entries do not allocate lines in the L2 that the x lines live in
+static hipError_t panel_stream_alloc(void** p, size_t bytes, int mode)
+{
+    if (mode == 1) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocUncached);
+    if (mode == 2) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained);
+    return hipMalloc(p, bytes);
+}
+
 static void panel_pack(spmv_mat* m, int ngroups, int max_rows)
 {
     spmv_ctx*   ctx     = m->ctx;
@@ -694,8 +703,8 @@ static void panel_pack(spmv_mat* m, int ngroups, int max_rows)
             hipMalloc(&scount, sizeof(int32_t) * (size_t)total) != hipSuccess ||
             hipMalloc(&sbase, sizeof(int32_t) * (size_t)total) != hipSuccess ||
             hipMalloc(&d_soff, sizeof(int32_t) * soff.size()) != hipSuccess ||
-            hipMalloc(&pack, sizeof(uint32_t) * (size_t)padded) != hipSuccess ||
-            hipMalloc(&pval, sizeof(double) * (size_t)padded) != hipSuccess)
+            panel_stream_alloc((void**)&pack, sizeof(uint32_t) * (size_t)padded, m->pb_uncached) != hipSuccess ||
+            panel_stream_alloc((void**)&pval, sizeof(double) * (size_t)padded, m->pb_uncached) != hipSuccess)
             break;
         if (hipMemcpyAsync(d_soff, soff.data(), sizeof(int32_t) * soff.size(), hipMemcpyHostToDevice, s) != hipSuccess) break;
         hipLaunchKernelGGL(panel_cut_kernel, dim3(gb), dim3(64), 0, s, m->pb_gstart, ngroups, m->a, m->pb_col, colbits,
@@ -744,7 +753,7 @@ int csr_panel_build(spmv_mat* m)
     const bool aos = m->pb_aos == 1;  // 2 = three arrays read with system-scope loads (experiment)
     const bool pack = m->pb_aos == 3 && sort;  // 12-byte entries (needs the line order); kept only if every slice fits
     if ((m->pb_val || m->pb_rec) && m->pb_built_rows == G && m->pb_built_width == W && m->pb_built_sort == (int)sort &&
-        aos == (m->pb_rec != nullptr) && m->pb_built_layout == m->pb_aos)
+        aos == (m->pb_rec != nullptr) && m->pb_built_layout == m->pb_aos + 16 * m->pb_uncached)
         return panel_choose_pace(m);  // the layout in memory was built with these parameters
     csr_panel_free(m);
     // Row groups.  Requested size (panel_rows): equal groups of G rows.  Otherwise the boundaries balance the
@@ -867,7 +876,7 @@ int csr_panel_build(spmv_mat* m)
         m->pb_max_group_nnz = h_max;
     }
     m->pb_bytes       = (int64_t)(nnz * 14);
-    m->pb_built_layout = m->pb_aos;
+    m->pb_built_layout = m->pb_aos + 16 * m->pb_uncached;
     if (pack) panel_pack(m, ngroups, max_rows);  // keeps the three arrays when packing does not pay
     if (aos)
     {

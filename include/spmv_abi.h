@@ -168,7 +168,7 @@ int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
  *                   than two chunks behind it (default; get "panel_pace_scale" / "panel_pace_bumps" to see), 0 = off
  *   "panel_stagger" offsets of the paced schedule: 2 = XCDs 1/8 of the pace apart unless plain lockstep wins the
  *                   trial (default), 0 = none, 1 = wavefronts of a workgroup apart (experiment: loses)
- *   "panel_skew", "panel_pace_slack", "panel_two_per_cu", "panel_ablate"   experiments kept for the record
+ *   "panel_skew", "panel_pace_slack", "panel_two_per_cu", "panel_uncached", "panel_ablate"   experiments kept for the record
  *                   (DESIGN.md 4.2); "panel_ablate" > 0 gives WRONG results by design (timing only) */
 int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value);
 /* What is in effect: "panel_rows", "panel_width", "panel_sort", "panel_groups", "panel_layout", "panel_unroll",
