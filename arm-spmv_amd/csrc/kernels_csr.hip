@@ -17,6 +17,8 @@
 //                           oracle's orc_csr_spmv_fma.  Used for parity pinning and for very short rows.
 //   csr_ldswin_kernel       banded matrices: a workgroup stages the x window its rows touch into LDS
 //                           with coalesced loads, then gathers from LDS instead of L2/HBM.
+#include <atomic>
+
 #include "common.hpp"
 #include "wave.hpp"
 
@@ -276,12 +278,12 @@ int launch_ldswin(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, 
 #define SPMV_LAUNCH_LPR(L)                                                                                      \
     case L:                                                                                                     \
     {                                                                                                           \
-        static unsigned long long granted = 0; /* bit per device */                                                                            \
-        if (!((granted >> ctx->device) & 1ull))                                                                                         \
+        static std::atomic<unsigned long long> granted{0}; /* bit per device */                                                                            \
+        if (!((granted.load(std::memory_order_relaxed) >> ctx->device) & 1ull))                                                                                         \
         {                                                                                                       \
             SPMV_HIP(hipFuncSetAttribute((const void*)csr_ldswin_kernel<L, false>,                              \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, kWinDoubles * 8));         \
-            granted |= 1ull << ctx->device;                                                                                     \
+            granted.fetch_or(1ull << ctx->device, std::memory_order_relaxed);                                                                                     \
         }                                                                                                       \
         hipLaunchKernelGGL((csr_ldswin_kernel<L, false>), dim3(nblocks), dim3(kBlock), lds, s, A->nrow, A->a, A->b, \
                            A->v, x, y, A->win_lo, A->win_span);                                                 \

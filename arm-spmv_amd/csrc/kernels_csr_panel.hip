@@ -34,6 +34,8 @@
 // that, so what is left between achieved and roofline is the x traffic and the gather path, not layout overhead.
 #include <vector>
 
+#include <atomic>
+
 #include "common.hpp"
 #include "wave.hpp"
 
@@ -1129,12 +1131,12 @@ static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, doubl
 #define SPMV_PANEL_CASE(U, GT, LY)                                                                                   \
     if (unroll == U && gated == GT && layout == LY)                                                                   \
     {                                                                                                                \
-        static unsigned long long granted = 0; /* bit per device */                                                                                 \
-        if (!((granted >> ctx->device) & 1ull))                                                                                              \
+        static std::atomic<unsigned long long> granted{0}; /* bit per device */                                                                                 \
+        if (!((granted.load(std::memory_order_relaxed) >> ctx->device) & 1ull))                                                                                              \
         {                                                                                                            \
             SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_kernel<U, GT, LY>,                                   \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160008));                       \
-            granted |= 1ull << ctx->device;                                                                                          \
+            granted.fetch_or(1ull << ctx->device, std::memory_order_relaxed);                                                                                          \
         }                                                                                                            \
         hipLaunchKernelGGL((csr_panel_kernel<U, GT, LY>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream,           \
                            A->pb_gstart, A->pb_ngroups, A->a, arg_col, A->pb_row,                  \
@@ -1172,12 +1174,12 @@ static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, doubl
 #define SPMV_PANEL_PIPE_T(U, LY, PP, TR)                                                                             \
     if (unroll == U && layout == LY && pp == PP && trial == TR)                                                      \
     {                                                                                                                \
-        static unsigned long long granted = 0; /* bit per device */                                                  \
-        if (!((granted >> ctx->device) & 1ull))                                                                      \
+        static std::atomic<unsigned long long> granted{0}; /* bit per device */                                                  \
+        if (!((granted.load(std::memory_order_relaxed) >> ctx->device) & 1ull))                                                                      \
         {                                                                                                            \
             SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_kernel<U, false, LY, 0, PP, TR>,                     \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160008));                       \
-            granted |= 1ull << ctx->device;                                                                          \
+            granted.fetch_or(1ull << ctx->device, std::memory_order_relaxed);                                                                          \
         }                                                                                                            \
         hipLaunchKernelGGL((csr_panel_kernel<U, false, LY, 0, PP, TR>), dim3(grid), dim3(kPanelThreads), lds,        \
                            ctx->stream, A->pb_gstart, A->pb_ngroups, A->a, arg_col, A->pb_row, A->pb_val, x, y, gate, \

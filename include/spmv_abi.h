@@ -19,6 +19,11 @@
  *   - host arrays passed to *_upload stay owned by the caller and may be freed on return; device
  *     pointers passed to *_wrap_device are borrowed and must outlive the handle.
  *   - work is queued on the context's HIP stream and is asynchronous; spmv_sync() waits.
+ *   - threading: like the reference's entry points (synchronous, one caller), a context and the
+ *     handles made from it are driven by ONE host thread at a time; different contexts (e.g. one
+ *     per GPU) may be driven by different threads concurrently.  A matrix handle carries run-time
+ *     state (the pace guard of the panel kernel), so do not apply the same handle from two streams
+ *     at once.
  *   - the library is HIP-only.  There is no CPU fallback: without a usable GPU spmv_ctx_create
  *     fails with SPMV_ERR_NO_DEVICE and nothing else can be called.
  */
