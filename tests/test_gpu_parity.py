@@ -798,3 +798,65 @@ def test_handles_give_their_device_memory_back(ctx, pkg):
     ctx.sync()
     free1, _ = ctx.mem_info()
     assert free0 - free1 < 256 << 20, f"{(free0 - free1) >> 20} MiB of device memory not returned"
+
+
+def test_full_size_c3_ell_and_c4_coo_row_samples(ctx, orc, pkg):
+    """BASELINE configs 3 and 4 at full size (ELL N = 4M, K = 64 circulant band; COO N = 2M power-law rows, max 4096):
+    rows sampled across the matrix are regenerated on the host from the seed (counter-based generators) and checked
+    against the oracle's product; plus linearity A(2x) = 2 Ax over the whole vector"""
+    synth = pkg.synth
+    # ---- C3
+    n, k = 4_000_000, 64
+    E = ctx.gen_ell_banded(n, n, k, seed=1)
+    x = ctx.gen_vector(n, seed=1)
+    hx = synth.vec_uniform(n, seed=1)
+    y = ctx.vector(n)
+    y.fill(0.0)
+    ctx.apply(E, x, y)
+    ctx.sync()
+    hy = y.download()
+    key = synth.stream_key(1, synth.STREAM_VAL)
+    for r0 in (0, 1_234_567, n - 3000):
+        rows = np.arange(r0, r0 + 3000, dtype=np.int64)
+        d = np.arange(k, dtype=np.int64)
+        cc = ((rows[:, None] + d[None, :] - k // 2) % n).astype(np.int32).ravel()
+        cv = synth.to_sym(synth._draw(key, (rows[:, None] * k + d[None, :]).astype(np.uint64).ravel()))
+        rp = (np.arange(len(rows) + 1) * k).astype(np.int32)
+        ref, scale = np.zeros(len(rows)), np.zeros(len(rows))
+        ol.csr_spmv(orc, rp, cc, cv, hx, ref)
+        ol.csr_abs_row_sums(orc, rp, cc, cv, hx, scale)
+        ol.assert_parity(hy[r0:r0 + 3000], ref, scale, f"C3 rows {r0}..")
+    x2, y2 = ctx.vector(n), ctx.vector(n)
+    ctx.axpby(2.0, x, 0.0, x, x2)
+    y2.fill(0.0)
+    ctx.apply(E, x2, y2)
+    ctx.sync()
+    assert np.max(np.abs(y2.download() - 2.0 * hy)) <= ol.REL_TOL * k
+    del E, x, y, x2, y2
+    # ---- C4
+    n, max_len = 2_000_000, 4096
+    P = ctx.gen_coo_powerlaw(n, n, max_len, seed=1)
+    lens = synth.powerlaw_lengths(n, max_len, 1).astype(np.int64)
+    assert P.info.nnz == int(lens.sum()) and P.info.sorted_rows == 1
+    x = ctx.gen_vector(n, seed=1)
+    hx = synth.vec_uniform(n, seed=1)
+    y = ctx.vector(n)
+    y.fill(0.0)
+    ctx.apply(P, x, y)
+    ctx.sync()
+    hy = y.download()
+    kc, kv = synth.stream_key(1, synth.STREAM_COL), synth.stream_key(1, synth.STREAM_VAL)
+    for r0 in (0, 777_777, n - 2500):
+        rows = np.arange(r0, r0 + 2500, dtype=np.int64)
+        ln = lens[r0:r0 + 2500]
+        rr = np.repeat(rows, ln)
+        start = np.concatenate(([0], np.cumsum(ln)))
+        s = np.arange(rr.size, dtype=np.int64) - np.repeat(start[:-1], ln)
+        gidx = (rr * max_len + s).astype(np.uint64)
+        cc = synth.to_range(synth._draw(kc, gidx), n).astype(np.int32)
+        cv = synth.to_sym(synth._draw(kv, gidx))
+        rp = start.astype(np.int32)
+        ref, scale = np.zeros(len(rows)), np.zeros(len(rows))
+        ol.csr_spmv(orc, rp, cc, cv, hx, ref)
+        ol.csr_abs_row_sums(orc, rp, cc, cv, hx, scale)
+        ol.assert_parity(hy[r0:r0 + 2500], ref, scale, f"C4 rows {r0}..")
