@@ -860,3 +860,26 @@ def test_full_size_c3_ell_and_c4_coo_row_samples(ctx, orc, pkg):
         ol.csr_spmv(orc, rp, cc, cv, hx, ref)
         ol.csr_abs_row_sums(orc, rp, cc, cv, hx, scale)
         ol.assert_parity(hy[r0:r0 + 2500], ref, scale, f"C4 rows {r0}..")
+
+
+def test_full_size_c5_last_shard_row_sample(ctx, orc, pkg):
+    """BASELINE config 5, the shard of the LAST of 8 ranks at full size: rows [70M, 80M) of the 80M x 80M matrix (global
+    row / entry indices beyond 2^31, x of 640 MB).  Sampled rows against the oracle on rows regenerated from the seed."""
+    synth = pkg.synth
+    nglob, k = 80_000_000, 32
+    b, e = 70_000_000, 80_000_000
+    A = ctx.gen_csr_uniform(b, e, nglob, k, seed=1)
+    assert A.info.nnz == (e - b) * k and A.info.row_begin == b and A.info.kernel == pkg.capi.CSR_PANEL
+    x = ctx.gen_vector(nglob, seed=1)
+    hx = synth.vec_uniform(nglob, seed=1)
+    y = ctx.vector(e - b)
+    y.fill(0.0)
+    ctx.apply(A, x, y)
+    ctx.sync()
+    hy = y.download()
+    for r0 in (b, b + 4_321_000, e - 2000):
+        rp, cc, cv = synth.csr_uniform(r0, r0 + 2000, nglob, k, seed=1)
+        ref, scale = np.zeros(2000), np.zeros(2000)
+        ol.csr_spmv(orc, rp, cc, cv, hx, ref)
+        ol.csr_abs_row_sums(orc, rp, cc, cv, hx, scale)
+        ol.assert_parity(hy[r0 - b:r0 - b + 2000], ref, scale, f"C5 shard rows {r0}..")
