@@ -1001,13 +1001,20 @@ int panel_choose_pace(spmv_mat* m)
                 c.pace = m->pb_pace_ns;
             }
         }
-        // the optimum sits right above a cliff (a pace the CUs cannot hold lets them drift apart)
+        // the optimum sits right above a cliff (a pace the CUs cannot hold lets them drift apart): walk down in 2 %
+        // steps, over more launches than the coarse pass used, while it does not get slower (past the cliff it gets
+        // slower by tens of per cent, so a tie is still on the safe side)
+        if (c.pace > 0)
+        {
+            SPMV_TRY(timed(c.pace, 6, &ms));
+            c.ms = ms;
+        }
         for (int step = 1; c.pace > 0 && step <= 8; ++step)
         {
             const int cand = (int)(c.pace * 0.98);
-            SPMV_TRY(timed(cand, 3, &ms));
-            if (ms >= c.ms) break;
-            c.ms   = ms;
+            SPMV_TRY(timed(cand, 6, &ms));
+            if (ms > c.ms * 1.002) break;
+            c.ms   = std::min<double>(c.ms, ms);
             c.pace = cand;
         }
         return SPMV_OK;
