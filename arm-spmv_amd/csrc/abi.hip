@@ -620,6 +620,10 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         m->pb_ablate = (int32_t)value;
     else if (!strcmp(name, "panel_two_per_cu"))
         m->pb_two_per_cu = (int32_t)value;
+    else if (!strcmp(name, "panel_sync"))
+        m->pb_sync = (int32_t)value;
+    else if (!strcmp(name, "panel_trace"))
+        m->pb_trace = (int32_t)value;
     else
         SPMV_FAIL(SPMV_ERR_INVALID, "unknown parameter '%s'", name);
     return SPMV_OK;
@@ -628,6 +632,7 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
 int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
 {
     SPMV_REQUIRE(m && name && value, "null argument");
+    if (!strncmp(name, "panel_trace@", 12)) return csr_panel_read_trace(m->ctx, atoll(name + 12), value);
     if (!strcmp(name, "panel_rows"))
         *value = m->pb_built_rows;
     else if (!strcmp(name, "panel_width"))
@@ -648,6 +653,8 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         *value = m->pb_pipe >= 0 ? m->pb_pipe : (m->pb_pipe_tuned > 0 ? m->pb_pipe_tuned : 1);
     else if (!strcmp(name, "panel_stagger"))
         *value = m->pb_stagger_tuned >= 0 ? m->pb_stagger_tuned : m->pb_stagger;
+    else if (!strcmp(name, "panel_sync"))
+        *value = m->pb_sync >= 0 ? m->pb_sync : m->pb_sync_tuned;
     else if (!strcmp(name, "panel_pace_scale") || !strcmp(name, "panel_pace_bumps"))
     {
         // the run-time guard's state: pace stretch in 1/1024 and how often it was stretched (synchronous read)

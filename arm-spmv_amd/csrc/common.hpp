@@ -178,6 +178,10 @@ struct spmv_mat
     int32_t   pb_pace_tuned_unroll = 0; // what the trial was made for: requested unroll, -1 = unroll chosen too, 0 = not tried
     int32_t   pb_unroll_tuned = 0;       // chunk size found by trying (in effect while pb_unroll == 0)
     int64_t   pb_max_group_nnz = 0;      // entries of the fullest row group
+    int32_t   pb_sync        = -1;       // keep a workgroup's wavefronts together: 0 no, 1 barrier per chunk, 2 priority to late ones,
+                                         // 3 barrier between a chunk's loads and its LDS adds; -1 = by trial
+    int32_t   pb_sync_tuned  = 0;        // what the trial found (in effect while pb_sync == -1)
+    int32_t   pb_trace       = 0;        // diagnostic: stamp the phases of every chunk (gather-first pipeline, U = 8)
     int32_t   pb_two_per_cu  = 1;        // allow two workgroups per CU when the accumulators fit twice
     int32_t   pb_ngroups     = 0;
     int32_t   pb_max_rows    = 0;        // rows of the fullest group (sizes the LDS accumulators)
@@ -200,6 +204,7 @@ int  csr_panel_build(spmv_mat* m);
 int  panel_choose_pace(spmv_mat* m);
 void csr_panel_free(spmv_mat* m);
 int  csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
+int  csr_panel_read_trace(spmv_ctx* ctx, int64_t index, int64_t* value);
 // A sum that thousands of wavefronts add into is kept as kDotSlots partial sums on different 128-byte lines (an
 // atomic on ONE word costs ~12 ns each at the L2, serialised: 8192 of them are 100 us); readers add the slots up.
 constexpr int kDotSlots   = 32;

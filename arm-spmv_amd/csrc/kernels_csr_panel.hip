@@ -441,9 +441,15 @@ __device__ __forceinline__ void gate_wait(GateLds* lds, const unsigned* gate_x, 
     }
 }
 
+// Diagnostic build of the gather-first pipeline (panel_trace = 1): lane 0 of wavefronts 0 and 15 of the first 256
+// workgroups stamps 32 chunks of the first round with the chip-wide 100 MHz clock: chunk start, loads issued,
+// gathers back, LDS adds done, next chunk's stream back.  Read through spmv_mat_get_param("panel_trace@<i>").
+constexpr int kTraceWgs = 256, kTraceChunks = 32, kTraceFirst = 16, kTraceStamps = 5;
+__device__ unsigned g_panel_trace[kTraceWgs * 2 * kTraceChunks * kTraceStamps];
+
 // TRIAL: same code under another name, so that the launches of the build-time trials (panel_choose_pace) show up
 // apart from the products in a kernel trace
-template <int UNROLL, bool GATED, int LAYOUT, int ABLATE = 0, int PIPE = 0, bool TRIAL = false>
+template <int UNROLL, bool GATED, int LAYOUT, int ABLATE = 0, int PIPE = 0, bool TRIAL = false, bool TRACE = false>
 __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t* __restrict__ gstart, int ngroups,
                                                                   const int32_t* __restrict__ row_ptr,
                                                                   const int32_t* __restrict__ pcol,
@@ -509,10 +515,24 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
             // while the L2->L1 path is busy and vice versa.  Offsetting the wavefronts of a workgroup against each other
             // (mode 1) loses: the x window in use doubles and drops out of L2.  Offsetting whole XCDs against each other
             // (mode 2, the default) keeps the lockstep where it matters — inside an L2 — and evens out the HBM demand.
+            // keeping the 16 wavefronts of the workgroup together (bits 18-19 of pace_slack): 1 = a workgroup barrier per
+            // chunk; 2 = a wavefront that is behind the schedule raises its issue priority.  Without either, the oldest-
+            // first issue arbitration lets wavefront 0 start the next chunk while wavefront 15 is still issuing this
+            // one, which then takes twice as long (tools/trace_panel.py: 2 % of the chunks take 15 us instead of 7).
+            const int sync_mode = (pace_slack >> 18) & 3;
+            if (sync_mode == 1) __syncthreads();
+            if (sync_mode == 2 && pace_fp)
+            {
+                const unsigned long long due = t0 + (((unsigned long long)b * pace_fp) >> 10);
+                if (__builtin_amdgcn_s_memrealtime() > due + (pace_fp >> 12))  // more than a quarter of a chunk late
+                    __builtin_amdgcn_s_setprio(3);
+                else
+                    __builtin_amdgcn_s_setprio(0);
+            }
             if (pace_fp && lane == 0)
             {
                 const int                slack = pace_slack & 0xFFFF;
-                const int                mode  = pace_slack >> 16;  // 1: wavefronts apart, 2: XCDs apart (L2s are per XCD)
+                const int                mode  = (pace_slack >> 16) & 3;  // 1: wavefronts apart, 2: XCDs apart (L2s are per XCD)
                 const unsigned long long phase = mode == 1   ? ((unsigned long long)(threadIdx.x >> 6) * pace_fp) / NWAVES
                                                  : mode == 2 ? ((unsigned long long)xcd_id() * pace_fp) / kNumXcd
                                                  : mode == 3 ? ((unsigned long long)((blockIdx.x >> 3) & 1) * pace_fp) / 2 +
@@ -538,13 +558,40 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
                 // Vector loads return in order, so the adds of chunk b wait for the gathers only, and the HBM
                 // latency of the next chunk's stream runs under them instead of in front of the gathers
                 if (b == 0) cur.load_raw(pcol, prow, pval, e);
+                unsigned tr[kTraceStamps];
+                if constexpr (TRACE) tr[0] = (unsigned)__builtin_amdgcn_s_memrealtime();
                 cur.unpack(sb + b * UNROLL, rowbits);
                 double xv[UNROLL];
                 cur.gather(x, xv);
                 // unconditional (the last chunk re-reads itself): behind a branch, the wait-count bookkeeping of the
                 // compiler would make the adds wait for these loads as well
                 nxt.load_raw(pcol, prow, pval, b + 1 < nfull ? e + STEP : e);
+                if constexpr (TRACE)
+                {
+                    tr[1] = (unsigned)__builtin_amdgcn_s_memrealtime();
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * UNROLL) : "memory");  // the gathers are back
+                    tr[2] = (unsigned)__builtin_amdgcn_s_memrealtime();
+                }
+                // sync 3: the barrier between issue and adds.  A wavefront that has issued its loads early waits here with
+                // its gathers long back; when the last one has issued, all add and go on to the next chunk, so the vector
+                // memory pipe idles for one wavefront's adds instead of for the last wavefront's adds + stream latency.
+                if (sync_mode == 3) __syncthreads();
                 cur.add(acc, xv);
+                if constexpr (TRACE)
+                {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the LDS adds are done
+                    tr[3] = (unsigned)__builtin_amdgcn_s_memrealtime();
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next chunk's entries are back
+                    tr[4] = (unsigned)__builtin_amdgcn_s_memrealtime();
+                    const int wave = threadIdx.x >> 6;
+                    if (lane == 0 && blockIdx.x < kTraceWgs && round == 0 && (wave == 0 || wave == 15) && b >= kTraceFirst &&
+                        b < kTraceFirst + kTraceChunks)
+                    {
+                        unsigned* o = g_panel_trace + (((size_t)blockIdx.x * 2 + (wave ? 1 : 0)) * kTraceChunks + (b - kTraceFirst)) * kTraceStamps;
+#pragma unroll
+                        for (int i = 0; i < kTraceStamps; ++i) o[i] = tr[i];
+                    }
+                }
                 cur = nxt;
             }
             else if constexpr (PIPE == 1)
@@ -616,6 +663,158 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
         }
     }
     if (ABLATE && sink == 123.456) y[0] = sink;  // keeps the ablated products alive
+}
+
+// ---- the product, ring-pipelined (packed layout only) -------------------------------------------------------
+// What the two-stage pipelines above leave on the table (profiles/r01_pmc_csr_c2_stalls.txt): a chunk costs the CU
+// ~5.9 us of L2->L1 line transfers (gathers + stream), ~2.5 us of ds_add_f64 and ~4 us of HBM time, and with one
+// chunk of look-ahead the three run largely one after the other (8.4 us per chunk).  Here every wavefront keeps a
+// ring of NS chunks of packed entries in registers:
+//     step b:   issue the gathers of chunk b+1   (its entries arrived a step ago)
+//               issue the streamed loads of chunk b+NS-1 into the slot chunk b-1 has left
+//               ds_add_f64 the products of chunk b (its gathers were issued a step ago)
+// so the vector memory pipe always has the next chunk's gathers queued while the LDS works on the current one, and
+// the HBM latency of the stream has NS-2 whole steps to run.  Vector loads return in order; the order above makes
+// the adds of chunk b wait for gathers(b) and stream(b+NS-2) only, both a full step old.
+// The ring is unrolled UF = lcm(NS, 2) steps so that slot and gather-buffer indices are compile-time constants.
+template <int U, int NS, bool TRIAL = false>
+__global__ __launch_bounds__(kPanelThreads) void csr_panel_ring_kernel(
+    const int32_t* __restrict__ gstart, int ngroups, const uint32_t* __restrict__ pack, const double* __restrict__ pval,
+    const double* __restrict__ x, double* __restrict__ y, unsigned long long pace_fp, int xcd_offsets,
+    const int32_t* __restrict__ sbase, const int32_t* __restrict__ soff, int rowbits, unsigned pad_row, int overwrite,
+    const double* __restrict__ dot_w, double* __restrict__ dot_out, unsigned* __restrict__ ctl)
+{
+    extern __shared__ double acc[];
+    constexpr int STEP = U * kPanelThreads;
+    constexpr int UF   = (NS % 2 == 0) ? NS : 2 * NS;
+    const int      lane = threadIdx.x & 63;
+    const unsigned mask = (1u << rowbits) - 1u;
+    if (ctl && pace_fp) pace_fp = (pace_fp * __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 10;
+    const unsigned long long phase = (pace_fp && (xcd_offsets & 1)) ? ((unsigned long long)xcd_id() * pace_fp) / kNumXcd : 0ull;
+    unsigned lag_max = 0;
+    struct Slot
+    {
+        unsigned w[U];
+        double   v[U];
+    };
+    for (int g = blockIdx.x; g < ngroups; g += gridDim.x)
+    {
+        const int r0   = gstart[g];
+        const int rows = gstart[g + 1] - r0;
+        for (int i = threadIdx.x; i < rows; i += kPanelThreads) acc[i] = 0.0;
+        __syncthreads();
+        const int s0 = soff[g], nslices = soff[g + 1] - s0;
+        const int nfull = nslices / U;
+        const int32_t* __restrict__ sb = sbase + s0;
+        // uniform bases + one 32-bit lane offset: the loads take the scalar-base form, no per-load address arithmetic
+        const uint32_t* __restrict__ gp = pack + (size_t)s0 * kPanelThreads;
+        const double* __restrict__ gv   = pval + (size_t)s0 * kPanelThreads;
+        const unsigned tid = threadIdx.x;
+        const unsigned long long t0 = pace_fp ? __builtin_amdgcn_s_memrealtime() : 0ull;
+        if (nfull > 0)
+        {
+            Slot   slot[NS];
+            double xv[2][U];
+            const int last = nfull - 1;
+            // the fill steps gather from slots that have not been loaded yet: word 0 = column `slice base`, a valid one
+#pragma unroll
+            for (int k = 0; k < NS; ++k)
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                {
+                    slot[k].w[u] = 0u;
+                    slot[k].v[u] = 0.0;
+                }
+            auto load = [&](Slot& s, int b) {
+                const size_t off = (size_t)min(max(b, 0), last) * STEP;  // look-ahead past either end re-reads a chunk
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                {
+                    s.w[u] = load_stream(gp + off + u * kPanelThreads + tid);
+                    s.v[u] = load_stream(gv + off + u * kPanelThreads + tid);
+                }
+            };
+            auto gather = [&](const Slot& s, int b, double(&xo)[U]) {
+                const int32_t* __restrict__ base = sb + min(max(b, 0), last) * U;
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                {
+                    const unsigned byte_off = (unsigned)(base[u] + (int)(s.w[u] >> rowbits)) << 3;  // ncol < 2^29 (host check)
+                    xo[u] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(x) + byte_off);
+                }
+            };
+            // chunks outside [0, nfull) (pipeline fill and the rounding of the last turn) add into the pads' spare
+            // accumulator; mask/or are scalars, so the address stays a per-lane value and the adds stay plain ds_add_f64
+            auto add = [&](const Slot& s, const double(&xi)[U], bool valid) {
+                const unsigned m = valid ? mask : 0u, o = valid ? 0u : pad_row;
+#pragma unroll
+                for (int u = 0; u < U; ++u) atomicAdd(&acc[(s.w[u] & m) | o], s.v[u] * xi[u]);  // ds_add_f64
+            };
+            // One body for fill, steady state and drain (no prologue: a separate one would meet the steady state at the
+            // loop header with a different order of outstanding loads and the compiler's wait counts would turn
+            // conservative there).  Step b: gathers(b+1), stream(b+NS-1), adds(b); b runs from -NS.
+            for (int b0 = -NS; b0 < nfull; b0 += UF)
+            {
+#pragma unroll
+                for (int k = 0; k < UF; ++k)
+                {
+                    const int b = b0 + k;
+                    if (xcd_offsets & 2) __syncthreads();  // keep the wavefronts of the workgroup in the same step
+                    if (pace_fp && b >= 0)
+                    {
+                        // the gathers of chunk c (c >= 1) do not start before t0 + c * pace on the chip-wide 100 MHz
+                        // clock.  Every operand is uniform: scalar branches, no lane masks.
+                        const unsigned long long target = t0 + (((unsigned long long)(b + 1) * pace_fp + phase) >> 10);
+                        const unsigned long long now    = __builtin_amdgcn_s_memrealtime();
+                        if (now > target) lag_max = max(lag_max, (unsigned)min(now - target, 0xFFFFFFFFull));
+                        int spins = 0;
+                        while (__builtin_amdgcn_s_memrealtime() < target && ++spins < (1 << 16)) __builtin_amdgcn_s_sleep(1);
+                    }
+                    gather(slot[(k + 1) % NS], b + 1, xv[(k + 1) % 2]);
+                    load(slot[(k + NS - 1) % NS], b + NS - 1);
+                    add(slot[k % NS], xv[k % 2], b >= 0 && b < nfull);
+                }
+            }
+        }
+        // slices beyond the last whole chunk
+        for (int t = nfull * U; t < nslices; ++t)
+        {
+            const unsigned w  = load_stream(gp + (size_t)t * kPanelThreads + tid);
+            const double   v  = load_stream(gv + (size_t)t * kPanelThreads + tid);
+            const double   xx = x[sb[t] + (int)(w >> rowbits)];
+            atomicAdd(&acc[w & mask], v * xx);
+        }
+        __syncthreads();
+        double part = 0.0;
+        for (int i = threadIdx.x; i < rows; i += kPanelThreads)
+        {
+            const double yn = overwrite ? acc[i] : y[r0 + i] + acc[i];
+            y[r0 + i]       = yn;
+            if (dot_w) part = fma(dot_w[r0 + i], yn, part);
+        }
+        if (dot_w)
+        {
+            part = wave_sum(part);
+            if (lane == 0) slot_add(dot_out, part);
+        }
+        __syncthreads();
+    }
+    if (ctl && pace_fp && threadIdx.x == 0)
+    {
+        __hip_atomic_fetch_max(ctl + 1, lag_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        if (__hip_atomic_fetch_add(ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1)
+        {
+            const unsigned worst = __hip_atomic_exchange(ctl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ctl + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (worst > 2u * (unsigned)(pace_fp >> 10))  // ticks of 10 ns
+            {
+                const unsigned scale = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ctl, min(scale + scale / 20u, 2048u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(ctl + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 }  // namespace
 
@@ -922,40 +1121,40 @@ static void panel_guard_reset(spmv_mat* m)
 
 int panel_choose_pace(spmv_mat* m)
 {
+    // Chooses, by timing a few launches on scratch vectors (the gather addresses, not the values, set the time), the
+    // chunk size, the order of a chunk's loads and how the 16 wavefronts of a workgroup are kept together:
+    //   scattered columns (C2): U = 8, gather-first, a workgroup barrier per chunk, NO clock throttle.  With the barrier
+    //     the workgroups of an XCD fall into step by themselves (whoever leads the sweep of x takes the L2 misses and
+    //     slows down); without it wavefront 0 starts the next chunk while wavefront 15 is still issuing this one and
+    //     starves it (tools/trace_panel.py), which is what the clock pace of round 1 was really compensating;
+    //   local columns (bands): U = 4, stream-first, no barrier.
+    // A requested pace (panel_pace_ns >= 0) is applied to every candidate; there is no pace search any more.
     spmv_ctx* ctx = m->ctx;
-    panel_guard_reset(m);  // whatever is chosen below starts with an unstretched pace
-    // what is tried: the chunk size (unless requested) and the pace (unless requested)
-    // (key: the requests the trial was made under; unroll 0 / pipe -1 = chosen here as well)
-    const int key = 1000 + std::max(m->pb_unroll, 0) * 10 + (m->pb_pipe + 1) + (m->pb_stagger & 3) * 100000;
-    if (m->pb_pace_tuned_unroll == key)
-    {
-        // already tried for this layout; a requested pace only overrides the pace
-        m->pb_pace_ns = m->pb_pace_req >= 0 ? m->pb_pace_req : m->pb_pace_tuned_ns;
-        return SPMV_OK;
-    }
-    m->pb_pace_tuned_unroll = 0;  // what was found for other requests no longer applies
-    m->pb_stagger_tuned = -1;
-    m->pb_unroll_tuned  = 0;
-    m->pb_pipe_tuned    = 0;
-    m->pb_pace_ns       = m->pb_pace_req >= 0 ? m->pb_pace_req : 0;
-    m->pb_pace_tuned_ns = 0;
-    if (m->pb_pace_req >= 0 && m->pb_unroll > 0 && m->pb_pipe >= 0) return SPMV_OK;  // nothing left to choose
-    const int  u_first = m->pb_unroll > 0 ? m->pb_unroll : 8;
-    const bool worth   = (double)m->ncol * 8.0 > 4.0 * 1048576.0 && m->pb_max_group_nnz >= 8LL * u_first * kPanelThreads;
+    panel_guard_reset(m);
+    const int key = 1000 + std::max(m->pb_unroll, 0) * 10 + (m->pb_pipe + 1) + (m->pb_stagger & 3) * 100000 + ((m->pb_sync + 1) & 7) * 1000000;
+    m->pb_pace_ns = m->pb_pace_req >= 0 ? m->pb_pace_req : 0;
+    if (m->pb_pace_tuned_unroll == key) return SPMV_OK;  // already tried for this layout and these requests
+    m->pb_pace_tuned_unroll = 0;
+    m->pb_stagger_tuned     = -1;
+    m->pb_unroll_tuned      = 0;
+    m->pb_pipe_tuned        = 0;
+    m->pb_sync_tuned        = 0;
+    m->pb_pace_tuned_ns     = 0;
+    if (m->pb_unroll > 0 && m->pb_pipe >= 0 && m->pb_sync >= 0) return SPMV_OK;  // nothing left to choose
+    const bool worth = (double)m->ncol * 8.0 > 4.0 * 1048576.0 && m->pb_max_group_nnz >= 8LL * 8 * kPanelThreads;
     if (!worth) return SPMV_OK;  // x fits L2 or the groups are a few chunks long: nothing to keep in step
     double *x = nullptr, *y = nullptr;
     if (hipMalloc(&x, sizeof(double) * (size_t)m->ncol) != hipSuccess || hipMalloc(&y, sizeof(double) * (size_t)m->nrow) != hipSuccess)
     {
         if (x) (void)hipFree(x);
         (void)hipGetLastError();
-        return SPMV_OK;  // no room to try: run unthrottled
+        return SPMV_OK;  // no room to try: defaults
     }
     (void)hipMemsetAsync(x, 0, sizeof(double) * (size_t)m->ncol, ctx->stream);
     (void)hipMemsetAsync(y, 0, sizeof(double) * (size_t)m->nrow, ctx->stream);
     int  rc    = SPMV_OK;
-    auto timed = [&](int pace_ns, int launches, float* ms) -> int {
-        m->pb_pace_ns = pace_ns;
-        int r         = panel_launch(ctx, m, x, y, true, apply_extra{});  // warm
+    auto timed = [&](int launches, float* ms) -> int {
+        int r = panel_launch(ctx, m, x, y, true, apply_extra{});  // warm
         if (r != SPMV_OK) return r;
         (void)hipEventRecord(ctx->ev_begin, ctx->stream);
         for (int i = 0; i < launches && r == SPMV_OK; ++i) r = panel_launch(ctx, m, x, y, true, apply_extra{});
@@ -966,124 +1165,60 @@ int panel_choose_pace(spmv_mat* m)
         *ms /= (float)launches;
         return r;
     };
-    struct Config
+    struct Try
     {
-        int    unroll, pipe, stagger, pace;
-        double ms;  // per launch
+        int unroll, pipe, sync;
     };
-    // best pace of one configuration: coarse candidates, then 2 % steps down from the coarse winner
-    auto search = [&](Config& c) -> int {
-        m->pb_unroll_tuned = c.unroll;
-        m->pb_pipe_tuned   = c.pipe;
-        m->pb_stagger      = c.stagger;
-        c.ms               = 1e30;
-        c.pace             = 0;
-        float ms           = 0.f;
-        if (m->pb_pace_req >= 0)
+    const Try packed_tries[] = {{8, 2, 3}, {8, 2, 1}, {4, 2, 1}, {4, 1, 0}, {8, 1, 0}};
+    const Try plain_tries[]  = {{8, 1, 1}, {8, 1, 0}, {4, 1, 0}, {2, 1, 0}};
+    const Try* tries  = m->pb_pack ? packed_tries : plain_tries;
+    const int  ntries = m->pb_pack ? 5 : 4;
+    Try    best{m->pb_unroll > 0 ? m->pb_unroll : 8, m->pb_pipe >= 0 ? m->pb_pipe : 1, m->pb_sync >= 0 ? m->pb_sync : 0};
+    double best_ms = 1e30;
+    int    tried   = 0;
+    for (int pass = 0; pass < 2 && rc == SPMV_OK; ++pass)
+    {
+        // pass 1 only if no candidate matches the requests: the requested values with the remaining defaults
+        for (int i = 0; i < (pass == 0 ? ntries : 1) && rc == SPMV_OK; ++i)
         {
-            SPMV_TRY(timed(m->pb_pace_req, 3, &ms));
-            c.ms   = ms;
-            c.pace = m->pb_pace_req;
-            return SPMV_OK;
-        }
-        const double base_ns   = 1.33 * c.unroll * kPanelThreads;
-        const double factors[] = {0.0, 0.76, 0.82, 0.88, 0.94, 1.0, 1.06, 1.12, 1.2, 1.32, 1.5, 1.7, 1.95, 2.25, 2.6};
-        double       unthrottled_ms = 1e30;
-        for (double f : factors)
-        {
-            SPMV_TRY(timed((int32_t)(f * base_ns), 3, &ms));
-            // a throttle has to beat the unthrottled run (first candidate) by a clear margin, or timing noise
-            // would switch it on where the columns are local and there is nothing to keep in step
-            if (f == 0.0) unthrottled_ms = ms;
-            if (ms < c.ms && (f == 0.0 || ms < 0.93 * unthrottled_ms))
+            const Try t = pass == 0 ? tries[i] : best;
+            if (pass == 0 && ((m->pb_unroll > 0 && m->pb_unroll != t.unroll) || (m->pb_pipe >= 0 && m->pb_pipe != t.pipe) ||
+                              (m->pb_sync >= 0 && m->pb_sync != t.sync)))
+                continue;
+            if (pass == 1 && tried > 0) break;
+            m->pb_unroll_tuned = t.unroll;
+            m->pb_pipe_tuned   = t.pipe;
+            m->pb_sync_tuned   = t.sync;
+            float a = 0.f, b = 0.f;
+            if ((rc = timed(4, &a)) != SPMV_OK || (rc = timed(4, &b)) != SPMV_OK) break;
+            ++tried;
+            const double ms = std::min(a, b);
+            if (ms < best_ms * (best_ms < 1e29 ? 0.99 : 1.0))  // later candidates have to win by 1 %
             {
-                c.ms   = ms;
-                c.pace = m->pb_pace_ns;
+                best_ms = ms;
+                best    = t;
             }
         }
-        // the optimum sits right above a cliff (a pace the CUs cannot hold lets them drift apart): walk down in 2 %
-        // steps, over more launches than the coarse pass used, while it does not get slower (past the cliff it gets
-        // slower by tens of per cent, so a tie is still on the safe side)
-        if (c.pace > 0)
-        {
-            SPMV_TRY(timed(c.pace, 6, &ms));
-            c.ms = ms;
-        }
-        for (int step = 1; c.pace > 0 && step <= 8; ++step)
-        {
-            const int cand = (int)(c.pace * 0.98);
-            SPMV_TRY(timed(cand, 6, &ms));
-            if (ms > c.ms * 1.002) break;
-            c.ms   = std::min<double>(c.ms, ms);
-            c.pace = cand;
-        }
-        return SPMV_OK;
-    };
-    const int stagger_req = m->pb_stagger;
-    const int unrolls[3]  = {u_first, 4, 2};
-    const int n_unroll    = m->pb_unroll > 0 ? 1 : 3;
-    const int n_pipe      = m->pb_pipe >= 0 || m->pb_pack == nullptr ? 1 : 2;  // gather-first: packed layout
-    Config    cand[8];
-    int       ncand = 0;
-    for (int ui = 0; ui < n_unroll * n_pipe && rc == SPMV_OK; ++ui)
-    {
-        Config c{unrolls[ui / n_pipe], n_pipe == 2 ? 1 + ui % 2 : 0, stagger_req, 0, 1e30};
-        if (c.pipe == 2 && c.unroll == 2) continue;  // gather-first is not instantiated for U = 2
-        if ((rc = search(c)) == SPMV_OK) cand[ncand++] = c;
     }
-    // The configurations are often within a few per cent of each other: decide among them (and, for the winner,
-    // between XCD-offset and plain lockstep schedules) over more launches than the search used.
-    Config best{u_first, 0, stagger_req, 0, 1e30};
-    for (int i = 0; i < ncand && rc == SPMV_OK; ++i)
-    {
-        Config& c = cand[i];
-        m->pb_unroll_tuned = c.unroll;
-        m->pb_pipe_tuned   = c.pipe;
-        m->pb_stagger      = c.stagger;
-        float a = 0.f, b = 0.f;
-        if ((rc = timed(c.pace, 6, &a)) != SPMV_OK || (rc = timed(c.pace, 6, &b)) != SPMV_OK) break;
-        c.ms = std::min(a, b);
-        if (c.ms < best.ms * (i == 0 ? 1.0 : 0.99)) best = c;
-    }
-    if (rc == SPMV_OK && ncand > 0 && best.pace > 0 && m->pb_pace_req < 0 && stagger_req == 2)
-    {
-        Config alt = best;
-        alt.stagger = 0;
-        float a = 0.f, b = 0.f;
-        if ((rc = search(alt)) == SPMV_OK && (rc = timed(alt.pace, 6, &a)) == SPMV_OK && (rc = timed(alt.pace, 6, &b)) == SPMV_OK)
-        {
-            alt.ms = std::min(a, b);
-            if (alt.ms < 0.99 * best.ms) best = alt;
-        }
-    }
-    // The winner sits close to the cliff.  Step back 2 % from it, then check the choice over more launches and
-    // step back further while it does not hold (a pace the chip cannot keep costs 60-80 %, a cautious one 2-3 %).
-    m->pb_unroll_tuned = best.unroll;
-    m->pb_pipe_tuned   = best.pipe;
-    m->pb_stagger      = best.stagger;
-    if (rc == SPMV_OK && best.pace > 0 && m->pb_pace_req < 0)
-    {
-        best.pace = (int)(best.pace * 1.02);
-        for (int attempt = 0; attempt < 4 && rc == SPMV_OK; ++attempt)
-        {
-            float ms_a = 0.f, ms_b = 0.f;
-            if ((rc = timed(best.pace, 3, &ms_a)) != SPMV_OK || (rc = timed(best.pace, 3, &ms_b)) != SPMV_OK) break;
-            if (std::max(ms_a, ms_b) <= 1.08 * best.ms) break;
-            best.pace = (int)(best.pace * 1.03);
-        }
-    }
-    const int all_best_pace = best.pace, all_best_unroll = best.unroll, all_best_pipe = best.pipe;
-    m->pb_stagger_tuned = rc == SPMV_OK ? best.stagger : stagger_req;
-    m->pb_stagger       = stagger_req;  // the request stays what the caller set; the launch uses the tuned value
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(x);
     (void)hipFree(y);
-    m->pb_unroll_tuned      = rc == SPMV_OK && m->pb_unroll <= 0 ? all_best_unroll : 0;
-    m->pb_pipe_tuned        = rc == SPMV_OK ? all_best_pipe : 0;
-    m->pb_pace_tuned_ns     = rc == SPMV_OK ? all_best_pace : 0;
-    m->pb_pace_ns           = m->pb_pace_req >= 0 ? m->pb_pace_req : m->pb_pace_tuned_ns;
+    m->pb_unroll_tuned      = rc == SPMV_OK && m->pb_unroll <= 0 ? best.unroll : 0;
+    m->pb_pipe_tuned        = rc == SPMV_OK ? best.pipe : 0;
+    m->pb_sync_tuned        = rc == SPMV_OK ? best.sync : 0;
     m->pb_pace_tuned_unroll = rc == SPMV_OK ? key : 0;
     return rc;
+}
+
+int csr_panel_read_trace(spmv_ctx* ctx, int64_t index, int64_t* value)
+{
+    constexpr int64_t n = (int64_t)kTraceWgs * 2 * kTraceChunks * kTraceStamps;
+    if (index < 0 || index >= n) SPMV_FAIL(SPMV_ERR_INVALID, "panel_trace@%lld: the trace holds %lld stamps", (long long)index, (long long)n);
+    unsigned v = 0;
+    SPMV_HIP(hipStreamSynchronize(ctx->stream));
+    SPMV_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_panel_trace), sizeof(v), (size_t)index * sizeof(unsigned)));
+    *value = v;
+    return SPMV_OK;
 }
 
 int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
@@ -1114,7 +1249,8 @@ static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, doubl
     const bool gated = skew > 0 && grid > 1 && !A->pb_pack;
     // pace: nanoseconds per chunk -> 10 ns ticks in 22.10 fixed point
     const unsigned long long pace_fp = A->pb_pace_ns > 0 ? (unsigned long long)((double)A->pb_pace_ns * 102.4) : 0ull;
-    const int  pace_slack = std::min(std::max(0, A->pb_pace_slack), 0xFFFF) | (((A->pb_stagger_tuned >= 0 ? A->pb_stagger_tuned : A->pb_stagger) & 3) << 16);
+    const int  pace_slack = std::min(std::max(0, A->pb_pace_slack), 0xFFFF) | (((A->pb_stagger_tuned >= 0 ? A->pb_stagger_tuned : A->pb_stagger) & 3) << 16) |
+                            (((A->pb_sync >= 0 ? A->pb_sync : A->pb_sync_tuned) & 3) << 18);
     const int  layout = A->pb_pack ? 3 : A->pb_rec ? 1 : (A->pb_aos == 2 ? 2 : 0);
     // the kernel dereferences exactly these arrays: refuse on the host rather than fault on the GPU
     const bool have = layout == 1   ? A->pb_rec != nullptr
@@ -1173,6 +1309,35 @@ static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, doubl
 #undef SPMV_PANEL_ABLATE
     }
     const int pipe = A->pb_pipe >= 0 ? A->pb_pipe : (A->pb_pipe_tuned > 0 ? A->pb_pipe_tuned : 1);
+    if (pipe >= 3 && layout == 3 && !gated)
+    {
+        // ring-pipelined chunks: pipe = slots of the ring (3..6)
+        const int xcd_offsets = (((pace_slack >> 16) & 3) == 2 ? 1 : 0) | (((pace_slack >> 18) & 3) == 1 ? 2 : 0);  // bit 1: barrier per step
+#define SPMV_PANEL_RING_T(U, NS, TR)                                                                                 \
+    if (unroll == U && pipe == NS && trial == TR)                                                                    \
+    {                                                                                                                \
+        static std::atomic<unsigned long long> granted{0}; /* bit per device */                                      \
+        if (!((granted.load(std::memory_order_relaxed) >> ctx->device) & 1ull))                                      \
+        {                                                                                                            \
+            SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_ring_kernel<U, NS, TR>,                              \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160008));                       \
+            granted.fetch_or(1ull << ctx->device, std::memory_order_relaxed);                                        \
+        }                                                                                                            \
+        hipLaunchKernelGGL((csr_panel_ring_kernel<U, NS, TR>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream,    \
+                           A->pb_gstart, A->pb_ngroups, A->pb_pack, A->pb_val, x, y, pace_fp, xcd_offsets, pk.sbase,   \
+                           pk.soff, pk.rowbits, (unsigned)A->pb_max_rows, ex.overwrite ? 1 : 0, ex.dot_w, ex.dot_out, ctl); \
+        SPMV_HIP(hipGetLastError());                                                                                 \
+        return SPMV_OK;                                                                                              \
+    }
+#define SPMV_PANEL_RING(U, NS) SPMV_PANEL_RING_T(U, NS, false) SPMV_PANEL_RING_T(U, NS, true)
+        SPMV_PANEL_RING(4, 4)
+        SPMV_PANEL_RING(4, 6)
+        SPMV_PANEL_RING(2, 4)
+        SPMV_PANEL_RING(2, 6)
+#undef SPMV_PANEL_RING
+#undef SPMV_PANEL_RING_T
+        SPMV_FAIL(SPMV_ERR_INVALID, "panel kernel: ring of %d slots with unroll %d is not instantiated", pipe, unroll);
+    }
     // gather-first is instantiated for the chunk sizes that are tried; the others take the stream-first order
     const int pp = (pipe == 2 && (unroll == 4 || unroll == 8 || (unroll == 16 && layout == 3))) ? 2 : 1;
     if (pipe && !gated && (layout == 0 || layout == 3))
@@ -1194,6 +1359,16 @@ static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, doubl
         SPMV_HIP(hipGetLastError());                                                                                 \
         return SPMV_OK;                                                                                              \
     }
+        if (A->pb_trace && unroll == 8 && layout == 3 && pp == 2 && !trial)
+        {
+            SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_kernel<8, false, 3, 0, 2, false, true>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160008));
+            hipLaunchKernelGGL((csr_panel_kernel<8, false, 3, 0, 2, false, true>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream,
+                               A->pb_gstart, A->pb_ngroups, A->a, arg_col, A->pb_row, A->pb_val, x, y, gate, pop, nchunk, skew, pace_fp,
+                               pace_slack, pk.sbase, pk.soff, pk.rowbits, ex.overwrite ? 1 : 0, ex.dot_w, ex.dot_out, ctl);
+            SPMV_HIP(hipGetLastError());
+            return SPMV_OK;
+        }
 #define SPMV_PANEL_PIPE(U, LY, PP) SPMV_PANEL_PIPE_T(U, LY, PP, false) SPMV_PANEL_PIPE_T(U, LY, PP, true)
         SPMV_PANEL_PIPE(2, 0, 1)
         SPMV_PANEL_PIPE(4, 0, 1)

@@ -126,7 +126,10 @@ __global__ __launch_bounds__(kBlock) void csc_kernel(int ncol, const int32_t* __
 }
 
 // ---- DIA: one lane per row, diagonals left to right from y[i] (bit-identical to orc_dia_spmv_fma) ------------
-// The bound check is against nrow, as in the reference (src/mat_vec.cpp:140).
+// The column bound is min(nrow, ncol): the reference checks `j < nrow` (src/mat_vec.cpp:140) while x has ncol entries,
+// so for nrow > ncol it reads past the end of x (times a stored 0.0: DIAMatrix(CSR) never stores such an entry); here
+// those slots are skipped, which is the same sum whenever the reference's overread is finite and cannot fault.  For
+// nrow < ncol the reference's bound drops columns [nrow, ncol) and so does this kernel.
 // The reference stores the diagonals ROW-major (values[i*ndiags + d], src/matrix.cpp:721): a lane walking its own
 // row would make every load instruction touch 64 different lines.  So a workgroup copies a tile of 256 rows x 16
 // diagonals (one 128-byte line per row) into LDS with 16 consecutive lanes per line, and every lane then reads its
@@ -136,7 +139,7 @@ constexpr int kDiaChunk = 16;
 // WIDE: 16-byte loads (two adjacent diagonals per lane, 8 lanes per 128-byte line); needs an even ndiags so that every
 // pair is 16-byte aligned.  8-byte accesses reach only ~0.65x of the streaming rate on this chip.
 template <bool WIDE>
-__global__ __launch_bounds__(kBlock) void dia_kernel(int nrow, int ndiags, const int32_t* __restrict__ offsets,
+__global__ __launch_bounds__(kBlock) void dia_kernel(int nrow, int jmax, int ndiags, const int32_t* __restrict__ offsets,
                                                      const double* __restrict__ val, const double* __restrict__ x,
                                                      double* __restrict__ y)
 {
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void dia_kernel(int nrow, int ndiags, const
             for (int d = 0; d < dn; ++d)
             {
                 const int j = i + offsets[d0 + d];  // wave-uniform address: scalar load
-                if (j >= 0 && j < nrow) acc = fma(tile[threadIdx.x * (kDiaChunk + 1) + d], x[j], acc);
+                if (j >= 0 && j < jmax) acc = fma(tile[threadIdx.x * (kDiaChunk + 1) + d], x[j], acc);
             }
     }
     if (i < nrow) y[i] = acc;
@@ -324,9 +327,9 @@ int dia_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
     if (A->nrow == 0 || A->k == 0) return SPMV_OK;
     const dim3 grid((unsigned)ceil_div(A->nrow, kBlock));
     if (A->k % 2 == 0 && (((uintptr_t)A->v) & 15) == 0)
-        hipLaunchKernelGGL(dia_kernel<true>, grid, dim3(kBlock), 0, ctx->stream, A->nrow, A->k, A->a, A->v, x, y);
+        hipLaunchKernelGGL(dia_kernel<true>, grid, dim3(kBlock), 0, ctx->stream, A->nrow, std::min(A->nrow, A->ncol), A->k, A->a, A->v, x, y);
     else
-        hipLaunchKernelGGL(dia_kernel<false>, grid, dim3(kBlock), 0, ctx->stream, A->nrow, A->k, A->a, A->v, x, y);
+        hipLaunchKernelGGL(dia_kernel<false>, grid, dim3(kBlock), 0, ctx->stream, A->nrow, std::min(A->nrow, A->ncol), A->k, A->a, A->v, x, y);
     SPMV_HIP(hipGetLastError());
     return SPMV_OK;
 }

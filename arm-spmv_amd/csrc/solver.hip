@@ -120,7 +120,11 @@ __global__ __launch_bounds__(kBlock) void pcg_update_kernel(int64_t n, int k, co
     slot_sum2_block(s->pq[k & 3], s->rz[k & 3], &pq, &rz_k);
     if (!(pq > 0.0))
     {
-        if (blockIdx.x == 0 && threadIdx.x == 0) s->status = 1.0;
+        // Breakdown (the matrix is not positive definite) only while there is a residual to speak of.  Once r is zero
+        // or has shrunk to where r.r and p.Ap underflow (the system was solved between two looks of the host), p.Ap = 0
+        // is the end of the iteration, not an error: x and r stay, r.r of the next iteration stays at its cleared 0,
+        // so every queued iteration ends here as well and the host reads a residual of 0.
+        if (blockIdx.x == 0 && threadIdx.x == 0 && slot_sum(s->rr[k & 3]) > 1e-60 * slot_sum(s->bb)) s->status = 1.0;
         return;
     }
     const double alpha = rz_k / pq;
@@ -189,7 +193,8 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, int k, con
     slot_sum2_block(s->pq[k & 3], s->rr[k & 3], &pq, &rr_k);
     if (!(pq > 0.0))
     {
-        if (blockIdx.x == 0 && threadIdx.x == 0) s->status = 1.0;
+        // a breakdown only while there is a residual to speak of (see pcg_update_kernel)
+        if (blockIdx.x == 0 && threadIdx.x == 0 && rr_k > 1e-60 * slot_sum(s->bb)) s->status = 1.0;
         return;  // uniform over the grid: every thread read the same scalar
     }
     const double alpha = rr_k / pq;
@@ -217,7 +222,8 @@ __global__ __launch_bounds__(kBlock) void cg_update2_kernel(int64_t n, int k, co
     slot_sum2_block(s->pq[k & 3], s->rr[k & 3], &pq, &rr_k);
     if (!(pq > 0.0))
     {
-        if (blockIdx.x == 0 && threadIdx.x == 0) s->status = 1.0;
+        // a breakdown only while there is a residual to speak of (see pcg_update_kernel)
+        if (blockIdx.x == 0 && threadIdx.x == 0 && rr_k > 1e-60 * slot_sum(s->bb)) s->status = 1.0;
         return;
     }
     const double  alpha  = rr_k / pq;
@@ -489,6 +495,8 @@ int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int m
             {
                 if ((rc = fetch(k & 3)) != SPMV_OK) break;
                 rr = host_sum(h.rr[k & 3]);
+                // the status word is only set with r != 0 (an exactly solved system ends the queued iterations quietly, see
+                // the update kernels); it is looked at first because a breakdown leaves the next r.r at its cleared 0
                 if (h.status != 0.0)
                 {
                     set_error("spmv_cg: p.Ap <= 0 at or before iteration %d: the matrix is not positive definite", k);

@@ -63,7 +63,7 @@ int mat_validate(const spmv_mat* m)
             if (total) hipLaunchKernelGGL(check_range_kernel, dim3(grid_for(total)), dim3(kBlock), 0, s, m->b, total, m->ncol, flags);
             break;
         }
-        case SPMV_FMT_DIA: break;  // offsets are bounds-checked by the product itself
+        case SPMV_FMT_DIA: break;  // the product bounds every column by min(nrow, ncol) itself (kernels_misc.hip)
         default: SPMV_FAIL(SPMV_ERR_INVALID, "unknown format %d", m->format);
     }
     SPMV_HIP(hipGetLastError());

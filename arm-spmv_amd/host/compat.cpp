@@ -60,11 +60,11 @@ spmv_ctx* Engine::ctx(int device)
     return ctxs_[(size_t)device];
 }
 
-void Engine::adopt(const void* key, int device, spmv_mat* m)
+void Engine::adopt(const void* key, int device, spmv_mat* m, uint64_t fingerprint, const void* owner)
 {
     auto it = cache_.find({key, device});
-    if (it != cache_.end()) spmv_mat_destroy(it->second);
-    cache_[{key, device}] = m;
+    if (it != cache_.end()) spmv_mat_destroy(it->second.mat);
+    cache_[{key, device}] = Entry{m, fingerprint, owner};
 }
 
 void Engine::invalidate(const void* key)
@@ -72,9 +72,9 @@ void Engine::invalidate(const void* key)
     if (!key) return;
     for (auto it = cache_.begin(); it != cache_.end();)
     {
-        if (it->first.first == key)
+        if (it->first.first == key || it->second.owner == key)
         {
-            spmv_mat_destroy(it->second);
+            spmv_mat_destroy(it->second.mat);
             it = cache_.erase(it);
         }
         else
@@ -105,7 +105,7 @@ void Engine::apply_host(int device, const spmv_mat* A, const double* x, int64_t 
 
 Engine::~Engine()
 {
-    for (auto& kv : cache_) spmv_mat_destroy(kv.second);
+    for (auto& kv : cache_) spmv_mat_destroy(kv.second.mat);
     for (auto& kv : pool_) spmv_vec_destroy(kv.second);
     for (spmv_ctx* c : ctxs_) spmv_ctx_destroy(c);
 }
@@ -130,6 +130,62 @@ void drop(T*& p)
     p = 0;
 }
 
+// Fingerprint of a host container for the device-copy cache (engine.hpp): dimensions, array addresses and up to
+// 2048 evenly spaced elements of every array (first and last included).  Cheap enough for every call (a few
+// thousand reads next to the PCIe copies of x and y); catches a re-pointed or re-allocated container and edits that
+// touch a sampled element.  An in-place edit that dodges every sample needs spmv_compat_invalidate().
+inline uint64_t fp_mix(uint64_t h, uint64_t v)
+{
+    h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+    return h * 0xBF58476D1CE4E5B9ull;
+}
+template <class T>
+uint64_t fp_array(uint64_t h, const T* p, size_t n)
+{
+    h = fp_mix(h, (uint64_t)(uintptr_t)p);
+    h = fp_mix(h, (uint64_t)n);
+    if (!p || n == 0) return h;
+    const size_t samples = std::min<size_t>(n, 2048);
+    for (size_t k = 0; k < samples; ++k)
+    {
+        const size_t i = samples > 1 ? (size_t)(((unsigned __int128)k * (n - 1)) / (samples - 1)) : 0;
+        uint64_t     bits = 0;
+        std::memcpy(&bits, p + i, sizeof(T));
+        h = fp_mix(h, bits);
+    }
+    return h;
+}
+uint64_t fingerprint(const COOMatrix& A)
+{
+    uint64_t h = fp_mix(fp_mix(fp_mix(1, (uint64_t)A.nrow), (uint64_t)A.ncol), (uint64_t)A.nnz);
+    const size_t n = A.nnz > 0 ? (size_t)A.nnz : 0;
+    return fp_array(fp_array(fp_array(h, A.row_ind, n), A.col_ind, n), A.values, n);
+}
+uint64_t fingerprint(const CSRMatrix& A)
+{
+    uint64_t h = fp_mix(fp_mix(2, (uint64_t)A.nrow), (uint64_t)A.ncol);
+    const size_t n = (A.row_ptr && A.nrow >= 0) ? (size_t)std::max(A.row_ptr[A.nrow], 0) : 0;
+    return fp_array(fp_array(fp_array(h, A.row_ptr, A.row_ptr ? (size_t)A.nrow + 1 : 0), A.col_ind, n), A.values, n);
+}
+uint64_t fingerprint(const CSCMatrix& A)
+{
+    uint64_t h = fp_mix(fp_mix(3, (uint64_t)A.nrow), (uint64_t)A.ncol);
+    const size_t n = (A.col_ptr && A.ncol >= 0) ? (size_t)std::max(A.col_ptr[A.ncol], 0) : 0;
+    return fp_array(fp_array(fp_array(h, A.col_ptr, A.col_ptr ? (size_t)A.ncol + 1 : 0), A.row_ind, n), A.values, n);
+}
+uint64_t fingerprint(const ELLMatrix& A)
+{
+    uint64_t h = fp_mix(fp_mix(fp_mix(fp_mix(4, (uint64_t)A.nrow), (uint64_t)A.ncol), (uint64_t)A.nnz), (uint64_t)A.nonzeros_in_row);
+    const size_t n = (size_t)std::max(A.nrow, 0) * (size_t)std::max(A.nonzeros_in_row, 0);
+    return fp_array(fp_array(h, A.col_ind, n), A.values, n);
+}
+uint64_t fingerprint(const DIAMatrix& A)
+{
+    uint64_t h = fp_mix(fp_mix(fp_mix(5, (uint64_t)A.nrow), (uint64_t)A.ncol), (uint64_t)A.ndiags);
+    const size_t n = (size_t)std::max(A.nrow, 0) * (size_t)std::max(A.ndiags, 0);
+    return fp_array(fp_array(h, A.offsets, (size_t)std::max(A.ndiags, 0)), A.values, n);
+}
+
 // packed diagonal, entries in COO encounter order (src/matrix.cpp:146-153); never read by a product
 double* pack_diagonal(const COOMatrix& A)
 {
@@ -142,7 +198,7 @@ double* pack_diagonal(const COOMatrix& A)
 
 spmv_mat* device_coo(const COOMatrix& A, int device = 0)
 {
-    return Engine::get().cached(A.values, device, [&](spmv_ctx* c) {
+    return Engine::get().cached(A.values, device, fingerprint(A), &A, [&](spmv_ctx* c) {
         spmv_mat* m = nullptr;
         check(spmv_coo_upload(c, A.nrow, A.ncol, A.nnz, A.row_ind, A.col_ind, A.values, &m), "spmv_coo_upload");
         return m;
@@ -290,7 +346,7 @@ static void csr_from_coo(CSRMatrix& dst, const COOMatrix& A)
     dst.values   = new double[A.nnz > 0 ? A.nnz : 1];
     dst.diagonal = pack_diagonal(A);
     check(spmv_mat_download(csr, dst.row_ptr, dst.col_ind, dst.values), "spmv_mat_download(csr)");
-    E.adopt(dst.values, 0, csr);
+    E.adopt(dst.values, 0, csr, fingerprint(dst), &dst);
 }
 
 CSRMatrix::CSRMatrix(const CSRMatrix& A) { csr_copy_from(*this, A); }
@@ -423,7 +479,7 @@ static void ell_from_coo(ELLMatrix& dst, const COOMatrix& A)
     dst.values          = new double[total > 0 ? total : 1];
     dst.diagonal        = pack_diagonal(A);
     check(spmv_mat_download(ell, nullptr, dst.col_ind, dst.values), "spmv_mat_download(ell)");
-    E.adopt(dst.values, 0, ell);
+    E.adopt(dst.values, 0, ell, fingerprint(dst), &dst);
 }
 
 ELLMatrix::ELLMatrix(const ELLMatrix& A) { ell_copy_from(*this, A); }
@@ -533,7 +589,7 @@ void COOMatirxMatVector(const COOMatrix& A, const Vector& x, Vector& y)
 
 static spmv_mat* device_csr(const CSRMatrix& A, int device = 0)
 {
-    return Engine::get().cached(A.values, device, [&](spmv_ctx* c) {
+    return Engine::get().cached(A.values, device, fingerprint(A), &A, [&](spmv_ctx* c) {
         spmv_mat* m = nullptr;
         check(spmv_csr_upload(c, A.nrow, A.ncol, A.row_ptr, A.col_ind, A.values, &m), "spmv_csr_upload");
         return m;
@@ -547,7 +603,7 @@ void CSRMatrixMatVector(const CSRMatrix& A, const Vector& x, Vector& y)
 
 static spmv_mat* device_csc(const CSCMatrix& A)
 {
-    return Engine::get().cached(A.values, 0, [&](spmv_ctx* c) {
+    return Engine::get().cached(A.values, 0, fingerprint(A), &A, [&](spmv_ctx* c) {
         spmv_mat* m = nullptr;
         check(spmv_csc_upload(c, A.nrow, A.ncol, A.col_ptr, A.row_ind, A.values, &m), "spmv_csc_upload");
         return m;
@@ -561,7 +617,7 @@ void CSCMatrixMatVector(const CSCMatrix& A, const Vector& x, Vector& y)
 
 static spmv_mat* device_ell(const ELLMatrix& A)
 {
-    return Engine::get().cached(A.values, 0, [&](spmv_ctx* c) {
+    return Engine::get().cached(A.values, 0, fingerprint(A), &A, [&](spmv_ctx* c) {
         spmv_mat* m = nullptr;
         check(spmv_ell_upload(c, A.nrow, A.ncol, A.nonzeros_in_row, A.nnz, A.col_ind, A.values, &m), "spmv_ell_upload");
         return m;
@@ -575,7 +631,7 @@ void ELLMatrixMatVector(const ELLMatrix& A, const Vector& x, Vector& y)
 
 static spmv_mat* device_dia(const DIAMatrix& A)
 {
-    return Engine::get().cached(A.values, 0, [&](spmv_ctx* c) {
+    return Engine::get().cached(A.values, 0, fingerprint(A), &A, [&](spmv_ctx* c) {
         spmv_mat* m = nullptr;
         check(spmv_dia_upload(c, A.nrow, A.ncol, A.ndiags, A.offsets, A.values, &m), "spmv_dia_upload");
         return m;

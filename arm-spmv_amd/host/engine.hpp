@@ -25,18 +25,28 @@ public:
     int       ngpus();
     spmv_ctx* ctx(int device);  // created on first use
 
-    // device copy of a host container, keyed by its `values` pointer; `make` uploads on a miss
+    // Device copy of a host container, keyed by its `values` pointer and checked against a fingerprint of the
+    // container (dimensions, array addresses, a sample of the array contents: fingerprint() in compat.cpp).  The
+    // reference's products read the public host arrays on every call; a cached copy must not outlive an edit, a
+    // re-pointed `values` or an address that was freed and handed out again: on a mismatch the copy is rebuilt.
+    // `owner` = address of the container object, so that spmv_compat_invalidate(&A) works as well as (A.values).
     template <class Make>
-    spmv_mat* cached(const void* key, int device, Make make)
+    spmv_mat* cached(const void* key, int device, uint64_t fingerprint, const void* owner, Make make)
     {
         auto it = cache_.find({key, device});
-        if (it != cache_.end()) return it->second;
+        if (it != cache_.end())
+        {
+            if (it->second.fingerprint == fingerprint) return it->second.mat;
+            spmv_mat_destroy(it->second.mat);  // stale: the host arrays changed under the key
+            cache_.erase(it);
+        }
         spmv_mat* m = make(ctx(device));
-        cache_[{key, device}] = m;
+        cache_[{key, device}] = Entry{m, fingerprint, owner};
         return m;
     }
-    void adopt(const void* key, int device, spmv_mat* m);  // conversions hand their result to the cache
-    void invalidate(const void* key);                     // all devices
+    // conversions hand their result to the cache (fingerprint 0 = not known yet: taken on the first product)
+    void adopt(const void* key, int device, spmv_mat* m, uint64_t fingerprint, const void* owner);
+    void invalidate(const void* key_or_owner);  // all devices; matches the `values` pointer or the container address
 
     // y += A*x with host vectors: upload x and y, apply, download y (synchronous)
     void apply_host(int device, const spmv_mat* A, const double* x, int64_t nx, double* y, int64_t ny);
@@ -48,7 +58,13 @@ public:
 private:
     Engine() = default;
     std::vector<spmv_ctx*>                               ctxs_;
-    std::map<std::pair<const void*, int>, spmv_mat*>     cache_;
+    struct Entry
+    {
+        spmv_mat*   mat;
+        uint64_t    fingerprint;
+        const void* owner;
+    };
+    std::map<std::pair<const void*, int>, Entry>         cache_;
     std::map<std::tuple<int, int, int64_t>, spmv_vec*>   pool_;
     int                                                  ngpus_ = -1;
 };

@@ -189,6 +189,26 @@ int main(int argc, char* argv[])
         y.Fill(0);
         CSRMatrixMatVector(B, x, y);
         verify("CSR");
+        if (o.verify && B.row_ptr[B.nrow] > 0)
+        {
+            // The reference reads the host arrays on every call (src/mat_vec.cpp:46-52): an edit between two calls
+            // must reach the product although the device copy of B is cached.  Doubling entry 0 (row r0, column c0)
+            // adds values[0] * x[c0] to y[r0] and nothing else.
+            int r0 = 0;
+            while (B.row_ptr[r0 + 1] == 0) ++r0;
+            const double before = y.values[r0], v0 = B.values[0];
+            B.values[0] = 2.0 * v0;
+            y.Fill(0);
+            CSRMatrixMatVector(B, x, y);
+            const double want = before + v0 * x.values[B.col_ind[0]];
+            const double d    = fabs(y.values[r0] - want) / (fabs(want) + 1e-300);
+            printf("### CSR EDIT-IN-PLACE VERIFY |y[r0] - expected|/|expected| = %.3e %s\n", d, d <= 1e-10 ? "OK" : "FAILED");
+            if (d > 1e-10) exit(2);
+            B.values[0] = v0;
+            y.Fill(0);
+            CSRMatrixMatVector(B, x, y);
+            verify("CSR (edit undone)");
+        }
         if (o.numa)
         {
             y.Fill(0);

@@ -234,7 +234,7 @@ def main() -> None:
         kernel_names = {1: "csr_vector_kernel", 2: "csr_ldswin_kernel", 3: "csr_scalar_kernel", 4: "csr_panel_kernel"}
         panel = None
         if int(info.kernel) == 4:
-            panel = {k: A.get_param("panel_" + k) for k in ("rows", "width", "groups", "layout", "unroll", "pipe", "stagger", "pace_ns", "skew", "bytes")}
+            panel = {k: A.get_param("panel_" + k) for k in ("rows", "width", "groups", "layout", "unroll", "pipe", "sync", "stagger", "pace_ns", "skew", "bytes")}
         out = {
             "metric": "SpMV GFLOP/s + achieved HBM GB/s (% roofline), fp64 CSR, 1/2/4/8 MI355X",
             "value": round(gflops, 3),

@@ -16,7 +16,9 @@
 // Differences a caller can observe (all documented in INTEGRATION.md):
 //   * each *MatVector call copies x and y to the GPU and y back (the signature hands over host
 //     memory); the matrix itself is uploaded once and cached per container (keyed by its `values`
-//     pointer).  After editing a matrix's arrays in place call spmv_compat_invalidate(&A).
+//     pointer and re-checked on every call against a fingerprint: dimensions, array addresses and a sample of the
+//     array contents).  An in-place edit that misses every sampled element needs spmv_compat_invalidate(A.values)
+//     — or (&A) — before the next product.
 //   * the `...Numa` drivers shard over GPUs instead of NUMA nodes: `nthreads` = number of shards,
 //     shard i lives on GPU i % ngpus (reference: node i % numanodes, src/mat_vec.cpp:242).  They
 //     print the same `### <FMT> NUMA GFLOPS = %.5f` line.  Unlike the reference (which drops the

@@ -236,6 +236,30 @@ def test_dia_matches_reference_golden(ctx, orc):
     assert np.array_equal(y1, ref)
 
 
+@pytest.mark.parametrize("tall", [True, False])
+def test_dia_rectangular_bounds_columns_by_min_nrow_ncol(ctx, orc, tall):
+    """rect64x48 and its transpose through DIA.  The reference bounds columns by nrow (src/mat_vec.cpp:140): for a
+    tall matrix it reads x[ncol..nrow) (times stored zeros), for a wide one it drops columns >= nrow.  The oracle
+    gets x padded with zeros to max(nrow, ncol), which makes its overread defined; the kernel must give the same
+    sums without touching anything past x's ncol entries (x is the last allocation made before the product and
+    non-finite padding would show)."""
+    c = cases.rect64x48()
+    nrow, ncol, row, col = (c["nrow"], c["ncol"], c["row"], c["col"]) if tall else (c["ncol"], c["nrow"], c["col"], c["row"])
+    rp, cc, cv = ol.coo_to_csr(orc, nrow, row, col, c["val"])
+    off, dv = ol.csr_to_dia(orc, nrow, ncol, rp, cc, cv)
+    x = np.random.default_rng(12).uniform(0.5, 1.5, ncol)
+    xpad = np.zeros(max(nrow, ncol))
+    xpad[:ncol] = x
+    ref = np.zeros(nrow)
+    ol.dia_spmv(orc, nrow, ol.i32(off), ol.f64(dv), xpad, ref, fma=True)
+    A = ctx.dia(nrow, ncol, off, dv)
+    dx, dy = ctx.vector_from(x), ctx.vector(nrow)
+    dy.fill(0.0)
+    ctx.apply(A, dx, dy)
+    ctx.sync()
+    assert np.array_equal(dy.download(), ref), ("tall" if tall else "wide")
+
+
 # ---------------------------------------------------------------------------------- BLAS-1
 def test_dot_and_axpby(ctx, orc):
     g = golden("tri8")

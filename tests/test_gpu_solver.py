@@ -143,6 +143,23 @@ def test_cg_reports_a_matrix_that_is_not_positive_definite(ctx, pkg):
         ctx.cg(rect, b, x, max_iter=10, rel_tol=1e-8)
 
 
+def test_cg_exact_convergence_between_host_checks_is_not_a_breakdown(ctx, pkg):
+    """A = 2 I is solved exactly by the first step: r = 0, and the iterations queued up to the next look of the host
+    (check_every = 16) run with p = 0, p.Ap = 0.  That is convergence, not `not positive definite`.  Same with a
+    diagonal A under Jacobi (D^-1 A = I)."""
+    n = 4096
+    rp = np.arange(n + 1, dtype=np.int32)
+    cc = np.arange(n, dtype=np.int32)
+    b_host = np.random.default_rng(4).uniform(-1, 1, n)
+    for diag, jacobi in ((np.full(n, 2.0), False), (np.random.default_rng(5).uniform(0.5, 50.0, n), True)):
+        A = ctx.csr(n, n, rp, cc, diag)
+        b, x = ctx.vector_from(b_host), ctx.vector(n)
+        x.fill(0.0)
+        iters, relres = ctx.cg(A, b, x, max_iter=64, rel_tol=1e-12, check_every=16, jacobi=jacobi)
+        assert iters <= 16 and relres <= 1e-12, (jacobi, iters, relres)
+        np.testing.assert_allclose(x.download(), b_host / diag, rtol=1e-14, atol=0)
+
+
 def test_sharded_cg_with_the_engine_as_local_ops():
     """dist.cg_sharded + dist.HipShardOps on one GPU (world 1; the N > 1 collectives are covered on CPU with gloo in
     tests/test_dist_gloo.py): same answer as the single-device spmv_cg.  In a child process, because torch must
