@@ -622,6 +622,8 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         m->pb_two_per_cu = (int32_t)value;
     else if (!strcmp(name, "panel_sync"))
         m->pb_sync = (int32_t)value;
+    else if (!strcmp(name, "panel_legacy"))
+        m->pb_legacy = (int32_t)value;
     else if (!strcmp(name, "panel_trace"))
         m->pb_trace = (int32_t)value;
     else

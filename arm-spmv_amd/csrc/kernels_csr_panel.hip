@@ -407,6 +407,7 @@ struct GateLds
     unsigned released;      // chunks [0, released) are complete on this XCD
     unsigned lock;          // 1 while a wavefront of this workgroup polls the global counter
     unsigned wave_done[16]; // per chunk slot: wavefronts of this workgroup that finished the chunk
+    unsigned issued[2];     // split barrier (SYNCT 2): lanes that have issued the loads of the even / odd chunks
 };
 
 __device__ __forceinline__ unsigned gate_read(const unsigned* p)
@@ -449,7 +450,7 @@ __device__ unsigned g_panel_trace[kTraceWgs * 2 * kTraceChunks * kTraceStamps];
 
 // TRIAL: same code under another name, so that the launches of the build-time trials (panel_choose_pace) show up
 // apart from the products in a kernel trace
-template <int UNROLL, bool GATED, int LAYOUT, int ABLATE = 0, int PIPE = 0, bool TRIAL = false, bool TRACE = false>
+template <int UNROLL, bool GATED, int LAYOUT, int ABLATE = 0, int PIPE = 0, bool TRIAL = false, bool TRACE = false, int SYNCT = -1>
 __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t* __restrict__ gstart, int ngroups,
                                                                   const int32_t* __restrict__ row_ptr,
                                                                   const int32_t* __restrict__ pcol,
@@ -484,6 +485,7 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
         const int r0   = gstart[g];
         const int rows = gstart[g + 1] - r0;
         for (int i = threadIdx.x; i < rows; i += kPanelThreads) acc[i] = 0.0;
+        if (SYNCT == 2 && threadIdx.x == 0) gl.issued[0] = gl.issued[1] = 0u;
         unsigned*       gate_x = nullptr;
         const unsigned* pop_x  = nullptr;
         if constexpr (GATED)
@@ -519,8 +521,19 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
             // chunk; 2 = a wavefront that is behind the schedule raises its issue priority.  Without either, the oldest-
             // first issue arbitration lets wavefront 0 start the next chunk while wavefront 15 is still issuing this
             // one, which then takes twice as long (tools/trace_panel.py: 2 % of the chunks take 15 us instead of 7).
-            const int sync_mode = (pace_slack >> 18) & 3;
+            const int sync_mode = SYNCT >= 0 ? SYNCT : (pace_slack >> 18) & 3;  // SYNCT: the same choice at compile time
             if (sync_mode == 1) __syncthreads();
+            if constexpr (SYNCT == 2 && PIPE == 2)
+            {
+                // split barrier through a counter in LDS: start chunk b when all 16 wavefronts have ISSUED the loads of
+                // chunk b-1 (nobody waits for the last one's adds and stream latency).  Bounded spin.
+                if (b > 0 && lane == 0)
+                {
+                    const unsigned need  = (unsigned)kPanelThreads * (unsigned)((b - 1) / 2 + 1);
+                    int            spins = 0;
+                    while (lds_read(&gl.issued[(b - 1) & 1]) < need && ++spins < (1 << 18)) __builtin_amdgcn_s_sleep(1);
+                }
+            }
             if (sync_mode == 2 && pace_fp)
             {
                 const unsigned long long due = t0 + (((unsigned long long)b * pace_fp) >> 10);
@@ -566,6 +579,12 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
                 // unconditional (the last chunk re-reads itself): behind a branch, the wait-count bookkeeping of the
                 // compiler would make the adds wait for these loads as well
                 nxt.load_raw(pcol, prow, pval, b + 1 < nfull ? e + STEP : e);
+                if constexpr (SYNCT == 2)
+                {
+                    // all 64 lanes (no lane mask, no branch), right behind the loads
+                    (void)__builtin_amdgcn_atomic_inc32(&gl.issued[b & 1], 0xFFFFFFFFu, __ATOMIC_RELAXED, "workgroup");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 if constexpr (TRACE)
                 {
                     tr[1] = (unsigned)__builtin_amdgcn_s_memrealtime();
@@ -665,157 +684,6 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
     if (ABLATE && sink == 123.456) y[0] = sink;  // keeps the ablated products alive
 }
 
-// ---- the product, ring-pipelined (packed layout only) -------------------------------------------------------
-// What the two-stage pipelines above leave on the table (profiles/r01_pmc_csr_c2_stalls.txt): a chunk costs the CU
-// ~5.9 us of L2->L1 line transfers (gathers + stream), ~2.5 us of ds_add_f64 and ~4 us of HBM time, and with one
-// chunk of look-ahead the three run largely one after the other (8.4 us per chunk).  Here every wavefront keeps a
-// ring of NS chunks of packed entries in registers:
-//     step b:   issue the gathers of chunk b+1   (its entries arrived a step ago)
-//               issue the streamed loads of chunk b+NS-1 into the slot chunk b-1 has left
-//               ds_add_f64 the products of chunk b (its gathers were issued a step ago)
-// so the vector memory pipe always has the next chunk's gathers queued while the LDS works on the current one, and
-// the HBM latency of the stream has NS-2 whole steps to run.  Vector loads return in order; the order above makes
-// the adds of chunk b wait for gathers(b) and stream(b+NS-2) only, both a full step old.
-// The ring is unrolled UF = lcm(NS, 2) steps so that slot and gather-buffer indices are compile-time constants.
-template <int U, int NS, bool TRIAL = false>
-__global__ __launch_bounds__(kPanelThreads) void csr_panel_ring_kernel(
-    const int32_t* __restrict__ gstart, int ngroups, const uint32_t* __restrict__ pack, const double* __restrict__ pval,
-    const double* __restrict__ x, double* __restrict__ y, unsigned long long pace_fp, int xcd_offsets,
-    const int32_t* __restrict__ sbase, const int32_t* __restrict__ soff, int rowbits, unsigned pad_row, int overwrite,
-    const double* __restrict__ dot_w, double* __restrict__ dot_out, unsigned* __restrict__ ctl)
-{
-    extern __shared__ double acc[];
-    constexpr int STEP = U * kPanelThreads;
-    constexpr int UF   = (NS % 2 == 0) ? NS : 2 * NS;
-    const int      lane = threadIdx.x & 63;
-    const unsigned mask = (1u << rowbits) - 1u;
-    if (ctl && pace_fp) pace_fp = (pace_fp * __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 10;
-    const unsigned long long phase = (pace_fp && (xcd_offsets & 1)) ? ((unsigned long long)xcd_id() * pace_fp) / kNumXcd : 0ull;
-    unsigned lag_max = 0;
-    struct Slot
-    {
-        unsigned w[U];
-        double   v[U];
-    };
-    for (int g = blockIdx.x; g < ngroups; g += gridDim.x)
-    {
-        const int r0   = gstart[g];
-        const int rows = gstart[g + 1] - r0;
-        for (int i = threadIdx.x; i < rows; i += kPanelThreads) acc[i] = 0.0;
-        __syncthreads();
-        const int s0 = soff[g], nslices = soff[g + 1] - s0;
-        const int nfull = nslices / U;
-        const int32_t* __restrict__ sb = sbase + s0;
-        // uniform bases + one 32-bit lane offset: the loads take the scalar-base form, no per-load address arithmetic
-        const uint32_t* __restrict__ gp = pack + (size_t)s0 * kPanelThreads;
-        const double* __restrict__ gv   = pval + (size_t)s0 * kPanelThreads;
-        const unsigned tid = threadIdx.x;
-        const unsigned long long t0 = pace_fp ? __builtin_amdgcn_s_memrealtime() : 0ull;
-        if (nfull > 0)
-        {
-            Slot   slot[NS];
-            double xv[2][U];
-            const int last = nfull - 1;
-            // the fill steps gather from slots that have not been loaded yet: word 0 = column `slice base`, a valid one
-#pragma unroll
-            for (int k = 0; k < NS; ++k)
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                {
-                    slot[k].w[u] = 0u;
-                    slot[k].v[u] = 0.0;
-                }
-            auto load = [&](Slot& s, int b) {
-                const size_t off = (size_t)min(max(b, 0), last) * STEP;  // look-ahead past either end re-reads a chunk
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                {
-                    s.w[u] = load_stream(gp + off + u * kPanelThreads + tid);
-                    s.v[u] = load_stream(gv + off + u * kPanelThreads + tid);
-                }
-            };
-            auto gather = [&](const Slot& s, int b, double(&xo)[U]) {
-                const int32_t* __restrict__ base = sb + min(max(b, 0), last) * U;
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                {
-                    const unsigned byte_off = (unsigned)(base[u] + (int)(s.w[u] >> rowbits)) << 3;  // ncol < 2^29 (host check)
-                    xo[u] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(x) + byte_off);
-                }
-            };
-            // chunks outside [0, nfull) (pipeline fill and the rounding of the last turn) add into the pads' spare
-            // accumulator; mask/or are scalars, so the address stays a per-lane value and the adds stay plain ds_add_f64
-            auto add = [&](const Slot& s, const double(&xi)[U], bool valid) {
-                const unsigned m = valid ? mask : 0u, o = valid ? 0u : pad_row;
-#pragma unroll
-                for (int u = 0; u < U; ++u) atomicAdd(&acc[(s.w[u] & m) | o], s.v[u] * xi[u]);  // ds_add_f64
-            };
-            // One body for fill, steady state and drain (no prologue: a separate one would meet the steady state at the
-            // loop header with a different order of outstanding loads and the compiler's wait counts would turn
-            // conservative there).  Step b: gathers(b+1), stream(b+NS-1), adds(b); b runs from -NS.
-            for (int b0 = -NS; b0 < nfull; b0 += UF)
-            {
-#pragma unroll
-                for (int k = 0; k < UF; ++k)
-                {
-                    const int b = b0 + k;
-                    if (xcd_offsets & 2) __syncthreads();  // keep the wavefronts of the workgroup in the same step
-                    if (pace_fp && b >= 0)
-                    {
-                        // the gathers of chunk c (c >= 1) do not start before t0 + c * pace on the chip-wide 100 MHz
-                        // clock.  Every operand is uniform: scalar branches, no lane masks.
-                        const unsigned long long target = t0 + (((unsigned long long)(b + 1) * pace_fp + phase) >> 10);
-                        const unsigned long long now    = __builtin_amdgcn_s_memrealtime();
-                        if (now > target) lag_max = max(lag_max, (unsigned)min(now - target, 0xFFFFFFFFull));
-                        int spins = 0;
-                        while (__builtin_amdgcn_s_memrealtime() < target && ++spins < (1 << 16)) __builtin_amdgcn_s_sleep(1);
-                    }
-                    gather(slot[(k + 1) % NS], b + 1, xv[(k + 1) % 2]);
-                    load(slot[(k + NS - 1) % NS], b + NS - 1);
-                    add(slot[k % NS], xv[k % 2], b >= 0 && b < nfull);
-                }
-            }
-        }
-        // slices beyond the last whole chunk
-        for (int t = nfull * U; t < nslices; ++t)
-        {
-            const unsigned w  = load_stream(gp + (size_t)t * kPanelThreads + tid);
-            const double   v  = load_stream(gv + (size_t)t * kPanelThreads + tid);
-            const double   xx = x[sb[t] + (int)(w >> rowbits)];
-            atomicAdd(&acc[w & mask], v * xx);
-        }
-        __syncthreads();
-        double part = 0.0;
-        for (int i = threadIdx.x; i < rows; i += kPanelThreads)
-        {
-            const double yn = overwrite ? acc[i] : y[r0 + i] + acc[i];
-            y[r0 + i]       = yn;
-            if (dot_w) part = fma(dot_w[r0 + i], yn, part);
-        }
-        if (dot_w)
-        {
-            part = wave_sum(part);
-            if (lane == 0) slot_add(dot_out, part);
-        }
-        __syncthreads();
-    }
-    if (ctl && pace_fp && threadIdx.x == 0)
-    {
-        __hip_atomic_fetch_max(ctl + 1, lag_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        if (__hip_atomic_fetch_add(ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1)
-        {
-            const unsigned worst = __hip_atomic_exchange(ctl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(ctl + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (worst > 2u * (unsigned)(pace_fp >> 10))  // ticks of 10 ns
-            {
-                const unsigned scale = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(ctl, min(scale + scale / 20u, 2048u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(ctl + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-}
 }  // namespace
 
 void csr_panel_free(spmv_mat* m)
@@ -1309,34 +1177,25 @@ static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, doubl
 #undef SPMV_PANEL_ABLATE
     }
     const int pipe = A->pb_pipe >= 0 ? A->pb_pipe : (A->pb_pipe_tuned > 0 ? A->pb_pipe_tuned : 1);
-    if (pipe >= 3 && layout == 3 && !gated)
+    const int sync = (pace_slack >> 18) & 3;
+    if (pipe == 2 && layout == 3 && !gated && unroll == 8 && !A->pb_legacy && !A->pb_trace)
     {
-        // ring-pipelined chunks: pipe = slots of the ring (3..6)
-        const int xcd_offsets = (((pace_slack >> 16) & 3) == 2 ? 1 : 0) | (((pace_slack >> 18) & 3) == 1 ? 2 : 0);  // bit 1: barrier per step
-#define SPMV_PANEL_RING_T(U, NS, TR)                                                                                 \
-    if (unroll == U && pipe == NS && trial == TR)                                                                    \
+        // the C2 instance: the wavefront sync is a compile-time choice (panel_legacy = 1: the run-time switch, for A/B)
+#define SPMV_PANEL_CT(SY, TR)                                                                                        \
+    if (sync == SY && trial == TR)                                                                                   \
     {                                                                                                                \
-        static std::atomic<unsigned long long> granted{0}; /* bit per device */                                      \
-        if (!((granted.load(std::memory_order_relaxed) >> ctx->device) & 1ull))                                      \
-        {                                                                                                            \
-            SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_ring_kernel<U, NS, TR>,                              \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160008));                       \
-            granted.fetch_or(1ull << ctx->device, std::memory_order_relaxed);                                        \
-        }                                                                                                            \
-        hipLaunchKernelGGL((csr_panel_ring_kernel<U, NS, TR>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream,    \
-                           A->pb_gstart, A->pb_ngroups, A->pb_pack, A->pb_val, x, y, pace_fp, xcd_offsets, pk.sbase,   \
-                           pk.soff, pk.rowbits, (unsigned)A->pb_max_rows, ex.overwrite ? 1 : 0, ex.dot_w, ex.dot_out, ctl); \
+        SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_kernel<8, false, 3, 0, 2, TR, false, SY>,                \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160008));                           \
+        hipLaunchKernelGGL((csr_panel_kernel<8, false, 3, 0, 2, TR, false, SY>), dim3(grid), dim3(kPanelThreads), lds, \
+                           ctx->stream, A->pb_gstart, A->pb_ngroups, A->a, arg_col, A->pb_row, A->pb_val, x, y, gate,  \
+                           pop, nchunk, skew, pace_fp, pace_slack, pk.sbase, pk.soff, pk.rowbits, ex.overwrite ? 1 : 0, \
+                           ex.dot_w, ex.dot_out, ctl);                                                               \
         SPMV_HIP(hipGetLastError());                                                                                 \
         return SPMV_OK;                                                                                              \
     }
-#define SPMV_PANEL_RING(U, NS) SPMV_PANEL_RING_T(U, NS, false) SPMV_PANEL_RING_T(U, NS, true)
-        SPMV_PANEL_RING(4, 4)
-        SPMV_PANEL_RING(4, 6)
-        SPMV_PANEL_RING(2, 4)
-        SPMV_PANEL_RING(2, 6)
-#undef SPMV_PANEL_RING
-#undef SPMV_PANEL_RING_T
-        SPMV_FAIL(SPMV_ERR_INVALID, "panel kernel: ring of %d slots with unroll %d is not instantiated", pipe, unroll);
+        SPMV_PANEL_CT(0, false) SPMV_PANEL_CT(1, false) SPMV_PANEL_CT(2, false) SPMV_PANEL_CT(3, false)
+        SPMV_PANEL_CT(0, true) SPMV_PANEL_CT(1, true) SPMV_PANEL_CT(2, true) SPMV_PANEL_CT(3, true)
+#undef SPMV_PANEL_CT
     }
     // gather-first is instantiated for the chunk sizes that are tried; the others take the stream-first order
     const int pp = (pipe == 2 && (unroll == 4 || unroll == 8 || (unroll == 16 && layout == 3))) ? 2 : 1;

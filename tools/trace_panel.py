@@ -29,14 +29,15 @@ def main():
     ap.add_argument("--k", type=int, default=32)
     ap.add_argument("--pace", type=int, default=-1, help="ns per chunk (-1: the trial's choice, 0: unthrottled)")
     ap.add_argument("--stagger", type=int, default=2)
-    ap.add_argument("--sync", type=int, default=0, help="0 none, 1 barrier per chunk, 2 priority to late wavefronts")
+    ap.add_argument("--sync", type=int, default=0, help="0 none, 1 barrier per chunk, 2 split barrier, 3 barrier between loads and adds")
+    ap.add_argument("--legacy", type=int, default=0, help="1: the general kernel (run-time sync switch)")
     a = ap.parse_args()
     ctx = capi.Context(0)
     ncol = a.ncol or a.n
     A = ctx.gen_csr_uniform(0, a.n, ncol, a.k, seed=1)
     x, y = ctx.gen_vector(ncol, seed=1), ctx.vector(a.n)
     y.fill(0.0)
-    for name, v in (("panel_aos", 3), ("panel_unroll", 8), ("panel_pipe", 2), ("panel_stagger", a.stagger), ("panel_sync", a.sync), ("panel_pace_ns", a.pace)):
+    for name, v in (("panel_aos", 3), ("panel_unroll", 8), ("panel_pipe", 2), ("panel_stagger", a.stagger), ("panel_sync", a.sync), ("panel_legacy", a.legacy), ("panel_pace_ns", a.pace)):
         A.set_param(name, v)
     A.set_kernel(capi.CSR_PANEL)
     pace = A.get_param("panel_pace_ns")
@@ -47,7 +48,7 @@ def main():
     WGS, CH, ST = 256, 32, 5
     t = np.array([A.get_param(f"panel_trace@{i}") for i in range(WGS * 2 * CH * ST)], dtype=np.int64).reshape(WGS, 2, CH, ST)
     A.set_param("panel_trace", 0)
-    print(f"C2-shape n={a.n} ncol={ncol}: pace {pace} ns, stagger {a.stagger}, sync {a.sync}: {ms:.4f} ms per product; traced build {ms_tr:.4f} ms")
+    print(f"C2-shape n={a.n} ncol={ncol}: pace {pace} ns, stagger {a.stagger}, sync {a.sync}, legacy {a.legacy}: {ms:.4f} ms per product; traced build {ms_tr:.4f} ms")
     d = (np.diff(t, axis=3) & 0xFFFFFFFF) / 100.0          # [wg, wave, chunk, phase] in us
     busy = ((t[..., 4] - t[..., 0]) & 0xFFFFFFFF) / 100.0   # chunk start -> next chunk's entries back
     per = (np.diff(t[..., 0], axis=2) & 0xFFFFFFFF) / 100.0

@@ -162,9 +162,11 @@ def main():
             rows = combo[10] if len(combo) > 10 else rows
             uncached = combo[11] if len(combo) > 11 else 0
             sync = combo[12] if len(combo) > 12 else 0
+            legacy = combo[13] if len(combo) > 13 else 0
 
-            def setup(A, rows=rows, width=width, srt=srt, unroll=unroll, skew=skew, pace=pace, pipe=pipe, slack=slack, aos=aos, stagger=stagger, uncached=uncached, sync=sync):
+            def setup(A, rows=rows, width=width, srt=srt, unroll=unroll, skew=skew, pace=pace, pipe=pipe, slack=slack, aos=aos, stagger=stagger, uncached=uncached, sync=sync, legacy=legacy):
                 A.set_param("panel_sync", sync)
+                A.set_param("panel_legacy", legacy)
                 A.set_param("panel_aos", aos)
                 A.set_param("panel_uncached", uncached)
                 A.set_param("panel_stagger", stagger)
@@ -178,7 +180,7 @@ def main():
                 A.set_param("panel_pipe", pipe)
                 A.set_param("panel_ablate", 0)
                 A.set_kernel(capi.CSR_PANEL)  # rebuilds the layout when the parameters changed
-            variants.append((f"panel U={unroll} skew={skew} pace={pace}ns pipe={pipe} slack={slack} layout={aos} stagger={stagger} rows={rows} uncached={uncached} sync={sync}", setup))
+            variants.append((f"panel U={unroll} skew={skew} pace={pace}ns pipe={pipe} slack={slack} layout={aos} stagger={stagger} rows={rows} uncached={uncached} sync={sync} legacy={legacy}", setup))
         for ab, what in ((1, "no LDS adds"), (2, "gathers always hit L1"), (3, "neither")) if a.ablate else ():
             def setup(A, ab=ab):
                 for k, v in (("panel_rows", 0), ("panel_width", 0), ("panel_sort", 1), ("panel_unroll", 8), ("panel_skew", 0),
@@ -191,7 +193,7 @@ def main():
                 variants.append((f"ldswin L={lanes}", lambda A, lanes=lanes: A.set_kernel(capi.CSR_LDSWIN, lanes)))
         sweep(ctx, A, x, y, variants, a.rounds, a.reps, algorithmic_bytes("csr", n, ncol, n * k), n * k)
         for name, v in (("panel_aos", 3), ("panel_unroll", 0), ("panel_pace_ns", -1), ("panel_pipe", -1), ("panel_skew", 0),
-                        ("panel_pace_slack", 0), ("panel_ablate", 0), ("panel_stagger", 2), ("panel_uncached", 0), ("panel_sync", -1)):
+                        ("panel_pace_slack", 0), ("panel_ablate", 0), ("panel_stagger", 2), ("panel_uncached", 0), ("panel_sync", -1), ("panel_legacy", 0)):
             A.set_param(name, v)
         A.set_kernel(capi.CSR_PANEL)
         chosen = {k: A.get_param("panel_" + k) for k in ("rows", "groups", "layout", "unroll", "pipe", "sync", "stagger", "pace_ns", "bytes")}
