@@ -43,62 +43,213 @@ def algorithmic_bytes(fmt: str, nrow: int, ncol: int, nnz: int, k: int = 0) -> i
     raise ValueError(fmt)
 
 
-def cpu_baseline(args, synth, nrow_total: int) -> dict:
-    """Time the reference's own OpenMP CSR loop (oracle/_ref, built from the reference sources) — or, if
-    that library did not travel, our restatement of it — on a bounded sample of the SAME matrix: the first
-    `sample_rows` rows (regenerated bit-exactly on the host by the numpy twin of the device generator),
-    with the full x.  The gather footprint per entry (all of x) is therefore the benchmark's."""
+def host_topology() -> dict:
+    """sockets / NUMA nodes / physical cores of the host and of the CPUs this process may run on"""
+    import subprocess
+
+    info = {}
+    try:
+        for line in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=20).stdout.splitlines():
+            key, _, val = line.partition(":")
+            key, val = key.strip(), val.strip()
+            if key in ("Model name", "Socket(s)", "NUMA node(s)", "Core(s) per socket", "Thread(s) per core", "CPU(s)"):
+                info[key] = val
+    except (OSError, subprocess.SubprocessError):
+        pass
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    cores = set()
+    for c in allowed:
+        try:
+            base = Path(f"/sys/devices/system/cpu/cpu{c}/topology")
+            cores.add((int((base / "physical_package_id").read_text()), int((base / "core_id").read_text())))
+        except (OSError, ValueError):
+            cores.add((0, c))
+    return {
+        "model": info.get("Model name"),
+        "sockets": int(info["Socket(s)"]) if info.get("Socket(s)", "").isdigit() else None,
+        "numa_nodes": int(info["NUMA node(s)"]) if info.get("NUMA node(s)", "").isdigit() else None,
+        "cores_per_socket": int(info["Core(s) per socket"]) if info.get("Core(s) per socket", "").isdigit() else None,
+        "threads_per_core": int(info["Thread(s) per core"]) if info.get("Thread(s) per core", "").isdigit() else None,
+        "logical_cpus": int(info["CPU(s)"]) if info.get("CPU(s)", "").isdigit() else None,
+        "allowed_cpus": len(allowed),
+        "allowed_physical_cores": len(cores),
+    }
+
+
+def cpu_baseline_child(args) -> dict:
+    """The CPU leg of the report, in a process of its own (no torch: its OpenMP runtime and thread pools would be in
+    the way; OMP_PROC_BIND / OMP_PLACES have to be in the environment before libgomp starts).  Times, on the GPU box's
+    host cores, the reference's own code (oracle/_ref = the reference's sources compiled by oracle/Makefile) — or our
+    restatement where that library did not travel — on a bounded sample of the SAME matrix: the first `sample_rows`
+    rows (regenerated bit-exactly by the numpy twin of the device generator) with the full x, so the gather footprint
+    per entry is the benchmark's.  Modes:
+      openmp           CSRMatrixMatVector (src/mat_vec.cpp:44-67), one thread per allowed physical core, spread binding
+      numa_reference   CSRMatrixMatVectorNuma (src/mat_vec.cpp:230-297) as it is: 50 repetitions inside, pthreads
+                       re-created in every repetition (:274-281); its own "### CSR NUMA GFLOPS" line is what is reported
+      numa_persistent  the same sharding with persistent pinned workers (oracle/spmv_oracle.c: orc_csr_spmv_sharded)
+      single_thread_c1 BASELINE configs[0]: 10k x 10k, 16 per row, one thread, through a Matrix Market file
+    """
+    import ctypes as C
+    import tempfile
+
     import numpy as np
 
-    # the host share that goes with one GPU of the box is 16 cores; more OpenMP threads than that only
-    # oversubscribe (measured: 256 threads = 0.8 GFLOP/s, slower than 8 threads in the survey container)
-    try:
-        allowed = len(os.sched_getaffinity(0))
-    except AttributeError:
-        allowed = os.cpu_count() or 1
-    cores = max(1, min(allowed, args.cpu_threads))
-    os.environ["OMP_NUM_THREADS"] = str(cores)
-    os.environ.setdefault("OMP_PROC_BIND", "close")
+    from __graft_entry__ import load_package
+
+    synth = load_package().synth
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle_lib as ol  # the checker / baseline only — never on the product path
 
+    topo = host_topology()
+    threads = max(1, min(topo["allowed_physical_cores"], args.cpu_threads if args.cpu_threads > 0 else 1 << 30))
+    nrow_total = args.n * max(args.gpus, 1)
     m = min(args.cpu_sample_rows, args.n)
     t0 = time.perf_counter()
     row_ptr, col, val = synth.csr_uniform(0, m, nrow_total, args.k, band=args.band, seed=args.seed)
     x = synth.vec_uniform(nrow_total, seed=args.seed)
-    y = np.zeros(m)
     gen_s = time.perf_counter() - t0
-    kind = "reference"
+    nnz = int(row_ptr[-1])
+    p = ol._p
+    orc = ol.load_oracle()
     try:
         ref = ol.load_ref()
-        p = ol._p
-
-        def run():
-            ref.ref_csr_spmv(m, nrow_total, p(row_ptr), p(col), p(val), p(x), p(y))
     except OSError:
-        kind = "port"
-        orc = ol.load_oracle()
+        ref = None
+    gomp = C.CDLL("libgomp.so.1")
+    budget = args.cpu_seconds
 
-        def run():
-            ol.csr_spmv_omp(orc, row_ptr, col, val, x, y)
+    def timed(run, max_reps=50):
+        run()  # warm-up + first touch
+        reps, total = 0, 0.0
+        while reps < max_reps and total < budget:
+            t = time.perf_counter()
+            run()
+            total += time.perf_counter() - t
+            reps += 1
+        return reps, total
 
-    run()  # warm-up + first touch
-    reps, t_total = 0, 0.0
-    while reps < 50 and t_total < args.cpu_seconds:
-        t = time.perf_counter()
-        run()
-        t_total += time.perf_counter() - t
-        reps += 1
-    nnz = int(row_ptr[-1])
+    modes = []
+    # ---- OpenMP mode
+    y = np.zeros(m)
+    gomp.omp_set_num_threads(threads)
+    if ref is not None:
+        reps, total = timed(lambda: ref.ref_csr_spmv(m, nrow_total, p(row_ptr), p(col), p(val), p(x), p(y)))
+    else:
+        reps, total = timed(lambda: ol.csr_spmv_omp(orc, row_ptr, col, val, x, y))
+    openmp = {"mode": "openmp", "kind": "reference" if ref is not None else "port", "threads": threads,
+              "bind": f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} OMP_PLACES={os.environ.get('OMP_PLACES')}",
+              "value": round(2.0 * nnz * reps / total / 1e9, 4), "unit": "GFLOP/s", "ms_per_apply": round(1e3 * total / reps, 3), "reps": reps}
+    modes.append(openmp)
+    # ---- the reference's NUMA driver as it is (prints its own line; 50 repetitions inside)
+    if ref is not None:
+        y = np.zeros(m)
+        sys.stdout.flush()
+        with tempfile.TemporaryFile(mode="w+b") as cap:
+            saved = os.dup(1)
+            os.dup2(cap.fileno(), 1)
+            try:
+                t = time.perf_counter()
+                ref.ref_csr_spmv_numa(m, nrow_total, p(row_ptr), p(col), p(val), p(x), p(y), threads)
+                C.CDLL(None).fflush(None)
+                wall = time.perf_counter() - t
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
+            cap.seek(0)
+            text = cap.read().decode(errors="replace")
+        gf = None
+        for line in text.splitlines():
+            if "CSR NUMA GFLOPS" in line:
+                gf = float(line.split("=")[1])
+        modes.append({"mode": "numa_reference", "kind": "reference", "shards": threads, "value": gf, "unit": "GFLOP/s",
+                      "note": "the reference's own print-out over its 50 repetitions; it re-creates its pthreads in every one "
+                              "(src/mat_vec.cpp:274-281) and builds the shards inside the call", "call_seconds": round(wall, 2)})
+    # ---- the same sharding with persistent pinned workers
+    y = np.zeros(m)
+    orc.orc_csr_spmv_sharded.restype = C.c_double
+    reps_p = max(3, min(50, int(budget / max(openmp["ms_per_apply"] * 1e-3, 1e-4))))
+    ms = orc.orc_csr_spmv_sharded(C.c_int32(m), C.c_int32(nrow_total), p(row_ptr), p(col), p(val), p(x), p(y), C.c_int32(threads), C.c_int32(reps_p))
+    modes.append({"mode": "numa_persistent", "kind": "port", "shards": threads, "value": round(2.0 * nnz / (ms * 1e-3) / 1e9, 4) if ms > 0 else None,
+                  "unit": "GFLOP/s", "ms_per_apply": round(ms, 3), "reps": reps_p,
+                  "note": "one pinned persistent worker per shard, private shard + x replica first-touched by its worker"})
+    # ---- BASELINE configs[0]: C1 through a Matrix Market file, one thread
+    n1, k1 = 10_000, 16
+    rp1, c1, v1 = synth.csr_uniform(0, n1, n1, k1, seed=args.seed)
+    x1 = synth.vec_uniform(n1, seed=args.seed)
+    gomp.omp_set_num_threads(1)
+    y1 = np.zeros(n1)
+    via = "arrays (no reference library here)"
+    if ref is not None:
+        # the reference's own reader (src/data_io.cpp:45-105) and converting constructor (src/matrix.cpp:115-154)
+        class Coo(C.Structure):  # include/matrix.h:9-16
+            _fields_ = [("nrow", C.c_int), ("ncol", C.c_int), ("nnz", C.c_int), ("row_ind", C.POINTER(C.c_int)),
+                        ("col_ind", C.POINTER(C.c_int)), ("values", C.POINTER(C.c_double))]
+
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "c1.mtx")
+            rows1 = np.repeat(np.arange(n1), np.diff(rp1))
+            with open(path, "w") as f:
+                f.write("%%MatrixMarket matrix coordinate real general\n")
+                f.write(f"{n1} {n1} {len(v1)}\n")
+                np.savetxt(f, np.column_stack([rows1 + 1, c1 + 1, v1]), fmt=["%d", "%d", "%.17g"])
+            A = Coo()
+            sys.stdout.flush()
+            saved = os.dup(1)
+            devnull = os.open(os.devnull, os.O_WRONLY)
+            os.dup2(devnull, 1)
+            try:
+                ref._Z13COOMatrixReadPKcR9COOMatrix(path.encode(), C.byref(A))
+                C.CDLL(None).fflush(None)
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
+                os.close(devnull)
+        rp1 = np.zeros(n1 + 1, np.int32)
+        c1 = np.zeros(A.nnz, np.int32)
+        v1 = np.zeros(A.nnz, np.float64)
+        ref.ref_coo_to_csr(A.nrow, A.ncol, A.nnz, A.row_ind, A.col_ind, A.values, p(rp1), p(c1), p(v1))
+        via = "read back from a Matrix Market file by the reference's COOMatrixRead, CSRMatrix(COO) by the reference"
+    run1 = (lambda: ref.ref_csr_spmv(n1, n1, p(rp1), p(c1), p(v1), p(x1), p(y1))) if ref is not None else (lambda: ol.csr_spmv(orc, rp1, c1, v1, x1, y1))
+    reps1, total1 = timed(run1, max_reps=2000)
+    modes.append({"mode": "single_thread_c1", "kind": "reference" if ref is not None else "port", "threads": 1,
+                  "value": round(2.0 * int(rp1[-1]) * reps1 / total1 / 1e9, 4), "unit": "GFLOP/s", "ms_per_apply": round(1e3 * total1 / reps1, 5),
+                  "workload": f"{n1} x {n1}, {k1} per row (BASELINE configs[0]); {via}"})
     return {
-        "value": round(2.0 * nnz * reps / t_total / 1e9, 4),
+        "value": openmp["value"],
         "unit": "GFLOP/s",
-        "cores": cores,
-        "kind": kind,
-        "sample": f"rows [0,{m}) of the benchmark matrix ({nnz} entries, full x of {nrow_total}), {reps} reps of "
-                  f"CSRMatrixMatVector with OMP_NUM_THREADS={cores}; {gen_s:.1f}s to regenerate the rows on the host",
-        "ms_per_apply": round(1e3 * t_total / reps, 3),
+        "cores": threads,
+        "kind": openmp["kind"],
+        "sample": f"rows [0,{m}) of the benchmark matrix ({nnz} entries, full x of {nrow_total}); headline value = the OpenMP mode "
+                  f"({openmp['reps']} reps of CSRMatrixMatVector, {threads} threads = the physical cores this process may use); "
+                  f"{gen_s:.1f}s to regenerate the rows on the host",
+        "ms_per_apply": openmp["ms_per_apply"],
+        "host": topo,
+        "compiler": "g++ -O2 -fopenmp -DUSE_OPENMP (the reference's flags, oracle/Makefile); restatement: gcc -O2 -fopenmp -ffp-contract=off",
+        "modes": modes,
     }
+
+
+def cpu_baseline(args) -> dict:
+    """runs cpu_baseline_child() in a fresh interpreter (see there) and returns its JSON"""
+    import subprocess
+
+    env = dict(os.environ)
+    env.update({"OMP_PROC_BIND": "spread", "OMP_PLACES": "cores", "OMP_DYNAMIC": "false"})
+    env.pop("OMP_NUM_THREADS", None)
+    cmd = [sys.executable, str(Path(__file__).resolve()), "--cpu-baseline-child", "--rows", str(args.n), "--per-row", str(args.k),
+           "--band", str(args.band), "--seed", str(args.seed), "--cpu-sample-rows", str(args.cpu_sample_rows),
+           "--cpu-seconds", str(args.cpu_seconds), "--cpu-threads", str(args.cpu_threads), "--gpus", str(args.gpus)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and line:
+            return json.loads(line[-1])
+        return {"value": None, "unit": "GFLOP/s", "cores": 0, "kind": "reference", "sample": "the CPU leg failed: " + (r.stderr or r.stdout)[-400:]}
+    except subprocess.SubprocessError as e:
+        return {"value": None, "unit": "GFLOP/s", "cores": 0, "kind": "reference", "sample": f"the CPU leg failed: {e}"}
 
 
 def main() -> None:
@@ -117,8 +268,13 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the CPU baseline (host share of one GPU)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = every physical core this process may use)")
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-extra", action="store_true", help="skip the C3 / C4 / band lines after the headline loop")
     args = ap.parse_args()
+    if args.cpu_baseline_child:
+        print(json.dumps(cpu_baseline_child(args)), flush=True)
+        return
 
     import torch
     import torch.distributed as dist
@@ -215,6 +371,42 @@ def main() -> None:
             torch.cuda.synchronize()
             allgather_ms = e0.elapsed_time(e1) / 10
 
+        # N = 1 only, after the headline loop: the other single-GPU configurations of BASELINE.json (C3: ELL, C4: COO) and
+        # the band-random variant of C2, each 5 warm-up + 50 applications between HIP events on the
+        # engine's stream.  Reported in "extra"; they never enter "value".
+        extra = []
+        if world == 1 and not args.no_extra:
+            def one(name, fmt, make):
+                t = time.perf_counter()
+                M = make()
+                inf = M.info
+                ctx.sync()
+                t_set = time.perf_counter() - t
+                vx2, vy2 = ctx.gen_vector(int(inf.ncol), seed=args.seed), ctx.vector(int(inf.nrow))
+                vy2.fill(0.0)
+                for _ in range(5):
+                    ctx.apply(M, vx2, vy2)
+                ms = ctx.apply_timed(M, vx2, vy2, 50)
+                nnz2 = int(inf.nnz)
+                kk = int(inf.ell_k) if fmt == "ell" else 0
+                b = algorithmic_bytes(fmt, int(inf.nrow), int(inf.ncol), nnz2, kk)
+                extra.append({
+                    "name": name, "format": fmt, "nrow": int(inf.nrow), "ncol": int(inf.ncol), "nnz": nnz2,
+                    "max_row_nnz": int(inf.max_row_nnz), "kernel_id": int(inf.kernel), "ms": round(ms, 5),
+                    "value": round(2.0 * nnz2 / ms / 1e6, 2), "unit": "GFLOP/s", "setup_seconds": round(t_set, 3),
+                    "roofline": {"bound": "hbm", "achieved": round(b / ms / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(b / ms / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": b},
+                })
+                del M, vx2, vy2
+
+            one("C3: ELL N=4M, 64 per row, circulant band (BASELINE configs[2])", "ell",
+                lambda: ctx.gen_ell_banded(4_000_000, 4_000_000, 64, seed=args.seed))
+            one("C4: COO N=2M, power-law rows up to 4096, row-sorted (BASELINE configs[3]; realised nnz reported)", "coo",
+                lambda: ctx.gen_coo_powerlaw(2_000_000, 2_000_000, 4096, seed=args.seed))
+            if args.band == 0:
+                one(f"C2 shape, columns random in a band of 65536 (CSR N={n}, {k} per row)", "csr",
+                    lambda: ctx.gen_csr_uniform(0, n, n, k, band=65536, seed=args.seed))
+
         times = torch.tensor([wall_s, kernel_ms, exch_s or 0.0], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(times, op=dist.ReduceOp.MAX)
@@ -283,8 +475,10 @@ def main() -> None:
                 "allgather_ms": round(allgather_ms, 4) if allgather_ms else None,
                 "bytes_per_rank": 8 * n,
             }
+        if extra:
+            out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, synth, ncol)
+            out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
 
     if world > 1:

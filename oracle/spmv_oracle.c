@@ -7,6 +7,9 @@
  *   -DORC_FMA -mfma                        -> orc_<name>_fma   (arithmetic loops only)
  * Each function cites the reference loop it follows (paths relative to the reference root).
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE /* pthread_setaffinity_np, CPU_SET */
+#endif
 #include "spmv_oracle.h"
 
 #include <math.h>
@@ -126,6 +129,124 @@ void orc_csr_spmv_omp(int32_t nrow, const int32_t* row_ptr, const int32_t* col,
             sum += val[j] * x[col[j]];
         y[i] += sum;
     }
+}
+
+/* src/mat_vec.cpp:230-297 + :507-530, the NUMA driver's protocol with PERSISTENT workers (cpu_baseline "port" leg,
+ * BASELINE.md section 4): equal-row shards (last takes the remainder, :245-246), every shard a private copy of its
+ * rebased row_ptr (:260-263), its col/val slices and a FULL replica of x (:257,:266), a local y slice (:258,:267) —
+ * all allocated and first-touched by the worker that owns them, which is pinned to one of the allowed CPUs (the
+ * reference pins to a NUMA node with numa_run_on_node, :511).  Differences from the reference, both deliberate: the
+ * workers live across the repetitions (the reference re-creates its pthreads in every one, :274-281, and measures
+ * mostly that), and the y slices are copied back (the reference drops them, :287-296).
+ * Returns milliseconds per repetition (reps timed between two barriers), < 0 on failure. */
+#include <pthread.h>
+#include <sched.h>
+#include <time.h>
+
+typedef struct
+{
+    int                shard, nshards, reps, cpu;
+    int32_t            nrow, ncol, r0, r1;
+    const int32_t *    row_ptr, *col;
+    const double *     val, *x;
+    double*            y;
+    pthread_barrier_t* bar;
+    int                failed;
+} orc_shard_job;
+
+static void* orc_shard_worker(void* arg)
+{
+    orc_shard_job* j = (orc_shard_job*)arg;
+    if (j->cpu >= 0)
+    {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(j->cpu, &set);
+        (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+    }
+    const int32_t rows = j->r1 - j->r0;
+    const int64_t e0 = j->row_ptr[j->r0], e1 = j->row_ptr[j->r1];
+    int32_t* rp  = (int32_t*)malloc(sizeof(int32_t) * ((size_t)rows + 1));
+    int32_t* col = (int32_t*)malloc(sizeof(int32_t) * (size_t)(e1 - e0 > 0 ? e1 - e0 : 1));
+    double*  val = (double*)malloc(sizeof(double) * (size_t)(e1 - e0 > 0 ? e1 - e0 : 1));
+    double*  x   = (double*)malloc(sizeof(double) * (size_t)(j->ncol > 0 ? j->ncol : 1));
+    double*  y   = (double*)malloc(sizeof(double) * (size_t)(rows > 0 ? rows : 1));
+    j->failed    = !(rp && col && val && x && y);
+    if (!j->failed)
+    {
+        for (int32_t i = 0; i <= rows; ++i) rp[i] = (int32_t)(j->row_ptr[j->r0 + i] - e0);
+        memcpy(col, j->col + e0, sizeof(int32_t) * (size_t)(e1 - e0));
+        memcpy(val, j->val + e0, sizeof(double) * (size_t)(e1 - e0));
+        memcpy(x, j->x, sizeof(double) * (size_t)j->ncol);
+        memset(y, 0, sizeof(double) * (size_t)rows);
+    }
+    pthread_barrier_wait(j->bar); /* shards built */
+    pthread_barrier_wait(j->bar); /* clock started by the caller */
+    if (!j->failed)
+        for (int r = 0; r < j->reps; ++r)
+            for (int32_t i = 0; i < rows; ++i) /* src/mat_vec.cpp:517-527 */
+            {
+                double sum = 0.0;
+                for (int32_t k = rp[i]; k < rp[i + 1]; ++k) sum += val[k] * x[col[k]];
+                y[i] += sum;
+            }
+    pthread_barrier_wait(j->bar); /* all repetitions done */
+    if (!j->failed)
+        for (int32_t i = 0; i < rows; ++i) j->y[j->r0 + i] += y[i];
+    free(rp);
+    free(col);
+    free(val);
+    free(x);
+    free(y);
+    return 0;
+}
+
+double orc_csr_spmv_sharded(int32_t nrow, int32_t ncol, const int32_t* row_ptr, const int32_t* col, const double* val,
+                            const double* x, double* y, int32_t nshards, int32_t reps)
+{
+    if (nshards < 1 || reps < 1) return -1.0;
+    cpu_set_t allowed;
+    int       cpus[1024], ncpu = 0;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0)
+        for (int c = 0; c < CPU_SETSIZE && ncpu < 1024; ++c)
+            if (CPU_ISSET(c, &allowed)) cpus[ncpu++] = c;
+    pthread_barrier_t bar;
+    if (pthread_barrier_init(&bar, 0, (unsigned)nshards + 1) != 0) return -1.0;
+    orc_shard_job* jobs = (orc_shard_job*)calloc((size_t)nshards, sizeof(orc_shard_job));
+    pthread_t*     thr  = (pthread_t*)calloc((size_t)nshards, sizeof(pthread_t));
+    const int32_t  per  = nrow / nshards;
+    int            started = 0;
+    for (int s = 0; jobs && thr && s < nshards; ++s)
+    {
+        orc_shard_job* j = &jobs[s];
+        j->shard = s, j->nshards = nshards, j->reps = reps, j->cpu = ncpu ? cpus[s % ncpu] : -1;
+        j->nrow = nrow, j->ncol = ncol, j->r0 = s * per, j->r1 = s == nshards - 1 ? nrow : (s + 1) * per;
+        j->row_ptr = row_ptr, j->col = col, j->val = val, j->x = x, j->y = y, j->bar = &bar;
+        if (pthread_create(&thr[s], 0, orc_shard_worker, j) != 0) break;
+        ++started;
+    }
+    double ms = -1.0;
+    if (started == nshards)
+    {
+        struct timespec t0, t1;
+        pthread_barrier_wait(&bar);
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        pthread_barrier_wait(&bar);
+        pthread_barrier_wait(&bar);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        ms = ((double)(t1.tv_sec - t0.tv_sec) * 1e3 + (double)(t1.tv_nsec - t0.tv_nsec) * 1e-6) / reps;
+        for (int s = 0; s < nshards; ++s)
+        {
+            pthread_join(thr[s], 0);
+            if (jobs[s].failed) ms = -1.0;
+        }
+    }
+    /* (a failed pthread_create leaves the started workers at the first barrier: not recoverable here, and
+     * never seen with the handful of shards the baseline uses) */
+    pthread_barrier_destroy(&bar);
+    free(jobs);
+    free(thr);
+    return ms;
 }
 
 /* src/matrix.cpp:125-153 */

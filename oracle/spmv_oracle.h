@@ -41,6 +41,9 @@ void orc_csr_spmv_fma(int32_t nrow, const int32_t* row_ptr, const int32_t* col,
 /* same loop with `#pragma omp parallel for` as in src/mat_vec.cpp:54-57 (cpu_baseline "port") */
 void orc_csr_spmv_omp(int32_t nrow, const int32_t* row_ptr, const int32_t* col,
                       const double* val, const double* x, double* y);
+/* NUMA-driver protocol with persistent pinned workers (src/mat_vec.cpp:230-297); returns ms per repetition */
+double orc_csr_spmv_sharded(int32_t nrow, int32_t ncol, const int32_t* row_ptr, const int32_t* col, const double* val,
+                            const double* x, double* y, int32_t nshards, int32_t reps);
 /* src/mat_vec.cpp:82-93  (CSCMatrixMatVector, serial) */
 void orc_csc_spmv(int32_t ncol, const int32_t* col_ptr, const int32_t* row, const double* val,
                   const double* x, double* y);

@@ -227,7 +227,10 @@ def main():
         print(f"COO power-law n={n} nnz={nnz} mean={nnz/n:.1f} sorted={A.info.sorted_rows}")
         x, y = ctx.gen_vector(n, seed=1), ctx.vector(n)
         y.fill(0.0)
-        sweep(ctx, A, x, y, [("coo segscan", lambda A: None)], a.rounds, a.reps, algorithmic_bytes("coo", n, n, nnz), nnz)
+        # AUTO regroups a large COO handle by row and runs the panel product; CSR_VECTOR forces the segmented scan
+        sweep(ctx, A, x, y, [("coo auto (row-grouped, panel)", lambda A: A.set_kernel(capi.CSR_AUTO)),
+                             ("coo segmented scan", lambda A: A.set_kernel(capi.CSR_VECTOR))],
+              a.rounds, a.reps, algorithmic_bytes("coo", n, n, nnz), nnz)
         csr = ctx.coo_to_csr(A)
         print(f"same matrix as CSR: auto kernel={csr.info.kernel} lanes={csr.info.lanes_per_row} max_row={csr.info.max_row_nnz}")
         variants = [(f"csr vector L={l}", lambda A, l=l: A.set_kernel(capi.CSR_VECTOR, l)) for l in (16, 64)]
