@@ -620,6 +620,11 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         m->pb_ablate = (int32_t)value;
     else if (!strcmp(name, "panel_two_per_cu"))
         m->pb_two_per_cu = (int32_t)value;
+    else if (!strcmp(name, "dia_col_bound"))
+    {
+        SPMV_REQUIRE(m->format == SPMV_FMT_DIA && value >= 0 && value <= m->ncol, "dia_col_bound: a DIA handle and 0 <= bound <= ncol");
+        m->dia_col_bound = (int32_t)value;
+    }
     else if (!strcmp(name, "panel_sync"))
         m->pb_sync = (int32_t)value;
     else if (!strcmp(name, "panel_legacy"))

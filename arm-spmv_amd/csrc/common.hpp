@@ -130,6 +130,7 @@ struct spmv_mat
     int64_t        device_bytes = 0;
 
     // ---- analysis results (filled by analyse_*) ----
+    int32_t dia_col_bound = 0;  // DIA: columns >= this are skipped (0 = min(nrow, ncol)); row shards keep the global bound
     int32_t max_row_nnz   = 0;
     int32_t kernel        = SPMV_CSR_AUTO;
     int32_t lanes_per_row = 0;
@@ -249,6 +250,9 @@ int mat_validate(const spmv_mat* m);
 // convert.hip
 int exclusive_scan_i32(spmv_ctx* ctx, const int32_t* in, int32_t* out, int64_t n);
 int coo_to_csr(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out);
+// convert_sort.hip
+int coo_place_by_stable_sort(spmv_ctx* ctx, int64_t nnz, int32_t nrow, const int32_t* row, const int32_t* col, const double* val,
+                             int32_t* out_col, double* out_val);
 int csr_to_ell(spmv_ctx* ctx, const spmv_mat* csr, spmv_mat** out);
 int csr_split_columns(spmv_ctx* ctx, const spmv_mat* csr, int32_t c0, int32_t c1, spmv_mat** out_in, spmv_mat** out_out);
 int reduce_max_i32(spmv_ctx* ctx, const int32_t* in, int64_t n, int32_t* result);

@@ -187,6 +187,16 @@ int coo_to_csr(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out)
         }
         else
         {
+            // The slot-claim + rank placement below is O(len^2) per row; rows beyond kRankRowLimit entries (a hub row of an
+            // unsorted file) go through a stable sort of the entry ids by row instead (convert_sort.hip).
+            constexpr int32_t kRankRowLimit = 2048;
+            int32_t           longest       = 0;
+            if ((rc = reduce_max_i32(ctx, count, nrow, &longest)) != SPMV_OK) break;
+            if (longest > kRankRowLimit)
+            {
+                rc = coo_place_by_stable_sort(ctx, nnz, nrow, coo->a, coo->b, coo->v, out_col, out_val);
+                break;
+            }
             if (hipMalloc(&perm, sizeof(int32_t) * (size_t)nnz) != hipSuccess) { rc = SPMV_ERR_ALLOC; break; }
             (void)hipMemsetAsync(count, 0, sizeof(int32_t) * ((size_t)nrow + 1), s);  // reuse as per-row cursor
             hipLaunchKernelGGL(claim_slot_kernel, dim3((unsigned)std::min<int64_t>(kMaxGrid, ceil_div(nnz, kBlock))),
@@ -206,7 +216,11 @@ int coo_to_csr(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out)
         SPMV_FAIL(rc, "spmv_coo_to_csr failed (%s)", hipGetErrorString(hipGetLastError()));
     }
     csr->row_begin = coo->row_begin;
-    SPMV_TRY(csr_analyse(csr));
+    if ((rc = csr_analyse(csr)) != SPMV_OK)
+    {
+        mat_free(csr);
+        return rc;
+    }
     *out = csr;
     return SPMV_OK;
 }

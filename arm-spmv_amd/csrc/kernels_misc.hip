@@ -326,10 +326,12 @@ int dia_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
 {
     if (A->nrow == 0 || A->k == 0) return SPMV_OK;
     const dim3 grid((unsigned)ceil_div(A->nrow, kBlock));
+    // a row shard (offsets shifted by its first row) keeps the bound of the whole matrix; never past the end of x
+    const int jmax = std::min(A->dia_col_bound > 0 ? A->dia_col_bound : std::min(A->nrow, A->ncol), A->ncol);
     if (A->k % 2 == 0 && (((uintptr_t)A->v) & 15) == 0)
-        hipLaunchKernelGGL(dia_kernel<true>, grid, dim3(kBlock), 0, ctx->stream, A->nrow, std::min(A->nrow, A->ncol), A->k, A->a, A->v, x, y);
+        hipLaunchKernelGGL(dia_kernel<true>, grid, dim3(kBlock), 0, ctx->stream, A->nrow, jmax, A->k, A->a, A->v, x, y);
     else
-        hipLaunchKernelGGL(dia_kernel<false>, grid, dim3(kBlock), 0, ctx->stream, A->nrow, std::min(A->nrow, A->ncol), A->k, A->a, A->v, x, y);
+        hipLaunchKernelGGL(dia_kernel<false>, grid, dim3(kBlock), 0, ctx->stream, A->nrow, jmax, A->k, A->a, A->v, x, y);
     SPMV_HIP(hipGetLastError());
     return SPMV_OK;
 }

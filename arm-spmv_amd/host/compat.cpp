@@ -738,12 +738,20 @@ void COOMatrixMatVectorNuma(const COOMatrix& A, const Vector& x, Vector& y, int 
     // unsorted input; here every entry goes to the shard that owns its row, in file order.
     Engine&                          E      = Engine::get();
     std::vector<Shard>               shards = plan_shards(A.nrow, nthreads);
-    const int64_t                    per    = std::max<int64_t>(A.nrow / (int64_t)shards.size(), 1);
     std::vector<std::vector<int>>    rows(shards.size()), cols(shards.size());
     std::vector<std::vector<double>> vals(shards.size());
+    // owner of a row = the planned shard whose range holds it (with more shards than rows all but the last are empty,
+    // src/mat_vec.cpp:233: rows_per_thread = nrow / nthreads = 0, and the last one takes every row)
+    std::vector<int64_t> first(shards.size());
+    for (size_t s = 0; s < shards.size(); ++s) first[s] = shards[s].row0;
+    auto owner = [&](int64_t r) {
+        size_t s = (size_t)(std::upper_bound(first.begin(), first.end(), r) - first.begin()) - 1;
+        while (s + 1 < shards.size() && r >= shards[s].row1) ++s;  // empty ranges share their first row with the next one
+        return s;
+    };
     for (int k = 0; k < A.nnz; ++k)
     {
-        const size_t s = (size_t)std::min<int64_t>(A.row_ind[k] / per, (int64_t)shards.size() - 1);
+        const size_t s = owner(A.row_ind[k]);
         rows[s].push_back(A.row_ind[k] - (int)shards[s].row0);  // local row, as the thread body does (:500)
         cols[s].push_back(A.col_ind[k]);
         vals[s].push_back(A.values[k]);
@@ -791,12 +799,21 @@ void CSCMatrixMatVectorNuma(const CSCMatrix& A, const Vector& x, Vector& y, int)
     run_shards("CSC", shards, x, y, 2.0 * (double)A.col_ptr[A.ncol]);
 }
 
-void DIAMatrixMatVectorNuma(const DIAMatrix& A, const Vector& x, Vector& y, int)
+void DIAMatrixMatVectorNuma(const DIAMatrix& A, const Vector& x, Vector& y, int nthreads)
 {
-    Engine&            E = Engine::get();
-    std::vector<Shard> shards(1);
-    shards[0].row1 = A.nrow;
-    check(spmv_dia_upload(E.ctx(0), A.nrow, A.ncol, A.ndiags, A.offsets, A.values, &shards[0].mat), "spmv_dia_upload");
+    // Row shards (src/mat_vec.cpp:428-484: rows_per_thread rows of the row-major diagonal array per thread, :449-452).
+    // A shard's local row i is global row row0 + i, so its diagonals sit at offsets + row0 against the full x; the
+    // column bound stays the global one (the reference checks `j < nrow` with the global nrow, :572 / :140).
+    Engine&            E      = Engine::get();
+    std::vector<Shard> shards = plan_shards(A.nrow, nthreads);
+    std::vector<int>   off((size_t)std::max(A.ndiags, 1));
+    for (Shard& s : shards)
+    {
+        for (int d = 0; d < A.ndiags; ++d) off[(size_t)d] = A.offsets[d] + (int)s.row0;
+        check(spmv_dia_upload(E.ctx(s.device), (int)(s.row1 - s.row0), A.ncol, A.ndiags, off.data(),
+                              A.values + (size_t)s.row0 * (size_t)A.ndiags, &s.mat), "spmv_dia_upload(shard)");
+        check(spmv_mat_set_param(s.mat, "dia_col_bound", std::min(A.nrow, A.ncol)), "spmv_mat_set_param(dia_col_bound)");
+    }
     run_shards("DIA", shards, x, y, 2.0 * (double)A.nnz);
 }
 

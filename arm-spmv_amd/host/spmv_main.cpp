@@ -258,6 +258,21 @@ int main(int argc, char* argv[])
         // with duplicates or nrow != ncol the DIA result legitimately differs.
         if (o.verify && A.nrow == A.ncol)
             printf("### DIA VERIFY (informational) max|y - y_coo|/max|y_coo| = %.3e\n", rel_diff(y, y_coo));
+        if (o.numa)
+        {
+            // the row-sharded driver against the one-shard product of the same DIA arrays (not against COO: see above)
+            Vector y_dia;
+            y_dia = y;
+            y.Fill(0);
+            DIAMatrixMatVectorNuma(E, x, y, o.shards);
+            for (int i = 0; i < y.size; ++i) y.values[i] /= o.reps;
+            if (o.verify)
+            {
+                const double d = rel_diff(y, y_dia);
+                printf("### DIA NUMA VERIFY max|y - y_dia|/max|y_dia| = %.3e %s\n", d, d <= 1e-10 ? "OK" : "FAILED");
+                if (d > 1e-10) exit(2);
+            }
+        }
     }
     if (o.has("coo") && o.numa)
     {

@@ -8,6 +8,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
+import cases
 from test_host_io import _write_mtx
 
 pytestmark = pytest.mark.gpu
@@ -38,6 +39,22 @@ def test_spmv_main_verifies_every_format_and_the_sharded_drivers(tmp_path, pkg):
     assert re.search(r"### DIA VERIFY \(informational\)", out)
     for name in ("COO", "CSR", "ELL"):
         assert re.search(rf"### {name} NUMA GFLOPS = [0-9.]+", out) and re.search(rf"### {name} GPU-RESIDENT GFLOPS = [0-9.]+", out)
+    m = re.search(r"### DIA NUMA VERIFY .* = ([0-9.e+-]+) OK", out)
+    assert m and float(m.group(1)) <= 1e-10 and re.search(r"### DIA NUMA GFLOPS = [0-9.]+", out), out
+
+
+def test_sharded_drivers_with_more_shards_than_rows(tmp_path, pkg):
+    """`spmv_main tri8.mtx 64`: 64 shards over 8 rows.  The reference gives every thread nrow / nthreads = 0 rows and the
+    last one all of them (src/mat_vec.cpp:233,245-246); every driver must run (empty shards included) and verify."""
+    c = cases.tri8()
+    p = tmp_path / "tri8.mtx"
+    _write_mtx(p, c)
+    r = subprocess.run([str(BIN / "spmv_main"), str(p), "64", "--format", "coo,csr,ell,dia", "--verify", "--reps", "3"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for name in ("CSR NUMA", "ELL NUMA", "COO NUMA", "DIA NUMA"):
+        m = re.search(rf"### {name} VERIFY .* = ([0-9.e+-]+) OK", r.stdout)
+        assert m and float(m.group(1)) <= 1e-10, (name, r.stdout)
 
 
 def test_reference_main_cpp_runs_unchanged_on_the_engine(tmp_path, pkg):

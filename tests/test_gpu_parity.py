@@ -211,6 +211,25 @@ def test_coo_to_csr_large_unsorted(ctx, orc):
     assert np.array_equal(got[0], rp) and np.array_equal(got[1], cc) and np.array_equal(got[2], cv)
 
 
+def test_coo_to_csr_unsorted_hub_row(ctx, orc):
+    """one shuffled row of 300 000 entries among ordinary ones, unsorted input: the conversion must keep the COO order
+    inside the hub row (src/matrix.cpp:140-144) and finish promptly (rank-by-scanning would be ~10^11 steps there)"""
+    import time
+
+    rng = np.random.RandomState(9)
+    nrow, ncol, hub = 20_000, 400_000, 300_000
+    row = np.concatenate([np.full(hub, 1234, np.int32), rng.randint(0, nrow, size=200_000).astype(np.int32)])
+    col = rng.randint(0, ncol, size=row.size).astype(np.int32)
+    val = rng.uniform(-1, 1, size=row.size)
+    perm = rng.permutation(row.size)
+    row, col, val = row[perm], col[perm], val[perm]
+    rp, cc, cv = ol.coo_to_csr(orc, nrow, row, col, val)
+    t = time.perf_counter()
+    got = ctx.coo_to_csr(ctx.coo(nrow, ncol, row, col, val)).download()
+    assert time.perf_counter() - t < 20.0
+    assert np.array_equal(got[0], rp) and np.array_equal(got[1], cc) and np.array_equal(got[2], cv)
+
+
 # ---------------------------------------------------------------------------------- CSC / DIA ("next" rows)
 @pytest.mark.parametrize("make", cases.SMALL_CASES, ids=lambda f: f.__name__)
 def test_csc_matches_reference_golden(ctx, orc, make):

@@ -183,3 +183,81 @@ def test_binary_cache_round_trip(lib, tmp_path, monkeypatch):
     _write_mtx(p, c2)
     fourth = load()
     assert len(fourth[4]) == len(first[4]) + 1 and fourth[4][-1] == 2.5
+
+
+# ---------------------------------------------------------------------------------- differential: reader vs the reference's
+REF_SO = ROOT / "oracle" / "_ref" / "libarmspmv_ref.so"
+
+
+def _odd_files(tmp_path):
+    """Matrix Market files whose reading is DEFINED in the reference (every `fscanf("%d %d %lg\\n")` of
+    src/data_io.cpp:83-88 converts three tokens) but that a reader written from the format description would treat
+    differently.  (Files with fewer than 3 x nnz tokens are left out: there the reference returns uninitialised heap
+    for the missing entries, the shim stops with a message — no common answer exists.)"""
+    rng = np.random.RandomState(11)
+    files = {}
+
+    def put(name, text):
+        p = tmp_path / name
+        p.write_text(text)
+        files[name] = p
+
+    put("comments_blank_tabs.mtx",
+        "%%MatrixMarket matrix coordinate real general\n% c1\n%\n%%% c3\n\n  5 4   6  \n\n1\t1\t 1.5\n\n2 3 -2.25   \n\n\n"
+        "5 4 1e-3\n3 2 +4\n 4 1 .5\n1 4 -7.0E+2\n% a trailing comment is not an entry\n9 9 9\n")
+    put("integer_field.mtx", "%%MatrixMarket matrix coordinate integer general\n3 3 4\n1 1 7\n2 2 -3\n3 1 12\n1 3 0\n")
+    # symmetric / skew / hermitian-free variants: read as stored, NOT expanded
+    put("symmetric.mtx", "%%MatrixMarket matrix coordinate real symmetric\n4 4 5\n1 1 2.0\n2 1 -1.0\n3 2 -1.0\n4 4 3.0\n4 1 0.25\n")
+    put("skew.mtx", "%%MatrixMarket matrix coordinate real skew-symmetric\n3 3 2\n2 1 5.0\n3 1 -6.0\n")
+    # four integer tokens per line: the reference re-chunks the token stream in threes, whatever the lines look like
+    lines = "".join(f"{i + 1} {(i * 7) % 9 + 1} {i - 4} {i + 100}\n" for i in range(9))
+    put("extra_column.mtx", "%%MatrixMarket matrix coordinate real general\n9 9 9\n" + lines)
+    # a `pattern` file that declares fewer entries than it has tokens for: (i, j, next i) triples, all conversions succeed
+    put("pattern_short_count.mtx", "%%MatrixMarket matrix coordinate pattern general\n6 6 4\n1 2\n3 4\n5 6\n6 1\n2 2\n4 4\n")
+    # what %lg accepts: hex floats, infinities, nan, many digits
+    put("float_forms.mtx", "%%MatrixMarket matrix coordinate real general\n2 8 8\n1 1 0x1.8p1\n1 2 inf\n1 3 -INF\n1 4 nan\n"
+        "1 5 123456789012345678901234567890\n1 6 1e-400\n1 7 0.1000000000000000055511151231257827\n1 8 -0\n")
+    put("more_lines_than_declared.mtx", "%%MatrixMarket matrix coordinate real general\n3 3 2\n1 1 1\n2 2 2\n3 3 3\n1 2 4\n")
+    put("zero_entries.mtx", "%%MatrixMarket matrix coordinate real general\n7 5 0\n")
+    put("array_of_ints_as_indices.mtx", "%%MatrixMarket matrix coordinate real general\n10 10 3\n007 +3 1\n10 010 2\n1 1 3\n")
+    # big enough for the parallel parser (>= 65536 entries), with ragged formatting
+    n = 70_001
+    r, c = rng.randint(1, 5000, n), rng.randint(1, 4000, n)
+    v = rng.uniform(-1, 1, n)
+    seps = [" ", "\t", "  ", " \t "]
+    body = []
+    for k in range(n):
+        s = seps[k % 4]
+        val = ("%.17g" % v[k]) if k % 5 else ("%+.6e" % v[k])
+        body.append(f"{r[k]}{s}{c[k]}{s}{val}" + ("\n\n" if k % 97 == 0 else "\n"))
+    put("large_ragged.mtx", f"%%MatrixMarket matrix coordinate real general\n% big\n5000 4000 {n}\n" + "".join(body))
+    big_sym = "".join(f"{max(a, b)} {min(a, b)} {k % 13 - 6}\n" for k, (a, b) in enumerate(zip(r, c)))
+    put("large_symmetric_integer.mtx", f"%%MatrixMarket matrix coordinate integer symmetric\n5000 5000 {n}\n" + big_sym)
+    return files
+
+
+@pytest.mark.parametrize("threads", ["1", "6"])
+def test_reader_is_the_references_reader_on_odd_files(tmp_path, threads):
+    """COOMatrixRead of the shim (arm-spmv_amd/host/mtx_io.cpp, every SPMV_MTX_* switch off) against the reference's
+    COOMatrixRead (src/data_io.cpp:45-105, compiled from its sources into oracle/_ref): same dimensions, same entries in
+    the same order, values bit for bit, with the reference's loop (threads = 1) and with the parallel parser."""
+    if not REF_SO.exists():
+        pytest.skip("oracle/_ref/libarmspmv_ref.so not built (make -C oracle ref needs the reference sources)")
+    if not LIB.exists():
+        subprocess.run(["make", "host"], cwd=ROOT, check=True, capture_output=True)
+    files = _odd_files(tmp_path)
+    names = sorted(files)
+    child = Path(__file__).with_name("reader_child.py")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("SPMV_MTX_")}
+    env["SPMV_MTX_THREADS"] = threads
+    got = {}
+    for tag, so in (("ref", REF_SO), ("ours", LIB)):
+        out = tmp_path / f"{tag}.npz"
+        r = subprocess.run(["python3", str(child), str(so), str(out)] + [str(files[n]) for n in names],
+                           capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, (tag, r.stdout[-2000:], r.stderr[-2000:])
+        got[tag] = np.load(out)
+    for i, name in enumerate(names):
+        for key in ("dims", "row", "col", "val"):
+            a, b = got["ref"][f"{key}{i}"], got["ours"][f"{key}{i}"]
+            assert a.shape == b.shape and np.array_equal(a, b), (name, key, threads, a[:8], b[:8])
