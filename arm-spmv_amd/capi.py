@@ -61,6 +61,11 @@ SIGNATURES = {
     "spmv_vec_upload": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp]),
     "spmv_vec_download": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp]),
     "spmv_vec_fill": (C.c_int, [_vp, C.c_double]),
+    "spmv_vec_copy": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, C.c_int64]),
+    "spmv_comm_create": (C.c_int, [C.POINTER(_vp), C.c_int32, C.POINTER(_vp)]),
+    "spmv_comm_destroy": (None, [_vp]),
+    "spmv_comm_backend": (C.c_char_p, [_vp]),
+    "spmv_comm_allgather": (C.c_int, [_vp, C.POINTER(_vp), _i64p]),
     "spmv_csr_upload": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, C.POINTER(_vp)]),
     "spmv_csr_wrap_device": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, C.POINTER(_vp)]),
     "spmv_csr_upload_shard": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int32, _vp, _vp, _vp, C.POINTER(_vp)]),
@@ -363,6 +368,34 @@ class Context:
         return Matrix(self, h)
 
 
+class Comm:
+    """exchange between several contexts of this process (spmv_comm_*): the x all-gather of the sharded drivers"""
+
+    def __init__(self, ctxs):
+        self.ctxs = list(ctxs)
+        self._lib = self.ctxs[0]._lib
+        arr = (_vp * len(self.ctxs))(*[c.h for c in self.ctxs])
+        self.h = _vp()
+        _check(self._lib.spmv_comm_create(arr, len(self.ctxs), C.byref(self.h)))
+
+    def __del__(self):
+        try:
+            if self.h:
+                self._lib.spmv_comm_destroy(self.h)
+        except Exception:
+            pass
+        self.h = None
+
+    @property
+    def backend(self) -> str:
+        return self._lib.spmv_comm_backend(self.h).decode()
+
+    def allgather(self, vecs, offsets) -> None:
+        arr = (_vp * len(vecs))(*[v.h for v in vecs])
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        _check(self._lib.spmv_comm_allgather(self.h, arr, off.ctypes.data_as(_i64p)))
+
+
 class Vector:
     def __init__(self, ctx: Context, h, n: int):
         self.ctx, self.h, self.n = ctx, h, n
@@ -388,6 +421,9 @@ class Vector:
 
     def fill(self, a: float) -> None:
         _check(self.ctx._lib.spmv_vec_fill(self.h, a))
+
+    def copy_from(self, src: "Vector", n: int, dst_offset: int = 0, src_offset: int = 0) -> None:
+        _check(self.ctx._lib.spmv_vec_copy(self.h, dst_offset, src.h, src_offset, n))
 
     @property
     def device_ptr(self) -> int:

@@ -667,25 +667,49 @@ struct Shard
 // runs the timed loop over ready-made shards, prints the line, copies y back, frees the shards
 void run_shards(const char* fmt_name, std::vector<Shard>& shards, const Vector& x, Vector& y, double flops_per_apply)
 {
-    Engine&                E = Engine::get();
-    std::vector<spmv_vec*> xrep((size_t)E.ngpus(), nullptr);
+    Engine& E = Engine::get();
+    // One full replica of x per device in use (src/mat_vec.cpp:257,266), assembled ON the devices: device k receives
+    // only its own slice of x from the host, the rest arrives from the other devices through spmv_comm_allgather (RCCL
+    // or peer copies over xGMI).  SPMV_COMPAT_X_PARTS=n (tests) cuts x into n slices even on one GPU, so that the
+    // exchange runs there too (several participants on one device).
+    std::vector<int> devices;
+    for (Shard& s : shards)
+        if (std::find(devices.begin(), devices.end(), s.device) == devices.end()) devices.push_back(s.device);
+    const char* env_parts = getenv("SPMV_COMPAT_X_PARTS");
+    const int   parts     = std::max((int)devices.size(), env_parts ? atoi(env_parts) : 0);
+    std::vector<spmv_ctx*> pctx((size_t)parts);
+    std::vector<spmv_vec*> xrep((size_t)parts, nullptr);
+    std::vector<int64_t>   xoff((size_t)parts + 1, 0);
+    for (int p = 0; p < parts; ++p)
+    {
+        pctx[(size_t)p] = E.ctx(devices[(size_t)p % devices.size()]);
+        int64_t b = 0, e = 0;
+        check(spmv_partition_rows(x.size, parts, p, &b, &e), "spmv_partition_rows(x)");
+        xoff[(size_t)p]     = b;
+        xoff[(size_t)p + 1] = e;
+        check(spmv_vec_create(pctx[(size_t)p], x.size, &xrep[(size_t)p]), "spmv_vec_create(x replica)");
+        check(spmv_vec_upload(xrep[(size_t)p], b, e - b, x.values + b), "spmv_vec_upload(x slice)");
+    }
+    spmv_comm* comm = nullptr;
+    check(spmv_comm_create(pctx.data(), parts, &comm), "spmv_comm_create");
+    check(spmv_comm_allgather(comm, xrep.data(), xoff.data()), "spmv_comm_allgather(x)");
+    auto replica_of = [&](int device) {
+        for (int p = 0; p < parts; ++p)
+            if (devices[(size_t)p % devices.size()] == device) return xrep[(size_t)p];
+        return xrep[0];
+    };
     for (Shard& s : shards)
     {
-        if (!xrep[(size_t)s.device])
-        {
-            // full replica of x per device (src/mat_vec.cpp:257,266)
-            check(spmv_vec_create(E.ctx(s.device), x.size, &xrep[(size_t)s.device]), "spmv_vec_create(x replica)");
-            check(spmv_vec_upload(xrep[(size_t)s.device], 0, x.size, x.values), "spmv_vec_upload(x replica)");
-        }
         check(spmv_vec_create(E.ctx(s.device), s.row1 - s.row0, &s.y), "spmv_vec_create(y shard)");
         check(spmv_vec_fill(s.y, 0.0), "spmv_vec_fill");  // memset(Y, 0), src/mat_vec.cpp:267
     }
     for (Shard& s : shards) check(spmv_sync(E.ctx(s.device)), "spmv_sync");
+    for (int p = 0; p < parts; ++p) check(spmv_sync(pctx[(size_t)p]), "spmv_sync");
 
     const auto t0 = std::chrono::steady_clock::now();
     for (int k = 0; k < g_numa_reps; ++k)
     {
-        for (Shard& s : shards) check(spmv_apply(E.ctx(s.device), s.mat, xrep[(size_t)s.device], s.y), "spmv_apply(shard)");
+        for (Shard& s : shards) check(spmv_apply(E.ctx(s.device), s.mat, replica_of(s.device), s.y), "spmv_apply(shard)");
         for (Shard& s : shards) check(spmv_sync(E.ctx(s.device)), "spmv_sync");  // the reference joins all threads per repetition
     }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -694,12 +718,21 @@ void run_shards(const char* fmt_name, std::vector<Shard>& shards, const Vector& 
     g_last_numa_ms     = secs * 1000.0 / g_numa_reps;
     printf("### %s NUMA GFLOPS = %.5f\n", fmt_name, flops_per_apply / t_avg / 1e6);
 
+    // y: the shards' slices are concatenated on the first device (device-to-device / peer copies), one copy to the host
+    spmv_vec* yfull = nullptr;
+    check(spmv_vec_create(pctx[0], y.size, &yfull), "spmv_vec_create(y)");
     for (Shard& s : shards)
     {
-        check(spmv_vec_download(s.y, 0, s.row1 - s.row0, y.values + s.row0), "spmv_vec_download(y shard)");
+        check(spmv_vec_copy(yfull, s.row0, s.y, 0, s.row1 - s.row0), "spmv_vec_copy(y shard)");
+    }
+    check(spmv_vec_download(yfull, 0, y.size, y.values), "spmv_vec_download(y)");
+    spmv_vec_destroy(yfull);
+    for (Shard& s : shards)
+    {
         spmv_vec_destroy(s.y);
         spmv_mat_destroy(s.mat);
     }
+    spmv_comm_destroy(comm);
     for (spmv_vec* v : xrep)
         if (v) spmv_vec_destroy(v);
     shards.clear();

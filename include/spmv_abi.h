@@ -115,6 +115,25 @@ int spmv_vec_device_ptr(const spmv_vec* v, double** device_ptr);
 int spmv_vec_upload(spmv_vec* v, int64_t offset, int64_t n, const double* host);
 int spmv_vec_download(const spmv_vec* v, int64_t offset, int64_t n, double* host);
 int spmv_vec_fill(spmv_vec* v, double a); /* Vector::Fill, src/vector.cpp:59-63 */
+/* dst[dst_offset..+n) = src[src_offset..+n) between vectors of ANY two contexts (same GPU or peers over xGMI), queued on
+ * the destination's stream behind the work already queued on the source's.  The sharded drivers assemble y with it
+ * (the reference leaves the per-thread Y slices where they are, src/mat_vec.cpp:287-296; DIA copies them, :474-477). */
+int spmv_vec_copy(spmv_vec* dst, int64_t dst_offset, const spmv_vec* src, int64_t src_offset, int64_t n);
+
+/* ---- exchange between the contexts (GPUs) of ONE process -------------------------------------------------
+ * Replaces the x replication of the reference's sharded drivers — memcpy(p[i].X, x.values, ...) per NUMA node,
+ * src/mat_vec.cpp:257,266 — by an all-gather on the devices: participant i holds slice [offsets[i], offsets[i+1]) of x
+ * in its own (full-length) vector; afterwards every participant's vector holds all of [0, offsets[n]).  Asynchronous:
+ * ordered by events behind the work queued on the participants' streams, and the streams continue behind it.
+ * Transport: RCCL (ncclCommInitAll + a group of broadcasts, one per slice; loaded with dlopen) when every participant
+ * has a GPU of its own, else — or with SPMV_COMM=peer — concurrent hipMemcpyPeerAsync pulls, one stream per peer link.
+ * Participants may share a GPU (several shards on one device): then the copies are device-to-device.
+ * (One process per GPU instead: arm-spmv_amd/dist.py does the same exchange through torch.distributed.) */
+typedef struct spmv_comm spmv_comm;
+int         spmv_comm_create(spmv_ctx* const* ctxs, int32_t n, spmv_comm** out);
+void        spmv_comm_destroy(spmv_comm* comm);
+const char* spmv_comm_backend(const spmv_comm* comm); /* "rccl" or "peer-copy" */
+int         spmv_comm_allgather(spmv_comm* comm, spmv_vec* const* vecs, const int64_t* offsets /* n + 1 */);
 
 /* ---- matrices ------------------------------------------------------------------------------ */
 /* CSR (include/matrix.h:27-47).  nnz = row_ptr[nrow]. */

@@ -43,6 +43,21 @@ def test_spmv_main_verifies_every_format_and_the_sharded_drivers(tmp_path, pkg):
     assert m and float(m.group(1)) <= 1e-10 and re.search(r"### DIA NUMA GFLOPS = [0-9.]+", out), out
 
 
+def test_sharded_drivers_assemble_x_through_the_native_exchange(tmp_path, pkg):
+    """SPMV_COMPAT_X_PARTS=3: x reaches the GPU in three slices owned by three participants and every replica is
+    assembled by spmv_comm_allgather (device-to-device on this one-GPU box, peer copies / RCCL between GPUs)"""
+    import os
+
+    p = _mtx(tmp_path, pkg, 2500, 9, 23)
+    env = dict(os.environ, SPMV_COMPAT_X_PARTS="3")
+    r = subprocess.run([str(BIN / "spmv_main"), str(p), "5", "--format", "coo,csr,ell,dia", "--verify", "--reps", "4"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for name in ("CSR NUMA", "ELL NUMA", "COO NUMA", "DIA NUMA"):
+        m = re.search(rf"### {name} VERIFY .* = ([0-9.e+-]+) OK", r.stdout)
+        assert m and float(m.group(1)) <= 1e-10, (name, r.stdout)
+
+
 def test_sharded_drivers_with_more_shards_than_rows(tmp_path, pkg):
     """`spmv_main tri8.mtx 64`: 64 shards over 8 rows.  The reference gives every thread nrow / nthreads = 0 rows and the
     last one all of them (src/mat_vec.cpp:233,245-246); every driver must run (empty shards included) and verify."""

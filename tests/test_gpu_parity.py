@@ -279,6 +279,43 @@ def test_dia_rectangular_bounds_columns_by_min_nrow_ncol(ctx, orc, tall):
     assert np.array_equal(dy.download(), ref), ("tall" if tall else "wide")
 
 
+def test_native_exchange_allgather_and_vec_copy(pkg):
+    """spmv_comm_* with three contexts of this process (on a one-GPU box they share the device: the copies are
+    device-to-device; with a GPU each they are RCCL broadcasts or peer copies): ragged slices, repeated calls with the
+    slices rewritten in between, and spmv_vec_copy between contexts"""
+    capi = pkg.capi
+    ctxs = [capi.Context(0) for _ in range(3)]
+    comm = capi.Comm(ctxs)
+    assert comm.backend in ("peer-copy", "rccl")
+    n = 1_000_003
+    offsets = np.array([0, 333_334, 333_334 + 400_000, n], dtype=np.int64)  # ragged, like the reference's last shard
+    vecs = [c.vector(n) for c in ctxs]
+    rng = np.random.default_rng(3)
+    for rep in range(3):
+        full = rng.uniform(-1, 1, n)
+        for i, v in enumerate(vecs):
+            v.fill(float("nan"))  # whatever is not the participant's own slice must come from the others
+            v.upload(full[offsets[i]:offsets[i + 1]], offset=int(offsets[i]))
+        comm.allgather(vecs, offsets)
+        for c in ctxs:
+            c.sync()
+        for v in vecs:
+            assert np.array_equal(v.download(), full), rep
+    # one participant: nothing to move, nothing to break
+    solo = capi.Comm(ctxs[:1])
+    solo.allgather(vecs[:1], np.array([0, n], dtype=np.int64))
+    # copy between contexts, ordered behind the source's queued work
+    dst = ctxs[2].vector(50)
+    dst.fill(0.0)
+    vecs[0].fill(7.0)
+    dst.copy_from(vecs[0], 20, dst_offset=10, src_offset=12345)
+    ctxs[2].sync()
+    got = dst.download()
+    assert np.array_equal(got[10:30], np.full(20, 7.0)) and not got[:10].any() and not got[30:].any()
+    with pytest.raises(capi.SpmvError):
+        dst.copy_from(vecs[0], 60)
+
+
 # ---------------------------------------------------------------------------------- BLAS-1
 def test_dot_and_axpby(ctx, orc):
     g = golden("tri8")
