@@ -571,10 +571,13 @@ int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
         }
         return SPMV_OK;
     }
+    if (m->format == SPMV_FMT_CSR && m->nnz > 0 && (!m->b || !m->v))
+        SPMV_REQUIRE(kernel == SPMV_CSR_PANEL || (kernel == SPMV_CSR_AUTO && m->kernel == SPMV_CSR_PANEL),
+                     "this handle gave up its CSR arrays (panel_keep_csr = 0): only the panel product is left");
     if (kernel == SPMV_CSR_AUTO)
     {
         m->kernel_forced = false;
-        if (m->format == SPMV_FMT_CSR) csr_choose_kernel(m);
+        if (m->format == SPMV_FMT_CSR && m->b && m->v) csr_choose_kernel(m);
     }
     else
     {
@@ -620,6 +623,25 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         m->pb_ablate = (int32_t)value;
     else if (!strcmp(name, "panel_two_per_cu"))
         m->pb_two_per_cu = (int32_t)value;
+    else if (!strcmp(name, "panel_keep_csr"))
+    {
+        // 0: release col_ind / values of a CSR handle whose product runs from the panel layout (which holds the same
+        // entries re-ordered; row_ptr stays).  Memory goes from 2x to 1x the matrix; what needs the arrays afterwards
+        // (download, another kernel, a re-build with other parameters, conversions, the Jacobi diagonal) is refused.
+        SPMV_REQUIRE(value == 0 || (m->b && m->v) || m->nnz == 0, "panel_keep_csr: the arrays are gone already");
+        if (value == 0 && m->b && m->v)
+        {
+            SPMV_REQUIRE(m->format == SPMV_FMT_CSR && m->owned && m->kernel == SPMV_CSR_PANEL && (m->pb_val || m->pb_rec),
+                         "panel_keep_csr = 0 needs an owned CSR handle whose panel layout is built");
+            SPMV_HIP(hipSetDevice(m->ctx->device));
+            SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
+            (void)hipFree(const_cast<int32_t*>(m->b));
+            (void)hipFree(const_cast<double*>(m->v));
+            m->b = nullptr;
+            m->v = nullptr;
+            m->device_bytes -= m->nnz * 12;
+        }
+    }
     else if (!strcmp(name, "dia_col_bound"))
     {
         SPMV_REQUIRE(m->format == SPMV_FMT_DIA && value >= 0 && value <= m->ncol, "dia_col_bound: a DIA handle and 0 <= bound <= ncol");
@@ -629,6 +651,8 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         m->pb_sync = (int32_t)value;
     else if (!strcmp(name, "panel_legacy"))
         m->pb_legacy = (int32_t)value;
+    else if (!strcmp(name, "panel_trial"))
+        m->pb_trial = (int32_t)value;
     else if (!strcmp(name, "panel_trace"))
         m->pb_trace = (int32_t)value;
     else
@@ -640,7 +664,11 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
 {
     SPMV_REQUIRE(m && name && value, "null argument");
     if (!strncmp(name, "panel_trace@", 12)) return csr_panel_read_trace(m->ctx, atoll(name + 12), value);
-    if (!strcmp(name, "panel_rows"))
+    if (!strcmp(name, "panel_keep_csr"))
+        *value = (m->b && m->v) || m->nnz == 0 ? 1 : 0;
+    else if (!strcmp(name, "device_bytes"))
+        *value = m->device_bytes;
+    else if (!strcmp(name, "panel_rows"))
         *value = m->pb_built_rows;
     else if (!strcmp(name, "panel_width"))
         *value = m->pb_built_width;
@@ -706,6 +734,7 @@ int spmv_mat_download(const spmv_mat* m, int32_t* a, int32_t* b, double* v)
         case SPMV_FMT_DIA: na = (size_t)m->k; nv = (size_t)m->nrow * (size_t)m->k; break;
         default: SPMV_FAIL(SPMV_ERR_INVALID, "unknown format %d", m->format);
     }
+    SPMV_REQUIRE(!((b && nb && !m->b) || (v && nv && !m->v)), "spmv_mat_download: this handle gave up its arrays (panel_keep_csr = 0)");
     hipStream_t s = m->ctx->stream;
     if (a && na) SPMV_HIP(hipMemcpyAsync(a, m->a, na * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     if (b && nb) SPMV_HIP(hipMemcpyAsync(b, m->b, nb * sizeof(int32_t), hipMemcpyDeviceToHost, s));

@@ -182,6 +182,7 @@ struct spmv_mat
     int32_t   pb_sync        = -1;       // keep a workgroup's wavefronts together: 0 no, 1 barrier per chunk, 2 priority to late ones,
                                          // 3 barrier between a chunk's loads and its LDS adds; -1 = by trial
     int32_t   pb_sync_tuned  = 0;        // what the trial found (in effect while pb_sync == -1)
+    int32_t   pb_trial       = -1;       // timing launches when the layout is built: 1 yes, 0 no, -1 = SPMV_PANEL_TRIAL (default yes)
     int32_t   pb_legacy      = 0;        // A/B: run the gather-first order through the general kernel (run-time sync switch)
     int32_t   pb_trace       = 0;        // diagnostic: stamp the phases of every chunk (gather-first pipeline, U = 8)
     int32_t   pb_two_per_cu  = 1;        // allow two workgroups per CU when the accumulators fit twice

@@ -228,6 +228,7 @@ int coo_to_csr(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out)
 int csr_to_ell(spmv_ctx* ctx, const spmv_mat* csr, spmv_mat** out)
 {
     SPMV_REQUIRE(csr->format == SPMV_FMT_CSR, "spmv_csr_to_ell: input is not CSR");
+    SPMV_REQUIRE(csr->nnz == 0 || (csr->b && csr->v), "spmv_csr_to_ell: the handle gave up its CSR arrays (panel_keep_csr = 0)");
     const int    nrow  = csr->nrow;
     const int    k     = csr->max_row_nnz;
     const size_t total = (size_t)nrow * (size_t)k;

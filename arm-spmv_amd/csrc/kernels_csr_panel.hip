@@ -824,6 +824,7 @@ int csr_panel_build(spmv_mat* m)
     if ((m->pb_val || m->pb_rec) && m->pb_built_rows == G && m->pb_built_width == W && m->pb_built_sort == (int)sort &&
         aos == (m->pb_rec != nullptr) && m->pb_built_layout == m->pb_aos + 16 * m->pb_uncached)
         return panel_choose_pace(m);  // the layout in memory was built with these parameters
+    if (!m->b || !m->v) SPMV_FAIL(SPMV_ERR_INVALID, "the panel layout cannot be re-built: this handle gave up its CSR arrays (panel_keep_csr = 0)");
     csr_panel_free(m);
     // Row groups.  Requested size (panel_rows): equal groups of G rows.  Otherwise the boundaries balance the
     // ENTRIES per group — a workgroup's time is its group's entry count, and the slowest of a round sets the pace
@@ -1011,6 +1012,17 @@ int panel_choose_pace(spmv_mat* m)
     if (m->pb_unroll > 0 && m->pb_pipe >= 0 && m->pb_sync >= 0) return SPMV_OK;  // nothing left to choose
     const bool worth = (double)m->ncol * 8.0 > 4.0 * 1048576.0 && m->pb_max_group_nnz >= 8LL * 8 * kPanelThreads;
     if (!worth) return SPMV_OK;  // x fits L2 or the groups are a few chunks long: nothing to keep in step
+    // SPMV_PANEL_TRIAL=0 (or panel_trial = 0): no timing launches at all; take what wins on scattered columns and costs
+    // 2 % on local ones (U = 8, gather-first, barrier between loads and adds)
+    const char* env_trial = getenv("SPMV_PANEL_TRIAL");
+    if (m->pb_trial == 0 || (m->pb_trial < 0 && env_trial && atoi(env_trial) == 0))
+    {
+        m->pb_unroll_tuned      = m->pb_unroll <= 0 ? 8 : 0;
+        m->pb_pipe_tuned        = m->pb_pack ? 2 : 1;
+        m->pb_sync_tuned        = m->pb_pack ? 3 : 1;
+        m->pb_pace_tuned_unroll = key;
+        return SPMV_OK;
+    }
     double *x = nullptr, *y = nullptr;
     if (hipMalloc(&x, sizeof(double) * (size_t)m->ncol) != hipSuccess || hipMalloc(&y, sizeof(double) * (size_t)m->nrow) != hipSuccess)
     {

@@ -279,6 +279,45 @@ def test_dia_rectangular_bounds_columns_by_min_nrow_ncol(ctx, orc, tall):
     assert np.array_equal(dy.download(), ref), ("tall" if tall else "wide")
 
 
+def test_csr_handle_can_give_up_its_arrays_once_the_panel_layout_is_built(ctx, pkg):
+    """panel_keep_csr = 0: col_ind / values of the CSR copy are released (the panel layout holds the same entries),
+    memory drops to ~1x the matrix, the product is unchanged, and what needs the arrays is refused with a message"""
+    capi = pkg.capi
+    n, k = 1_000_000, 16
+    A = ctx.gen_csr_uniform(0, n, n, k, seed=31)
+    assert A.info.kernel == capi.CSR_PANEL and A.get_param("panel_layout") == 3
+    x, y0, y1 = ctx.gen_vector(n, seed=31), ctx.vector(n), ctx.vector(n)
+    y0.fill(0.0)
+    y1.fill(0.0)
+    ctx.apply(A, x, y0)
+    before = A.get_param("device_bytes")
+    free0, _ = ctx.mem_info()
+    A.set_param("panel_keep_csr", 0)
+    after = A.get_param("device_bytes")
+    free1, _ = ctx.mem_info()
+    nnz = n * k
+    assert before - after == 12 * nnz and after <= 1.1 * (12 * nnz + 4 * (n + 1)), (before, after)
+    assert free1 - free0 >= 0.9 * 12 * nnz  # the driver really got the memory back
+    assert A.get_param("panel_keep_csr") == 0
+    ctx.apply(A, x, y1)
+    ctx.sync()
+    assert np.allclose(y0.download(), y1.download(), rtol=0, atol=1e-10 * k)
+    Err = capi.SpmvError
+    with pytest.raises(Err, match="gave up"):
+        A.download()
+    with pytest.raises(Err, match="gave up"):
+        A.set_kernel(capi.CSR_VECTOR)
+    with pytest.raises(Err, match="gave up"):
+        ctx.csr_to_ell(A)
+    A.set_param("panel_rows", 5000)
+    with pytest.raises(Err, match="gave up"):
+        A.set_kernel(capi.CSR_PANEL)  # a re-build with other parameters needs the CSR arrays
+    A.set_param("panel_rows", 0)
+    A.set_kernel(capi.CSR_PANEL)  # same parameters: nothing to re-build
+    ctx.apply(A, x, y1)
+    ctx.sync()
+
+
 def test_native_exchange_allgather_and_vec_copy(pkg):
     """spmv_comm_* with three contexts of this process (on a one-GPU box they share the device: the copies are
     device-to-device; with a GPU each they are RCCL broadcasts or peer copies): ragged slices, repeated calls with the
