@@ -17,7 +17,7 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "lib" / "libspmv_hip.so"
 
 FMT_COO, FMT_CSR, FMT_CSC, FMT_ELL, FMT_DIA = 0, 1, 2, 3, 4
-CSR_AUTO, CSR_VECTOR, CSR_LDSWIN, CSR_SCALAR, CSR_PANEL = 0, 1, 2, 3, 4
+CSR_AUTO, CSR_VECTOR, CSR_LDSWIN, CSR_SCALAR, CSR_PANEL, CSR_TWOPHASE = 0, 1, 2, 3, 4, 5
 FLAG_DPP_REDUCE, FLAG_XCD_REMAP = 1, 2
 
 _i32p = C.POINTER(C.c_int32)

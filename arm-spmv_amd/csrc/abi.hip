@@ -84,6 +84,7 @@ void mat_free(spmv_mat* m)
     if (m->win_lo) (void)hipFree(m->win_lo);
     if (m->win_span) (void)hipFree(m->win_span);
     csr_panel_free(m);
+    csr_twophase_free(m);
     if (m->coo_csr) mat_free(m->coo_csr);
     delete m;
 }
@@ -534,7 +535,7 @@ int spmv_mat_get_info(const spmv_mat* m, spmv_mat_info* info)
 int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
 {
     SPMV_REQUIRE(m, "null matrix");
-    SPMV_REQUIRE(kernel >= SPMV_CSR_AUTO && kernel <= SPMV_CSR_PANEL, "unknown kernel id %d", kernel);
+    SPMV_REQUIRE(kernel >= SPMV_CSR_AUTO && kernel <= SPMV_CSR_TWOPHASE, "unknown kernel id %d", kernel);
     SPMV_REQUIRE(lanes_per_row == 0 || (lanes_per_row >= 1 && lanes_per_row <= 64 &&
                                         (lanes_per_row & (lanes_per_row - 1)) == 0),
                  "lanes_per_row must be 0 or a power of two in 1..64, got %d", lanes_per_row);
@@ -572,8 +573,9 @@ int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
         return SPMV_OK;
     }
     if (m->format == SPMV_FMT_CSR && m->nnz > 0 && (!m->b || !m->v))
-        SPMV_REQUIRE(kernel == SPMV_CSR_PANEL || (kernel == SPMV_CSR_AUTO && m->kernel == SPMV_CSR_PANEL),
-                     "this handle gave up its CSR arrays (panel_keep_csr = 0): only the panel product is left");
+        SPMV_REQUIRE((kernel == SPMV_CSR_PANEL && (m->pb_val || m->pb_rec)) || (kernel == SPMV_CSR_TWOPHASE && m->tp_val) ||
+                         (kernel == SPMV_CSR_AUTO && (m->kernel == SPMV_CSR_PANEL || m->kernel == SPMV_CSR_TWOPHASE)),
+                     "this handle gave up its CSR arrays (panel_keep_csr = 0): only the product it was built for is left");
     if (kernel == SPMV_CSR_AUTO)
     {
         m->kernel_forced = false;
@@ -588,6 +590,11 @@ int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
     {
         SPMV_HIP(hipSetDevice(m->ctx->device));
         SPMV_TRY(csr_panel_build(m));  // (re)build with the current parameters
+    }
+    if (m->format == SPMV_FMT_CSR && m->kernel == SPMV_CSR_TWOPHASE)
+    {
+        SPMV_HIP(hipSetDevice(m->ctx->device));
+        SPMV_TRY(csr_twophase_build(m));
     }
     return SPMV_OK;
 }
@@ -631,8 +638,9 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         SPMV_REQUIRE(value == 0 || (m->b && m->v) || m->nnz == 0, "panel_keep_csr: the arrays are gone already");
         if (value == 0 && m->b && m->v)
         {
-            SPMV_REQUIRE(m->format == SPMV_FMT_CSR && m->owned && m->kernel == SPMV_CSR_PANEL && (m->pb_val || m->pb_rec),
-                         "panel_keep_csr = 0 needs an owned CSR handle whose panel layout is built");
+            SPMV_REQUIRE(m->format == SPMV_FMT_CSR && m->owned &&
+                             ((m->kernel == SPMV_CSR_PANEL && (m->pb_val || m->pb_rec)) || (m->kernel == SPMV_CSR_TWOPHASE && m->tp_val)),
+                         "panel_keep_csr = 0 needs an owned CSR handle whose panel or two-phase layout is built");
             SPMV_HIP(hipSetDevice(m->ctx->device));
             SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
             (void)hipFree(const_cast<int32_t*>(m->b));

@@ -191,6 +191,17 @@ struct spmv_mat
     int32_t   pb_built_rows = 0, pb_built_width = 0, pb_built_sort = -1;  // parameters of the layout in memory
     int64_t   pb_bytes       = 0;
 
+    // CSR two-phase kernel (kernels_csr_twophase.hip): entries in (column panel, row group) order
+    double*   tp_val       = nullptr;  // [nnz]
+    uint16_t* tp_col       = nullptr;  // [nnz] column - panel base
+    uint16_t* tp_row       = nullptr;  // [nnz] row - group base
+    double*   tp_xg        = nullptr;  // [nnz] the stream between the two phases
+    void*     tp_run       = nullptr;  // [groups * panels] {first entry, entries} of every run, group-major
+    int32_t*  tp_panel_ptr = nullptr;  // [panels + 1]
+    int32_t*  tp_gstart    = nullptr;  // [groups + 1]
+    int32_t   tp_ngroups = 0, tp_panels = 0, tp_pcols = 0, tp_max_rows = 0;
+    int64_t   tp_bytes   = 0;
+
     // COO / CSC / ELL: internal row-grouped copy in the panel layout (coo_build_panel, csc_analyse, ell_build_panel); owned
     spmv_mat* coo_csr = nullptr;
 };
@@ -208,6 +219,10 @@ int  panel_choose_pace(spmv_mat* m);
 void csr_panel_free(spmv_mat* m);
 int  csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 int  csr_panel_read_trace(spmv_ctx* ctx, int64_t index, int64_t* value);
+// kernels_csr_twophase.hip
+int  csr_twophase_build(spmv_mat* m);
+void csr_twophase_free(spmv_mat* m);
+bool csr_twophase_worth(const spmv_mat* m);
 // A sum that thousands of wavefronts add into is kept as kDotSlots partial sums on different 128-byte lines (an
 // atomic on ONE word costs ~12 ns each at the L2, serialised: 8192 of them are 100 us); readers add the slots up.
 constexpr int kDotSlots   = 32;
@@ -222,6 +237,7 @@ struct apply_extra
     double*       dot_out   = nullptr;  // slotted accumulator on the device (kDotDoubles doubles)
 };
 int  csr_panel_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, const apply_extra& ex);
+int  csr_twophase_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, const apply_extra& ex);
 bool csr_vector_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, const apply_extra& ex, int* rc);
 // solver.hip
 int mat_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);

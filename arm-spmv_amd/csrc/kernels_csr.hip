@@ -338,7 +338,7 @@ void csr_choose_kernel(spmv_mat* m)
     const bool   fits       = m->win_max_span > 0 && m->win_max_span <= kWinDoubles;
     const double reuse      = m->win_max_span > 0 ? mean * kWinRows / (double)m->win_max_span : 0.0;
     if (big_enough)
-        m->kernel = SPMV_CSR_PANEL;
+        m->kernel = csr_twophase_worth(m) ? SPMV_CSR_TWOPHASE : SPMV_CSR_PANEL;
     else if (fits && reuse >= 2.0)
         m->kernel = SPMV_CSR_LDSWIN;
     else
@@ -390,6 +390,7 @@ int csr_analyse(spmv_mat* m)
     }
     if (!m->kernel_forced) csr_choose_kernel(m);
     if (m->kernel == SPMV_CSR_PANEL) SPMV_TRY(csr_panel_build(m));
+    if (m->kernel == SPMV_CSR_TWOPHASE) SPMV_TRY(csr_twophase_build(m));
     return SPMV_OK;
 }
 
@@ -427,6 +428,7 @@ int csr_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
                           A->win_max_span, kWinDoubles);
             return launch_ldswin(ctx, A, x, y, lanes);
         case SPMV_CSR_PANEL: return csr_panel_apply(ctx, A, x, y);
+        case SPMV_CSR_TWOPHASE: return csr_twophase_apply_ex(ctx, A, x, y, apply_extra{});
         case SPMV_CSR_VECTOR:
         case SPMV_CSR_AUTO:
         default:

@@ -325,6 +325,7 @@ int mat_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, c
         panel = A->coo_csr;
     if (A->format == SPMV_FMT_CSC && A->coo_csr && !A->kernel_forced && A->nnz > 0 && A->ncol > 0) panel = A->coo_csr;
     if (panel) return csr_panel_apply_ex(ctx, panel, x, y, ex);
+    if (A->format == SPMV_FMT_CSR && A->kernel == SPMV_CSR_TWOPHASE) return csr_twophase_apply_ex(ctx, A, x, y, ex);
     int rc = SPMV_OK;
     if (A->format == SPMV_FMT_CSR && csr_vector_apply_ex(ctx, A, x, y, ex, &rc)) return rc;  // row-parallel kernel: fused too
     if (ex.overwrite) SPMV_TRY(vec_fill(ctx, y, A->nrow, 0.0));

@@ -325,7 +325,7 @@ def main() -> None:
         # the panel layout holds every entry once more, re-ordered: the product needs nothing else of the CSR copy but
         # row_ptr, so the handle gives col_ind / values back (memory ~1x the matrix instead of 2x)
         bytes_with_csr = A.get_param("device_bytes")
-        if int(info.kernel) == 4 and not args.keep_csr:
+        if int(info.kernel) in (4, 5) and not args.keep_csr:
             A.set_param("panel_keep_csr", 0)
         bytes_held = A.get_param("device_bytes")
         setup_no_trial_s = None
@@ -439,7 +439,8 @@ def main() -> None:
         wl_key = f"csr_n{n}_k{k}_band{args.band}_ncol{ncol}"
         if tfile.exists():
             traffic = json.loads(tfile.read_text()).get(wl_key, {}).get("hbm_bytes_per_launch")
-        kernel_names = {1: "csr_vector_kernel", 2: "csr_ldswin_kernel", 3: "csr_scalar_kernel", 4: "csr_panel_kernel"}
+        kernel_names = {1: "csr_vector_kernel", 2: "csr_ldswin_kernel", 3: "csr_scalar_kernel", 4: "csr_panel_kernel",
+                        5: "tp_expand_kernel + tp_reduce_kernel (two-phase)"}
         panel = None
         if int(info.kernel) == 4:
             panel = {k: A.get_param("panel_" + k) for k in ("rows", "width", "groups", "layout", "unroll", "pipe", "sync", "stagger", "pace_ns", "skew", "bytes")}

@@ -65,7 +65,8 @@ typedef enum spmv_csr_kernel
     SPMV_CSR_VECTOR   = 1, /* 2^k lanes per row, ds_swizzle/DPP segment reduction */
     SPMV_CSR_LDSWIN   = 2, /* row blocks whose x window is staged in LDS (banded matrices) */
     SPMV_CSR_SCALAR   = 3, /* one lane per row, strictly left-to-right (bitwise = oracle _fma) */
-    SPMV_CSR_PANEL    = 4  /* row groups x column panels: x gathered from L2, y accumulated in LDS */
+    SPMV_CSR_PANEL    = 4, /* row groups x column panels: x gathered from L2, y accumulated in LDS */
+    SPMV_CSR_TWOPHASE = 5  /* x-stationary expand + y-stationary reduce (x far larger than the rows held: C5 shards) */
 } spmv_csr_kernel;
 
 /* Tuning bits for spmv_mat_set_flags (speed only; results stay within the parity tolerance). */

@@ -50,7 +50,7 @@ def test_csr_matches_reference_golden(ctx, orc, pkg, make):
     capi = pkg.capi
     for kernel, lanes in ((capi.CSR_AUTO, 0), (capi.CSR_VECTOR, 1), (capi.CSR_VECTOR, 2), (capi.CSR_VECTOR, 4),
                           (capi.CSR_VECTOR, 8), (capi.CSR_VECTOR, 16), (capi.CSR_VECTOR, 32), (capi.CSR_VECTOR, 64),
-                          (capi.CSR_SCALAR, 0)):
+                          (capi.CSR_SCALAR, 0), (capi.CSR_TWOPHASE, 0)):
         for flags in (0, capi.FLAG_DPP_REDUCE, capi.FLAG_XCD_REMAP):
             if kernel != capi.CSR_VECTOR and flags:
                 continue
@@ -316,6 +316,58 @@ def test_csr_handle_can_give_up_its_arrays_once_the_panel_layout_is_built(ctx, p
     A.set_kernel(capi.CSR_PANEL)  # same parameters: nothing to re-build
     ctx.apply(A, x, y1)
     ctx.sync()
+
+
+def test_csr_twophase_kernel_on_wide_and_ragged_matrices(ctx, orc, pkg):
+    """expand (x panels in LDS) + reduce (row groups in LDS): several panels and groups, empty rows, a hub row, a last
+    panel that is not full, accumulation over two calls, and the solver's fused overwrite + dot; against the
+    row-parallel kernel and the oracle's row sums as the scale"""
+    capi = pkg.capi
+    rng = np.random.RandomState(17)
+    nrow, ncol = 45_000, 130_001  # 3 groups, 7 panels (the last one 10001 columns wide)
+    lens = rng.randint(0, 40, size=nrow)
+    lens[::97] = 0
+    lens[12345] = 6000
+    rp = np.zeros(nrow + 1, np.int32)
+    rp[1:] = np.cumsum(lens)
+    nnz = int(rp[-1])
+    cc = rng.randint(0, ncol, size=nnz).astype(np.int32)
+    cv = rng.uniform(-1, 1, size=nnz)
+    x = rng.uniform(0, 1, size=ncol)
+    ref = np.zeros(nrow)
+    ol.csr_spmv(orc, rp, cc, cv, x, ref)
+    scale = np.zeros(nrow)
+    ol.csr_abs_row_sums(orc, rp, cc, cv, x, scale)
+    A = ctx.csr(nrow, ncol, rp, cc, cv)
+    A.set_kernel(capi.CSR_TWOPHASE)
+    assert A.info.kernel == capi.CSR_TWOPHASE
+    dx, dy = ctx.vector_from(x), ctx.vector(nrow)
+    dy.fill(0.0)
+    ctx.apply(A, dx, dy)
+    ctx.sync()
+    ol.assert_parity(dy.download(), ref, scale, "twophase 1 call")
+    ctx.apply(A, dx, dy)
+    ctx.sync()
+    ol.assert_parity(dy.download(), 2 * ref, scale, "twophase 2 calls", reps=2)
+    w = rng.uniform(-1, 1, size=nrow)
+    dw = ctx.vector_from(w)
+    d = ctx.apply_dot(A, dx, dy, dw, overwrite=True)
+    got = dy.download()
+    ol.assert_parity(got, ref, scale, "twophase overwrite")
+    assert abs(d - float(w @ got)) <= 1e-9 * float(np.abs(w) @ np.abs(got))
+    # the automatic choice: a shard far wider than tall takes it, a square matrix of the same size does not
+    wide = ctx.gen_csr_uniform(0, 600_000, 40_000_000, 8, seed=3)
+    assert wide.info.kernel == capi.CSR_TWOPHASE
+    xw, yw, yv = ctx.gen_vector(40_000_000, seed=3), ctx.vector(600_000), ctx.vector(600_000)
+    yw.fill(0.0)
+    yv.fill(0.0)
+    ctx.apply(wide, xw, yw)
+    wide.set_kernel(capi.CSR_VECTOR)
+    ctx.apply(wide, xw, yv)
+    ctx.sync()
+    assert np.max(np.abs(yw.download() - yv.download())) <= ol.REL_TOL * 8
+    square = ctx.gen_csr_uniform(0, 600_000, 600_000, 8, seed=3)
+    assert square.info.kernel == capi.CSR_PANEL
 
 
 def test_native_exchange_allgather_and_vec_copy(pkg):
@@ -988,17 +1040,20 @@ def test_full_size_c5_last_shard_row_sample(ctx, orc, pkg):
     nglob, k = 80_000_000, 32
     b, e = 70_000_000, 80_000_000
     A = ctx.gen_csr_uniform(b, e, nglob, k, seed=1)
-    assert A.info.nnz == (e - b) * k and A.info.row_begin == b and A.info.kernel == pkg.capi.CSR_PANEL
+    # x (640 MB) is 8x what the shard's rows can keep busy per sweep: the automatic choice is the two-phase kernel
+    assert A.info.nnz == (e - b) * k and A.info.row_begin == b and A.info.kernel == pkg.capi.CSR_TWOPHASE
     x = ctx.gen_vector(nglob, seed=1)
     hx = synth.vec_uniform(nglob, seed=1)
     y = ctx.vector(e - b)
-    y.fill(0.0)
-    ctx.apply(A, x, y)
-    ctx.sync()
-    hy = y.download()
-    for r0 in (b, b + 4_321_000, e - 2000):
-        rp, cc, cv = synth.csr_uniform(r0, r0 + 2000, nglob, k, seed=1)
-        ref, scale = np.zeros(2000), np.zeros(2000)
-        ol.csr_spmv(orc, rp, cc, cv, hx, ref)
-        ol.csr_abs_row_sums(orc, rp, cc, cv, hx, scale)
-        ol.assert_parity(hy[r0 - b:r0 - b + 2000], ref, scale, f"C5 shard rows {r0}..")
+    for kernel in (pkg.capi.CSR_TWOPHASE, pkg.capi.CSR_PANEL):  # both at full size
+        A.set_kernel(kernel)
+        y.fill(0.0)
+        ctx.apply(A, x, y)
+        ctx.sync()
+        hy = y.download()
+        for r0 in (b, b + 4_321_000, e - 2000):
+            rp, cc, cv = synth.csr_uniform(r0, r0 + 2000, nglob, k, seed=1)
+            ref, scale = np.zeros(2000), np.zeros(2000)
+            ol.csr_spmv(orc, rp, cc, cv, hx, ref)
+            ol.csr_abs_row_sums(orc, rp, cc, cv, hx, scale)
+            ol.assert_parity(hy[r0 - b:r0 - b + 2000], ref, scale, f"C5 shard rows {r0}.. kernel {kernel}")

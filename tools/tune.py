@@ -181,6 +181,7 @@ def main():
                 A.set_param("panel_ablate", 0)
                 A.set_kernel(capi.CSR_PANEL)  # rebuilds the layout when the parameters changed
             variants.append((f"panel U={unroll} skew={skew} pace={pace}ns pipe={pipe} slack={slack} layout={aos} stagger={stagger} rows={rows} uncached={uncached} sync={sync} legacy={legacy}", setup))
+        variants.append(("two-phase (expand + reduce)", lambda A: A.set_kernel(capi.CSR_TWOPHASE)))
         for ab, what in ((1, "no LDS adds"), (2, "gathers always hit L1"), (3, "neither")) if a.ablate else ():
             def setup(A, ab=ab):
                 for k, v in (("panel_rows", 0), ("panel_width", 0), ("panel_sort", 1), ("panel_unroll", 8), ("panel_skew", 0),
