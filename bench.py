@@ -406,12 +406,16 @@ def main() -> None:
                 nnz2 = int(inf.nnz)
                 kk = int(inf.ell_k) if fmt == "ell" else 0
                 b = algorithmic_bytes(fmt, int(inf.nrow), int(inf.ncol), nnz2, kk)
+                tkey = {"ell": f"ell_n{int(inf.nrow)}_k{kk}", "coo": f"coo_n{int(inf.nrow)}_nnz{nnz2}",
+                        "csr": f"csr_n{int(inf.nrow)}_k{k}_band65536_ncol{int(inf.ncol)}"}[fmt]
+                tfile2 = ROOT / "profiles" / "pmc_traffic.json"
+                traffic2 = json.loads(tfile2.read_text()).get(tkey, {}).get("hbm_bytes_per_launch") if tfile2.exists() else None
                 extra.append({
                     "name": name, "format": fmt, "nrow": int(inf.nrow), "ncol": int(inf.ncol), "nnz": nnz2,
                     "max_row_nnz": int(inf.max_row_nnz), "kernel_id": int(inf.kernel), "ms": round(ms, 5),
                     "value": round(2.0 * nnz2 / ms / 1e6, 2), "unit": "GFLOP/s", "setup_seconds": round(t_set, 3),
                     "roofline": {"bound": "hbm", "achieved": round(b / ms / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": round(b / ms / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": b},
+                                 "frac": round(b / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": traffic2, "algorithmic_bytes_per_launch": b},
                 })
                 del M, vx2, vy2
 

@@ -1,39 +1,42 @@
 #!/usr/bin/env bash
 # tools/profile_round.sh TAG — collect the evidence of one round on the GPU box into gpurun_out/TAG/
-# (bench line, rocprofv3 kernel stats, PMC passes in separate runs, per-config sweeps).  Copy what is to be judged
-# into profiles/ afterwards.  Run from anywhere; every GPU step has its own timeout.
+# (bench line with extras and CPU modes, rocprofv3 kernel stats of the same command, PMC passes in separate runs).
+# Copy what is to be judged into profiles/ afterwards.  Run from anywhere; every GPU step has its own timeout.
 set -u
 TAG=${1:-rXX}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
 cd "$R" || exit 1
-timeout -k 10 300 python3 bench.py > "$O/bench_c2_uniform.json" 2> "$O/bench_c2_uniform.err" || exit 1
-timeout -k 10 300 python3 bench.py --band 65536 --no-cpu-baseline > "$O/bench_c2_band65536.json" 2>/dev/null || exit 1
+timeout -k 10 600 python3 bench.py > "$O/bench_c2_uniform.json" 2> "$O/bench_c2_uniform.err" || exit 1
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 "$R/bench.py" --steps 50 --warmup 5 --no-cpu-baseline > "$O/rocprof_stats.log" 2>&1 || exit 1
-timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$O/pmc_fetch.log" 2>&1 || exit 1
-timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$O/pmc_write.log" 2>&1 || exit 1
-timeout -k 10 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --output-format csv -d "$O/pmc_tcc" -- python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$O/pmc_tcc.log" 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 "$R/bench.py" --steps 50 --warmup 5 --no-cpu-baseline > "$O/rocprof_stats.log" 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$O/pmc_fetch.log" 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$O/pmc_write.log" 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --output-format csv -d "$O/pmc_tcc" -- python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$O/pmc_tcc.log" 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_BUSY_sum --output-format csv -d "$O/pmc_req" -- python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$O/pmc_req.log" 2>&1 || exit 1
 cd "$R" || exit 1
 python3 - "$O" <<'PY'
-import csv, glob, statistics, sys
+import csv, glob, re, statistics, sys
 O = sys.argv[1]
-f = glob.glob(O + "/stats/*/*_kernel_trace.csv")[0]
-# the product launches; the build-time trials run the same code under the name csr_panel_kernel<..., true>
-rows = [r for r in csv.DictReader(open(f)) if "csr_panel_kernel" in r["Kernel_Name"] and ", true>" not in r["Kernel_Name"]]
-d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
-name = rows[-1]["Kernel_Name"].split("(anonymous namespace)::")[-1].split("(")[0]
-st = [r for r in csv.DictReader(open(glob.glob(O + "/stats/*/*_kernel_stats.csv")[0])) if name in r["Name"]]
+trace = list(csv.DictReader(open(glob.glob(O + "/stats/*/*_kernel_trace.csv")[0])))
+stats = list(csv.DictReader(open(glob.glob(O + "/stats/*/*_kernel_stats.csv")[0])))
+def short(n):
+    return n.split("(anonymous namespace)::")[-1].split("(")[0]
+def is_trial(n):  # csr_panel_kernel<U, GATED, LAYOUT, ABLATE, PIPE, TRIAL, TRACE, SYNCT>
+    m = re.search(r"csr_panel_kernel<([^>]*)>", n)
+    return bool(m) and m.group(1).split(",")[5].strip() == "true"
 with open(O + "/timed_region.txt", "w") as out:
-    out.write(f"{name}: {len(d)} dispatches in the kernel trace (warm-up + timed steps); mean {statistics.mean(d):.4f} ms, "
-              f"median {statistics.median(d):.4f}, min {min(d):.4f}, max {max(d):.4f}; the last 50 (the timed region): mean "
-              f"{statistics.mean(d[-50:]):.4f} ms.  kernel_stats.csv row of the same kernel: Calls {st[0]['Calls']}, "
-              f"AverageNs {float(st[0]['AverageNs']):.0f}\n")
+    for key, last in (("csr_panel_kernel", 50), ("ell_kernel", 50), ("tp_expand_kernel", 0), ("tp_reduce_kernel", 0)):
+        names = sorted({r["Kernel_Name"] for r in trace if key in r["Kernel_Name"] and not is_trial(r["Kernel_Name"])})
+        for name in names:
+            d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in trace if r["Kernel_Name"] == name]
+            st = [r for r in stats if r["Name"] == name]
+            tail = d[-last:] if last and len(d) >= last else d
+            out.write(f"{short(name)}: {len(d)} dispatches in the kernel trace; mean {statistics.mean(d):.4f} ms, median {statistics.median(d):.4f}, "
+                      f"min {min(d):.4f}, max {max(d):.4f}; the last {len(tail)}: mean {statistics.mean(tail):.4f} ms.  kernel_stats.csv row: "
+                      f"Calls {st[0]['Calls'] if st else '?'}, AverageNs {float(st[0]['AverageNs']) if st else 0:.0f}\n")
 print(open(O + "/timed_region.txt").read())
 PY
-for what in ell coo dia blas1; do timeout -k 10 200 python3 tools/tune.py $what --rounds 3 > "$O/tune_$what.log" 2>&1 || exit 1; done
-timeout -k 10 300 python3 tools/tune.py csr --rounds 3 --reps 10 --panel "0,0,-1,-1,0,3;8,0,-1,1,0,3;8,0,0,2,0,3;8,0,-1,1,0,0" > "$O/tune_csr_uniform.log" 2>&1 || exit 1
-timeout -k 10 300 python3 tools/tune.py csr --band 4096 --rounds 3 --reps 10 --panel "0,0,-1,-1,0,3;8,0,-1,1,0,0" > "$O/tune_csr_band4096.log" 2>&1 || exit 1
-for d in pmc_fetch pmc_write pmc_tcc; do python3 tools/pmc_summary.py "$O/$d" csr_panel | tail -3; done
-tail -n 3 "$O"/tune_*.log
+for d in pmc_fetch pmc_write pmc_tcc pmc_req; do echo "== $d"; python3 tools/pmc_summary.py "$O/$d" csr_panel | tail -4; python3 tools/pmc_summary.py "$O/$d" ell_kernel | tail -2; done > "$O/pmc_summary.txt" 2>&1
+cat "$O/pmc_summary.txt"
