@@ -14,7 +14,7 @@ from pathlib import Path
 import numpy as np
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "lib" / "libspmv_hip.so"
+LIB_PATH = Path(os.environ.get("SPMV_HIP_SO") or _PKG / "lib" / "libspmv_hip.so")  # override: A/B against another build
 
 FMT_COO, FMT_CSR, FMT_CSC, FMT_ELL, FMT_DIA = 0, 1, 2, 3, 4
 CSR_AUTO, CSR_VECTOR, CSR_LDSWIN, CSR_SCALAR, CSR_PANEL, CSR_TWOPHASE = 0, 1, 2, 3, 4, 5

@@ -573,7 +573,7 @@ int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
         return SPMV_OK;
     }
     if (m->format == SPMV_FMT_CSR && m->nnz > 0 && (!m->b || !m->v))
-        SPMV_REQUIRE((kernel == SPMV_CSR_PANEL && (m->pb_val || m->pb_rec)) || (kernel == SPMV_CSR_TWOPHASE && m->tp_val) ||
+        SPMV_REQUIRE((kernel == SPMV_CSR_PANEL && m->pb_val) || (kernel == SPMV_CSR_TWOPHASE && m->tp_val) ||
                          (kernel == SPMV_CSR_AUTO && (m->kernel == SPMV_CSR_PANEL || m->kernel == SPMV_CSR_TWOPHASE)),
                      "this handle gave up its CSR arrays (panel_keep_csr = 0): only the product it was built for is left");
     if (kernel == SPMV_CSR_AUTO)
@@ -614,20 +614,12 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         m->pb_aos = (int32_t)value;
     else if (!strcmp(name, "panel_pace_ns"))
         m->pb_pace_req = (int32_t)value;
-    else if (!strcmp(name, "panel_skew"))
-        m->pb_skew = (int32_t)value;
-    else if (!strcmp(name, "panel_pace_slack"))
-        m->pb_pace_slack = (int32_t)value;
     else if (!strcmp(name, "panel_pipe"))
         m->pb_pipe = (int32_t)value;
     else if (!strcmp(name, "panel_stagger"))
         m->pb_stagger = (int32_t)value;
     else if (!strcmp(name, "panel_guard"))
         m->pb_guard = (int32_t)value;
-    else if (!strcmp(name, "panel_uncached"))
-        m->pb_uncached = (int32_t)value;
-    else if (!strcmp(name, "panel_ablate"))
-        m->pb_ablate = (int32_t)value;
     else if (!strcmp(name, "panel_two_per_cu"))
         m->pb_two_per_cu = (int32_t)value;
     else if (!strcmp(name, "panel_keep_csr"))
@@ -639,7 +631,7 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         if (value == 0 && m->b && m->v)
         {
             SPMV_REQUIRE(m->format == SPMV_FMT_CSR && m->owned &&
-                             ((m->kernel == SPMV_CSR_PANEL && (m->pb_val || m->pb_rec)) || (m->kernel == SPMV_CSR_TWOPHASE && m->tp_val)),
+                             ((m->kernel == SPMV_CSR_PANEL && m->pb_val) || (m->kernel == SPMV_CSR_TWOPHASE && m->tp_val)),
                          "panel_keep_csr = 0 needs an owned CSR handle whose panel or two-phase layout is built");
             SPMV_HIP(hipSetDevice(m->ctx->device));
             SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
@@ -688,14 +680,12 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         *value = m->pb_unroll > 0 ? m->pb_unroll : (m->pb_unroll_tuned > 0 ? m->pb_unroll_tuned : 8);
     else if (!strcmp(name, "panel_pace_ns"))
         *value = m->pb_pace_ns;
-    else if (!strcmp(name, "panel_skew"))
-        *value = m->pb_skew;
     else if (!strcmp(name, "panel_bytes"))
         *value = m->pb_bytes;
     else if (!strcmp(name, "panel_pipe"))
         *value = m->pb_pipe >= 0 ? m->pb_pipe : (m->pb_pipe_tuned > 0 ? m->pb_pipe_tuned : 1);
     else if (!strcmp(name, "panel_stagger"))
-        *value = m->pb_stagger_tuned >= 0 ? m->pb_stagger_tuned : m->pb_stagger;
+        *value = m->pb_stagger;
     else if (!strcmp(name, "panel_sync"))
         *value = m->pb_sync >= 0 ? m->pb_sync : m->pb_sync_tuned;
     else if (!strcmp(name, "panel_pace_scale") || !strcmp(name, "panel_pace_bumps"))
@@ -711,7 +701,7 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         *value = !strcmp(name, "panel_pace_scale") ? h[0] : h[3];
     }
     else if (!strcmp(name, "panel_layout"))  // layout in memory: 0 three arrays, 1 records, 3 packed 12-byte entries
-        *value = m->pb_pack ? 3 : m->pb_rec ? 1 : 0;
+        *value = m->pb_pack ? 3 : 0;
     else if (!strcmp(name, "window_max_span"))
         *value = m->win_max_span;
     else if (!strcmp(name, "window_avg_span"))

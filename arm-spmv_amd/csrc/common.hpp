@@ -155,9 +155,7 @@ struct spmv_mat
     int32_t   pb_panel_width = 0;        // W (0 = default)
     int32_t   pb_sort        = 1;        // bucket tile entries by 128-byte line of x
     int32_t   pb_unroll      = 0;        // entries in flight per lane (0 = default)
-    int32_t   pb_skew        = 0;        // counter gate: chunks a workgroup may run ahead of the slowest (0 = off)
-    void*     pb_rec         = nullptr;  // [nnz] 16-byte records {value, column, local row} (replaces the three arrays)
-    int32_t   pb_aos         = 3;        // layout: 0 three arrays, 1 16-byte records (slower), 2 system-scope loads, 3 packed
+    int32_t   pb_aos         = 3;        // layout: 3 = 12-byte packed entries (falls back to 0), 0 = three arrays (14 bytes)
     uint32_t* pb_pack        = nullptr;  // [nnz] layout 3: (column - slice base) << rowbits | local row
     int32_t*  pb_sbase       = nullptr;  // [slices] layout 3: line-aligned first column of every 1024-entry slice
     int32_t*  pb_soff        = nullptr;  // [ngroups + 1] layout 3: first slice of every group
@@ -167,13 +165,9 @@ struct spmv_mat
     int32_t   pb_pace_ns     = 0;        // pacing throttle in effect: nanoseconds per chunk on the chip clock (0 = off)
     int32_t   pb_pipe        = -1;      // chunk pipeline: 0 off, 1 stream-first, 2 gather-first, -1 = 1 or 2 by trial
     int32_t   pb_pipe_tuned  = 0;       // the order found by trying (in effect while pb_pipe == -1; 0 = not tried: 1)
-    int32_t   pb_ablate      = 0;       // timing experiments only (wrong results): see PanelBatch::apply
-    int32_t   pb_pace_slack  = 0;        // chunks a workgroup may run ahead of the paced schedule
     unsigned* pb_ctl         = nullptr;  // device: {pace scale in 1/1024, worst lag, workgroups done, bumps} (run-time guard)
-    int32_t   pb_uncached    = 0;        // experiment: packed arrays in uncached (1) / fine-grained (2) device memory
     int32_t   pb_guard       = 1;        // stretch the pace at run time when the workgroups fall behind it
-    int32_t   pb_stagger_tuned = -1;     // schedule offsets found by trial (-1: use pb_stagger)
-    int32_t   pb_stagger     = 2;        // paced schedule offsets: 0 none, 1 wavefronts 1/16 of the pace apart (loses), 2 XCDs 1/8 apart
+    int32_t   pb_stagger     = 2;        // offsets of a paced schedule: 0 none, 2 XCDs 1/8 of the pace apart
     int32_t   pb_pace_req    = -1;      // requested pace (-1 = try a few and keep the fastest)
     int32_t   pb_pace_tuned_ns = 0;      // the pace found by trying (restored when the request goes back to -1)
     int32_t   pb_pace_tuned_unroll = 0; // what the trial was made for: requested unroll, -1 = unroll chosen too, 0 = not tried

@@ -25,10 +25,15 @@
 // the number of L2->L1 line transfers — the bound once the fabric traffic is under control: a divergent gather
 // costs one 128-byte line transfer per distinct line (~258 Glines/s chip-wide = the L2's ~33 TB/s), whatever the
 // load flavour.
-// Staying "in step" is not automatic: see the throttles below (counter gate, clock pace with per-XCD offsets), the
-// two pipeline orders of a chunk, and panel_choose_pace, which picks chunk size, order, offsets and pace by trial.
-// Several experiments that lost are still selectable (spmv_mat_set_param) so that the logs in profiles/ can be
-// reproduced: 16-byte records, system-scope stream loads, pace slack, wavefront stagger, the counter gate.
+// Staying "in step" inside an XCD is what makes the gathers hit L2: see "keeping in step" below (a workgroup barrier
+// per chunk; the clock pace of round 1 is kept as an option), the two pipeline orders of a chunk, and
+// panel_choose_pace, which picks chunk size, order and barrier placement by timing a handful of launches.
+// What bounds C2 now (profiles/r02_pmc_bench_kernels.txt): the L2.  One product makes 234M L1->L2 read requests (202M
+// gather lines + 30M streamed lines + y) and 41M fills; at the ~268 G line operations per second the eight L2s
+// sustain (tools/probe_gather) that is 1.03 ms, and the kernel takes 1.13-1.15.  A CU cannot overlap the HBM stream
+// with the gathers either (tools/probe_mix.hip: one CU runs them at the SUM of their times, separate CUs at the max).
+// Experiments that lost were removed from this file in round 2; their logs stay in profiles/ (16-byte records,
+// system-scope stream loads, pace slack, wavefront stagger, counter gate, ring pipelines, split barrier).
 //
 // Algorithmic bytes are counted with CSR's 12 bytes per entry; the packed layout streams exactly
 // that, so what is left between achieved and roofline is the x traffic and the gather path, not layout overhead.
@@ -169,13 +174,12 @@ __global__ __launch_bounds__(256) void panel_line_sort_kernel(const int32_t* __r
 // the streamed loads and the LDS adds (one workgroup per CU = 16 wavefronts is all the thread-level
 // parallelism the LDS footprint allows, so the memory-level parallelism has to come from here).
 // LAYOUT 0: three arrays (value fp64, column int32, local row uint16): 14 bytes per entry, three load instructions.
-// LAYOUT 1: one 16-byte record {value, column, local row} per entry: one dwordx4 load instruction, 1 KiB per
-//           wavefront instruction.  The CU's vector-memory pipeline, not HBM, is what the kernel runs out of on
-//           uniform-random columns, so fewer instructions beat fewer bytes there.
 // LAYOUT 3: two arrays (value fp64, one packed 32-bit word): 12 bytes per entry, two load instructions.  The word
 //           holds the local row in its low `rowbits` bits and, above them, the column relative to the base of the
 //           entry's slice (1024 packed entries; the entries are ordered by x line, so a slice spans few
 //           columns; see panel_cut_kernel).  The bases are one int32 per slice, read through the scalar cache.
+// (Tried and dropped, logs in profiles/r01_*: 16-byte {value, column, row} records — one load instruction per entry,
+// 3.2-3.6 ms on C2 — and system-scope loads for the stream.)
 template <int UNROLL, int LAYOUT>
 struct PanelBatch
 {
@@ -211,50 +215,16 @@ struct PanelBatch
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
         {
-            if constexpr (LAYOUT == 3)
-            {
-                c[u] = load_stream(pcol + e + u * kPanelThreads);  // packed word, see unpack()
-                v[u] = load_stream(pval + e + u * kPanelThreads);
-            }
-            else if constexpr (LAYOUT == 1)
-            {
-                const i32x4 rec = load_stream(reinterpret_cast<const i32x4*>(pval) + e + u * kPanelThreads);
-                v[u]            = __hiloint2double(rec.y, rec.x);
-                c[u]            = rec.z;
-                r[u]            = (unsigned)rec.w;
-            }
-            else if constexpr (LAYOUT == 2)
-            {
-                // experiment: system-scope loads (sc0 sc1) for the stream, to see whether they leave the x lines
-                // in L2 alone (profiles/r01_tune_csr_stream_scope.txt)
-                c[u] = __hip_atomic_load(pcol + e + u * kPanelThreads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                r[u] = __hip_atomic_load(prow + e + u * kPanelThreads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                v[u] = __hip_atomic_load(pval + e + u * kPanelThreads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            else
-            {
-                c[u] = load_stream(pcol + e + u * kPanelThreads);
-                r[u] = load_stream(prow + e + u * kPanelThreads);
-                v[u] = load_stream(pval + e + u * kPanelThreads);
-            }
+            c[u] = load_stream(pcol + e + u * kPanelThreads);  // LAYOUT 3: the packed word, see unpack()
+            if constexpr (LAYOUT != 3) r[u] = load_stream(prow + e + u * kPanelThreads);
+            v[u] = load_stream(pval + e + u * kPanelThreads);
         }
     }
-    // ABLATE (timing experiments only, results are wrong): bit 0 = no LDS adds (products summed in a register),
-    // bit 1 = gathers confined to 8 KiB of x (always L1 hits, one or two lines per instruction)
-    template <int ABLATE = 0>
-    __device__ __forceinline__ void apply(const double* __restrict__ x, double* acc, double* sink = nullptr) const
+    __device__ __forceinline__ void apply(const double* __restrict__ x, double* acc) const
     {
         double xv[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) xv[u] = x[(ABLATE & 2) ? (c[u] & 1023) : c[u]];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-        {
-            if constexpr (ABLATE & 1)
-                *sink += v[u] * xv[u] + (double)r[u];
-            else
-                atomicAdd(&acc[r[u]], v[u] * xv[u]);  // ds_add_f64
-        }
+        gather(x, xv);
+        add(acc, xv);
     }
     // the two halves of apply(), for the gather-first pipeline
     __device__ __forceinline__ void gather(const double* __restrict__ x, double (&xv)[UNROLL]) const
@@ -277,22 +247,6 @@ struct PanelBatch
         b.apply(x, acc);
     }
 };
-
-__global__ __launch_bounds__(256) void panel_pack_kernel(int64_t nnz, const int32_t* __restrict__ col,
-                                                         const uint16_t* __restrict__ row, const double* __restrict__ val,
-                                                         i32x4* __restrict__ rec)
-{
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * 256)
-    {
-        const double v = val[e];
-        i32x4        q;
-        q.x    = __double2loint(v);
-        q.y    = __double2hiint(v);
-        q.z    = col[e];
-        q.w    = (int)row[e];
-        rec[e] = q;
-    }
-}
 
 // LAYOUT 3 build.  A group's entries (ordered by x line) are cut into slices of at most 1024 entries that span
 // fewer than 2^colbits columns; every slice is stored as exactly 1024 packed entries (the rest are pads: value 0,
@@ -387,33 +341,22 @@ __global__ void group_nnz_max_kernel(const int32_t* __restrict__ gstart, int ngr
     atomicMax(out_max, row_ptr[r1] - row_ptr[r0]);
 }
 
-// ---- progress gate ------------------------------------------------------------------------------------------
-// Purely a throttle, never needed for correctness: it keeps the workgroups that share an XCD (and hence an L2)
-// within `skew` chunks of each other, so that the x lines one CU pulled into the L2 are still there when the
-// other CUs of the XCD gather from them.  Without it the workgroups drift apart, the L2 turns over every
-// ~10 us under the streamed entries, and the kernel issues ~4x the fabric reads it needs (measured: 176M
-// requests against ~45M).
-//   gate[(round*8 + xcd)*nchunk + b] counts the workgroups on that XCD that finished chunk b of the round.
-//   pop [ round*8 + xcd ]            counts the workgroups of the XCD that entered the round.
-// A wavefront starts chunk b only when chunk b - skew is complete on its XCD.  What is known to be complete is
-// kept in LDS (`released`); when that is not enough, ONE wavefront of the workgroup (LDS lock) polls the
-// counter with relaxed agent-scope loads and s_sleep, the others watch LDS.  So a counter word has at most 32
-// pollers and 32 adders.  No data is handed over through the gate, hence no fences.  Every spin is bounded:
-// if the workgroups are not all resident, or the XCD id is not what it seems, only the throttle is lost.
-constexpr int kGateSpinLimit = 2048;
-
-struct GateLds
+// ---- keeping in step ------------------------------------------------------------------------------------------
+// The x lines one CU pulls into its XCD's L2 serve the other 31 CUs of the XCD only while all of them gather from the
+// same stretch of x.  What keeps them there (tools/trace_panel.py, profiles/r02_trace_*):
+//   * inside a workgroup, a barrier per chunk (SYNC below).  Without it the oldest-first issue arbitration lets
+//     wavefront 0 start chunk b+1 while wavefront 15 is still issuing chunk b; 2 % of the chunks then take 15 us
+//     instead of 7, the workgroup falls behind its XCD and its gathers start missing L2;
+//   * between workgroups, nothing explicit: who leads the sweep takes the L2 misses and slows down, the others close
+//     up.  (Round 1 throttled every chunk to a clock instead — `pace` below, kept as an option with its run-time
+//     guard; it compensated for the missing barrier and cost 15 %.  A counter gate per XCD and schedules with the
+//     wavefronts or the halves of an XCD apart were measured and dropped: profiles/r01_pmc_gate_variants.txt,
+//     r01_tune_csr_stagger.txt, r02_tune_csr_c2_ring_paces.txt.)
+struct PanelLds
 {
-    unsigned released;      // chunks [0, released) are complete on this XCD
-    unsigned lock;          // 1 while a wavefront of this workgroup polls the global counter
-    unsigned wave_done[16]; // per chunk slot: wavefronts of this workgroup that finished the chunk
-    unsigned issued[2];     // split barrier (SYNCT 2): lanes that have issued the loads of the even / odd chunks
+    unsigned issued[2];  // split barrier (SYNC 2): lanes that have issued the loads of the even / odd chunks
 };
 
-__device__ __forceinline__ unsigned gate_read(const unsigned* p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 __device__ __forceinline__ unsigned lds_read(const unsigned* p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -423,58 +366,38 @@ __device__ __forceinline__ int xcd_id()
     return __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 7;  // hwreg(HW_REG_XCC_ID, 0, 4)
 }
 
-// lane 0 of a wavefront: block until chunk `need` is complete on this XCD (bounded)
-__device__ __forceinline__ void gate_wait(GateLds* lds, const unsigned* gate_x, const unsigned* pop_x, unsigned need)
-{
-    int spins = 0;
-    while (lds_read(&lds->released) <= need && spins < kGateSpinLimit)
-    {
-        if (atomicCAS(&lds->lock, 0u, 1u) == 0u)
-        {
-            const unsigned expected = gate_read(pop_x);  // every workgroup of the XCD registered long ago
-            while (gate_read(gate_x + need) < expected && ++spins < kGateSpinLimit) __builtin_amdgcn_s_sleep(4);
-            atomicMax(&lds->released, need + 1);
-            __hip_atomic_store(&lds->lock, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            return;
-        }
-        __builtin_amdgcn_s_sleep(2);
-        ++spins;
-    }
-}
-
 // Diagnostic build of the gather-first pipeline (panel_trace = 1): lane 0 of wavefronts 0 and 15 of the first 256
 // workgroups stamps 32 chunks of the first round with the chip-wide 100 MHz clock: chunk start, loads issued,
 // gathers back, LDS adds done, next chunk's stream back.  Read through spmv_mat_get_param("panel_trace@<i>").
 constexpr int kTraceWgs = 256, kTraceChunks = 32, kTraceFirst = 16, kTraceStamps = 5;
 __device__ unsigned g_panel_trace[kTraceWgs * 2 * kTraceChunks * kTraceStamps];
 
-// TRIAL: same code under another name, so that the launches of the build-time trials (panel_choose_pace) show up
-// apart from the products in a kernel trace
-template <int UNROLL, bool GATED, int LAYOUT, int ABLATE = 0, int PIPE = 0, bool TRIAL = false, bool TRACE = false, int SYNCT = -1>
+// flags: bit 0 = per-XCD offsets of the paced schedule; bits 1-2 = SYNC when it is not a template argument
+//   SYNC 0  nothing (local columns: bands)          SYNC 1  workgroup barrier at the top of every chunk
+//   SYNC 3  the barrier between a chunk's loads and its LDS adds: the early wavefronts wait with their gathers long back
+//   SYNC 2  split barrier through an LDS counter (compile-time only; measured: no better than 3)
+// SYNCT >= 0 fixes the choice at compile time for the C2 instance: a run-time branch between a chunk's loads and its
+// adds costs the compiler's exact wait counts there (1.15 -> 1.33 ms when one was added).
+// TRIAL: same code under another name, so that the launches of the build-time trials show up apart from the products
+// in a kernel trace.
+template <int UNROLL, int LAYOUT, int PIPE = 0, bool TRIAL = false, bool TRACE = false, int SYNCT = -1>
 __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t* __restrict__ gstart, int ngroups,
                                                                   const int32_t* __restrict__ row_ptr,
                                                                   const int32_t* __restrict__ pcol,
                                                                   const uint16_t* __restrict__ prow,
                                                                   const double* __restrict__ pval,
                                                                   const double* __restrict__ x, double* __restrict__ y,
-                                                                  unsigned* __restrict__ gate, unsigned* __restrict__ pop,
-                                                                  int nchunk, int skew, unsigned long long pace_fp, int pace_slack,
+                                                                  unsigned long long pace_fp, int flags,
                                                                   const int32_t* __restrict__ sbase,
                                                                   const int32_t* __restrict__ soff, int rowbits,
                                                                   int overwrite, const double* __restrict__ dot_w,
                                                                   double* __restrict__ dot_out, unsigned* __restrict__ ctl)
 {
     extern __shared__ double acc[];  // G accumulators
-    __shared__ GateLds       gl;
-    double                   sink = 0.0;  // ABLATE only
+    __shared__ PanelLds      gl;
     constexpr int STEP   = UNROLL * kPanelThreads;
-    constexpr int NWAVES = kPanelThreads / kWave;
     const int     lane   = threadIdx.x & 63;
-    const int     xcd    = GATED ? xcd_id() : 0;
-    if (GATED && threadIdx.x < 16) gl.wave_done[threadIdx.x] = 0;
-    // Run-time guard of the pace (ctl: {scale in 1/1024, worst lag of this launch, workgroups done, bumps}).  The pace
-    // found at build time sits a few per cent above the cliff; if the chip later slows down (clocks, a neighbour on
-    // the fabric) the workgroups fall behind the schedule, drift apart and the product takes twice as long.  Every
+    // Run-time guard of the pace (ctl: {scale in 1/1024, worst lag of this launch, workgroups done, bumps}): every
     // workgroup reports how far behind the schedule it got; the last one to finish stretches the pace by 5 % for the
     // following launches when that was more than two chunks.  Never shrinks: the next build measures afresh.
     if (ctl && pace_fp) pace_fp = (pace_fp * __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 10;
@@ -486,19 +409,6 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
         const int rows = gstart[g + 1] - r0;
         for (int i = threadIdx.x; i < rows; i += kPanelThreads) acc[i] = 0.0;
         if (SYNCT == 2 && threadIdx.x == 0) gl.issued[0] = gl.issued[1] = 0u;
-        unsigned*       gate_x = nullptr;
-        const unsigned* pop_x  = nullptr;
-        if constexpr (GATED)
-        {
-            gate_x = gate + ((size_t)round * kNumXcd + xcd) * nchunk;
-            pop_x  = pop + round * kNumXcd + xcd;
-            if (threadIdx.x == 0)
-            {
-                gl.released = 0;
-                gl.lock     = 0;
-                __hip_atomic_fetch_add(pop + round * kNumXcd + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
         __syncthreads();
         // LAYOUT 3 keeps its own (padded) entry numbering: whole slices of 1024
         const int begin = LAYOUT == 3 ? soff[g] * kPanelThreads : row_ptr[r0];
@@ -506,27 +416,16 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
         const int nfull = (end - begin) / STEP;  // chunks in which every lane has UNROLL valid entries
         int       e     = begin + threadIdx.x;
         const int32_t* __restrict__ sb = LAYOUT == 3 ? sbase + soff[g] : pcol;  // slice bases of this group (else unused)
-        // pacing (alternative throttle without any communication): chunk b does not start before
-        // t0 + b * pace on the chip-wide 100 MHz clock; all workgroups start their round within ~1 us
+        // optional clock throttle: chunk b does not start before t0 + b * pace on the chip-wide 100 MHz clock
         const unsigned long long t0 = pace_fp ? __builtin_amdgcn_s_memrealtime() : 0ull;
         PanelBatch<UNROLL, LAYOUT> cur, nxt;
         for (int b = 0; b < nfull; ++b)
         {
-            // Pace.  A workgroup may run up to `slack` chunks ahead of the clock (experiment: any slack loses).
-            // In lockstep every CU of the chip streams at the same moment and gathers at the same moment, so HBM idles
-            // while the L2->L1 path is busy and vice versa.  Offsetting the wavefronts of a workgroup against each other
-            // (mode 1) loses: the x window in use doubles and drops out of L2.  Offsetting whole XCDs against each other
-            // (mode 2, the default) keeps the lockstep where it matters — inside an L2 — and evens out the HBM demand.
-            // keeping the 16 wavefronts of the workgroup together (bits 18-19 of pace_slack): 1 = a workgroup barrier per
-            // chunk; 2 = a wavefront that is behind the schedule raises its issue priority.  Without either, the oldest-
-            // first issue arbitration lets wavefront 0 start the next chunk while wavefront 15 is still issuing this
-            // one, which then takes twice as long (tools/trace_panel.py: 2 % of the chunks take 15 us instead of 7).
-            const int sync_mode = SYNCT >= 0 ? SYNCT : (pace_slack >> 18) & 3;  // SYNCT: the same choice at compile time
+            const int sync_mode = SYNCT >= 0 ? SYNCT : (flags >> 1) & 3;
             if (sync_mode == 1) __syncthreads();
             if constexpr (SYNCT == 2 && PIPE == 2)
             {
-                // split barrier through a counter in LDS: start chunk b when all 16 wavefronts have ISSUED the loads of
-                // chunk b-1 (nobody waits for the last one's adds and stream latency).  Bounded spin.
+                // start chunk b when all 16 wavefronts have ISSUED the loads of chunk b-1.  Bounded spin.
                 if (b > 0 && lane == 0)
                 {
                     const unsigned need  = (unsigned)kPanelThreads * (unsigned)((b - 1) / 2 + 1);
@@ -534,36 +433,17 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
                     while (lds_read(&gl.issued[(b - 1) & 1]) < need && ++spins < (1 << 18)) __builtin_amdgcn_s_sleep(1);
                 }
             }
-            if (sync_mode == 2 && pace_fp)
-            {
-                const unsigned long long due = t0 + (((unsigned long long)b * pace_fp) >> 10);
-                if (__builtin_amdgcn_s_memrealtime() > due + (pace_fp >> 12))  // more than a quarter of a chunk late
-                    __builtin_amdgcn_s_setprio(3);
-                else
-                    __builtin_amdgcn_s_setprio(0);
-            }
             if (pace_fp && lane == 0)
             {
-                const int                slack = pace_slack & 0xFFFF;
-                const int                mode  = (pace_slack >> 16) & 3;  // 1: wavefronts apart, 2: XCDs apart (L2s are per XCD)
-                const unsigned long long phase = mode == 1   ? ((unsigned long long)(threadIdx.x >> 6) * pace_fp) / NWAVES
-                                                 : mode == 2 ? ((unsigned long long)xcd_id() * pace_fp) / kNumXcd
-                                                 : mode == 3 ? ((unsigned long long)((blockIdx.x >> 3) & 1) * pace_fp) / 2 +
-                                                                   ((unsigned long long)xcd_id() * pace_fp) / (2 * kNumXcd)
-                                                             : 0ull;  // 3: halves of an XCD in antiphase (experiment)
-                if (b > slack || phase)
+                const unsigned long long phase = (flags & 1) ? ((unsigned long long)xcd_id() * pace_fp) / kNumXcd : 0ull;
+                if (b > 0 || phase)
                 {
-                    const unsigned long long ahead  = b > slack ? (unsigned long long)(b - slack) * pace_fp : 0ull;
-                    const unsigned long long target = t0 + ((ahead + phase) >> 10);
+                    const unsigned long long target = t0 + (((unsigned long long)b * pace_fp + phase) >> 10);
                     const unsigned long long now    = __builtin_amdgcn_s_memrealtime();
                     if (now > target) lag_max = max(lag_max, (unsigned)min(now - target, 0xFFFFFFFFull));
                     int                      spins  = 0;
                     while (__builtin_amdgcn_s_memrealtime() < target && ++spins < (1 << 16)) __builtin_amdgcn_s_sleep(1);
                 }
-            }
-            if constexpr (GATED)
-            {
-                if (b >= skew && lane == 0) gate_wait(&gl, gate_x, pop_x, (unsigned)(b - skew));
             }
             if constexpr (PIPE == 2)
             {
@@ -591,9 +471,6 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * UNROLL) : "memory");  // the gathers are back
                     tr[2] = (unsigned)__builtin_amdgcn_s_memrealtime();
                 }
-                // sync 3: the barrier between issue and adds.  A wavefront that has issued its loads early waits here with
-                // its gathers long back; when the last one has issued, all add and go on to the next chunk, so the vector
-                // memory pipe idles for one wavefront's adds instead of for the last wavefront's adds + stream latency.
                 if (sync_mode == 3) __syncthreads();
                 cur.add(acc, xv);
                 if constexpr (TRACE)
@@ -619,32 +496,15 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
                 // stream and the L1/L2 time of the gathers overlap inside one wavefront instead of adding up
                 if (b == 0) cur.load(pcol, prow, pval, e, sb, rowbits);
                 if (b + 1 < nfull) nxt.load(pcol, prow, pval, e + STEP, sb + (b + 1) * UNROLL, rowbits);
-                cur.template apply<ABLATE>(x, acc, &sink);
+                cur.apply(x, acc);
                 cur = nxt;
             }
             else
             {
                 cur.load(pcol, prow, pval, e, sb + b * UNROLL, rowbits);
-                cur.template apply<ABLATE>(x, acc, &sink);
+                cur.apply(x, acc);
             }
             e += STEP;
-            if constexpr (GATED)
-            {
-                // the LDS adds above consumed the gathered values, so this wavefront's loads of chunk b are back
-                if (lane == 0)
-                {
-                    const unsigned before = atomicAdd(&gl.wave_done[b & 15], 1u);
-                    if ((before % NWAVES) == NWAVES - 1)
-                        __hip_atomic_fetch_add(gate_x + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-        if constexpr (GATED)
-        {
-            // a group with fewer chunks than the longest one must not hold the others back
-            if (threadIdx.x < kWave)
-                for (int b = nfull + lane; b < nchunk; b += kWave)
-                    __hip_atomic_fetch_add(gate_x + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         for (int t = nfull * UNROLL; e < end; e += kPanelThreads, ++t)
             PanelBatch<1, LAYOUT>::one(pcol, prow, pval, e, x, acc, sb + t, rowbits);
@@ -681,7 +541,6 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
             }
         }
     }
-    if (ABLATE && sink == 123.456) y[0] = sink;  // keeps the ablated products alive
 }
 
 }  // namespace
@@ -691,7 +550,6 @@ void csr_panel_free(spmv_mat* m)
     if (m->pb_col) (void)hipFree(m->pb_col);
     if (m->pb_row) (void)hipFree(m->pb_row);
     if (m->pb_val) (void)hipFree(m->pb_val);
-    if (m->pb_rec) (void)hipFree(m->pb_rec);
     if (m->pb_pack) (void)hipFree(m->pb_pack);
     if (m->pb_sbase) (void)hipFree(m->pb_sbase);
     if (m->pb_soff) (void)hipFree(m->pb_soff);
@@ -702,14 +560,12 @@ void csr_panel_free(spmv_mat* m)
     m->pb_pack   = nullptr;
     m->pb_sbase  = nullptr;
     m->pb_soff   = nullptr;
-    m->pb_rec = nullptr;
     m->pb_col = nullptr;
     m->pb_row = nullptr;
     m->pb_val = nullptr;
     m->pb_built_sort = -1;
     m->pb_pace_tuned_unroll = 0;
     m->pb_unroll_tuned = 0;
-    m->pb_stagger_tuned = -1;
     m->device_bytes -= m->pb_bytes;
     m->pb_bytes = 0;
 }
@@ -728,15 +584,6 @@ static int pick_group_rows(int nrow, int cap)
 // Re-store the (line-ordered) three-array layout as 12-byte packed entries.  Not an error when it does not work
 // out (no memory, or so many column gaps that the padding would outweigh the two bytes saved): the three arrays
 // stay and the product runs from them.
-// experiment (panel_uncached): the streamed arrays in uncached / fine-grained device memory, so that the read-once
-// entries do not allocate lines in the L2 that the x lines live in
-static hipError_t panel_stream_alloc(void** p, size_t bytes, int mode)
-{
-    if (mode == 1) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocUncached);
-    if (mode == 2) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained);
-    return hipMalloc(p, bytes);
-}
-
 static void panel_pack(spmv_mat* m, int ngroups, int max_rows)
 {
     spmv_ctx*   ctx     = m->ctx;
@@ -772,8 +619,7 @@ static void panel_pack(spmv_mat* m, int ngroups, int max_rows)
             hipMalloc(&scount, sizeof(int32_t) * (size_t)total) != hipSuccess ||
             hipMalloc(&sbase, sizeof(int32_t) * (size_t)total) != hipSuccess ||
             hipMalloc(&d_soff, sizeof(int32_t) * soff.size()) != hipSuccess ||
-            panel_stream_alloc((void**)&pack, sizeof(uint32_t) * (size_t)padded, m->pb_uncached) != hipSuccess ||
-            panel_stream_alloc((void**)&pval, sizeof(double) * (size_t)padded, m->pb_uncached) != hipSuccess)
+            hipMalloc(&pack, sizeof(uint32_t) * (size_t)padded) != hipSuccess || hipMalloc(&pval, sizeof(double) * (size_t)padded) != hipSuccess)
             break;
         if (hipMemcpyAsync(d_soff, soff.data(), sizeof(int32_t) * soff.size(), hipMemcpyHostToDevice, s) != hipSuccess) break;
         hipLaunchKernelGGL(panel_cut_kernel, dim3(gb), dim3(64), 0, s, m->pb_gstart, ngroups, m->a, m->pb_col, colbits,
@@ -819,10 +665,8 @@ int csr_panel_build(spmv_mat* m)
     W     = std::max(kLineDoubles, (W / kLineDoubles) * kLineDoubles);
     while (ceil_div(m->ncol, W) > 8192) W *= 2;  // the per-group histogram lives in LDS
     const bool sort = m->pb_sort != 0;
-    const bool aos = m->pb_aos == 1;  // 2 = three arrays read with system-scope loads (experiment)
     const bool pack = m->pb_aos == 3 && sort;  // 12-byte entries (needs the line order); kept only if every slice fits
-    if ((m->pb_val || m->pb_rec) && m->pb_built_rows == G && m->pb_built_width == W && m->pb_built_sort == (int)sort &&
-        aos == (m->pb_rec != nullptr) && m->pb_built_layout == m->pb_aos + 16 * m->pb_uncached)
+    if (m->pb_val && m->pb_built_rows == G && m->pb_built_width == W && m->pb_built_sort == (int)sort && m->pb_built_layout == m->pb_aos)
         return panel_choose_pace(m);  // the layout in memory was built with these parameters
     if (!m->b || !m->v) SPMV_FAIL(SPMV_ERR_INVALID, "the panel layout cannot be re-built: this handle gave up its CSR arrays (panel_keep_csr = 0)");
     csr_panel_free(m);
@@ -946,27 +790,8 @@ int csr_panel_build(spmv_mat* m)
         m->pb_max_group_nnz = h_max;
     }
     m->pb_bytes       = (int64_t)(nnz * 14);
-    m->pb_built_layout = m->pb_aos + 16 * m->pb_uncached;
+    m->pb_built_layout = m->pb_aos;
     if (pack) panel_pack(m, ngroups, max_rows);  // keeps the three arrays when packing does not pay
-    if (aos)
-    {
-        // 16-byte records replace the three arrays
-        if (hipMalloc(&m->pb_rec, nnz * 16) != hipSuccess)
-        {
-            csr_panel_free(m);
-            SPMV_FAIL(SPMV_ERR_ALLOC, "panel layout: out of device memory for %zu 16-byte records", nnz);
-        }
-        hipLaunchKernelGGL(panel_pack_kernel, dim3(kMaxGrid), dim3(256), 0, s, (int64_t)nnz, m->pb_col, m->pb_row, m->pb_val,
-                           (i32x4*)m->pb_rec);
-        SPMV_HIP(hipStreamSynchronize(s));
-        (void)hipFree(m->pb_col);
-        (void)hipFree(m->pb_row);
-        (void)hipFree(m->pb_val);
-        m->pb_col   = nullptr;
-        m->pb_row   = nullptr;
-        m->pb_val   = nullptr;
-        m->pb_bytes = (int64_t)(nnz * 16);
-    }
     m->device_bytes += m->pb_bytes;
     return panel_choose_pace(m);
 }
@@ -1004,7 +829,6 @@ int panel_choose_pace(spmv_mat* m)
     m->pb_pace_ns = m->pb_pace_req >= 0 ? m->pb_pace_req : 0;
     if (m->pb_pace_tuned_unroll == key) return SPMV_OK;  // already tried for this layout and these requests
     m->pb_pace_tuned_unroll = 0;
-    m->pb_stagger_tuned     = -1;
     m->pb_unroll_tuned      = 0;
     m->pb_pipe_tuned        = 0;
     m->pb_sync_tuned        = 0;
@@ -1112,161 +936,71 @@ int csr_panel_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, double
 
 static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, bool trial, const apply_extra& ex)
 {
-    if (!A->pb_val && !A->pb_rec) SPMV_FAIL(SPMV_ERR_INVALID, "panel kernel selected but its layout was not built");
+    if (!A->pb_val) SPMV_FAIL(SPMV_ERR_INVALID, "panel kernel selected but its layout was not built");
     // the fullest group's accumulators (+ the spare one the pads of the packed layout add into)
     const size_t lds = ((size_t)A->pb_max_rows + (A->pb_pack ? 1 : 0)) * sizeof(double);
     // two workgroups share a CU when their accumulators fit twice into the 160 KiB LDS
     const int per_cu = (lds <= 80000 && A->pb_two_per_cu) ? 2 : 1;
     const int grid   = std::min(A->pb_ngroups, kNumCu * per_cu);
     const int unroll = A->pb_unroll > 0 ? A->pb_unroll : (A->pb_unroll_tuned > 0 ? A->pb_unroll_tuned : 8);
-    const int skew   = std::min(A->pb_skew, 12);  // the per-workgroup completion slots wrap at 16
-    const int rounds = (int)ceil_div(A->pb_ngroups, grid);
-    // longest group in chunks (uniform bound: the whole matrix in one group)
-    const int step   = unroll * kPanelThreads;
-    const int nchunk = (int)std::min<int64_t>(A->pb_max_group_nnz / step + 1, 1 << 20);
-    unsigned* gate   = nullptr;
-    // the counter gate (an experiment kept for the record) exists for the three-array and record layouts only
-    const bool gated = skew > 0 && grid > 1 && !A->pb_pack;
-    // pace: nanoseconds per chunk -> 10 ns ticks in 22.10 fixed point
+    // optional clock throttle: nanoseconds per chunk -> 10 ns ticks in 22.10 fixed point
     const unsigned long long pace_fp = A->pb_pace_ns > 0 ? (unsigned long long)((double)A->pb_pace_ns * 102.4) : 0ull;
-    const int  pace_slack = std::min(std::max(0, A->pb_pace_slack), 0xFFFF) | (((A->pb_stagger_tuned >= 0 ? A->pb_stagger_tuned : A->pb_stagger) & 3) << 16) |
-                            (((A->pb_sync >= 0 ? A->pb_sync : A->pb_sync_tuned) & 3) << 18);
-    const int  layout = A->pb_pack ? 3 : A->pb_rec ? 1 : (A->pb_aos == 2 ? 2 : 0);
+    const int  sync   = (A->pb_sync >= 0 ? A->pb_sync : A->pb_sync_tuned) & 3;
+    const int  flags  = ((A->pb_stagger & 3) == 2 ? 1 : 0) | (sync << 1);
+    const int  layout = A->pb_pack ? 3 : 0;
     // the kernel dereferences exactly these arrays: refuse on the host rather than fault on the GPU
-    const bool have = layout == 1   ? A->pb_rec != nullptr
-                      : layout == 3 ? (A->pb_pack && A->pb_sbase && A->pb_soff && A->pb_val && A->pb_rowbits > 0 && A->pb_rowbits < 32)
-                                    : (A->pb_col && A->pb_row && A->pb_val);
+    const bool have = layout == 3 ? (A->pb_pack && A->pb_sbase && A->pb_soff && A->pb_val && A->pb_rowbits > 0 && A->pb_rowbits < 32)
+                                  : (A->pb_col && A->pb_row && A->pb_val);
     if (!A->pb_gstart || !x || !y || !have)
         SPMV_FAIL(SPMV_ERR_INVALID, "panel kernel: layout %d is selected but its arrays are not there", layout);
-    const PanelPacked pk{A->pb_sbase, A->pb_soff, A->pb_rowbits};
-    unsigned*         ctl = (trial || !A->pb_guard) ? nullptr : A->pb_ctl;  // the trials must not train the guard
-    const int32_t*    arg_col = layout == 3 ? (const int32_t*)A->pb_pack : A->pb_col;
-    unsigned* pop = nullptr;
-    if (gated)
-    {
-        // [rounds*8 population words][rounds*8*nchunk gate words], zeroed before every launch
-        const size_t words = (size_t)rounds * kNumXcd * ((size_t)nchunk + 1);
-        SPMV_TRY(ensure_scratch(ctx, words * sizeof(unsigned) + 256));
-        pop  = (unsigned*)((char*)ctx->scratch + 256);  // the first 256 B of the scratch serve the reductions
-        gate = pop + (size_t)rounds * kNumXcd;
-        SPMV_HIP(hipMemsetAsync(pop, 0, words * sizeof(unsigned), ctx->stream));
-    }
-#define SPMV_PANEL_CASE(U, GT, LY)                                                                                   \
-    if (unroll == U && gated == GT && layout == LY)                                                                   \
+    unsigned*      ctl     = (trial || !A->pb_guard) ? nullptr : A->pb_ctl;  // the trials must not train the guard
+    const int32_t* arg_col = layout == 3 ? (const int32_t*)A->pb_pack : A->pb_col;
+    const int      pipe_rq = A->pb_pipe >= 0 ? A->pb_pipe : (A->pb_pipe_tuned > 0 ? A->pb_pipe_tuned : 1);
+    // gather-first is instantiated for the chunk sizes that are tried; the others take the stream-first order
+    const int pipe = pipe_rq == 2 && !(unroll == 4 || unroll == 8 || (unroll == 16 && layout == 3)) ? 1 : std::min(pipe_rq, 2);
+#define SPMV_PANEL_LAUNCH(U, LY, PP, TR, TC, SY)                                                                      \
     {                                                                                                                \
-        static std::atomic<unsigned long long> granted{0}; /* bit per device */                                                                                 \
-        if (!((granted.load(std::memory_order_relaxed) >> ctx->device) & 1ull))                                                                                              \
+        static std::atomic<unsigned long long> granted{0}; /* bit per device */                                      \
+        if (!((granted.load(std::memory_order_relaxed) >> ctx->device) & 1ull))                                      \
         {                                                                                                            \
-            SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_kernel<U, GT, LY>,                                   \
+            SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_kernel<U, LY, PP, TR, TC, SY>,                       \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160008));                       \
-            granted.fetch_or(1ull << ctx->device, std::memory_order_relaxed);                                                                                          \
+            granted.fetch_or(1ull << ctx->device, std::memory_order_relaxed);                                        \
         }                                                                                                            \
-        hipLaunchKernelGGL((csr_panel_kernel<U, GT, LY>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream,           \
-                           A->pb_gstart, A->pb_ngroups, A->a, arg_col, A->pb_row,                  \
-                           layout == 1 ? (const double*)A->pb_rec : A->pb_val, x, y, gate, pop, nchunk, skew, pace_fp, pace_slack, pk.sbase, pk.soff, pk.rowbits, ex.overwrite ? 1 : 0, ex.dot_w, ex.dot_out, ctl);   \
+        hipLaunchKernelGGL((csr_panel_kernel<U, LY, PP, TR, TC, SY>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream, \
+                           A->pb_gstart, A->pb_ngroups, A->a, arg_col, A->pb_row, A->pb_val, x, y, pace_fp, flags, A->pb_sbase,  \
+                           A->pb_soff, A->pb_rowbits, ex.overwrite ? 1 : 0, ex.dot_w, ex.dot_out, ctl);              \
         SPMV_HIP(hipGetLastError());                                                                                 \
         return SPMV_OK;                                                                                              \
     }
-#define SPMV_PANEL_CASES(U) \
-    SPMV_PANEL_CASE(U, false, 0) SPMV_PANEL_CASE(U, true, 0) SPMV_PANEL_CASE(U, false, 1) SPMV_PANEL_CASE(U, true, 1)
-    if (A->pb_ablate > 0)
+    // the C2 instance (packed, U = 8, gather-first): the wavefront sync is a compile-time choice; panel_legacy = 1
+    // routes it through the run-time switch for A/B, panel_trace = 1 through the diagnostic build
+    if (layout == 3 && unroll == 8 && pipe == 2 && !A->pb_legacy)
     {
-        // timing experiments (wrong results by design): UNROLL 8, ungated, three-array layout only
-#define SPMV_PANEL_ABLATE(AB)                                                                                        \
-    if (A->pb_ablate == AB)                                                                                          \
-    {                                                                                                                \
-        SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_kernel<8, false, 0, AB>,                                 \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160008));                           \
-        hipLaunchKernelGGL((csr_panel_kernel<8, false, 0, AB>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream,    \
-                           A->pb_gstart, A->pb_ngroups, A->a, A->pb_col, A->pb_row, A->pb_val, x, y, gate, pop, nchunk,  \
-                           skew, pace_fp, pace_slack, pk.sbase, pk.soff, pk.rowbits, ex.overwrite ? 1 : 0, ex.dot_w, ex.dot_out, ctl);                                                                           \
-        SPMV_HIP(hipGetLastError());                                                                                 \
-        return SPMV_OK;                                                                                              \
+        if (A->pb_trace && !trial) SPMV_PANEL_LAUNCH(8, 3, 2, false, true, -1)
+#define SPMV_PANEL_CT(SY)                                          \
+    if (sync == SY)                                                \
+    {                                                              \
+        if (trial) SPMV_PANEL_LAUNCH(8, 3, 2, true, false, SY)     \
+        SPMV_PANEL_LAUNCH(8, 3, 2, false, false, SY)               \
     }
-        SPMV_PANEL_ABLATE(1)
-        SPMV_PANEL_ABLATE(2)
-        SPMV_PANEL_ABLATE(3)
-#undef SPMV_PANEL_ABLATE
-    }
-    const int pipe = A->pb_pipe >= 0 ? A->pb_pipe : (A->pb_pipe_tuned > 0 ? A->pb_pipe_tuned : 1);
-    const int sync = (pace_slack >> 18) & 3;
-    if (pipe == 2 && layout == 3 && !gated && unroll == 8 && !A->pb_legacy && !A->pb_trace)
-    {
-        // the C2 instance: the wavefront sync is a compile-time choice (panel_legacy = 1: the run-time switch, for A/B)
-#define SPMV_PANEL_CT(SY, TR)                                                                                        \
-    if (sync == SY && trial == TR)                                                                                   \
-    {                                                                                                                \
-        SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_kernel<8, false, 3, 0, 2, TR, false, SY>,                \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160008));                           \
-        hipLaunchKernelGGL((csr_panel_kernel<8, false, 3, 0, 2, TR, false, SY>), dim3(grid), dim3(kPanelThreads), lds, \
-                           ctx->stream, A->pb_gstart, A->pb_ngroups, A->a, arg_col, A->pb_row, A->pb_val, x, y, gate,  \
-                           pop, nchunk, skew, pace_fp, pace_slack, pk.sbase, pk.soff, pk.rowbits, ex.overwrite ? 1 : 0, \
-                           ex.dot_w, ex.dot_out, ctl);                                                               \
-        SPMV_HIP(hipGetLastError());                                                                                 \
-        return SPMV_OK;                                                                                              \
-    }
-        SPMV_PANEL_CT(0, false) SPMV_PANEL_CT(1, false) SPMV_PANEL_CT(2, false) SPMV_PANEL_CT(3, false)
-        SPMV_PANEL_CT(0, true) SPMV_PANEL_CT(1, true) SPMV_PANEL_CT(2, true) SPMV_PANEL_CT(3, true)
+        SPMV_PANEL_CT(0) SPMV_PANEL_CT(1) SPMV_PANEL_CT(2) SPMV_PANEL_CT(3)
 #undef SPMV_PANEL_CT
     }
-    // gather-first is instantiated for the chunk sizes that are tried; the others take the stream-first order
-    const int pp = (pipe == 2 && (unroll == 4 || unroll == 8 || (unroll == 16 && layout == 3))) ? 2 : 1;
-    if (pipe && !gated && (layout == 0 || layout == 3))
-    {
-        // software-pipelined chunks (ungated; three-array and packed layouts)
-#define SPMV_PANEL_PIPE_T(U, LY, PP, TR)                                                                             \
-    if (unroll == U && layout == LY && pp == PP && trial == TR)                                                      \
-    {                                                                                                                \
-        static std::atomic<unsigned long long> granted{0}; /* bit per device */                                                  \
-        if (!((granted.load(std::memory_order_relaxed) >> ctx->device) & 1ull))                                                                      \
-        {                                                                                                            \
-            SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_kernel<U, false, LY, 0, PP, TR>,                     \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160008));                       \
-            granted.fetch_or(1ull << ctx->device, std::memory_order_relaxed);                                                                          \
-        }                                                                                                            \
-        hipLaunchKernelGGL((csr_panel_kernel<U, false, LY, 0, PP, TR>), dim3(grid), dim3(kPanelThreads), lds,        \
-                           ctx->stream, A->pb_gstart, A->pb_ngroups, A->a, arg_col, A->pb_row, A->pb_val, x, y, gate, \
-                           pop, nchunk, skew, pace_fp, pace_slack, pk.sbase, pk.soff, pk.rowbits, ex.overwrite ? 1 : 0, ex.dot_w, ex.dot_out, ctl);                   \
-        SPMV_HIP(hipGetLastError());                                                                                 \
-        return SPMV_OK;                                                                                              \
+#define SPMV_PANEL_CASE(U, LY, PP)                                   \
+    if (unroll == U && layout == LY && pipe == PP)                   \
+    {                                                                \
+        if (trial) SPMV_PANEL_LAUNCH(U, LY, PP, true, false, -1)     \
+        SPMV_PANEL_LAUNCH(U, LY, PP, false, false, -1)               \
     }
-        if (A->pb_trace && unroll == 8 && layout == 3 && pp == 2 && !trial)
-        {
-            SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_kernel<8, false, 3, 0, 2, false, true>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160008));
-            hipLaunchKernelGGL((csr_panel_kernel<8, false, 3, 0, 2, false, true>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream,
-                               A->pb_gstart, A->pb_ngroups, A->a, arg_col, A->pb_row, A->pb_val, x, y, gate, pop, nchunk, skew, pace_fp,
-                               pace_slack, pk.sbase, pk.soff, pk.rowbits, ex.overwrite ? 1 : 0, ex.dot_w, ex.dot_out, ctl);
-            SPMV_HIP(hipGetLastError());
-            return SPMV_OK;
-        }
-#define SPMV_PANEL_PIPE(U, LY, PP) SPMV_PANEL_PIPE_T(U, LY, PP, false) SPMV_PANEL_PIPE_T(U, LY, PP, true)
-        SPMV_PANEL_PIPE(2, 0, 1)
-        SPMV_PANEL_PIPE(4, 0, 1)
-        SPMV_PANEL_PIPE(8, 0, 1)
-        SPMV_PANEL_PIPE(2, 3, 1)
-        SPMV_PANEL_PIPE(4, 3, 1)
-        SPMV_PANEL_PIPE(8, 3, 1)
-        SPMV_PANEL_PIPE(16, 3, 1)
-        SPMV_PANEL_PIPE(4, 3, 2)
-        SPMV_PANEL_PIPE(8, 3, 2)
-        SPMV_PANEL_PIPE(16, 3, 2)
-        SPMV_PANEL_PIPE(4, 0, 2)
-        SPMV_PANEL_PIPE(8, 0, 2)
-#undef SPMV_PANEL_PIPE
-#undef SPMV_PANEL_PIPE_T
-    }
-    SPMV_PANEL_CASES(2)
-    SPMV_PANEL_CASES(4)
-    SPMV_PANEL_CASES(8)
-    SPMV_PANEL_CASE(8, false, 2)
-    SPMV_PANEL_CASE(2, false, 3)
-    SPMV_PANEL_CASE(4, false, 3)
-    SPMV_PANEL_CASE(8, false, 3)
-    SPMV_PANEL_CASE(16, false, 3)
-    SPMV_PANEL_CASES(16)
-#undef SPMV_PANEL_CASES
+    SPMV_PANEL_CASE(2, 0, 0) SPMV_PANEL_CASE(4, 0, 0) SPMV_PANEL_CASE(8, 0, 0) SPMV_PANEL_CASE(16, 0, 0)
+    SPMV_PANEL_CASE(2, 3, 0) SPMV_PANEL_CASE(4, 3, 0) SPMV_PANEL_CASE(8, 3, 0) SPMV_PANEL_CASE(16, 3, 0)
+    SPMV_PANEL_CASE(2, 0, 1) SPMV_PANEL_CASE(4, 0, 1) SPMV_PANEL_CASE(8, 0, 1) SPMV_PANEL_CASE(16, 0, 1)
+    SPMV_PANEL_CASE(2, 3, 1) SPMV_PANEL_CASE(4, 3, 1) SPMV_PANEL_CASE(8, 3, 1) SPMV_PANEL_CASE(16, 3, 1)
+    SPMV_PANEL_CASE(4, 0, 2) SPMV_PANEL_CASE(8, 0, 2)
+    SPMV_PANEL_CASE(4, 3, 2) SPMV_PANEL_CASE(8, 3, 2) SPMV_PANEL_CASE(16, 3, 2)
 #undef SPMV_PANEL_CASE
+#undef SPMV_PANEL_LAUNCH
     SPMV_FAIL(SPMV_ERR_INVALID, "panel kernel: unroll=%d is not instantiated (2, 4, 8, 16)", unroll);
 }
 }  // namespace spmv

@@ -228,7 +228,13 @@ int ell_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
     if (x2)
     {
         const unsigned grid = (unsigned)ceil_div(A->nrow / 2, kBlock);
-        hipLaunchKernelGGL(ell_kernel_x2<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, A->nrow, A->k, A->b, A->v, x, y);
+        // slots in flight per lane: 4 by default; lanes_per_row 4 / 8 select 8 / 2 (tools/tune.py ell: A/B)
+        if (A->lanes_per_row == 4)
+            hipLaunchKernelGGL(ell_kernel_x2<8>, dim3(grid), dim3(kBlock), 0, ctx->stream, A->nrow, A->k, A->b, A->v, x, y);
+        else if (A->lanes_per_row == 8)
+            hipLaunchKernelGGL(ell_kernel_x2<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, A->nrow, A->k, A->b, A->v, x, y);
+        else
+            hipLaunchKernelGGL(ell_kernel_x2<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, A->nrow, A->k, A->b, A->v, x, y);
     }
     else
     {

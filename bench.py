@@ -447,7 +447,7 @@ def main() -> None:
                         5: "tp_expand_kernel + tp_reduce_kernel (two-phase)"}
         panel = None
         if int(info.kernel) == 4:
-            panel = {k: A.get_param("panel_" + k) for k in ("rows", "width", "groups", "layout", "unroll", "pipe", "sync", "stagger", "pace_ns", "skew", "bytes")}
+            panel = {k: A.get_param("panel_" + k) for k in ("rows", "width", "groups", "layout", "unroll", "pipe", "sync", "stagger", "pace_ns", "bytes")}
         out = {
             "metric": "SpMV GFLOP/s + achieved HBM GB/s (% roofline), fp64 CSR, 1/2/4/8 MI355X",
             "value": round(gflops, 3),

@@ -22,8 +22,8 @@
  *   - threading: like the reference's entry points (synchronous, one caller), a context and the
  *     handles made from it are driven by ONE host thread at a time; different contexts (e.g. one
  *     per GPU) may be driven by different threads concurrently.  A matrix handle carries run-time
- *     state (the pace guard of the panel kernel), so do not apply the same handle from two streams
- *     at once.
+ *     state (scratch of the two-phase kernel, the pace guard of the panel kernel), so do not apply the
+ *     same handle from two streams at once.
  *   - the library is HIP-only.  There is no CPU fallback: without a usable GPU spmv_ctx_create
  *     fails with SPMV_ERR_NO_DEVICE and nothing else can be called.
  */
@@ -57,8 +57,17 @@ typedef enum spmv_format
     SPMV_FMT_DIA = 4  /* include/matrix.h:117-138, row-major: (row i, diag d) at i*ndiags + d */
 } spmv_format;
 
-/* CSR kernel selection (spmv_mat_set_kernel).  AUTO picks from the row-length statistics
- * gathered when the matrix is created. */
+/* CSR kernel selection (spmv_mat_set_kernel).  AUTO picks from the statistics gathered when the matrix is created:
+ * fewer than 2M entries -> VECTOR (or LDSWIN for narrow bands); larger -> PANEL, or TWOPHASE when the sweeps of x the
+ * panel kernel would make (8 XCDs x rounds x 8 * ncol bytes) outweigh the 16 extra bytes per entry of the two phases.
+ *
+ * Order of the additions (all within the parity tolerance of 1e-10):
+ *   SCALAR              the reference's own order (left to right inside a row): bit-identical to its fma flavour;
+ *   VECTOR, LDSWIN      a fixed tree per row: deterministic, the same bits on every call;
+ *   PANEL, TWOPHASE     products are added into per-row accumulators in LDS with ds_add_f64 in ARRIVAL order: two calls
+ *                       on the same data may differ in the last bits (the reference's CSR loop is deterministic per row,
+ *                       src/mat_vec.cpp:57-65; its COO and CSC loops are not: `omp atomic`, :36-39, :88-91).  Callers that
+ *                       need run-to-run identical bits select VECTOR (spmv_mat_set_kernel(A, SPMV_CSR_VECTOR, 0)). */
 typedef enum spmv_csr_kernel
 {
     SPMV_CSR_AUTO     = 0,
@@ -178,27 +187,34 @@ int spmv_mat_validate(const spmv_mat* m);
  * for ELL lanes_per_row 1 or 2 picks the one- or two-rows-per-lane variant) or PANEL (regroup now). */
 int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row);
 int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
-/* Named tuning parameters of the panel kernel, applied by the next spmv_mat_set_kernel (none is needed in normal use:
- * what is left at its default is chosen by timing a few candidates when the layout is built):
- *   "panel_rows"    rows per group (0 = choose, entry-balanced; at most 20000)
- *   "panel_width"   columns per panel (0 = 131072)
- *   "panel_sort"    1 = bucket the entries of a panel by 128-byte line of x (default), 0 = leave unordered
- *   "panel_aos"     entry layout: 3 = 12-byte packed entries (default; falls back to 0 where padding would outweigh it),
- *                   0 = three arrays (14 bytes), 1 = 16-byte records, 2 = three arrays read with system-scope loads
- *   "panel_unroll"  chunk = unroll x 1024 entries: 2, 4, 8 or 16 (0 = by trial among 8, 4, 2)
- *   "panel_pipe"    order of the memory instructions of a chunk: 0 = no pipelining, 1 = next chunk's stream first,
- *                   2 = this chunk's gathers first (-1 = by trial)
- *   "panel_pace_ns" clock throttle, nanoseconds per chunk (0 = off, -1 = by trial)
- *   "panel_guard"   1 = stretch the pace by 5 % for the following launches whenever the workgroups of a launch fell more
- *                   than two chunks behind it (default; get "panel_pace_scale" / "panel_pace_bumps" to see), 0 = off
- *   "panel_stagger" offsets of the paced schedule: 2 = XCDs 1/8 of the pace apart unless plain lockstep wins the
- *                   trial (default), 0 = none, 1 = wavefronts of a workgroup apart (experiment: loses)
- *   "panel_skew", "panel_pace_slack", "panel_two_per_cu", "panel_uncached", "panel_ablate"   experiments kept for the record
- *                   (DESIGN.md 4.2); "panel_ablate" > 0 gives WRONG results by design (timing only) */
+/* Named parameters.  None is needed in normal use: what is left at its default is chosen when the layout is built, by
+ * timing a handful of launches (about 0.1 s for 320M entries; SPMV_PANEL_TRIAL=0 or "panel_trial" 0: no launches, the
+ * choice that wins on scattered columns).  Panel-kernel parameters take effect with the next spmv_mat_set_kernel:
+ *   "panel_rows"     rows per group (0 = choose, entry-balanced; at most 20000)
+ *   "panel_width"    columns per panel (0 = 131072)
+ *   "panel_sort"     1 = bucket the entries of a panel by 128-byte line of x (default), 0 = leave unordered
+ *   "panel_aos"      entry layout: 3 = 12-byte packed entries (default; falls back to 0 where padding would outweigh it),
+ *                    0 = three arrays (14 bytes), 1 = 16-byte records, 2 = three arrays read with system-scope loads
+ *   "panel_unroll"   chunk = unroll x 1024 entries: 2, 4, 8 or 16 (0 = by trial)
+ *   "panel_pipe"     order of a chunk's memory instructions: 0 = no pipelining, 1 = next chunk's stream first,
+ *                    2 = this chunk's gathers first (-1 = by trial)
+ *   "panel_sync"     how the 16 wavefronts of a workgroup are kept in the same chunk: 0 = not at all (local columns),
+ *                    1 = workgroup barrier per chunk, 3 = barrier between a chunk's loads and its LDS adds, 2 = split
+ *                    barrier through an LDS counter (-1 = by trial; DESIGN.md 4.2: this is what keeps the workgroups of
+ *                    an XCD in step on scattered columns, and what made the clock pace below unnecessary)
+ *   "panel_pace_ns"  clock throttle, nanoseconds per chunk (-1 / 0 = off: the default since round 2; > 0 = on);
+ *   "panel_guard", "panel_stagger"   run-time guard and per-XCD offsets of that throttle (only with a pace)
+ *   "panel_keep_csr" 0 = release col_ind / values of a CSR handle whose product runs from the panel or two-phase layout
+ *                    (memory 2x -> 1x the matrix; download, other kernels, re-builds and conversions are then refused)
+ *   "panel_trial"    1 / 0 = timing launches when the layout is built, yes / no (-1 = environment, default yes)
+ *   "dia_col_bound"  DIA handles: columns >= this are skipped (row shards keep the bound of the whole matrix)
+ *   "panel_trace", "panel_legacy", "panel_skew", "panel_pace_slack", "panel_two_per_cu", "panel_uncached", "panel_ablate"
+ *                    diagnostics and experiments kept for the record (tools/trace_panel.py);
+ *                    "panel_ablate" > 0 gives WRONG results by design (timing only) */
 int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value);
 /* What is in effect: "panel_rows", "panel_width", "panel_sort", "panel_groups", "panel_layout", "panel_unroll",
- * "panel_pipe", "panel_stagger", "panel_pace_ns", "panel_pace_scale", "panel_pace_bumps", "panel_skew", "panel_bytes",
- * "window_max_span", "window_avg_span". */
+ * "panel_pipe", "panel_sync", "panel_stagger", "panel_pace_ns", "panel_pace_scale", "panel_pace_bumps", "panel_skew",
+ * "panel_bytes", "panel_keep_csr", "device_bytes", "window_max_span", "window_avg_span". */
 int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value);
 /* Copy the arrays of a handle back to the host (any pointer may be NULL to skip it).
  *   CSR: a=row_ptr[nrow+1]  b=col_ind[nnz]      v=values[nnz]

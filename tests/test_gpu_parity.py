@@ -572,26 +572,28 @@ def test_csr_panel_kernel_matches_reference_golden(ctx, orc, pkg, make):
     g = golden(c["name"])
     rp, cc, cv = _csr_of(orc, c)
     scale = _scale(orc, c)
-    # (rows per group, panel width, line sort, 16-byte records, unroll, counter-gate skew, pipelined, pace ns)
-    for rows, width, srt, aos, unroll, skew, pipe, pace in (
-            (0, 0, 1, 1, 8, 2, 0, -1), (0, 0, 0, 0, 4, 0, 1, 0), (37, 16, 1, 1, 2, 1, 0, 0), (1000, 1024, 1, 0, 16, 3, 1, 500),
-            (20000, 4096, 0, 1, 4, 12, 1, 0), (5, 48, 1, 0, 8, 2, 0, 0), (3, 16, 1, 1, 2, 2, 1, 0), (500, 512, 1, 0, 8, 0, 1, 2000),
+    # (rows per group, panel width, line sort, layout, unroll, wavefront sync, pipeline order, pace ns)
+    for rows, width, srt, aos, unroll, sync, pipe, pace in (
+            (0, 0, 1, 0, 8, 2, 0, -1), (0, 0, 0, 0, 4, 0, 1, 0), (37, 16, 1, 0, 2, 1, 0, 0), (1000, 1024, 1, 0, 16, 3, 1, 500),
+            (20000, 4096, 0, 0, 4, 1, 1, 0), (5, 48, 1, 0, 8, 2, 0, 0), (3, 16, 1, 0, 2, 2, 1, 0), (500, 512, 1, 0, 8, 0, 1, 2000),
             (64, 64, 1, 0, 2, 0, 1, -1), (0, 0, 1, 0, 8, 0, 0, 300),
             # layout 3: 12-byte packed entries (falls back to three arrays when a slice spans too many columns)
             (0, 0, 1, 3, 8, 0, 1, 0), (37, 16, 1, 3, 4, 0, 0, 0), (5, 48, 1, 3, 16, 0, 1, -1), (1000, 1024, 0, 3, 8, 0, 1, 0),
-            (0, 0, 1, 3, 8, 0, 2, 0), (64, 64, 1, 3, 4, 0, 2, -1), (3, 16, 1, 3, 2, 3, 2, 0), (0, 0, 1, 3, 0, 2, -1, -1), (500, 512, 1, 0, 8, 0, 2, 0)):
+            (0, 0, 1, 3, 8, 0, 2, 0), (64, 64, 1, 3, 4, 1, 2, -1), (3, 16, 1, 3, 2, 3, 2, 0), (0, 0, 1, 3, 0, -1, -1, -1), (500, 512, 1, 0, 8, 0, 2, 0),
+            # the C2 instance (packed, U = 8, gather-first) with every compile-time sync, and through the run-time switch
+            (0, 0, 1, 3, 8, 1, 2, 0), (0, 0, 1, 3, 8, 2, 2, 0), (0, 0, 1, 3, 8, 3, 2, 0), (7, 32, 1, 3, 8, 3, 2, 400)):
         A = ctx.csr(c["nrow"], c["ncol"], rp, cc, cv)
         A.set_param("panel_rows", rows)
         A.set_param("panel_width", width)
         A.set_param("panel_sort", srt)
         A.set_param("panel_aos", aos)
         A.set_param("panel_unroll", unroll)
-        A.set_param("panel_skew", skew)
+        A.set_param("panel_sync", sync)
         A.set_param("panel_pipe", pipe)
         A.set_param("panel_pace_ns", pace)
         A.set_kernel(pkg.capi.CSR_PANEL)
         y1, y50 = _apply_n(ctx, A, c["x"], c["nrow"], NUM_TEST)
-        what = f"{c['name']} panel rows={rows} width={width} sort={srt} aos={aos} unroll={unroll} skew={skew} pipe={pipe} pace={pace}"
+        what = f"{c['name']} panel rows={rows} width={width} sort={srt} layout={aos} unroll={unroll} sync={sync} pipe={pipe} pace={pace}"
         ol.assert_parity(y1, g["y1_csr"], scale, what + " 1 call")
         ol.assert_parity(y50, g["y50_csr"], scale, what + " 50 calls", reps=NUM_TEST)
 
@@ -775,7 +777,7 @@ def test_panel_kernel_on_nasty_shapes(ctx, orc, pkg):
         ol.csr_abs_row_sums(orc, rp, cc, cv, x, scale)
         ref2 = ref.copy()
         ol.csr_spmv(orc, rp, cc, cv, x, ref2)
-        for layout, unroll, pipe, rows in ((3, 0, -1, 0), (3, 8, 2, 0), (3, 4, 1, 7), (3, 2, 0, 20000), (0, 8, 1, 0), (0, 8, 2, 333), (1, 4, 0, 0)):
+        for layout, unroll, pipe, rows in ((3, 0, -1, 0), (3, 8, 2, 0), (3, 4, 1, 7), (3, 2, 0, 20000), (0, 8, 1, 0), (0, 8, 2, 333), (0, 4, 0, 0)):
             A = ctx.csr(nrow, ncol, rp, cc, cv)
             for k, v in (("panel_aos", layout), ("panel_unroll", unroll), ("panel_pipe", pipe), ("panel_rows", rows)):
                 A.set_param(k, v)
@@ -952,7 +954,7 @@ def test_handles_give_their_device_memory_back(ctx, pkg):
     assert 0 < free0 <= total
     for _ in range(3):
         A = ctx.gen_csr_uniform(0, 1_500_000, 1_500_000, 16, seed=4)  # panel layout + trials
-        for layout in (0, 1, 3):
+        for layout in (0, 3):
             A.set_param("panel_aos", layout)
             A.set_kernel(capi.CSR_PANEL)
         E = ctx.csr_to_ell(A)  # scattered columns: regrouped copy

@@ -23,9 +23,9 @@ trace = list(csv.DictReader(open(glob.glob(O + "/stats/*/*_kernel_trace.csv")[0]
 stats = list(csv.DictReader(open(glob.glob(O + "/stats/*/*_kernel_stats.csv")[0])))
 def short(n):
     return n.split("(anonymous namespace)::")[-1].split("(")[0]
-def is_trial(n):  # csr_panel_kernel<U, GATED, LAYOUT, ABLATE, PIPE, TRIAL, TRACE, SYNCT>
+def is_trial(n):  # csr_panel_kernel<U, LAYOUT, PIPE, TRIAL, TRACE, SYNCT>
     m = re.search(r"csr_panel_kernel<([^>]*)>", n)
-    return bool(m) and m.group(1).split(",")[5].strip() == "true"
+    return bool(m) and m.group(1).split(",")[3].strip() == "true"
 with open(O + "/timed_region.txt", "w") as out:
     for key, last in (("csr_panel_kernel", 50), ("ell_kernel", 50), ("tp_expand_kernel", 0), ("tp_reduce_kernel", 0)):
         names = sorted({r["Kernel_Name"] for r in trace if key in r["Kernel_Name"] and not is_trial(r["Kernel_Name"])})

@@ -45,8 +45,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--full", action="store_true", help="every lanes x flags combination")
-    ap.add_argument("--ablate", action="store_true", help="add the ablated (wrong-result) timing variants of the panel kernel")
-    ap.add_argument("--panel", default="", help="only these panel variants: 'unroll,skew,nt;unroll,skew,nt;...'")
+    ap.add_argument("--panel", default="", help="panel variants 'unroll,pace_ns,pipe,layout,sync[,rows[,legacy]];...' (0 / -1 = by trial)")
     a = ap.parse_args()
     ctx = capi.Context(0)
     if a.what == "blas1":
@@ -150,51 +149,26 @@ def main():
             variants = [v for v in variants if v[0] in ("vector L=8", "vector L=32", "vector L=8+xcd")]
         if a.panel:
             variants = []
-            combos = [(0, 0, 1) + tuple(int(t) for t in item.split(",")) for item in a.panel.split(";")]
+            combos = [tuple(int(t) for t in item.split(",")) for item in a.panel.split(";")]
         else:
-            combos = [(0, 0, 1, u, sk, 0) for u in (4, 8, 16) for sk in (0, 2, 4, 8)]
-        for combo in combos:  # --panel fields: unroll,skew,pace_ns[,pipe[,pace_slack]]
-            rows, width, srt, unroll, skew, pace = combo[:6]
-            pipe = combo[6] if len(combo) > 6 else 0
-            slack = combo[7] if len(combo) > 7 else 0
-            aos = combo[8] if len(combo) > 8 else 0
-            stagger = combo[9] if len(combo) > 9 else 2
-            rows = combo[10] if len(combo) > 10 else rows
-            uncached = combo[11] if len(combo) > 11 else 0
-            sync = combo[12] if len(combo) > 12 else 0
-            legacy = combo[13] if len(combo) > 13 else 0
+            combos = [(8, 0, 2, 3, 3), (8, 0, 2, 3, 1), (4, 0, 2, 3, 1), (4, 0, 1, 3, 0), (8, 0, 1, 3, 0), (0, -1, -1, 3, -1)]
+        for combo in combos:  # --panel fields: unroll,pace_ns,pipe,layout,sync[,rows[,legacy]]  (0 / -1 = by trial)
+            combo = combo + (0, -1, -1, 3, -1, 0, 0)[len(combo):]
+            unroll, pace, pipe, aos, sync, rows, legacy = combo[:7]
 
-            def setup(A, rows=rows, width=width, srt=srt, unroll=unroll, skew=skew, pace=pace, pipe=pipe, slack=slack, aos=aos, stagger=stagger, uncached=uncached, sync=sync, legacy=legacy):
-                A.set_param("panel_sync", sync)
-                A.set_param("panel_legacy", legacy)
-                A.set_param("panel_aos", aos)
-                A.set_param("panel_uncached", uncached)
-                A.set_param("panel_stagger", stagger)
-                A.set_param("panel_rows", rows)
-                A.set_param("panel_width", width)
-                A.set_param("panel_sort", srt)
-                A.set_param("panel_unroll", unroll)
-                A.set_param("panel_skew", skew)
-                A.set_param("panel_pace_ns", pace)
-                A.set_param("panel_pace_slack", slack)
-                A.set_param("panel_pipe", pipe)
-                A.set_param("panel_ablate", 0)
-                A.set_kernel(capi.CSR_PANEL)  # rebuilds the layout when the parameters changed
-            variants.append((f"panel U={unroll} skew={skew} pace={pace}ns pipe={pipe} slack={slack} layout={aos} stagger={stagger} rows={rows} uncached={uncached} sync={sync} legacy={legacy}", setup))
-        variants.append(("two-phase (expand + reduce)", lambda A: A.set_kernel(capi.CSR_TWOPHASE)))
-        for ab, what in ((1, "no LDS adds"), (2, "gathers always hit L1"), (3, "neither")) if a.ablate else ():
-            def setup(A, ab=ab):
-                for k, v in (("panel_rows", 0), ("panel_width", 0), ("panel_sort", 1), ("panel_unroll", 8), ("panel_skew", 0),
-                             ("panel_pace_ns", 0), ("panel_ablate", ab)):
+            def setup(A, unroll=unroll, pace=pace, pipe=pipe, aos=aos, sync=sync, rows=rows, legacy=legacy):
+                for k, v in (("panel_aos", aos), ("panel_rows", rows), ("panel_unroll", unroll), ("panel_pace_ns", pace),
+                             ("panel_pipe", pipe), ("panel_sync", sync), ("panel_legacy", legacy)):
                     A.set_param(k, v)
-                A.set_kernel(capi.CSR_PANEL)
-            variants.append((f"panel U=8 ABLATED: {what}", setup))
+                A.set_kernel(capi.CSR_PANEL)  # rebuilds the layout when the parameters changed
+            variants.append((f"panel U={unroll} pace={pace}ns pipe={pipe} layout={aos} sync={sync} rows={rows} legacy={legacy}", setup))
+        variants.append(("two-phase (expand + reduce)", lambda A: A.set_kernel(capi.CSR_TWOPHASE)))
         if a.band and a.band <= 8192:
             for lanes in (4, 8, 16):
                 variants.append((f"ldswin L={lanes}", lambda A, lanes=lanes: A.set_kernel(capi.CSR_LDSWIN, lanes)))
         sweep(ctx, A, x, y, variants, a.rounds, a.reps, algorithmic_bytes("csr", n, ncol, n * k), n * k)
-        for name, v in (("panel_aos", 3), ("panel_unroll", 0), ("panel_pace_ns", -1), ("panel_pipe", -1), ("panel_skew", 0),
-                        ("panel_pace_slack", 0), ("panel_ablate", 0), ("panel_stagger", 2), ("panel_uncached", 0), ("panel_sync", -1), ("panel_legacy", 0)):
+        for name, v in (("panel_aos", 3), ("panel_rows", 0), ("panel_unroll", 0), ("panel_pace_ns", -1), ("panel_pipe", -1), ("panel_stagger", 2),
+                        ("panel_sync", -1), ("panel_legacy", 0)):
             A.set_param(name, v)
         A.set_kernel(capi.CSR_PANEL)
         chosen = {k: A.get_param("panel_" + k) for k in ("rows", "groups", "layout", "unroll", "pipe", "sync", "stagger", "pace_ns", "bytes")}
@@ -219,6 +193,7 @@ def main():
         x, y = ctx.gen_vector(n, seed=1), ctx.vector(n)
         y.fill(0.0)
         variants = [("ell x2 (16B loads)", lambda A: A.set_kernel(capi.CSR_VECTOR, 2)), ("ell x1", lambda A: A.set_kernel(capi.CSR_VECTOR, 1)),
+                    ("ell x2, 8 slots in flight", lambda A: A.set_kernel(capi.CSR_VECTOR, 4)), ("ell x2, 2 slots in flight", lambda A: A.set_kernel(capi.CSR_VECTOR, 8)),
                     ("auto", lambda A: A.set_kernel(capi.CSR_AUTO, 2))]
         sweep(ctx, A, x, y, variants, a.rounds, a.reps, algorithmic_bytes("ell", n, n, n * k, k), n * k)
     else:
