@@ -655,6 +655,10 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         m->pb_trial = (int32_t)value;
     else if (!strcmp(name, "panel_trace"))
         m->pb_trace = (int32_t)value;
+    else if (!strcmp(name, "twophase_panel_cols"))  // takes effect at the next spmv_mat_set_kernel(TWOPHASE)
+        m->tp_pcols_req = (int32_t)value;
+    else if (!strcmp(name, "twophase_unroll"))
+        m->tp_unroll = (int32_t)value;
     else
         SPMV_FAIL(SPMV_ERR_INVALID, "unknown parameter '%s'", name);
     return SPMV_OK;
@@ -702,6 +706,10 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
     }
     else if (!strcmp(name, "panel_layout"))  // layout in memory: 0 three arrays, 1 records, 3 packed 12-byte entries
         *value = m->pb_pack ? 3 : 0;
+    else if (!strcmp(name, "twophase_panel_cols"))
+        *value = m->tp_pcols;
+    else if (!strcmp(name, "twophase_padded"))
+        *value = m->tp_padded;
     else if (!strcmp(name, "window_max_span"))
         *value = m->win_max_span;
     else if (!strcmp(name, "window_avg_span"))

@@ -186,14 +186,17 @@ struct spmv_mat
     int64_t   pb_bytes       = 0;
 
     // CSR two-phase kernel (kernels_csr_twophase.hip): entries in (column panel, row group) order
-    double*   tp_val       = nullptr;  // [nnz]
-    uint16_t* tp_col       = nullptr;  // [nnz] column - panel base
-    uint16_t* tp_row       = nullptr;  // [nnz] row - group base
-    double*   tp_xg        = nullptr;  // [nnz] the stream between the two phases
-    void*     tp_run       = nullptr;  // [groups * panels] {first entry, entries} of every run, group-major
+    double*   tp_val       = nullptr;  // [padded] (panel, group) order, runs padded to 16 entries
+    uint16_t* tp_col       = nullptr;  // [padded] column - panel base, same order
+    uint16_t* tp_row       = nullptr;  // [padded] row - group base, (group, panel) order; 0xFFFF = padding
+    double*   tp_xg        = nullptr;  // [padded] the stream between the two phases, (group, panel) order
+    int32_t*  tp_blk       = nullptr;  // [padded / 16] destination line of every source line
     int32_t*  tp_panel_ptr = nullptr;  // [panels + 1]
-    int32_t*  tp_gstart    = nullptr;  // [groups + 1]
+    int32_t*  tp_group_ptr = nullptr;  // [groups + 1]
+    int32_t*  tp_gstart    = nullptr;  // [groups + 1] first row of every group
     int32_t   tp_ngroups = 0, tp_panels = 0, tp_pcols = 0, tp_max_rows = 0;
+    int32_t   tp_pcols_req = 0, tp_unroll = 0;  // requested panel width / pairs per lane in flight (0 = default)
+    int64_t   tp_padded = 0;
     int64_t   tp_bytes   = 0;
 
     // COO / CSC / ELL: internal row-grouped copy in the panel layout (coo_build_panel, csc_analyse, ell_build_panel); owned

@@ -355,17 +355,32 @@ def test_csr_twophase_kernel_on_wide_and_ragged_matrices(ctx, orc, pkg):
     got = dy.download()
     ol.assert_parity(got, ref, scale, "twophase overwrite")
     assert abs(d - float(w @ got)) <= 1e-9 * float(np.abs(w) @ np.abs(got))
-    # the automatic choice: a shard far wider than tall takes it, a square matrix of the same size does not
-    wide = ctx.gen_csr_uniform(0, 600_000, 40_000_000, 8, seed=3)
+    # a narrower panel (two workgroups per CU in the expand phase) and the shorter pipeline: same sums
+    for cols, unroll in ((10_000, 6), (7_000, 4), (20_000, 4)):
+        A.set_param("twophase_panel_cols", cols)
+        A.set_param("twophase_unroll", unroll)
+        A.set_kernel(capi.CSR_TWOPHASE)
+        assert A.get_param("twophase_panel_cols") == cols and A.get_param("twophase_padded") % 16 == 0
+        dy.fill(0.0)
+        ctx.apply(A, dx, dy)
+        ctx.sync()
+        ol.assert_parity(dy.download(), ref, scale, f"twophase panel {cols} unroll {unroll}")
+    # the automatic choice: a shard far wider than tall takes it when its runs (panel x row group) are long enough to
+    # pad to whole lines; a sparser one and a square matrix of the same size do not
+    wide = ctx.gen_csr_uniform(0, 2_500_000, 40_000_000, 16, seed=3)
     assert wide.info.kernel == capi.CSR_TWOPHASE
-    xw, yw, yv = ctx.gen_vector(40_000_000, seed=3), ctx.vector(600_000), ctx.vector(600_000)
+    assert wide.info.nnz <= wide.get_param("twophase_padded") <= 1.25 * wide.info.nnz
+    xw, yw, yv = ctx.gen_vector(40_000_000, seed=3), ctx.vector(2_500_000), ctx.vector(2_500_000)
     yw.fill(0.0)
     yv.fill(0.0)
     ctx.apply(wide, xw, yw)
     wide.set_kernel(capi.CSR_VECTOR)
     ctx.apply(wide, xw, yv)
     ctx.sync()
-    assert np.max(np.abs(yw.download() - yv.download())) <= ol.REL_TOL * 8
+    assert np.max(np.abs(yw.download() - yv.download())) <= ol.REL_TOL * 16
+    del wide
+    thin = ctx.gen_csr_uniform(0, 600_000, 40_000_000, 8, seed=3)
+    assert thin.info.kernel == capi.CSR_PANEL
     square = ctx.gen_csr_uniform(0, 600_000, 600_000, 8, seed=3)
     assert square.info.kernel == capi.CSR_PANEL
 

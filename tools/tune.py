@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--full", action="store_true", help="every lanes x flags combination")
     ap.add_argument("--panel", default="", help="panel variants 'unroll,pace_ns,pipe,layout,sync[,rows[,legacy]];...' (0 / -1 = by trial)")
+    ap.add_argument("--twophase", default="20000,6;20000,4;10000,6;10000,4", help="two-phase variants 'panel_cols,unroll;...'")
+    ap.add_argument("--no-panel", action="store_true", help="csr: leave the panel variants out")
     a = ap.parse_args()
     ctx = capi.Context(0)
     if a.what == "blas1":
@@ -162,7 +164,16 @@ def main():
                     A.set_param(k, v)
                 A.set_kernel(capi.CSR_PANEL)  # rebuilds the layout when the parameters changed
             variants.append((f"panel U={unroll} pace={pace}ns pipe={pipe} layout={aos} sync={sync} rows={rows} legacy={legacy}", setup))
-        variants.append(("two-phase (expand + reduce)", lambda A: A.set_kernel(capi.CSR_TWOPHASE)))
+        if a.no_panel:
+            variants = []
+        for item in [t for t in a.twophase.split(";") if t]:
+            pcols, unroll = (int(t) for t in item.split(","))
+
+            def setup_tp(A, pcols=pcols, unroll=unroll):
+                A.set_param("twophase_panel_cols", pcols)
+                A.set_param("twophase_unroll", unroll)
+                A.set_kernel(capi.CSR_TWOPHASE)  # rebuilds the layout when the panel width changed
+            variants.append((f"two-phase cols={pcols} U={unroll}", setup_tp))
         if a.band and a.band <= 8192:
             for lanes in (4, 8, 16):
                 variants.append((f"ldswin L={lanes}", lambda A, lanes=lanes: A.set_kernel(capi.CSR_LDSWIN, lanes)))
