@@ -18,6 +18,7 @@ LIB_PATH = Path(os.environ.get("SPMV_HIP_SO") or _PKG / "lib" / "libspmv_hip.so"
 
 FMT_COO, FMT_CSR, FMT_CSC, FMT_ELL, FMT_DIA = 0, 1, 2, 3, 4
 CSR_AUTO, CSR_VECTOR, CSR_LDSWIN, CSR_SCALAR, CSR_PANEL, CSR_TWOPHASE = 0, 1, 2, 3, 4, 5
+PRECOND_NONE, PRECOND_JACOBI, PRECOND_SYMGS = 0, 1, 2
 FLAG_DPP_REDUCE, FLAG_XCD_REMAP = 1, 2
 
 _i32p = C.POINTER(C.c_int32)
@@ -90,6 +91,9 @@ SIGNATURES = {
     "spmv_axpby": (C.c_int, [_vp, C.c_double, _vp, C.c_double, _vp, _vp]),
     "spmv_apply_dot": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, _vp, _f64p]),
     "spmv_cg": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _f64p]),
+    "spmv_symgs": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32]),
+    "spmv_symgs_setup": (C.c_int, [_vp, _vp]),
+    "spmv_symgs_order": (C.c_int, [_vp, _vp, _i32p]),
     "spmv_coo_to_csr": (C.c_int, [_vp, _vp, C.POINTER(_vp)]),
     "spmv_coo_to_ell": (C.c_int, [_vp, _vp, C.POINTER(_vp)]),
     "spmv_csr_to_ell": (C.c_int, [_vp, _vp, C.POINTER(_vp)]),
@@ -337,12 +341,24 @@ class Context:
         _check(self._lib.spmv_apply_dot(self.h, A.h, x.h, y.h, 1 if overwrite else 0, w.h, C.byref(d)))
         return d.value
 
+    def symgs(self, A: "Matrix", b: "Vector", x: "Vector", sweeps: int = 1) -> None:
+        """`sweeps` symmetric Gauss-Seidel sweeps on A x = b, x updated in place (CSR handle holding the whole square
+        matrix; the first call analyses it).  Sweep order: A.set_param("symgs_order", 1 multicolour (default) | 0 rows)"""
+        _check(self._lib.spmv_symgs(self.h, A.h, b.h, x.h, sweeps))
+
+    def symgs_order(self, A: "Matrix"):
+        """sets the handle up if need be and returns order[k] = the k-th row of a forward sweep"""
+        _check(self._lib.spmv_symgs_setup(self.h, A.h))
+        out = np.zeros(A.info.nrow, dtype=np.int32)
+        _check(self._lib.spmv_symgs_order(self.h, A.h, out.ctypes.data_as(_i32p)))
+        return out
+
     def cg(self, A: "Matrix", b: "Vector", x: "Vector", max_iter: int = 1000, rel_tol: float = 1e-8, check_every: int = 1,
-           jacobi: bool = False):
-        """conjugate gradients on the device from the x passed in (jacobi: diagonal preconditioner, CSR handles);
-        returns (iterations, ||r|| / ||b||)"""
+           jacobi: bool = False, symgs: bool = False):
+        """conjugate gradients on the device from the x passed in (jacobi: diagonal preconditioner, symgs: one symmetric
+        Gauss-Seidel sweep per iteration; CSR handles); returns (iterations, ||r|| / ||b||)"""
         it, res = C.c_int32(0), C.c_double(0.0)
-        _check(self._lib.spmv_cg(self.h, A.h, b.h, x.h, max_iter, rel_tol, check_every, 1 if jacobi else 0, C.byref(it),
+        _check(self._lib.spmv_cg(self.h, A.h, b.h, x.h, max_iter, rel_tol, check_every, PRECOND_SYMGS if symgs else (PRECOND_JACOBI if jacobi else PRECOND_NONE), C.byref(it),
                                  C.byref(res)))
         return it.value, res.value
 

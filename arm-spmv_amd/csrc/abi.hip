@@ -85,6 +85,7 @@ void mat_free(spmv_mat* m)
     if (m->win_span) (void)hipFree(m->win_span);
     csr_panel_free(m);
     csr_twophase_free(m);
+    symgs_free(m);
     if (m->coo_csr) mat_free(m->coo_csr);
     delete m;
 }
@@ -655,6 +656,11 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         m->pb_trial = (int32_t)value;
     else if (!strcmp(name, "panel_trace"))
         m->pb_trace = (int32_t)value;
+    else if (!strcmp(name, "symgs_order"))  // 1 multicolour, 0 the matrix's own row order; takes effect at the next set-up / sweep
+    {
+        SPMV_REQUIRE(value == 0 || value == 1, "symgs_order: 0 (row order) or 1 (multicolour), got %lld", (long long)value);
+        m->gs_order = (int32_t)value;
+    }
     else if (!strcmp(name, "twophase_panel_cols"))  // takes effect at the next spmv_mat_set_kernel(TWOPHASE)
         m->tp_pcols_req = (int32_t)value;
     else if (!strcmp(name, "twophase_unroll"))
@@ -668,6 +674,11 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
 {
     SPMV_REQUIRE(m && name && value, "null argument");
     if (!strncmp(name, "panel_trace@", 12)) return csr_panel_read_trace(m->ctx, atoll(name + 12), value);
+    if (!strncmp(name, "symgs_", 6))
+    {
+        SPMV_REQUIRE(symgs_info(m, name, value) == SPMV_OK, "unknown parameter '%s'", name);
+        return SPMV_OK;
+    }
     if (!strcmp(name, "panel_keep_csr"))
         *value = (m->b && m->v) || m->nnz == 0 ? 1 : 0;
     else if (!strcmp(name, "device_bytes"))
@@ -858,9 +869,39 @@ int spmv_cg(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* b, spmv_vec* x, in
                  (long long)b->n, (long long)x->n, A->nrow);
     SPMV_REQUIRE(b->d != x->d || x->n == 0, "spmv_cg: b and x must not alias");
     SPMV_REQUIRE(max_iter >= 0 && rel_tol >= 0.0, "spmv_cg: max_iter=%d rel_tol=%g", max_iter, rel_tol);
-    SPMV_REQUIRE(precond == SPMV_PRECOND_NONE || precond == SPMV_PRECOND_JACOBI, "spmv_cg: unknown preconditioner %d", precond);
+    SPMV_REQUIRE(precond == SPMV_PRECOND_NONE || precond == SPMV_PRECOND_JACOBI || precond == SPMV_PRECOND_SYMGS,
+                 "spmv_cg: unknown preconditioner %d", precond);
     SPMV_TRY(use_device(ctx));
     return cg_solve(ctx, A, b->d, x->d, max_iter, rel_tol, check_every, precond, iters, rel_resid);
+}
+
+int spmv_symgs_setup(spmv_ctx* ctx, spmv_mat* A)
+{
+    SPMV_REQUIRE(ctx && A, "spmv_symgs_setup: null argument");
+    SPMV_REQUIRE(A->ctx == ctx, "spmv_symgs_setup: the matrix belongs to another context");
+    SPMV_TRY(use_device(ctx));
+    return symgs_setup(A);
+}
+
+int spmv_symgs_order(spmv_ctx* ctx, const spmv_mat* A, int32_t* order)
+{
+    SPMV_REQUIRE(ctx && A && (order || A->nrow == 0), "spmv_symgs_order: null argument");
+    SPMV_TRY(use_device(ctx));
+    return symgs_sequence(A, order);
+}
+
+int spmv_symgs(spmv_ctx* ctx, spmv_mat* A, const spmv_vec* b, spmv_vec* x, int32_t sweeps)
+{
+    SPMV_REQUIRE(ctx && A && b && x, "spmv_symgs: null argument");
+    SPMV_REQUIRE(A->ctx == ctx, "spmv_symgs: the matrix belongs to another context");
+    SPMV_REQUIRE(b->n == A->nrow && x->n == A->nrow, "spmv_symgs: b has %lld and x %lld entries, the matrix %d rows", (long long)b->n,
+                 (long long)x->n, A->nrow);
+    SPMV_REQUIRE(b->d != x->d || x->n == 0, "spmv_symgs: b and x must not alias");
+    SPMV_REQUIRE(sweeps >= 0, "spmv_symgs: sweeps = %d", sweeps);
+    SPMV_TRY(use_device(ctx));
+    SPMV_TRY(symgs_setup(A));  // first call: split, levels, schedule (synchronous); later calls: nothing
+    for (int k = 0; k < sweeps; ++k) SPMV_TRY(symgs_sweep(ctx, A, b->d, x->d, /*zero_guess=*/false));
+    return SPMV_OK;
 }
 
 // ---- conversions ------------------------------------------------------------------------------------------

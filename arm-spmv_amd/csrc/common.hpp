@@ -104,6 +104,11 @@ struct spmv_ctx
     double* dev_scalars  = nullptr;  // one slotted accumulator (kDotDoubles) for scalar results; never re-allocated
 };
 
+namespace spmv
+{
+struct symgs_plan;
+}
+
 struct spmv_vec
 {
     spmv_ctx* ctx   = nullptr;
@@ -201,6 +206,10 @@ struct spmv_mat
 
     // COO / CSC / ELL: internal row-grouped copy in the panel layout (coo_build_panel, csc_analyse, ell_build_panel); owned
     spmv_mat* coo_csr = nullptr;
+
+    // symmetric Gauss-Seidel (symgs.hip): L / D / U copies, rows by level, launch schedule; built by symgs_setup
+    struct spmv::symgs_plan* gs = nullptr;
+    int32_t                  gs_order = 1;  // sweep order: 1 multicolour (default), 0 the matrix's own row order
 };
 
 namespace spmv
@@ -264,7 +273,14 @@ int mat_validate(const spmv_mat* m);
 // convert.hip
 int exclusive_scan_i32(spmv_ctx* ctx, const int32_t* in, int32_t* out, int64_t n);
 int coo_to_csr(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out);
+// symgs.hip
+int  symgs_setup(spmv_mat* m);
+void symgs_free(spmv_mat* m);
+int  symgs_sweep(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, bool zero_guess);
+int  symgs_info(const spmv_mat* m, const char* what, int64_t* value);
+int  symgs_sequence(const spmv_mat* m, int32_t* out);
 // convert_sort.hip
+int sort_ids_by_key(spmv_ctx* ctx, const int32_t* keys, int64_t n, int bits, int32_t* out_ids);
 int coo_place_by_stable_sort(spmv_ctx* ctx, int64_t nnz, int32_t nrow, const int32_t* row, const int32_t* col, const double* val,
                              int32_t* out_col, double* out_val);
 int csr_to_ell(spmv_ctx* ctx, const spmv_mat* csr, spmv_mat** out);

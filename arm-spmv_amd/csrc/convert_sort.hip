@@ -33,6 +33,43 @@ __global__ __launch_bounds__(kBlock) void permute_entries_kernel(int64_t n, cons
 }
 }  // namespace
 
+// out_ids[k] = the k-th id of 0 .. n-1 in ascending key order, ids of equal keys ascending (stable); keys < 2^bits
+int sort_ids_by_key(spmv_ctx* ctx, const int32_t* keys, int64_t n, int bits, int32_t* out_ids)
+{
+    if (n == 0) return SPMV_OK;
+    hipStream_t s = ctx->stream;
+    int32_t *   ids = nullptr, *keys_sorted = nullptr;
+    void*       temp = nullptr;
+    size_t      temp_bytes = 0;
+    int         rc = SPMV_OK;
+    do
+    {
+        if (hipMalloc(&ids, sizeof(int32_t) * (size_t)n) != hipSuccess || hipMalloc(&keys_sorted, sizeof(int32_t) * (size_t)n) != hipSuccess)
+        {
+            rc = SPMV_ERR_ALLOC;
+            break;
+        }
+        hipLaunchKernelGGL(iota_kernel, dim3((unsigned)std::min<int64_t>(kMaxGrid, ceil_div(n, kBlock))), dim3(kBlock), 0, s, ids, n);
+        if (rocprim::radix_sort_pairs(nullptr, temp_bytes, keys, keys_sorted, ids, out_ids, (size_t)n, 0u, (unsigned)bits, s) != hipSuccess)
+        {
+            rc = SPMV_ERR_HIP;
+            break;
+        }
+        if (hipMalloc(&temp, std::max<size_t>(temp_bytes, 16)) != hipSuccess)
+        {
+            rc = SPMV_ERR_ALLOC;
+            break;
+        }
+        if (rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_sorted, ids, out_ids, (size_t)n, 0u, (unsigned)bits, s) != hipSuccess) rc = SPMV_ERR_HIP;
+    } while (0);
+    (void)hipStreamSynchronize(s);
+    if (ids) (void)hipFree(ids);
+    if (keys_sorted) (void)hipFree(keys_sorted);
+    if (temp) (void)hipFree(temp);
+    if (rc != SPMV_OK) SPMV_FAIL(rc, "ordering %lld ids by key failed (%s)", (long long)n, hipGetErrorString(hipGetLastError()));
+    return SPMV_OK;
+}
+
 // out_col/out_val[k] = col/val of the k-th entry in (row, entry id) order
 int coo_place_by_stable_sort(spmv_ctx* ctx, int64_t nnz, int32_t nrow, const int32_t* row, const int32_t* col, const double* val,
                              int32_t* out_col, double* out_val)

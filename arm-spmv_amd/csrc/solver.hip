@@ -4,7 +4,8 @@
 //
 //   mat_apply_ex   y = A*x or y += A*x with the dot product w.y of the updated y riding along (fused into the
 //                  write-back of the panel kernel: saves a pass over w and y; other kernels run a dot pass behind)
-//   cg_solve       conjugate gradients for symmetric positive definite A.  Three launches per iteration
+//   cg_solve       conjugate gradients for symmetric positive definite A, plain, Jacobi- or symmetric-Gauss-Seidel-
+//                  preconditioned (symgs.hip).  Three launches per iteration
 //                  (product+dot, x/r update+dot, direction update); alpha and beta are computed on the device from
 //                  scalars that never leave it, so iterations queue up without a host round trip; the host looks at
 //                  the residual every `check_every` iterations only.  (A hipGraph replay of the iterations in
@@ -156,6 +157,47 @@ __global__ __launch_bounds__(kBlock) void pcg_direction_kernel(int64_t n, int k,
     const double beta = rz_k > 0.0 ? rz_next / rz_k : 0.0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
         p[i] = fma(beta, p[i], r[i] * dinv[i]);
+    if (blockIdx.x == 0 && threadIdx.x < kDotSlots)
+    {
+        s->rr[(k + 2) & 3][threadIdx.x * kDotStride] = 0.0;
+        s->rz[(k + 2) & 3][threadIdx.x * kDotStride] = 0.0;
+        s->pq[(k + 2) & 3][threadIdx.x * kDotStride] = 0.0;
+    }
+}
+
+// General preconditioner (z = M^-1 r comes from a sweep between the two kernels, r . z from a dot pass behind it):
+// alpha = rz_k / pq_k; x += alpha p; r -= alpha q; rr_{k+1} += r.r    and    beta = rz_{k+1} / rz_k; p = z + beta p
+__global__ __launch_bounds__(kBlock) void gcg_update_kernel(int64_t n, int k, const double* __restrict__ p, const double* __restrict__ q,
+                                                            double* __restrict__ x, double* __restrict__ r, CgScalars* __restrict__ s)
+{
+    double pq, rz_k;
+    slot_sum2_block(s->pq[k & 3], s->rz[k & 3], &pq, &rz_k);
+    if (!(pq > 0.0))
+    {
+        // a breakdown only while there is a residual to speak of (see pcg_update_kernel)
+        if (blockIdx.x == 0 && threadIdx.x == 0 && slot_sum(s->rr[k & 3]) > 1e-60 * slot_sum(s->bb)) s->status = 1.0;
+        return;
+    }
+    const double alpha = rz_k / pq;
+    double       rr    = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    {
+        x[i]            = fma(alpha, p[i], x[i]);
+        const double ri = fma(-alpha, q[i], r[i]);
+        r[i]            = ri;
+        rr              = fma(ri, ri, rr);
+    }
+    const double total = block_sum(rr);
+    if (threadIdx.x == 0) slot_add(s->rr[(k + 1) & 3], total);
+}
+
+__global__ __launch_bounds__(kBlock) void gcg_direction_kernel(int64_t n, int k, const double* __restrict__ z, double* __restrict__ p,
+                                                               CgScalars* __restrict__ s)
+{
+    double rz_k, rz_next;
+    slot_sum2_block(s->rz[k & 3], s->rz[(k + 1) & 3], &rz_k, &rz_next);
+    const double beta = rz_k > 0.0 ? rz_next / rz_k : 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) p[i] = fma(beta, p[i], z[i]);
     if (blockIdx.x == 0 && threadIdx.x < kDotSlots)
     {
         s->rr[(k + 2) & 3][threadIdx.x * kDotStride] = 0.0;
@@ -342,16 +384,24 @@ int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int m
     *rel_resid      = 0.0;
     if (n == 0) return SPMV_OK;
     hipStream_t st = ctx->stream;
-    double *    r = nullptr, *p = nullptr, *q = nullptr, *dinv = nullptr;
+    double *    r = nullptr, *p = nullptr, *q = nullptr, *dinv = nullptr, *z = nullptr;
     CgScalars*  s = nullptr;
     auto        release = [&]() {
+        if (z) (void)hipFree(z);
         if (r) (void)hipFree(r);
         if (p) (void)hipFree(p);
         if (q) (void)hipFree(q);
         if (s) (void)hipFree(s);
         if (dinv) (void)hipFree(dinv);
     };
-    if (precond)
+    if (precond == SPMV_PRECOND_SYMGS)
+    {
+        // one symmetric Gauss-Seidel sweep from z = 0 per iteration (symgs.hip); the plan is built once and stays in the handle
+        SPMV_TRY(symgs_setup(const_cast<spmv_mat*>(A)));
+        if (hipMalloc(&z, sizeof(double) * (size_t)n) != hipSuccess)
+            SPMV_FAIL(SPMV_ERR_ALLOC, "spmv_cg: out of device memory for the preconditioned residual (%lld entries)", (long long)n);
+    }
+    else if (precond)
     {
         // Jacobi: the diagonal the reference's containers carry "for SymGS" (include/matrix.h:36); taken from the CSR arrays
         if (A->format != SPMV_FMT_CSR || !A->b || !A->v)
@@ -419,6 +469,17 @@ int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int m
             hipLaunchKernelGGL(cg_init_kernel<true>, dim3(grid), dim3(kBlock), 0, st, n, b, q, r, p, s, dinv);
         else
             hipLaunchKernelGGL(cg_init_kernel<false>, dim3(grid), dim3(kBlock), 0, st, n, b, q, r, p, s, dinv);
+        if (z)
+        {
+            // z_0 = M^-1 r_0, rz_0 = r_0 . z_0, p_0 = z_0
+            if ((rc = symgs_sweep(ctx, A, r, z, true)) != SPMV_OK) break;
+            if ((rc = vec_dot_accumulate(ctx, r, z, n, s->rz[0])) != SPMV_OK) break;
+            if (hipMemcpyAsync(p, z, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            {
+                rc = SPMV_ERR_HIP;
+                break;
+            }
+        }
         if ((rc = fetch(-1)) != SPMV_OK) break;
         const double bb    = host_sum(h.bb);
         const double limit = rel_tol * rel_tol * bb;  // compare squared norms
@@ -437,7 +498,14 @@ int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int m
             ex.dot_w     = p;
             ex.dot_out   = s->pq[kk & 3];
             SPMV_TRY(mat_apply_ex(ctx, A, p, q, ex));  // q = A p, pq_k = p . q
-            if (dinv)
+            if (z)
+            {
+                hipLaunchKernelGGL(gcg_update_kernel, dim3(grid), dim3(kBlock), 0, st, n, kk, p, q, x, r, s);
+                SPMV_TRY(symgs_sweep(ctx, A, r, z, true));
+                SPMV_TRY(vec_dot_accumulate(ctx, r, z, n, s->rz[(kk + 1) & 3]));
+                hipLaunchKernelGGL(gcg_direction_kernel, dim3(grid), dim3(kBlock), 0, st, n, kk, z, p, s);
+            }
+            else if (dinv)
             {
                 hipLaunchKernelGGL(pcg_update_kernel, dim3(grid), dim3(kBlock), 0, st, n, kk, p, q, x, r, s, dinv);
                 hipLaunchKernelGGL(pcg_direction_kernel, dim3(grid), dim3(kBlock), 0, st, n, kk, r, p, s, dinv);

@@ -257,10 +257,34 @@ int spmv_apply_dot(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* x, spmv_vec
 enum spmv_precond
 {
     SPMV_PRECOND_NONE   = 0,
-    SPMV_PRECOND_JACOBI = 1 /* z = D^-1 r, D = diag(A) read from a CSR handle (zero diagonal: SPMV_ERR_INVALID) */
+    SPMV_PRECOND_JACOBI = 1, /* z = D^-1 r, D = diag(A) read from a CSR handle (zero diagonal: SPMV_ERR_INVALID) */
+    SPMV_PRECOND_SYMGS  = 2  /* z = one symmetric Gauss-Seidel sweep on A z = r from z = 0 (spmv_symgs below; the handle is
+                                set up on first use although it is passed as const) */
 };
 int spmv_cg(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* b, spmv_vec* x, int32_t max_iter,
             double rel_tol, int32_t check_every, int32_t precond, int32_t* iters, double* rel_resid);
+/* spmv_symgs: `sweeps` symmetric Gauss-Seidel sweeps on A*x = b, x updated in place: forward over the rows in sweep
+ *   order with the newest x, then backward — the sweep the reference's `diagonal // for SymGS` fields were reserved
+ *   for (include/matrix.h:36,81) and that it never wrote.  A: CSR handle holding the whole square matrix with a non-zero
+ *   diagonal (duplicates of a diagonal entry are summed); symmetric or not.
+ *   Sweep order (spmv_mat_set_param "symgs_order", before the first use or between uses):
+ *     1 (default) multicolour: the greedy colouring in row order (colour(i) = smallest colour no coupled row j < i has),
+ *       rows swept colour by colour, ascending row index inside a colour — rows of a colour are solved together, a
+ *       sweep is a handful of launches (two colours, 6 launches for a 7-point Laplacian);
+ *     0 the matrix's own row order i = 0..n-1, exactly — as parallel as the matrix allows (the rows are solved in
+ *       dependency levels: ~480 levels, ~790 launches for a 7-point Laplacian on 160^3 points; a band matrix is sequential).
+ *   spmv_symgs_order returns the sequence (order[k] = the k-th row of a forward sweep), so that a host implementation can
+ *   repeat the sweep number by number.  Either way the result is exact for that order (only the sums inside a row are
+ *   taken by several lanes).
+ *   spmv_symgs_setup (also run by the first spmv_symgs / spmv_cg(SPMV_PRECOND_SYMGS) on the handle): colours the rows,
+ *   splits A into L + D + U by sweep order on the device, finds the dependency levels of both parts and fixes a launch
+ *   schedule; synchronous; kept in the handle (about the size of the matrix again).  A sweep is then t = b - U*x,
+ *   (L+D)*x = t level by level, t = b - L*x, (D+U)*x = t level by level — asynchronous.  spmv_mat_get_param
+ *   "symgs_colours" / "symgs_levels_forward" / "symgs_levels_backward" / "symgs_launches" (per sweep) / "symgs_bytes".
+ *   SPMV_ERR_UNSUPPORTED if a dependency chain exceeds 2^18 rows. */
+int spmv_symgs_setup(spmv_ctx* ctx, spmv_mat* A);
+int spmv_symgs_order(spmv_ctx* ctx, const spmv_mat* A, int32_t* order /* host, nrow entries */);
+int spmv_symgs(spmv_ctx* ctx, spmv_mat* A, const spmv_vec* b, spmv_vec* x, int32_t sweeps);
 
 /* ---- format conversion on the device (src/matrix.cpp:115-154, :450-500) -------------------------- */
 /* Both keep the COO order of the entries inside each row (stable), like the reference's backward

@@ -388,4 +388,71 @@ void orc_csr_abs_row_sums(int32_t nrow, const int32_t* row_ptr, const int32_t* c
         s[i] = acc;
     }
 }
+
+/* no reference loop (see spmv_oracle.h): the textbook symmetric Gauss-Seidel sweep in row order */
+static int32_t symgs_row(int32_t i, const int32_t* row_ptr, const int32_t* col, const double* val, const double* b, double* x)
+{
+    double sum = b[i], diag = 0.0;
+    for (int32_t j = row_ptr[i]; j < row_ptr[i + 1]; j++)
+    {
+        if (col[j] == i)
+            diag += val[j];
+        else
+            sum -= val[j] * x[col[j]];
+    }
+    if (diag == 0.0) return 1;
+    x[i] = sum / diag;
+    return 0;
+}
+
+int32_t orc_symgs_ordered(int32_t n, const int32_t* row_ptr, const int32_t* col, const double* val, const double* b,
+                          double* x, int32_t sweeps, const int32_t* order)
+{
+    for (int32_t s = 0; s < sweeps; s++)
+    {
+        for (int32_t k = 0; k < n; k++)
+        {
+            const int32_t i = order ? order[k] : k;
+            if (symgs_row(i, row_ptr, col, val, b, x)) return 1 + i;
+        }
+        for (int32_t k = n - 1; k >= 0; k--)
+        {
+            const int32_t i = order ? order[k] : k;
+            if (symgs_row(i, row_ptr, col, val, b, x)) return 1 + i;
+        }
+    }
+    return 0;
+}
+
+int32_t orc_symgs(int32_t n, const int32_t* row_ptr, const int32_t* col, const double* val, const double* b, double* x,
+                  int32_t sweeps)
+{
+    return orc_symgs_ordered(n, row_ptr, col, val, b, x, sweeps, 0);
+}
+
+/* colour[i] = smallest colour none of the rows j < i coupled to i (a_ij stored) has: the sequential greedy colouring
+ * the engine's multicolour sweep order is defined by; order[] = rows by (colour, row).  Returns the number of colours. */
+int32_t orc_greedy_colour_order(int32_t n, const int32_t* row_ptr, const int32_t* col, int32_t* colour, int32_t* order)
+{
+    int32_t ncolours = 0;
+    for (int32_t i = 0; i < n; i++)
+    {
+        int32_t c = 0;
+        for (;;)
+        {
+            int32_t clash = 0;
+            for (int32_t j = row_ptr[i]; j < row_ptr[i + 1] && !clash; j++)
+                if (col[j] < i && colour[col[j]] == c) clash = 1;
+            if (!clash) break;
+            c++;
+        }
+        colour[i] = c;
+        if (c + 1 > ncolours) ncolours = c + 1;
+    }
+    int32_t k = 0;
+    for (int32_t c = 0; c < ncolours; c++)
+        for (int32_t i = 0; i < n; i++)
+            if (colour[i] == c) order[k++] = i;
+    return ncolours;
+}
 #endif /* !ORC_FMA */

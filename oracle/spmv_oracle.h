@@ -105,6 +105,22 @@ void   orc_axpby_fma(int64_t n, double alpha, const double* x, double beta, cons
 void orc_csr_abs_row_sums(int32_t nrow, const int32_t* row_ptr, const int32_t* col,
                           const double* val, const double* x, double* s);
 
+/* ---- the sweep the `diagonal // for SymGS` fields were reserved for (include/matrix.h:36,81) --------------- */
+/* The reference holds the fields and no sweep, so there is no reference loop to restate and nothing of the
+ * reference's to pin this against (PARITY UNPINNED; the tests add properties: the exact solution is a fixed point, a
+ * triangular matrix is solved by one sweep, preconditioned CG needs fewer iterations).  The definition is the textbook
+ * one, rows in the matrix's own order, entries of a row left to right, duplicates of the diagonal entry summed:
+ *   forward  i = 0..n-1, then backward i = n-1..0:   x_i = (b_i - sum_{j != i} a_ij x_j) / a_ii   with the newest x.
+ * Returns 0, or 1 + the first row without a diagonal (x is then untouched from that row of the first sweep on). */
+int32_t orc_symgs(int32_t n, const int32_t* row_ptr, const int32_t* col, const double* val, const double* b, double* x,
+                  int32_t sweeps);
+/* the same sweep over the rows in the sequence order[0..n-1] (forward) and back (order == NULL: 0..n-1) */
+int32_t orc_symgs_ordered(int32_t n, const int32_t* row_ptr, const int32_t* col, const double* val, const double* b,
+                          double* x, int32_t sweeps, const int32_t* order);
+/* the engine's default sequence: greedy colouring in row order (colour[i] = smallest colour no coupled row j < i has),
+ * rows by (colour, row).  Returns the number of colours. */
+int32_t orc_greedy_colour_order(int32_t n, const int32_t* row_ptr, const int32_t* col, int32_t* colour, int32_t* order);
+
 #ifdef __cplusplus
 }
 #endif

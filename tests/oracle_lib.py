@@ -75,6 +75,21 @@ def csr_spmv(lib, row_ptr, col, val, x, y, fma=False):
     getattr(lib, "orc_csr_spmv" + _sfx(fma))(C.c_int32(len(row_ptr) - 1), _p(row_ptr), _p(col), _p(val), _p(x), _p(y))
 
 
+def symgs(lib, row_ptr, col, val, b, x, sweeps=1, order=None):
+    """x updated in place, rows swept in `order` (None: 0..n-1); returns 0 or 1 + the first row without a diagonal"""
+    lib.orc_symgs_ordered.restype = C.c_int32
+    return lib.orc_symgs_ordered(C.c_int32(len(row_ptr) - 1), _p(row_ptr), _p(col), _p(val), _p(b), _p(x), C.c_int32(sweeps),
+                                 _p(i32(order)) if order is not None else None)
+
+
+def greedy_colour_order(lib, row_ptr, col):
+    """(number of colours, colour[], order[]) of the sequential greedy colouring in row order"""
+    n = len(row_ptr) - 1
+    colour, order = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+    lib.orc_greedy_colour_order.restype = C.c_int32
+    return lib.orc_greedy_colour_order(C.c_int32(n), _p(row_ptr), _p(col), _p(colour), _p(order)), colour, order
+
+
 def csr_spmv_omp(lib, row_ptr, col, val, x, y):
     lib.orc_csr_spmv_omp(C.c_int32(len(row_ptr) - 1), _p(row_ptr), _p(col), _p(val), _p(x), _p(y))
 

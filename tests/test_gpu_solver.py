@@ -202,3 +202,171 @@ def test_jacobi_preconditioned_cg(ctx, orc, pkg):
     E = ctx.csr_to_ell(A)
     with pytest.raises(Err, match="CSR"):
         ctx.cg(E, b, x, jacobi=True)
+
+
+# ---- symmetric Gauss-Seidel (spmv_symgs; SPMV_PRECOND_SYMGS) ------------------------------------------------------
+def _laplacian_3d(m):
+    """7-point Laplacian on an m^3 grid, CSR, columns ascending"""
+    n = m * m * m
+    idx = np.arange(n).reshape(m, m, m)
+    rows, cols, vals = [idx.ravel()], [idx.ravel()], [np.full(n, 6.0)]
+    for a, b in ((idx[:, :, :-1], idx[:, :, 1:]), (idx[:, :-1, :], idx[:, 1:, :]), (idx[:-1, :, :], idx[1:, :, :])):
+        rows += [a.ravel(), b.ravel()]
+        cols += [b.ravel(), a.ravel()]
+        vals += [np.full(a.size, -1.0)] * 2
+    r, c, v = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    o = np.lexsort((c, r))
+    r, c, v = r[o], c[o], v[o]
+    rp = np.zeros(n + 1, np.int64)
+    np.add.at(rp, r + 1, 1)
+    return n, np.cumsum(rp).astype(np.int32), c.astype(np.int32), v
+
+
+def _dominant_random(n, k, seed, unsorted=True):
+    """NON-symmetric pattern, k random off-diagonal entries per row in random order, the diagonal entry given twice
+    (duplicates are summed), strictly diagonally dominant"""
+    rng = np.random.default_rng(seed)
+    cols = rng.integers(0, n, (n, k))
+    vals = rng.uniform(-1, 1, (n, k))
+    rows = np.repeat(np.arange(n), k).reshape(n, k)
+    vals[cols == rows] = 0.0  # an accidental diagonal hit: keep the slot, drop its weight
+    dom = np.abs(vals).sum(axis=1) + 1.0
+    cc = np.concatenate([cols, rows[:, :1], rows[:, :1]], axis=1)
+    cv = np.concatenate([vals, (0.75 * dom)[:, None], (0.25 * dom)[:, None]], axis=1)
+    if unsorted:
+        perm = np.argsort(rng.uniform(size=cc.shape), axis=1)
+        cc, cv = np.take_along_axis(cc, perm, 1), np.take_along_axis(cv, perm, 1)
+    rp = (np.arange(n + 1) * (k + 2)).astype(np.int32)
+    return n, rp, cc.ravel().astype(np.int32), cv.ravel()
+
+
+def _symgs_close(got, want, what):
+    err = np.max(np.abs(got - want)) / max(np.max(np.abs(want)), 1e-300)
+    assert err <= ol.REL_TOL, (what, err)
+
+
+@pytest.mark.parametrize("order", [0, 1], ids=["row_order", "multicolour"])
+@pytest.mark.parametrize("problem", ["tridiagonal_8", "laplacian_3d", "random_pattern", "lower_triangular"])
+def test_symgs_matches_the_sweep_in_the_same_order(ctx, orc, pkg, problem, order):
+    """spmv_symgs against oracle/spmv_oracle.c: orc_symgs_ordered (the textbook sweep; nothing in the reference to pin it
+    to), in the matrix's own row order and in the multicolour order the engine reports: 1, 2 and 3 sweeps from a random
+    x; the sequence against the oracle's sequential greedy colouring; the level structure the analysis found; the exact
+    solution as a fixed point"""
+    rng = np.random.default_rng(21)
+    if problem == "tridiagonal_8":
+        n = 8
+        dense = 2.0 * np.eye(n) - np.eye(n, k=1) - np.eye(n, k=-1)
+        r, c = np.nonzero(dense)
+        rp = np.concatenate([[0], np.cumsum(np.bincount(r, minlength=n))]).astype(np.int32)
+        cc, cv = c.astype(np.int32), dense[r, c]
+        levels, colours = (n, n), 2  # row order: every row waits for its neighbour, a chain; even / odd rows
+    elif problem == "laplacian_3d":
+        m = 24
+        n, rp, cc, cv = _laplacian_3d(m)
+        levels, colours = (3 * m - 2, 3 * m - 2), 2  # hyperplanes i + j + k = const; red-black
+    elif problem == "random_pattern":
+        n, rp, cc, cv = _dominant_random(30_000, 7, 4)
+        levels = colours = None
+    else:
+        n, rp, cc, cv = _dominant_random(5_000, 5, 6)
+        rows = np.repeat(np.arange(n), np.diff(rp))
+        keep = cc <= rows
+        cc, cv = cc[keep], cv[keep]
+        rp = np.concatenate([[0], np.cumsum(np.bincount(rows[keep], minlength=n))]).astype(np.int32)
+        levels = colours = None
+    A = ctx.csr(n, n, rp, cc, cv)
+    A.set_param("symgs_order", order)
+    seq = ctx.symgs_order(A)
+    assert A.get_param("symgs_order") == order
+    if order == 0:
+        assert np.array_equal(seq, np.arange(n)) and A.get_param("symgs_colours") == 0
+    else:
+        ncol, colour, want_seq = ol.greedy_colour_order(orc, rp, cc)
+        assert A.get_param("symgs_colours") == ncol and np.array_equal(seq, want_seq)
+        if colours:
+            assert ncol == colours
+    b_host, x0 = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    b = ctx.vector_from(b_host)
+    for sweeps in (1, 2, 3):
+        want = x0.copy()
+        assert ol.symgs(orc, rp, cc, cv, b_host, want, sweeps, order=seq) == 0
+        x = ctx.vector_from(x0)
+        ctx.symgs(A, b, x, sweeps)
+        ctx.sync()
+        _symgs_close(x.download(), want, f"{problem} order {order}: {sweeps} sweeps")
+    lf, lb = A.get_param("symgs_levels_forward"), A.get_param("symgs_levels_backward")
+    assert 1 <= lf <= n and 1 <= lb <= n and A.get_param("symgs_launches") >= 4
+    if levels and order == 0:
+        assert (lf, lb) == levels, (lf, lb, levels)
+    if colours and order == 1:
+        assert (lf, lb) == (colours, colours), (lf, lb)  # a proper colouring: one level per colour
+    if problem == "lower_triangular" and order == 0:
+        # (L + D) x = b is solved by the forward half; the backward half has nothing above the diagonal to add
+        assert lb == 1
+        x = ctx.vector_from(x0)
+        ctx.symgs(A, b, x, 1)
+        ax = np.zeros(n)
+        ol.csr_spmv(orc, rp, cc, cv, x.download(), ax)
+        assert np.max(np.abs(ax - b_host)) <= 1e-12 * np.max(np.abs(b_host))
+    # the solution of A x = b stays where it is: b := A x*
+    xs = rng.uniform(-1, 1, n)
+    bs = np.zeros(n)
+    ol.csr_spmv(orc, rp, cc, cv, xs, bs)
+    x = ctx.vector_from(xs)
+    ctx.symgs(A, ctx.vector_from(bs), x, 2)
+    assert np.max(np.abs(x.download() - xs)) <= 1e-12
+    # sweeps = 0 leaves x alone
+    x = ctx.vector_from(x0)
+    ctx.symgs(A, b, x, 0)
+    assert np.array_equal(x.download(), x0)
+    # the other order on the same handle: the plan is rebuilt
+    A.set_param("symgs_order", 1 - order)
+    seq2 = ctx.symgs_order(A)
+    want = x0.copy()
+    ol.symgs(orc, rp, cc, cv, b_host, want, 1, order=seq2)
+    x = ctx.vector_from(x0)
+    ctx.symgs(A, b, x, 1)
+    _symgs_close(x.download(), want, f"{problem}: order switched to {1 - order}")
+
+
+def test_symgs_preconditioned_cg_and_error_paths(ctx, orc, pkg):
+    """CG on a 3-D Laplacian, plain / Jacobi / one symmetric Gauss-Seidel sweep per iteration: all three answers
+    through the oracle's product; the sweep must save iterations (Jacobi cannot: the diagonal is constant)"""
+    capi = pkg.capi
+    n, rp, cc, cv = _laplacian_3d(40)
+    A = ctx.csr(n, n, rp, cc, cv)
+    b_host = np.random.default_rng(5).uniform(-1, 1, n)
+    b, x = ctx.vector_from(b_host), ctx.vector(n)
+    res = {}
+    for name, kw in (("plain", {}), ("jacobi", {"jacobi": True}), ("symgs", {"symgs": True}), ("symgs_rows", {"symgs": True})):
+        A.set_param("symgs_order", 0 if name == "symgs_rows" else 1)
+        for check_every in (1, 6):
+            x.fill(0.0)
+            iters, relres = ctx.cg(A, b, x, max_iter=1000, rel_tol=1e-9, check_every=check_every, **kw)
+            ax = np.zeros(n)
+            ol.csr_spmv(orc, rp, cc, cv, x.download(), ax)
+            true_res = np.linalg.norm(b_host - ax) / np.linalg.norm(b_host)
+            assert relres <= 1e-9 and true_res <= 2e-8, (name, check_every, iters, relres, true_res)
+            res[name, check_every] = iters
+    assert res["symgs", 1] * 1.8 < res["plain", 1] and res["symgs_rows", 1] * 1.8 < res["plain", 1], res
+    assert abs(res["jacobi", 1] - res["plain", 1]) <= 2, res
+    assert res["symgs", 1] <= res["symgs", 6] <= res["symgs", 1] + 6, res
+    # the same with the panel kernel doing the products
+    A.set_param("symgs_order", 1)
+    A.set_kernel(capi.CSR_PANEL)
+    x.fill(0.0)
+    iters, relres = ctx.cg(A, b, x, max_iter=1000, rel_tol=1e-9, symgs=True)
+    assert relres <= 1e-9 and abs(iters - res["symgs", 1]) <= 1, (iters, res)
+    # error paths
+    Err = capi.SpmvError
+    rp0 = np.arange(4, dtype=np.int32)
+    Z = ctx.csr(3, 3, rp0, np.array([1, 2, 0], np.int32), np.ones(3))  # no diagonal entries
+    with pytest.raises(Err, match="diagonal"):
+        ctx.symgs(Z, ctx.vector_from(np.ones(3)), ctx.vector(3))
+    with pytest.raises(Err, match="CSR"):
+        ctx.symgs(ctx.csr_to_ell(A), b, x)
+    R = ctx.csr(3, 4, rp0, np.array([0, 1, 2], np.int32), np.ones(3))
+    with pytest.raises(Err, match="square"):
+        ctx.symgs(R, ctx.vector_from(np.ones(3)), ctx.vector(3))
+    with pytest.raises(Err, match="alias"):
+        ctx.symgs(A, b, b)

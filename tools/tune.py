@@ -37,7 +37,7 @@ def sweep(ctx, A, x, y, variants, rounds, reps, bytes_launch, nnz):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["csr", "ell", "coo", "blas1", "bandwin", "dia", "cg"])
+    ap.add_argument("what", choices=["csr", "ell", "coo", "blas1", "bandwin", "dia", "cg", "symgs"])
     ap.add_argument("--n", type=int, default=0)
     ap.add_argument("--k", type=int, default=0)
     ap.add_argument("--band", type=int, default=0)
@@ -103,6 +103,63 @@ def main():
             bytes_it = 12 * nnz + 4 * n + 16 * n + 48 * n + 24 * n  # product (A, p, q) + x/r update + direction
             print(f"  check_every={every:3d}: {it} iterations in {dt*1e3:.2f} ms = {dt/it*1e6:.1f} us/iteration, "
                   f"{bytes_it/(dt/it)/1e9:.0f} GB/s algorithmic, residual {res:.3e}")
+        return
+    if a.what == "symgs":
+        # symmetric Gauss-Seidel (spmv_symgs) and CG preconditioned with it, 7-point Laplacian of an m^3 grid
+        import time
+
+        import numpy as np
+
+        m = a.n or 160
+        n = m * m * m
+        idx = np.arange(n, dtype=np.int64).reshape(m, m, m)
+        rows, cols, vals = [idx.ravel()], [idx.ravel()], [np.full(n, 6.0)]
+        for u, v in ((idx[:, :, :-1], idx[:, :, 1:]), (idx[:, :-1, :], idx[:, 1:, :]), (idx[:-1, :, :], idx[1:, :, :])):
+            rows += [u.ravel(), v.ravel()]
+            cols += [v.ravel(), u.ravel()]
+            vals += [np.full(u.size, -1.0)] * 2
+        r, c, v = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+        o = np.lexsort((c, r))
+        rp = np.zeros(n + 1, np.int64)
+        np.add.at(rp, r + 1, 1)
+        A = ctx.csr(n, n, np.cumsum(rp).astype(np.int32), c[o].astype(np.int32), v[o])
+        nnz = len(v)
+        b, x, y = ctx.gen_vector(n, seed=3), ctx.vector(n), ctx.vector(n)
+        y.fill(0.0)
+        prod = ctx.apply_timed(A, b, y, 20)
+        print(f"SymGS, 7-point Laplacian {m}^3: n={n} nnz={nnz} kernel={A.info.kernel}, product {prod*1e3:.1f} us")
+        for order in (1, 0):
+            A.set_param("symgs_order", order)
+            x.fill(0.0)
+            ctx.sync()
+            t = time.perf_counter()
+            ctx.symgs(A, b, x, 0)  # the analysis alone
+            ctx.sync()
+            setup = time.perf_counter() - t
+            print(f" order {order} ({'multicolour' if order else 'row order'}): set-up {setup*1e3:.1f} ms; {A.get_param('symgs_colours')} colours, levels "
+                  f"{A.get_param('symgs_levels_forward')} / {A.get_param('symgs_levels_backward')}, {A.get_param('symgs_launches')} launches per sweep, "
+                  f"{A.get_param('symgs_bytes')/1e6:.0f} MB")
+            for sweeps in (1, 10, 10):
+                ctx.sync()
+                t = time.perf_counter()
+                ctx.symgs(A, b, x, sweeps)
+                ctx.sync()
+                dt = (time.perf_counter() - t) / sweeps
+                print(f"  {sweeps:2d} sweeps: {dt*1e3:.3f} ms per sweep = {dt*1e3/prod:.1f} products; "
+                      f"{(2*12*nnz + 7*8*n) / dt / 1e9:.0f} GB/s algorithmic")
+            x.fill(0.0)
+            ctx.sync()
+            t = time.perf_counter()
+            it, res = ctx.cg(A, b, x, max_iter=2000, rel_tol=1e-8, check_every=10, symgs=True)
+            dt = time.perf_counter() - t
+            print(f"  CG + sweep: {it} iterations to {res:.2e} in {dt*1e3:.1f} ms = {dt/max(it,1)*1e6:.0f} us/iteration")
+        for name, kw in (("plain", {}), ("jacobi", {"jacobi": True})):
+            x.fill(0.0)
+            ctx.sync()
+            t = time.perf_counter()
+            it, res = ctx.cg(A, b, x, max_iter=2000, rel_tol=1e-8, check_every=10, **kw)
+            dt = time.perf_counter() - t
+            print(f"  CG {name}: {it} iterations to {res:.2e} in {dt*1e3:.1f} ms = {dt/max(it,1)*1e6:.0f} us/iteration")
         return
     if a.what == "dia":
         n, k = a.n or 4_000_000, a.k or 64
