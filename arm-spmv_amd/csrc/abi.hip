@@ -665,6 +665,7 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         m->tp_pcols_req = (int32_t)value;
     else if (!strcmp(name, "twophase_unroll"))
         m->tp_unroll = (int32_t)value;
+
     else
         SPMV_FAIL(SPMV_ERR_INVALID, "unknown parameter '%s'", name);
     return SPMV_OK;

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(THREADS) void tp_expand_kernel(int P, int pcols, in
                     f64x2 o;
                     o.x = vv[k].x * xs[cc[k].x];
                     o.y = vv[k].y * xs[cc[k].y];
-                    o2[(size_t)dd[k] * 8 + (t & 7)] = o;
+                    __builtin_nontemporal_store(o, o2 + ((size_t)dd[k] * 8 + (t & 7)));  // read again only 2.7 GB later: 2-3 %
                 }
             }
         };
