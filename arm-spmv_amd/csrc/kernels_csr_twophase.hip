@@ -28,6 +28,7 @@
 //   tp_xg[padded nnz]         the stream between the phases (scratch owned by the handle), in e' order
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "common.hpp"

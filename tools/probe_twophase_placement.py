@@ -2,7 +2,7 @@
 """tools/probe_twophase_placement.py — the two-phase product of the C5 shard shape, its layout built several times in
 one process (alternating two panel widths forces a re-build: every stream is freed and allocated again).  Measured
 (profiles/r02_probe_twophase_placement.txt): the streams come back at the SAME device addresses, filling the same
-memory again with the entries in another order changes nothing, and yet a re-build lands at 1.82-1.88 or at 1.95-2.00 ms
+memory again with the entries in another order changes nothing, and yet a re-build lands anywhere from 1.79 to 2.03 ms
 per product (phase A: 1.22 or 1.38 ms) — what differs is the physical memory behind the addresses."""
 import sys
 from pathlib import Path
