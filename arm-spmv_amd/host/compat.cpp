@@ -821,15 +821,67 @@ void ELLMatrixMatVectorNuma(const ELLMatrix& A, const Vector& x, Vector& y, int 
     run_shards("ELL", shards, x, y, 2.0 * (double)A.nrow * (double)K);
 }
 
-void CSCMatrixMatVectorNuma(const CSCMatrix& A, const Vector& x, Vector& y, int)
+void CSCMatrixMatVectorNuma(const CSCMatrix& A, const Vector& x, Vector& y, int nthreads)
 {
-    // column-range sharding (src/mat_vec.cpp:299-366) needs a reduction of full-length partial y vectors that the
-    // reference never performs; CSC is a "next" format: one shard on GPU 0, same protocol and print.
-    Engine&            E = Engine::get();
-    std::vector<Shard> shards(1);
-    shards[0].row1 = A.nrow;
-    check(spmv_csc_upload(E.ctx(0), A.nrow, A.ncol, A.col_ptr, A.row_ind, A.values, &shards[0].mat), "spmv_csc_upload");
-    run_shards("CSC", shards, x, y, 2.0 * (double)A.col_ptr[A.ncol]);
+    // COLUMN-range shards, as the reference cuts them (src/mat_vec.cpp:299-337): shard i holds columns [c0, c1) with a
+    // rebased col_ptr, ITS SLICE OF x ONLY (:329 — no replica, no exchange) and a private full-length Y (:330).  The
+    // reference leaves the partial Y vectors where they are; here they are summed on the first device (device-to-device
+    // / peer copies) and y comes back once — the reduction a column partition needs.
+    Engine&   E = Engine::get();
+    const int n = std::max(nthreads, 1);
+    struct ColShard
+    {
+        int       device = 0;
+        int64_t   c0 = 0, c1 = 0;
+        spmv_mat* mat = nullptr;
+        spmv_vec *x = nullptr, *y = nullptr;
+    };
+    std::vector<ColShard> shards((size_t)n);
+    std::vector<int>      sub_ptr;
+    for (int i = 0; i < n; ++i)
+    {
+        ColShard& s = shards[(size_t)i];
+        s.device    = i % E.ngpus();
+        check(spmv_partition_rows(A.ncol, n, i, &s.c0, &s.c1), "spmv_partition_rows(columns)");  // equal columns, the last takes the rest (:302,315)
+        const int     base = A.col_ptr[s.c0];
+        const int64_t cols = s.c1 - s.c0;
+        sub_ptr.resize((size_t)cols + 1);
+        for (int64_t j = 0; j <= cols; ++j) sub_ptr[(size_t)j] = A.col_ptr[s.c0 + j] - base;  // :333-336
+        spmv_ctx* c = E.ctx(s.device);
+        check(spmv_csc_upload(c, A.nrow, (int)cols, sub_ptr.data(), A.row_ind + base, A.values + base, &s.mat), "spmv_csc_upload(shard)");
+        check(spmv_vec_create(c, cols, &s.x), "spmv_vec_create(x slice)");
+        check(spmv_vec_upload(s.x, 0, cols, x.values + s.c0), "spmv_vec_upload(x slice)");
+        check(spmv_vec_create(c, A.nrow, &s.y), "spmv_vec_create(partial y)");
+        check(spmv_vec_fill(s.y, 0.0), "spmv_vec_fill");
+    }
+    for (ColShard& s : shards) check(spmv_sync(E.ctx(s.device)), "spmv_sync");
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < g_numa_reps; ++k)
+    {
+        for (ColShard& s : shards) check(spmv_apply(E.ctx(s.device), s.mat, s.x, s.y), "spmv_apply(shard)");
+        for (ColShard& s : shards) check(spmv_sync(E.ctx(s.device)), "spmv_sync");
+    }
+    const double secs  = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const double t_avg = (secs * 1000.0 + secs / 1000.0) / g_numa_reps;  // src/mat_vec.cpp:353
+    g_last_numa_ms     = secs * 1000.0 / g_numa_reps;
+    printf("### CSC NUMA GFLOPS = %.5f\n", 2.0 * (double)A.col_ptr[A.ncol] / t_avg / 1e6);
+    // y = sum of the partial vectors, in shard order, on the first shard's device
+    spmv_ctx* c0  = E.ctx(shards[0].device);
+    spmv_vec* tmp = nullptr;
+    if (n > 1) check(spmv_vec_create(c0, A.nrow, &tmp), "spmv_vec_create(reduction buffer)");
+    for (int i = 1; i < n; ++i)
+    {
+        check(spmv_vec_copy(tmp, 0, shards[(size_t)i].y, 0, A.nrow), "spmv_vec_copy(partial y)");
+        check(spmv_axpby(c0, 1.0, shards[0].y, 1.0, tmp, shards[0].y), "spmv_axpby(partial y)");
+    }
+    check(spmv_vec_download(shards[0].y, 0, A.nrow, y.values), "spmv_vec_download(y)");
+    if (tmp) spmv_vec_destroy(tmp);
+    for (ColShard& s : shards)
+    {
+        spmv_vec_destroy(s.x);
+        spmv_vec_destroy(s.y);
+        spmv_mat_destroy(s.mat);
+    }
 }
 
 void DIAMatrixMatVectorNuma(const DIAMatrix& A, const Vector& x, Vector& y, int nthreads)

@@ -224,6 +224,15 @@ int main(int argc, char* argv[])
         y.Fill(0);
         CSCMatrixMatVector(C, x, y);
         verify("CSC");
+        if (o.numa)
+        {
+            // column shards: every device gets its slice of x only, the partial y vectors are summed on the first device
+            y.Fill(0);
+            spmv_compat_set_numa_reps(o.reps);
+            CSCMatrixMatVectorNuma(C, x, y, o.shards);
+            for (int i = 0; i < y.size; ++i) y.values[i] /= o.reps;
+            verify("CSC NUMA");
+        }
     }
     if (o.has("ell"))
     {

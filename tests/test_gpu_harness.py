@@ -31,12 +31,13 @@ def test_spmv_main_verifies_every_format_and_the_sharded_drivers(tmp_path, pkg):
     assert r.returncode == 0, r.stdout + r.stderr
     out = r.stdout
     assert "### ROW=3000, COL=3000, NNZ=36000" in out
-    for name in ("CSR", "CSR EDIT-IN-PLACE", r"CSR \(edit undone\)", "CSR NUMA", "CSC", "ELL", "ELL NUMA", "COO NUMA"):
+    for name in ("CSR", "CSR EDIT-IN-PLACE", r"CSR \(edit undone\)", "CSR NUMA", "CSC", "CSC NUMA", "ELL", "ELL NUMA", "COO NUMA"):
         m = re.search(rf"### {name} VERIFY .* = ([0-9.e+-]+) OK", out)
         assert m and float(m.group(1)) <= 1e-10, (name, out)
     # the generated matrix has duplicate (i,j) entries in some rows: the reference's DIA keeps the last one
     # (src/matrix.cpp:721), so DIA is reported, not gated
     assert re.search(r"### DIA VERIFY \(informational\)", out)
+    assert re.search(r"### CSC NUMA GFLOPS = [0-9.]+", out)
     for name in ("COO", "CSR", "ELL"):
         assert re.search(rf"### {name} NUMA GFLOPS = [0-9.]+", out) and re.search(rf"### {name} GPU-RESIDENT GFLOPS = [0-9.]+", out)
     m = re.search(r"### DIA NUMA VERIFY .* = ([0-9.e+-]+) OK", out)
@@ -64,10 +65,10 @@ def test_sharded_drivers_with_more_shards_than_rows(tmp_path, pkg):
     c = cases.tri8()
     p = tmp_path / "tri8.mtx"
     _write_mtx(p, c)
-    r = subprocess.run([str(BIN / "spmv_main"), str(p), "64", "--format", "coo,csr,ell,dia", "--verify", "--reps", "3"],
+    r = subprocess.run([str(BIN / "spmv_main"), str(p), "64", "--format", "coo,csr,csc,ell,dia", "--verify", "--reps", "3"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    for name in ("CSR NUMA", "ELL NUMA", "COO NUMA", "DIA NUMA"):
+    for name in ("CSR NUMA", "CSC NUMA", "ELL NUMA", "COO NUMA", "DIA NUMA"):
         m = re.search(rf"### {name} VERIFY .* = ([0-9.e+-]+) OK", r.stdout)
         assert m and float(m.group(1)) <= 1e-10, (name, r.stdout)
 
