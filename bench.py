@@ -407,7 +407,7 @@ def main() -> None:
                 kk = int(inf.ell_k) if fmt == "ell" else 0
                 b = algorithmic_bytes(fmt, int(inf.nrow), int(inf.ncol), nnz2, kk)
                 tkey = {"ell": f"ell_n{int(inf.nrow)}_k{kk}", "coo": f"coo_n{int(inf.nrow)}_nnz{nnz2}",
-                        "csr": f"csr_n{int(inf.nrow)}_k{k}_band65536_ncol{int(inf.ncol)}"}[fmt]
+                        "csr": f"csr_n{int(inf.nrow)}_k{k}_band{65536 if int(inf.ncol) == int(inf.nrow) else 0}_ncol{int(inf.ncol)}"}[fmt]
                 tfile2 = ROOT / "profiles" / "pmc_traffic.json"
                 traffic2 = json.loads(tfile2.read_text()).get(tkey, {}).get("hbm_bytes_per_launch") if tfile2.exists() else None
                 extra.append({
@@ -426,6 +426,14 @@ def main() -> None:
             if args.band == 0:
                 one(f"C2 shape, columns random in a band of 65536 (CSR N={n}, {k} per row)", "csr",
                     lambda: ctx.gen_csr_uniform(0, n, n, k, band=65536, seed=args.seed))
+
+                def c5_shard():
+                    M = ctx.gen_csr_uniform(7 * n, 8 * n, 8 * n, k, band=0, seed=args.seed)
+                    if int(M.info.kernel) in (4, 5):
+                        M.set_param("panel_keep_csr", 0)
+                    return M
+                one(f"C5 shard: what the last rank of 8 holds in BASELINE configs[4] (rows {7 * n}-{8 * n} of {8 * n} x {8 * n}, {k} per row; "
+                    "x = 640 MB resident)", "csr", c5_shard)
 
         times = torch.tensor([wall_s, kernel_ms, exch_s or 0.0], dtype=torch.float64, device=dev)
         if world > 1:
