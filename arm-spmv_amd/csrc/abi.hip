@@ -490,6 +490,12 @@ int spmv_dia_upload(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t ndiags, c
     SPMV_TRY(use_device(ctx));
     spmv_mat* m = nullptr;
     SPMV_TRY(mat_alloc(ctx, SPMV_FMT_DIA, nrow, ncol, 0, ndiags, (size_t)ndiags, 0, total, &m));
+    if (ndiags > 0)
+    {
+        m->dia_off_known = true;
+        m->dia_off_min   = *std::min_element(offsets, offsets + ndiags);
+        m->dia_off_max   = *std::max_element(offsets, offsets + ndiags);
+    }
     int rc = upload(const_cast<int32_t*>(m->a), offsets, sizeof(int32_t) * (size_t)ndiags, ctx);
     if (rc == SPMV_OK) rc = upload(const_cast<double*>(m->v), values, sizeof(double) * total, ctx);
     if (rc != SPMV_OK)

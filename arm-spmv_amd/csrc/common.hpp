@@ -135,6 +135,8 @@ struct spmv_mat
     int64_t        device_bytes = 0;
 
     // ---- analysis results (filled by analyse_*) ----
+    bool    dia_off_known = false;  // DIA: smallest / largest diagonal offset (set where the offsets pass through the host)
+    int32_t dia_off_min = 0, dia_off_max = 0;
     int32_t dia_col_bound = 0;  // DIA: columns >= this are skipped (0 = min(nrow, ncol)); row shards keep the global bound
     int32_t max_row_nnz   = 0;
     int32_t kernel        = SPMV_CSR_AUTO;

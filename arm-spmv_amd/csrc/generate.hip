@@ -241,6 +241,12 @@ int gen_dia_banded(spmv_ctx* ctx, int32_t nrow, int32_t k, uint64_t seed, spmv_m
         mat_free(m);
         SPMV_FAIL(SPMV_ERR_HIP, "gen_dia_banded: %s", hipGetErrorString(e));
     }
+    if (k > 0)
+    {
+        m->dia_off_known = true;  // offsets d - k / 2, d = 0 .. k-1
+        m->dia_off_min   = -(k / 2);
+        m->dia_off_max   = k - 1 - k / 2;
+    }
     *out = m;
     return SPMV_OK;
 }

@@ -138,12 +138,16 @@ constexpr int kDiaChunk = 16;
 
 // WIDE: 16-byte loads (two adjacent diagonals per lane, 8 lanes per 128-byte line); needs an even ndiags so that every
 // pair is 16-byte aligned.  8-byte accesses reach only ~0.65x of the streaming rate on this chip.
-template <bool WIDE>
+// XWIN: the offsets lie within a narrow band (off_min .. off_max): the stretch x[r0 + off_min .. r0 + 255 + off_max] the
+// 256 rows of the workgroup multiply with is copied into LDS once, and the ndiags reads of x per row come from there
+// instead of from global memory (64 vector loads per row otherwise: the vector memory pipe, not HBM, was the limit).
+template <bool WIDE, bool XWIN>
 __global__ __launch_bounds__(kBlock) void dia_kernel(int nrow, int jmax, int ndiags, const int32_t* __restrict__ offsets,
                                                      const double* __restrict__ val, const double* __restrict__ x,
-                                                     double* __restrict__ y)
+                                                     double* __restrict__ y, int off_min, int off_max)
 {
     __shared__ double tile[kBlock * (kDiaChunk + 1)];
+    extern __shared__ double xs[];  // XWIN: kBlock + off_max - off_min entries of x
     constexpr int PER   = WIDE ? 2 : 1;                  // diagonals per lane and load
     constexpr int LPR   = kDiaChunk / PER;               // lanes per row of the tile
     constexpr int RPP   = kBlock / LPR;                  // rows per pass of the workgroup
@@ -173,6 +177,16 @@ __global__ __launch_bounds__(kBlock) void dia_kernel(int nrow, int jmax, int ndi
         }
     };
     fetch(0);
+    if constexpr (XWIN)
+    {
+        const int w = kBlock + off_max - off_min;
+        for (int k = threadIdx.x; k < w; k += kBlock)
+        {
+            const int64_t j = (int64_t)r0 + off_min + k;
+            xs[k]           = (j >= 0 && j < jmax) ? x[j] : 0.0;
+        }
+        // (visible after the barriers of the first chunk below)
+    }
     for (int d0 = 0; d0 < ndiags; d0 += kDiaChunk)
     {
         const int dn = min(kDiaChunk, ndiags - d0);
@@ -186,8 +200,10 @@ __global__ __launch_bounds__(kBlock) void dia_kernel(int nrow, int jmax, int ndi
         if (i < nrow)
             for (int d = 0; d < dn; ++d)
             {
-                const int j = i + offsets[d0 + d];  // wave-uniform address: scalar load
-                if (j >= 0 && j < jmax) acc = fma(tile[threadIdx.x * (kDiaChunk + 1) + d], x[j], acc);
+                const int off = offsets[d0 + d];  // wave-uniform address: scalar load
+                const int j   = i + off;
+                if (j >= 0 && j < jmax)
+                    acc = fma(tile[threadIdx.x * (kDiaChunk + 1) + d], XWIN ? xs[(int)threadIdx.x + off - off_min] : x[j], acc);
             }
     }
     if (i < nrow) y[i] = acc;
@@ -328,10 +344,23 @@ int dia_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
     const dim3 grid((unsigned)ceil_div(A->nrow, kBlock));
     // a row shard (offsets shifted by its first row) keeps the bound of the whole matrix; never past the end of x
     const int jmax = std::min(A->dia_col_bound > 0 ? A->dia_col_bound : std::min(A->nrow, A->ncol), A->ncol);
-    if (A->k % 2 == 0 && (((uintptr_t)A->v) & 15) == 0)
-        hipLaunchKernelGGL(dia_kernel<true>, grid, dim3(kBlock), 0, ctx->stream, A->nrow, jmax, A->k, A->a, A->v, x, y);
+    const bool wide = A->k % 2 == 0 && (((uintptr_t)A->v) & 15) == 0;
+    // offsets within a band of at most 1792 (known from the upload / the generator): x goes through LDS
+    const bool   xwin = A->dia_off_known && A->dia_off_min <= A->dia_off_max && (int64_t)A->dia_off_max - A->dia_off_min <= 1792 &&
+                      !(A->flags & SPMV_FLAG_DIA_GLOBAL_X);
+    const size_t lds  = xwin ? sizeof(double) * (size_t)(kBlock + A->dia_off_max - A->dia_off_min) : 0;
+#define SPMV_DIA(W, X)                                                                                                         \
+    hipLaunchKernelGGL((dia_kernel<W, X>), grid, dim3(kBlock), lds, ctx->stream, A->nrow, jmax, A->k, A->a, A->v, x, y, \
+                       xwin ? A->dia_off_min : 0, xwin ? A->dia_off_max : 0)
+    if (wide && xwin)
+        SPMV_DIA(true, true);
+    else if (wide)
+        SPMV_DIA(true, false);
+    else if (xwin)
+        SPMV_DIA(false, true);
     else
-        hipLaunchKernelGGL(dia_kernel<false>, grid, dim3(kBlock), 0, ctx->stream, A->nrow, jmax, A->k, A->a, A->v, x, y);
+        SPMV_DIA(false, false);
+#undef SPMV_DIA
     SPMV_HIP(hipGetLastError());
     return SPMV_OK;
 }

@@ -167,7 +167,8 @@ def main():
         x, y = ctx.gen_vector(n, seed=1), ctx.vector(n)
         y.fill(0.0)
         # DIA streams 8 bytes per stored entry (no index array): values + x + y read/write
-        sweep(ctx, A, x, y, [("dia tiled", lambda A: None)], a.rounds, a.reps, 8 * n * k + 8 * n + 16 * n, n * k)
+        sweep(ctx, A, x, y, [("dia tiled, x through LDS", lambda A: A.set_flags(0)), ("dia tiled, x from global memory", lambda A: A.set_flags(4))],
+              a.rounds, a.reps, 8 * n * k + 8 * n + 16 * n, n * k)
         return
     if a.what == "bandwin":
         # non-wrapping band: rows [w, n-w) of the band matrix, so that every row block's window fits LDS
