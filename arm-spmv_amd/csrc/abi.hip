@@ -723,7 +723,7 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         *value = !strcmp(name, "panel_pace_scale") ? h[0] : h[3];
     }
     else if (!strcmp(name, "panel_layout"))  // layout in memory: 0 three arrays, 1 records, 3 packed 12-byte entries
-        *value = m->pb_pack ? 3 : 0;
+        *value = m->pb_pack ? (m->pb_pair ? 4 : 3) : 0;
     else if (!strcmp(name, "twophase_panel_cols"))
         *value = m->tp_pcols;
     else if (!strcmp(name, "twophase_padded"))

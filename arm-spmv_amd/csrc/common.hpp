@@ -162,11 +162,13 @@ struct spmv_mat
     int32_t   pb_panel_width = 0;        // W (0 = default)
     int32_t   pb_sort        = 1;        // bucket tile entries by 128-byte line of x
     int32_t   pb_unroll      = 0;        // entries in flight per lane (0 = default)
-    int32_t   pb_aos         = 3;        // layout: 3 = 12-byte packed entries (falls back to 0), 0 = three arrays (14 bytes)
+    int32_t   pb_aos         = 4;        // layout: 4 = 12-byte packed entries, slices in interleaved pairs (falls back to 0), 3 = the same
+                                         // without the pairing, 0 = three arrays (14 bytes)
     uint32_t* pb_pack        = nullptr;  // [nnz] layout 3: (column - slice base) << rowbits | local row
     int32_t*  pb_sbase       = nullptr;  // [slices] layout 3: line-aligned first column of every 1024-entry slice
     int32_t*  pb_soff        = nullptr;  // [ngroups + 1] layout 3: first slice of every group
     int32_t   pb_rowbits     = 0;
+    bool      pb_pair        = false;    // layout 4: slices stored in interleaved pairs
     int32_t   pb_slices      = 0;        // layout 3: 1024-entry slices in all (padded entries / 1024)
     int32_t   pb_built_layout = -1;      // pb_aos the layout in memory was built for
     int32_t   pb_pace_ns     = 0;        // pacing throttle in effect: nanoseconds per chunk on the chip clock (0 = off)

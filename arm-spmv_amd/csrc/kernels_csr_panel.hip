@@ -174,12 +174,15 @@ __global__ __launch_bounds__(256) void panel_line_sort_kernel(const int32_t* __r
 // the streamed loads and the LDS adds (one workgroup per CU = 16 wavefronts is all the thread-level
 // parallelism the LDS footprint allows, so the memory-level parallelism has to come from here).
 // LAYOUT 0: three arrays (value fp64, column int32, local row uint16): 14 bytes per entry, three load instructions.
+// LAYOUT 4: LAYOUT 3 with the slices stored in interleaved pairs, read with 8- and 16-byte loads (see load_raw).
 // LAYOUT 3: two arrays (value fp64, one packed 32-bit word): 12 bytes per entry, two load instructions.  The word
 //           holds the local row in its low `rowbits` bits and, above them, the column relative to the base of the
 //           entry's slice (1024 packed entries; the entries are ordered by x line, so a slice spans few
 //           columns; see panel_cut_kernel).  The bases are one int32 per slice, read through the scalar cache.
 // (Tried and dropped, logs in profiles/r01_*: 16-byte {value, column, row} records — one load instruction per entry,
 // 3.2-3.6 ms on C2 — and system-scope loads for the stream.)
+using u32x2p = unsigned __attribute__((ext_vector_type(2)));
+
 template <int UNROLL, int LAYOUT>
 struct PanelBatch
 {
@@ -191,7 +194,7 @@ struct PanelBatch
     // sb: bases of the UNROLL slices this batch reads, uniform over the workgroup
     __device__ __forceinline__ void unpack(const int32_t* __restrict__ sb, int rowbits)
     {
-        if constexpr (LAYOUT == 3)
+        if constexpr (LAYOUT >= 3)
         {
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u)
@@ -209,15 +212,47 @@ struct PanelBatch
         load_raw(pcol, prow, pval, e);
         unpack(sb, rowbits);
     }
+    // e: index of this lane's entry in the first slice of the batch (slice * 1024 + lane)
     __device__ __forceinline__ void load_raw(const int32_t* __restrict__ pcol, const uint16_t* __restrict__ prow,
                                              const double* __restrict__ pval, int e)
     {
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
+        if constexpr (LAYOUT == 4 && UNROLL >= 2)
         {
-            c[u] = load_stream(pcol + e + u * kPanelThreads);  // LAYOUT 3: the packed word, see unpack()
-            if constexpr (LAYOUT != 3) r[u] = load_stream(prow + e + u * kPanelThreads);
-            v[u] = load_stream(pval + e + u * kPanelThreads);
+            // slices 2k and 2k+1 are stored interleaved (entry t of slice 2k at 2t, of slice 2k+1 at 2t + 1 of their
+            // 2048-entry block): one 8-byte and one 16-byte load bring this lane's entries of both — half the vector
+            // memory instructions for the stream (a wavefront instruction costs the same ~32 clocks of the CU's
+            // address pipe whether it moves 4 or 16 bytes per lane)
+            const int     t  = e & (kPanelThreads - 1);
+            const size_t  p0 = (size_t)(e >> 11) * kPanelThreads + t;  // pair index: (slice / 2) * 1024 + lane; the batch starts at an even slice
+            const u32x2p* w2 = reinterpret_cast<const u32x2p*>(pcol) + p0;
+            const f64x2*  v2 = reinterpret_cast<const f64x2*>(pval) + p0;
+#pragma unroll
+            for (int u = 0; u < UNROLL / 2; ++u)
+            {
+                const u32x2p w = load_stream(w2 + (size_t)u * kPanelThreads);
+                const f64x2  d = load_stream(v2 + (size_t)u * kPanelThreads);
+                c[2 * u]       = (int)w.x;
+                c[2 * u + 1]   = (int)w.y;
+                v[2 * u]       = d.x;
+                v[2 * u + 1]   = d.y;
+            }
+        }
+        else if constexpr (LAYOUT == 4)
+        {
+            const int    t  = e & (kPanelThreads - 1), sl = e >> 10;
+            const size_t at = ((size_t)(sl >> 1) << 11) + 2 * (size_t)t + (size_t)(sl & 1);
+            c[0]            = load_stream(pcol + at);
+            v[0]            = load_stream(pval + at);
+        }
+        else
+        {
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+            {
+                c[u] = load_stream(pcol + e + u * kPanelThreads);  // LAYOUT 3: the packed word, see unpack()
+                if constexpr (LAYOUT < 3) r[u] = load_stream(prow + e + u * kPanelThreads);
+                v[u] = load_stream(pval + e + u * kPanelThreads);
+            }
         }
     }
     __device__ __forceinline__ void apply(const double* __restrict__ x, double* acc) const
@@ -308,7 +343,7 @@ __global__ __launch_bounds__(256) void panel_expand_kernel(int total, const int3
                                                            const int32_t* __restrict__ ssrc,
                                                            const int32_t* __restrict__ scount, const int32_t* __restrict__ col,
                                                            const uint16_t* __restrict__ row, const double* __restrict__ val,
-                                                           int rowbits, unsigned pad_row,
+                                                           int rowbits, unsigned pad_row, int pair,
                                                            uint32_t* __restrict__ packed, double* __restrict__ pval)
 {
     const unsigned pad = pad_row;
@@ -317,7 +352,8 @@ __global__ __launch_bounds__(256) void panel_expand_kernel(int total, const int3
         const int base = sbase[sl], src = ssrc[sl], cnt = scount[sl];
         for (int j = threadIdx.x; j < kPanelThreads; j += 256)
         {
-            const size_t dst = (size_t)sl * kPanelThreads + j;
+            // pair: slices 2k, 2k+1 interleaved entry by entry (LAYOUT 4)
+            const size_t dst = pair ? ((size_t)(sl >> 1) << 11) + 2 * (size_t)j + (size_t)(sl & 1) : (size_t)sl * kPanelThreads + j;
             if (j < cnt)
             {
                 packed[dst] = ((unsigned)(col[src + j] - base) << rowbits) | (unsigned)row[src + j];
@@ -411,11 +447,11 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
         if (SYNCT == 2 && threadIdx.x == 0) gl.issued[0] = gl.issued[1] = 0u;
         __syncthreads();
         // LAYOUT 3 keeps its own (padded) entry numbering: whole slices of 1024
-        const int begin = LAYOUT == 3 ? soff[g] * kPanelThreads : row_ptr[r0];
-        const int end   = LAYOUT == 3 ? soff[g + 1] * kPanelThreads : row_ptr[r0 + rows];
+        const int begin = LAYOUT >= 3 ? soff[g] * kPanelThreads : row_ptr[r0];
+        const int end   = LAYOUT >= 3 ? soff[g + 1] * kPanelThreads : row_ptr[r0 + rows];
         const int nfull = (end - begin) / STEP;  // chunks in which every lane has UNROLL valid entries
         int       e     = begin + threadIdx.x;
-        const int32_t* __restrict__ sb = LAYOUT == 3 ? sbase + soff[g] : pcol;  // slice bases of this group (else unused)
+        const int32_t* __restrict__ sb = LAYOUT >= 3 ? sbase + soff[g] : pcol;  // slice bases of this group (else unused)
         // optional clock throttle: chunk b does not start before t0 + b * pace on the chip-wide 100 MHz clock
         const unsigned long long t0 = pace_fp ? __builtin_amdgcn_s_memrealtime() : 0ull;
         PanelBatch<UNROLL, LAYOUT> cur, nxt;
@@ -558,6 +594,7 @@ void csr_panel_free(spmv_mat* m)
     m->pb_ctl    = nullptr;
     m->pb_gstart = nullptr;
     m->pb_pack   = nullptr;
+    m->pb_pair   = false;
     m->pb_sbase  = nullptr;
     m->pb_soff   = nullptr;
     m->pb_col = nullptr;
@@ -584,7 +621,7 @@ static int pick_group_rows(int nrow, int cap)
 // Re-store the (line-ordered) three-array layout as 12-byte packed entries.  Not an error when it does not work
 // out (no memory, or so many column gaps that the padding would outweigh the two bytes saved): the three arrays
 // stay and the product runs from them.
-static void panel_pack(spmv_mat* m, int ngroups, int max_rows)
+static void panel_pack(spmv_mat* m, int ngroups, int max_rows, bool pair)
 {
     spmv_ctx*   ctx     = m->ctx;
     hipStream_t s       = ctx->stream;
@@ -608,13 +645,14 @@ static void panel_pack(spmv_mat* m, int ngroups, int max_rows)
         int64_t total = 0;
         for (int g = 1; g <= ngroups; ++g)
         {
-            total += soff[(size_t)g];
+            // pair: an even number of slices per group (the odd one out gets an empty partner: count 0, base 0)
+            total += pair ? (soff[(size_t)g] + 1) / 2 * 2 : soff[(size_t)g];
             if (total > INT32_MAX / kPanelThreads) break;
             soff[(size_t)g] = (int32_t)total;
         }
         // padded entries: whole slices.  Worth it while 12 B x padded < 14 B x stored (with a margin)
         const int64_t padded = total * kPanelThreads;
-        if (total > INT32_MAX / kPanelThreads || padded * 12 > m->nnz * 13 + (int64_t)ngroups * kPanelThreads * 12) break;
+        if (total > INT32_MAX / kPanelThreads || padded * 12 > m->nnz * 13 + (int64_t)ngroups * kPanelThreads * 12 * (pair ? 2 : 1)) break;
         if (hipMalloc(&ssrc, sizeof(int32_t) * (size_t)total) != hipSuccess ||
             hipMalloc(&scount, sizeof(int32_t) * (size_t)total) != hipSuccess ||
             hipMalloc(&sbase, sizeof(int32_t) * (size_t)total) != hipSuccess ||
@@ -622,10 +660,14 @@ static void panel_pack(spmv_mat* m, int ngroups, int max_rows)
             hipMalloc(&pack, sizeof(uint32_t) * (size_t)padded) != hipSuccess || hipMalloc(&pval, sizeof(double) * (size_t)padded) != hipSuccess)
             break;
         if (hipMemcpyAsync(d_soff, soff.data(), sizeof(int32_t) * soff.size(), hipMemcpyHostToDevice, s) != hipSuccess) break;
+        if (hipMemsetAsync(sbase, 0, sizeof(int32_t) * (size_t)total, s) != hipSuccess || hipMemsetAsync(ssrc, 0, sizeof(int32_t) * (size_t)total, s) != hipSuccess ||
+            hipMemsetAsync(scount, 0, sizeof(int32_t) * (size_t)total, s) != hipSuccess)
+            break;
         hipLaunchKernelGGL(panel_cut_kernel, dim3(gb), dim3(64), 0, s, m->pb_gstart, ngroups, m->a, m->pb_col, colbits,
                            (const int32_t*)d_soff, (int32_t*)nullptr, sbase, ssrc, scount);
         hipLaunchKernelGGL(panel_expand_kernel, dim3((unsigned)std::min<int64_t>(total, kMaxGrid * 4)), dim3(256), 0, s,
-                           (int)total, sbase, ssrc, scount, m->pb_col, m->pb_row, m->pb_val, rowbits, (unsigned)max_rows, pack, pval);
+                           (int)total, sbase, ssrc, scount, m->pb_col, m->pb_row, m->pb_val, rowbits, (unsigned)max_rows, pair ? 1 : 0, pack,
+                           pval);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) break;  // soff (host) is done with
         ok = true;
         // the packed words and padded values replace the three arrays
@@ -639,6 +681,7 @@ static void panel_pack(spmv_mat* m, int ngroups, int max_rows)
         m->pb_sbase   = sbase;
         m->pb_soff    = d_soff;
         m->pb_rowbits = rowbits;
+        m->pb_pair    = pair;
         m->pb_slices  = (int32_t)total;
         m->pb_bytes   = padded * 12 + (int64_t)sizeof(int32_t) * (total + ngroups + 1);
     } while (0);
@@ -665,7 +708,7 @@ int csr_panel_build(spmv_mat* m)
     W     = std::max(kLineDoubles, (W / kLineDoubles) * kLineDoubles);
     while (ceil_div(m->ncol, W) > 8192) W *= 2;  // the per-group histogram lives in LDS
     const bool sort = m->pb_sort != 0;
-    const bool pack = m->pb_aos == 3 && sort;  // 12-byte entries (needs the line order); kept only if every slice fits
+    const bool pack = (m->pb_aos == 3 || m->pb_aos == 4) && sort;  // 12-byte entries (needs the line order); kept only if every slice fits
     if (m->pb_val && m->pb_built_rows == G && m->pb_built_width == W && m->pb_built_sort == (int)sort && m->pb_built_layout == m->pb_aos)
         return panel_choose_pace(m);  // the layout in memory was built with these parameters
     if (!m->b || !m->v) SPMV_FAIL(SPMV_ERR_INVALID, "the panel layout cannot be re-built: this handle gave up its CSR arrays (panel_keep_csr = 0)");
@@ -791,7 +834,7 @@ int csr_panel_build(spmv_mat* m)
     }
     m->pb_bytes       = (int64_t)(nnz * 14);
     m->pb_built_layout = m->pb_aos;
-    if (pack) panel_pack(m, ngroups, max_rows);  // keeps the three arrays when packing does not pay
+    if (pack) panel_pack(m, ngroups, max_rows, m->pb_aos == 4);  // keeps the three arrays when packing does not pay
     m->device_bytes += m->pb_bytes;
     return panel_choose_pace(m);
 }
@@ -947,17 +990,17 @@ static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, doubl
     const unsigned long long pace_fp = A->pb_pace_ns > 0 ? (unsigned long long)((double)A->pb_pace_ns * 102.4) : 0ull;
     const int  sync   = (A->pb_sync >= 0 ? A->pb_sync : A->pb_sync_tuned) & 3;
     const int  flags  = ((A->pb_stagger & 3) == 2 ? 1 : 0) | (sync << 1);
-    const int  layout = A->pb_pack ? 3 : 0;
+    const int  layout = A->pb_pack ? (A->pb_pair ? 4 : 3) : 0;
     // the kernel dereferences exactly these arrays: refuse on the host rather than fault on the GPU
-    const bool have = layout == 3 ? (A->pb_pack && A->pb_sbase && A->pb_soff && A->pb_val && A->pb_rowbits > 0 && A->pb_rowbits < 32)
+    const bool have = layout >= 3 ? (A->pb_pack && A->pb_sbase && A->pb_soff && A->pb_val && A->pb_rowbits > 0 && A->pb_rowbits < 32)
                                   : (A->pb_col && A->pb_row && A->pb_val);
     if (!A->pb_gstart || !x || !y || !have)
         SPMV_FAIL(SPMV_ERR_INVALID, "panel kernel: layout %d is selected but its arrays are not there", layout);
     unsigned*      ctl     = (trial || !A->pb_guard) ? nullptr : A->pb_ctl;  // the trials must not train the guard
-    const int32_t* arg_col = layout == 3 ? (const int32_t*)A->pb_pack : A->pb_col;
+    const int32_t* arg_col = layout >= 3 ? (const int32_t*)A->pb_pack : A->pb_col;
     const int      pipe_rq = A->pb_pipe >= 0 ? A->pb_pipe : (A->pb_pipe_tuned > 0 ? A->pb_pipe_tuned : 1);
     // gather-first is instantiated for the chunk sizes that are tried; the others take the stream-first order
-    const int pipe = pipe_rq == 2 && !(unroll == 4 || unroll == 8 || (unroll == 16 && layout == 3)) ? 1 : std::min(pipe_rq, 2);
+    const int pipe = pipe_rq == 2 && !(unroll == 4 || unroll == 8 || (unroll == 16 && layout >= 3)) ? 1 : std::min(pipe_rq, 2);
 #define SPMV_PANEL_LAUNCH(U, LY, PP, TR, TC, SY)                                                                      \
     {                                                                                                                \
         static std::atomic<unsigned long long> granted{0}; /* bit per device */                                      \
@@ -987,6 +1030,17 @@ static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, doubl
         SPMV_PANEL_CT(0) SPMV_PANEL_CT(1) SPMV_PANEL_CT(2) SPMV_PANEL_CT(3)
 #undef SPMV_PANEL_CT
     }
+    if (layout == 4 && unroll == 8 && pipe == 2)
+    {
+#define SPMV_PANEL_CT(SY)                                          \
+    if (sync == SY)                                                \
+    {                                                              \
+        if (trial) SPMV_PANEL_LAUNCH(8, 4, 2, true, false, SY)     \
+        SPMV_PANEL_LAUNCH(8, 4, 2, false, false, SY)               \
+    }
+        SPMV_PANEL_CT(0) SPMV_PANEL_CT(1) SPMV_PANEL_CT(3)
+#undef SPMV_PANEL_CT
+    }
 #define SPMV_PANEL_CASE(U, LY, PP)                                   \
     if (unroll == U && layout == LY && pipe == PP)                   \
     {                                                                \
@@ -999,6 +1053,9 @@ static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, doubl
     SPMV_PANEL_CASE(2, 3, 1) SPMV_PANEL_CASE(4, 3, 1) SPMV_PANEL_CASE(8, 3, 1) SPMV_PANEL_CASE(16, 3, 1)
     SPMV_PANEL_CASE(4, 0, 2) SPMV_PANEL_CASE(8, 0, 2)
     SPMV_PANEL_CASE(4, 3, 2) SPMV_PANEL_CASE(8, 3, 2) SPMV_PANEL_CASE(16, 3, 2)
+    SPMV_PANEL_CASE(2, 4, 0) SPMV_PANEL_CASE(4, 4, 0) SPMV_PANEL_CASE(8, 4, 0) SPMV_PANEL_CASE(16, 4, 0)
+    SPMV_PANEL_CASE(2, 4, 1) SPMV_PANEL_CASE(4, 4, 1) SPMV_PANEL_CASE(8, 4, 1) SPMV_PANEL_CASE(16, 4, 1)
+    SPMV_PANEL_CASE(4, 4, 2) SPMV_PANEL_CASE(8, 4, 2) SPMV_PANEL_CASE(16, 4, 2)
 #undef SPMV_PANEL_CASE
 #undef SPMV_PANEL_LAUNCH
     SPMV_FAIL(SPMV_ERR_INVALID, "panel kernel: unroll=%d is not instantiated (2, 4, 8, 16)", unroll);

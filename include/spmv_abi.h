@@ -194,8 +194,9 @@ int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
  *   "panel_rows"     rows per group (0 = choose, entry-balanced; at most 20000)
  *   "panel_width"    columns per panel (0 = 131072)
  *   "panel_sort"     1 = bucket the entries of a panel by 128-byte line of x (default), 0 = leave unordered
- *   "panel_aos"      entry layout: 3 = 12-byte packed entries (default; falls back to 0 where padding would outweigh it),
- *                    0 = three arrays (14 bytes), 1 = 16-byte records, 2 = three arrays read with system-scope loads
+ *   "panel_aos"      entry layout: 4 = 12-byte packed entries, slices of 1024 stored in interleaved pairs and read with 8- and
+ *                    16-byte loads (default; falls back to 0 where padding would outweigh it), 3 = the same without the
+ *                    pairing (4-/8-byte loads), 0 = three arrays (14 bytes)
  *   "panel_unroll"   chunk = unroll x 1024 entries: 2, 4, 8 or 16 (0 = by trial)
  *   "panel_pipe"     order of a chunk's memory instructions: 0 = no pipelining, 1 = next chunk's stream first,
  *                    2 = this chunk's gathers first (-1 = by trial)

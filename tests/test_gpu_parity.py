@@ -285,7 +285,7 @@ def test_csr_handle_can_give_up_its_arrays_once_the_panel_layout_is_built(ctx, p
     capi = pkg.capi
     n, k = 1_000_000, 16
     A = ctx.gen_csr_uniform(0, n, n, k, seed=31)
-    assert A.info.kernel == capi.CSR_PANEL and A.get_param("panel_layout") == 3
+    assert A.info.kernel == capi.CSR_PANEL and A.get_param("panel_layout") == 4
     x, y0, y1 = ctx.gen_vector(n, seed=31), ctx.vector(n), ctx.vector(n)
     y0.fill(0.0)
     y1.fill(0.0)
@@ -596,7 +596,10 @@ def test_csr_panel_kernel_matches_reference_golden(ctx, orc, pkg, make):
             (0, 0, 1, 3, 8, 0, 1, 0), (37, 16, 1, 3, 4, 0, 0, 0), (5, 48, 1, 3, 16, 0, 1, -1), (1000, 1024, 0, 3, 8, 0, 1, 0),
             (0, 0, 1, 3, 8, 0, 2, 0), (64, 64, 1, 3, 4, 1, 2, -1), (3, 16, 1, 3, 2, 3, 2, 0), (0, 0, 1, 3, 0, -1, -1, -1), (500, 512, 1, 0, 8, 0, 2, 0),
             # the C2 instance (packed, U = 8, gather-first) with every compile-time sync, and through the run-time switch
-            (0, 0, 1, 3, 8, 1, 2, 0), (0, 0, 1, 3, 8, 2, 2, 0), (0, 0, 1, 3, 8, 3, 2, 0), (7, 32, 1, 3, 8, 3, 2, 400)):
+            (0, 0, 1, 3, 8, 1, 2, 0), (0, 0, 1, 3, 8, 2, 2, 0), (0, 0, 1, 3, 8, 3, 2, 0), (7, 32, 1, 3, 8, 3, 2, 400),
+            # layout 4: the packed slices stored in interleaved pairs (8- and 16-byte loads)
+            (0, 0, 1, 4, 8, 3, 2, 0), (0, 0, 1, 4, 8, 1, 2, 0), (37, 16, 1, 4, 4, 0, 0, 0), (5, 48, 1, 4, 16, 0, 1, -1), (3, 16, 1, 4, 2, 0, 1, 0),
+            (64, 64, 1, 4, 4, 1, 2, -1), (0, 0, 1, 4, 8, 0, 0, 0), (1000, 1024, 1, 4, 8, 0, 1, 0), (0, 0, 1, 4, 0, -1, -1, -1)):
         A = ctx.csr(c["nrow"], c["ncol"], rp, cc, cv)
         A.set_param("panel_rows", rows)
         A.set_param("panel_width", width)
@@ -625,13 +628,13 @@ def test_csr_panel_packed_layout_large(ctx, orc, pkg):
         yp.fill(0.0)
         A.set_kernel(capi.CSR_VECTOR)
         ctx.apply(A, x, yv)
-        for unroll, pipe in ((8, 1), (4, 0), (16, 1)):
-            A.set_param("panel_aos", 3)
+        for unroll, pipe, layout in ((8, 1, 3), (4, 0, 3), (16, 1, 3), (8, 2, 4), (4, 1, 4), (2, 0, 4)):
+            A.set_param("panel_aos", layout)
             A.set_param("panel_unroll", unroll)
             A.set_param("panel_pipe", pipe)
             A.set_kernel(capi.CSR_PANEL)
             # (the wrap-around band has two column clusters in its first and last groups: cut into separate slices)
-            assert A.get_param("panel_layout") == expect, (n, k, band)
+            assert A.get_param("panel_layout") == (layout if expect else 0), (n, k, band)
             yp.fill(0.0)
             ctx.apply(A, x, yp)
             ctx.sync()
@@ -792,7 +795,8 @@ def test_panel_kernel_on_nasty_shapes(ctx, orc, pkg):
         ol.csr_abs_row_sums(orc, rp, cc, cv, x, scale)
         ref2 = ref.copy()
         ol.csr_spmv(orc, rp, cc, cv, x, ref2)
-        for layout, unroll, pipe, rows in ((3, 0, -1, 0), (3, 8, 2, 0), (3, 4, 1, 7), (3, 2, 0, 20000), (0, 8, 1, 0), (0, 8, 2, 333), (0, 4, 0, 0)):
+        for layout, unroll, pipe, rows in ((3, 0, -1, 0), (3, 8, 2, 0), (3, 4, 1, 7), (3, 2, 0, 20000), (0, 8, 1, 0), (0, 8, 2, 333), (0, 4, 0, 0),
+                                           (4, 8, 2, 0), (4, 4, 1, 7), (4, 2, 0, 20000), (4, 0, -1, 0)):
             A = ctx.csr(nrow, ncol, rp, cc, cv)
             for k, v in (("panel_aos", layout), ("panel_unroll", unroll), ("panel_pipe", pipe), ("panel_rows", rows)):
                 A.set_param(k, v)
@@ -831,17 +835,18 @@ def test_packed_layout_pads_do_not_leak_non_finite_x(ctx, orc, pkg):
     xs[::16] = 0.0
     ol.csr_abs_row_sums(orc, rp, cc, cv, xs, scale)
     A = ctx.csr(nrow, ncol, rp, cc, cv)
-    A.set_param("panel_aos", 3)
-    A.set_kernel(capi.CSR_PANEL)
-    assert A.get_param("panel_layout") == 3
-    assert A.get_param("panel_bytes") > 12 * nnz  # there are pads
-    y = ctx.vector(nrow)
-    y.fill(0.0)
-    ctx.apply(A, ctx.vector_from(x), y)
-    ctx.sync()
-    got = y.download()
-    assert np.all(np.isfinite(got))
-    ol.assert_parity(got, ref, scale, "packed layout, inf at every slice base")
+    for layout in (3, 4):  # 4: an odd slice count gets an empty partner slice (base 0: x[0] is inf too)
+        A.set_param("panel_aos", layout)
+        A.set_kernel(capi.CSR_PANEL)
+        assert A.get_param("panel_layout") == layout
+        assert A.get_param("panel_bytes") > 12 * nnz  # there are pads
+        y = ctx.vector(nrow)
+        y.fill(0.0)
+        ctx.apply(A, ctx.vector_from(x), y)
+        ctx.sync()
+        got = y.download()
+        assert np.all(np.isfinite(got))
+        ol.assert_parity(got, ref, scale, f"packed layout {layout}, inf at every slice base")
 
 
 def test_panel_pace_guard_stretches_a_pace_the_chip_cannot_hold(ctx, pkg):
@@ -969,7 +974,7 @@ def test_handles_give_their_device_memory_back(ctx, pkg):
     assert 0 < free0 <= total
     for _ in range(3):
         A = ctx.gen_csr_uniform(0, 1_500_000, 1_500_000, 16, seed=4)  # panel layout + trials
-        for layout in (0, 3):
+        for layout in (0, 3, 4):
             A.set_param("panel_aos", layout)
             A.set_kernel(capi.CSR_PANEL)
         E = ctx.csr_to_ell(A)  # scattered columns: regrouped copy

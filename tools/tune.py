@@ -211,9 +211,9 @@ def main():
             variants = []
             combos = [tuple(int(t) for t in item.split(",")) for item in a.panel.split(";")]
         else:
-            combos = [(8, 0, 2, 3, 3), (8, 0, 2, 3, 1), (4, 0, 2, 3, 1), (4, 0, 1, 3, 0), (8, 0, 1, 3, 0), (0, -1, -1, 3, -1)]
+            combos = [(8, 0, 2, 4, 3), (8, 0, 2, 4, 1), (8, 0, 2, 3, 1), (4, 0, 2, 4, 1), (4, 0, 1, 4, 0), (8, 0, 1, 4, 0), (0, -1, -1, 4, -1)]
         for combo in combos:  # --panel fields: unroll,pace_ns,pipe,layout,sync[,rows[,legacy]]  (0 / -1 = by trial)
-            combo = combo + (0, -1, -1, 3, -1, 0, 0)[len(combo):]
+            combo = combo + (0, -1, -1, 4, -1, 0, 0)[len(combo):]
             unroll, pace, pipe, aos, sync, rows, legacy = combo[:7]
 
             def setup(A, unroll=unroll, pace=pace, pipe=pipe, aos=aos, sync=sync, rows=rows, legacy=legacy):
@@ -236,7 +236,7 @@ def main():
             for lanes in (4, 8, 16):
                 variants.append((f"ldswin L={lanes}", lambda A, lanes=lanes: A.set_kernel(capi.CSR_LDSWIN, lanes)))
         sweep(ctx, A, x, y, variants, a.rounds, a.reps, algorithmic_bytes("csr", n, ncol, n * k), n * k)
-        for name, v in (("panel_aos", 3), ("panel_rows", 0), ("panel_unroll", 0), ("panel_pace_ns", -1), ("panel_pipe", -1), ("panel_stagger", 2),
+        for name, v in (("panel_aos", 4), ("panel_rows", 0), ("panel_unroll", 0), ("panel_pace_ns", -1), ("panel_pipe", -1), ("panel_stagger", 2),
                         ("panel_sync", -1), ("panel_legacy", 0)):
             A.set_param(name, v)
         A.set_kernel(capi.CSR_PANEL)
