@@ -26,17 +26,35 @@ def short(n):
 def is_trial(n):  # csr_panel_kernel<U, LAYOUT, PIPE, TRIAL, TRACE, SYNCT>
     m = re.search(r"csr_panel_kernel<([^>]*)>", n)
     return bool(m) and m.group(1).split(",")[3].strip() == "true"
+rows = sorted(trace, key=lambda r: int(r["Start_Timestamp"]))
+# runs of consecutive dispatches of one kernel: bench.py launches every workload's product 5 + 50 times back to back
+runs, cur = [], []
+for r in rows:
+    if cur and r["Kernel_Name"] != cur[0]["Kernel_Name"]:
+        runs.append(cur)
+        cur = []
+    cur.append(r)
+if cur:
+    runs.append(cur)
 with open(O + "/timed_region.txt", "w") as out:
-    for key, last in (("csr_panel_kernel", 50), ("ell_kernel", 50), ("tp_expand_kernel", 0), ("tp_reduce_kernel", 0)):
-        names = sorted({r["Kernel_Name"] for r in trace if key in r["Kernel_Name"] and not is_trial(r["Kernel_Name"])})
-        for name in names:
+    for run in runs:
+        name = run[0]["Kernel_Name"]
+        if len(run) < 50 or is_trial(name) or not any(k in name for k in ("csr_panel_kernel", "ell_kernel", "tp_expand_kernel", "tp_reduce_kernel")):
+            continue
+        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in run]
+        tail = d[-50:]
+        st = [r for r in stats if r["Name"] == name]
+        out.write(f"{short(name)}: run of {len(d)} consecutive dispatches; mean {statistics.mean(d):.4f} ms, median {statistics.median(d):.4f}, "
+                  f"min {min(d):.4f}, max {max(d):.4f}; the last 50: mean {statistics.mean(tail):.4f} ms.  (kernel_stats.csv row of this name, all its "
+                  f"dispatches in the process: Calls {st[0]['Calls'] if st else '?'}, AverageNs {float(st[0]['AverageNs']) if st else 0:.0f})\n")
+with open(O + "/timed_region.txt", "a") as out:
+    for key in ("tp_expand_kernel", "tp_reduce_kernel"):  # the two phases alternate: no runs, all dispatches of the name
+        for name in sorted({r["Kernel_Name"] for r in trace if key in r["Kernel_Name"]}):
             d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in trace if r["Kernel_Name"] == name]
-            st = [r for r in stats if r["Name"] == name]
-            tail = d[-last:] if last and len(d) >= last else d
-            out.write(f"{short(name)}: {len(d)} dispatches in the kernel trace; mean {statistics.mean(d):.4f} ms, median {statistics.median(d):.4f}, "
-                      f"min {min(d):.4f}, max {max(d):.4f}; the last {len(tail)}: mean {statistics.mean(tail):.4f} ms.  kernel_stats.csv row: "
-                      f"Calls {st[0]['Calls'] if st else '?'}, AverageNs {float(st[0]['AverageNs']) if st else 0:.0f}\n")
+            out.write(f"{short(name)}: {len(d)} dispatches (alternating with the other phase); mean {statistics.mean(d):.4f} ms, median "
+                      f"{statistics.median(d):.4f}, min {min(d):.4f}, max {max(d):.4f}\n")
 print(open(O + "/timed_region.txt").read())
 PY
-for d in pmc_fetch pmc_write pmc_tcc pmc_req; do echo "== $d"; python3 tools/pmc_summary.py "$O/$d" csr_panel | tail -4; python3 tools/pmc_summary.py "$O/$d" ell_kernel | tail -2; done > "$O/pmc_summary.txt" 2>&1
+# product launches only (the trial launches carry `true` as their fourth template argument); per workload: 1 warm-up + 5
+for d in pmc_fetch pmc_write pmc_tcc pmc_req; do echo "== $d"; python3 tools/pmc_summary.py "$O/$d" csr_panel --runs | grep -v ", true," ; python3 tools/pmc_summary.py "$O/$d" ell_kernel --runs; python3 tools/pmc_summary.py "$O/$d" tp_ | tail -4; done > "$O/pmc_summary.txt" 2>&1
 cat "$O/pmc_summary.txt"
