@@ -141,7 +141,7 @@ template <int THREADS, int UNROLL>
 __global__ __launch_bounds__(THREADS) void tp_expand_kernel(int P, int pcols, int ncol, const int32_t* __restrict__ panel_ptr,
                                                             const unsigned short* __restrict__ tp_col, const double* __restrict__ tp_val,
                                                             const int32_t* __restrict__ tp_blk, const double* __restrict__ x,
-                                                            double* __restrict__ xg)
+                                                            double* __restrict__ xg, int rotate)
 {
     extern __shared__ double xs[];  // pcols entries of x
     const u16x2* __restrict__ c2 = reinterpret_cast<const u16x2*>(tp_col);
@@ -153,34 +153,41 @@ __global__ __launch_bounds__(THREADS) void tp_expand_kernel(int P, int pcols, in
         const int c0 = p * pcols;
         const int n  = min(pcols, ncol - c0);
         const int t_begin = panel_ptr[p] / 2, t_end = panel_ptr[p + 1] / 2;  // pairs: runs are padded to 16 entries
+        const int len = t_end - t_begin;
+        // rotate: workgroup b starts b / 256 of the way through its panel and wraps around, so that at any moment the
+        // workgroups write into different row groups' stretches of xg instead of all into the same one (4-5 % on
+        // average over allocations: profiles/r02_probe_twophase_placement.txt)
+        const int rot = rotate ? (int)(((int64_t)len * (int)(blockIdx.x % 256u) / 256) & ~7) : 0;
+        auto      phys = [&](int u) { return t_begin + (u + rot >= len ? u + rot - len : u + rot); };
         u16x2 c[2][UNROLL];
         f64x2 v[2][UNROLL];
         int   d[2][UNROLL];
-        auto  fetch = [&](int t0, u16x2(&cc)[UNROLL], f64x2(&vv)[UNROLL], int(&dd)[UNROLL]) {
+        auto  fetch = [&](int u0, u16x2(&cc)[UNROLL], f64x2(&vv)[UNROLL], int(&dd)[UNROLL]) {
 #pragma unroll
             for (int k = 0; k < UNROLL; ++k)
             {
-                const int t = min(t0 + k * THREADS + (int)threadIdx.x, t_end - 1);  // past the end: re-read the last pair
+                const int t = phys(min(u0 + k * THREADS + (int)threadIdx.x, len - 1));  // past the end: re-read the last pair
                 cc[k]       = __builtin_nontemporal_load(c2 + t);
                 vv[k]       = __builtin_nontemporal_load(v2 + t);
                 dd[k]       = __builtin_nontemporal_load(tp_blk + (t >> 3));
             }
         };
-        auto emit = [&](int t0, const u16x2(&cc)[UNROLL], const f64x2(&vv)[UNROLL], const int(&dd)[UNROLL]) {
+        auto emit = [&](int u0, const u16x2(&cc)[UNROLL], const f64x2(&vv)[UNROLL], const int(&dd)[UNROLL]) {
 #pragma unroll
             for (int k = 0; k < UNROLL; ++k)
             {
-                const int t = t0 + k * THREADS + (int)threadIdx.x;
-                if (t < t_end)
+                const int u = u0 + k * THREADS + (int)threadIdx.x;
+                if (u < len)
                 {
-                    f64x2 o;
+                    const int t = phys(u);
+                    f64x2     o;
                     o.x = vv[k].x * xs[cc[k].x];
                     o.y = vv[k].y * xs[cc[k].y];
                     __builtin_nontemporal_store(o, o2 + ((size_t)dd[k] * 8 + (t & 7)));  // read again only 2.7 GB later: 2-3 %
                 }
             }
         };
-        if (t_begin < t_end) fetch(t_begin, c[0], v[0], d[0]);  // (workgroup-uniform)
+        if (len > 0) fetch(0, c[0], v[0], d[0]);  // (workgroup-uniform)
         // the panel: 16-byte loads when x allows (panel bases are multiples of pcols entries)
         const double* __restrict__ xp = x + c0;
         if ((reinterpret_cast<uintptr_t>(xp) & 15) == 0)
@@ -210,12 +217,12 @@ __global__ __launch_bounds__(THREADS) void tp_expand_kernel(int P, int pcols, in
         else
             for (int i = threadIdx.x; i < n; i += THREADS) xs[i] = xp[i];
         __syncthreads();
-        for (int t0 = t_begin; t0 < t_end; t0 += 2 * SET)
+        for (int u0 = 0; u0 < len; u0 += 2 * SET)
         {
-            fetch(t0 + SET, c[1], v[1], d[1]);  // (clamped when past the end)
-            emit(t0, c[0], v[0], d[0]);
-            fetch(t0 + 2 * SET, c[0], v[0], d[0]);
-            emit(t0 + SET, c[1], v[1], d[1]);
+            fetch(u0 + SET, c[1], v[1], d[1]);  // (clamped when past the end)
+            emit(u0, c[0], v[0], d[0]);
+            fetch(u0 + 2 * SET, c[0], v[0], d[0]);
+            emit(u0 + SET, c[1], v[1], d[1]);
         }
         __syncthreads();  // the panel is replaced next
     }
@@ -454,9 +461,10 @@ int csr_twophase_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, dou
     const int    unr   = A->tp_unroll == 4 ? 4 : 6;
     const size_t xlds  = sizeof(double) * (size_t)A->tp_pcols;
     const dim3   egrid((unsigned)std::min(A->tp_panels, half ? 2 * kNumCu : kNumCu));
+    static const int rotate = [] { const char* e = getenv("SPMV_TP_ROTATE"); return e ? atoi(e) : 1; }();  // (0: A/B)
 #define SPMV_TP_EXPAND(T, U)                                                                                                                  \
     hipLaunchKernelGGL((tp_expand_kernel<T, U>), egrid, dim3(T), xlds, ctx->stream, A->tp_panels, A->tp_pcols, A->ncol, A->tp_panel_ptr,       \
-                       (const unsigned short*)A->tp_col, (const double*)A->tp_val, (const int32_t*)A->tp_blk, x, A->tp_xg)
+                       (const unsigned short*)A->tp_col, (const double*)A->tp_val, (const int32_t*)A->tp_blk, x, A->tp_xg, rotate)
     if (half && unr == 6)
         SPMV_TP_EXPAND(512, 6);
     else if (half)
