@@ -83,6 +83,8 @@ void mat_free(spmv_mat* m)
     }
     if (m->win_lo) (void)hipFree(m->win_lo);
     if (m->win_span) (void)hipFree(m->win_span);
+    if (m->ell_diag) (void)hipFree(m->ell_diag);
+    if (m->ell_diag_mask) (void)hipFree(m->ell_diag_mask);
     csr_panel_free(m);
     csr_twophase_free(m);
     symgs_free(m);
@@ -724,6 +726,8 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
     }
     else if (!strcmp(name, "panel_layout"))  // layout in memory: 0 three arrays, 1 records, 3 packed 12-byte entries
         *value = m->pb_pack ? (m->pb_pair ? 4 : 3) : 0;
+    else if (!strcmp(name, "ell_diagonal_slots"))  // ELL: 1 if the slots were found to be diagonals (no column stream for conforming rows)
+        *value = m->ell_diag ? 1 : 0;
     else if (!strcmp(name, "twophase_panel_cols"))
         *value = m->tp_pcols;
     else if (!strcmp(name, "twophase_padded"))

@@ -81,6 +81,7 @@ typedef enum spmv_csr_kernel
 /* Tuning bits for spmv_mat_set_flags (speed only; results stay within the parity tolerance). */
 #define SPMV_FLAG_DPP_REDUCE 1u /* CSR vector kernel: DPP row shifts instead of ds_swizzle for the <=16-lane steps */
 #define SPMV_FLAG_XCD_REMAP  2u /* CSR vector kernel: each XCD walks one contiguous eighth of the rows */
+#define SPMV_FLAG_ELL_READ_COLUMNS 8u /* ELL kernel: read the column indices even where the slots were found to be diagonals (A/B switch) */
 #define SPMV_FLAG_DIA_GLOBAL_X 4u /* DIA kernel: read x from global memory even when the offsets lie in a band (A/B switch) */
 
 typedef struct spmv_ctx spmv_ctx; /* one HIP device + one stream */

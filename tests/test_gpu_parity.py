@@ -109,6 +109,59 @@ def test_ell_odd_row_count_uses_one_row_kernel(ctx, orc):
     assert np.array_equal(y1, ref)
 
 
+@pytest.mark.parametrize("shape", ["stencil", "wide_band", "circulant", "mostly_irregular"])
+def test_ell_slots_that_are_diagonals_need_no_column_stream(ctx, orc, pkg, shape):
+    """ELL handles of stencil / band matrices: slot s of (nearly) every row holds column i + off[s]; the product then
+    reads no column index for those rows and takes x through an LDS window.  Rows that do not conform (boundary rows
+    padded with (0, 0.0), wrap-around rows, a few rows with arbitrary columns) read their columns as before.  Same
+    products, same order: equal to the fma oracle bit for bit, with the detection on and switched off."""
+    rng = np.random.RandomState(11)
+    if shape == "stencil":  # 5-point-like: offsets -70, -1, 0, 1, 70; boundary entries are padding
+        nrow = ncol = 6000
+        offs = np.array([-70, -1, 0, 1, 70])
+    elif shape == "wide_band":  # offsets too far apart for the LDS window: x from global memory
+        nrow = ncol = 30_000
+        offs = np.array([-9000, -3, 0, 3, 9000, 12_000])
+    elif shape == "circulant":  # wraps around like C3; rectangular: more columns than rows
+        nrow, ncol = 4096, 5000
+        offs = np.arange(-6, 7)
+    else:  # most rows arbitrary: the detection must decline
+        nrow = ncol = 5000
+        offs = np.array([-2, 0, 2, 5])
+    k = len(offs)
+    rows = np.arange(nrow)
+    col = rows[None, :] + offs[:, None]  # [slot, row]: column-major ELL (include/matrix.h:70)
+    val = rng.uniform(-1, 1, size=(k, nrow))
+    if shape == "circulant":
+        col = col % ncol
+    else:
+        out = (col < 0) | (col >= ncol)
+        col[out], val[out] = 0, 0.0  # padding as the reference's constructor writes it (src/matrix.cpp:473-474)
+    odd = rng.choice(nrow, size=(nrow * 9 // 10 if shape == "mostly_irregular" else 25), replace=False)
+    if shape != "mostly_irregular":
+        odd = odd[odd != nrow // 2]  # the detection reads the offsets off the middle row
+    col[:, odd] = rng.randint(0, ncol, size=(k, len(odd)))  # rows with arbitrary columns
+    col, val = col.astype(np.int32).ravel(), val.ravel()
+    x = rng.uniform(0, 1, size=ncol)
+    ref = np.zeros(nrow)
+    ol.ell_spmv(orc, nrow, k, col, val, x, ref, fma=True)
+    A = ctx.ell(nrow, ncol, k, nrow * k, col, val)
+    assert A.get_param("ell_diagonal_slots") == (0 if shape == "mostly_irregular" else 1)
+    for flags in (0, 8):  # 8 = SPMV_FLAG_ELL_READ_COLUMNS
+        A.set_flags(flags)
+        y1, y50 = _apply_n(ctx, A, x, nrow, NUM_TEST)
+        assert np.array_equal(y1, ref), (shape, flags)
+    # x with NaN where only padding looks (x[0] times 0.0 poisons the padded rows in the reference as well: keep it)
+    if shape == "stencil":
+        xn = x.copy()
+        xn[0] = np.inf
+        refn = np.zeros(nrow)
+        ol.ell_spmv(orc, nrow, k, col, val, xn, refn, fma=True)
+        A.set_flags(0)
+        yn, _ = _apply_n(ctx, A, xn, nrow, 1)
+        assert np.array_equal(np.isnan(yn), np.isnan(refn)) and np.array_equal(yn[~np.isnan(refn)], refn[~np.isnan(refn)])
+
+
 @pytest.mark.parametrize("make", cases.ALL_CASES, ids=lambda f: f.__name__)
 def test_coo_matches_reference_golden(ctx, orc, pkg, make):
     c = make()
