@@ -376,16 +376,29 @@ int ell_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
     const bool aligned = (A->nrow % 2 == 0) && (((uintptr_t)A->b % 8) == 0) && (((uintptr_t)A->v % 16) == 0) &&
                          (((uintptr_t)y % 16) == 0);
     const bool x2 = aligned && !(A->lanes_per_row == 1);  // lanes_per_row==1 forces the one-row kernel
-    if (x2 && A->ell_diag && A->ell_diag_mask && (A->lanes_per_row == 0 || A->lanes_per_row == 2) && !(A->flags & SPMV_FLAG_ELL_READ_COLUMNS))
+    if (x2 && A->ell_diag && A->ell_diag_mask && !(A->flags & SPMV_FLAG_ELL_READ_COLUMNS))
     {
         const unsigned grid = (unsigned)ceil_div(A->nrow / 2, kBlock);
         const int64_t  band = (int64_t)A->ell_diag_max - A->ell_diag_min;
-        if (band >= 0 && band <= 3584)  // the x stretch of 512 rows fits 32 KB of LDS
-            hipLaunchKernelGGL((ell_diag_kernel_x2<4, true>), dim3(grid), dim3(kBlock), sizeof(double) * (size_t)(2 * kBlock + band), ctx->stream, A->nrow,
-                               A->k, A->b, A->v, x, y, A->ell_diag, (const u64*)A->ell_diag_mask, A->ncol, A->ell_diag_min, A->ell_diag_max);
+        const bool     xwin = band >= 0 && band <= 3584;  // the x stretch of 512 rows fits 32 KB of LDS
+        const size_t   lds  = xwin ? sizeof(double) * (size_t)(2 * kBlock + band) : 0;
+#define SPMV_ELL_DIAG(U, W)                                                                                                                 \
+    hipLaunchKernelGGL((ell_diag_kernel_x2<U, W>), dim3(grid), dim3(kBlock), lds, ctx->stream, A->nrow, A->k, A->b, A->v, x, y, A->ell_diag, \
+                       (const u64*)A->ell_diag_mask, A->ncol, xwin ? A->ell_diag_min : 0, xwin ? A->ell_diag_max : 0)
+        // slots in flight per lane: 4 by default; lanes_per_row 4 / 8 select 8 / 2 (tools/tune.py ell: A/B)
+        if (A->lanes_per_row == 4)
+        {
+            if (xwin) SPMV_ELL_DIAG(8, true); else SPMV_ELL_DIAG(8, false);
+        }
+        else if (A->lanes_per_row == 8)
+        {
+            if (xwin) SPMV_ELL_DIAG(2, true); else SPMV_ELL_DIAG(2, false);
+        }
         else
-            hipLaunchKernelGGL((ell_diag_kernel_x2<4, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, A->nrow, A->k, A->b, A->v, x, y, A->ell_diag,
-                               (const u64*)A->ell_diag_mask, A->ncol, 0, 0);
+        {
+            if (xwin) SPMV_ELL_DIAG(4, true); else SPMV_ELL_DIAG(4, false);
+        }
+#undef SPMV_ELL_DIAG
     }
     else if (x2)
     {

@@ -261,13 +261,12 @@ def main():
         print(f"ELL n={n} k={k} {'uniform columns' if a.band < 0 else 'circulant band'}: auto kernel={A.info.kernel} (4 = panel copy, 1 = one lane per row)")
         x, y = ctx.gen_vector(n, seed=1), ctx.vector(n)
         y.fill(0.0)
-        def x2(A, flags):
+        def x2(A, flags, lanes=2):
             A.set_flags(flags)
-            A.set_kernel(capi.CSR_VECTOR, 2)
-        variants = [("ell x2, slots as diagonals (no index stream)", lambda A: x2(A, 0)), ("ell x2, column indices read", lambda A: x2(A, 8)),
-                    ("ell x1", lambda A: A.set_kernel(capi.CSR_VECTOR, 1)),
-                    ("ell x2, 8 slots in flight", lambda A: A.set_kernel(capi.CSR_VECTOR, 4)), ("ell x2, 2 slots in flight", lambda A: A.set_kernel(capi.CSR_VECTOR, 8)),
-                    ("auto", lambda A: A.set_kernel(capi.CSR_AUTO, 2))]
+            A.set_kernel(capi.CSR_VECTOR, lanes)
+        variants = [("ell x2, slots as diagonals (no index stream)", lambda A: x2(A, 0)), ("the same, 8 slots in flight", lambda A: x2(A, 0, 4)),
+                    ("the same, 2 slots in flight", lambda A: x2(A, 0, 8)), ("ell x2, column indices read", lambda A: x2(A, 8)),
+                    ("the same, 8 slots in flight", lambda A: x2(A, 8, 4)), ("ell x1", lambda A: x2(A, 8, 1))]
         sweep(ctx, A, x, y, variants, a.rounds, a.reps, algorithmic_bytes("ell", n, n, n * k, k), n * k)
     else:
         n = a.n or 2_000_000
