@@ -334,7 +334,11 @@ int tp_panel_cols(const spmv_mat* m) { return m->tp_pcols_req > 0 ? std::min(m->
 // must be long enough that padding them to whole lines costs little.
 bool csr_twophase_worth(const spmv_mat* m)
 {
-    if (m->nnz < ((int64_t)2 << 20) || m->nrow <= 0) return false;
+    if (m->nnz < ((int64_t)8 << 20) || m->nrow <= 0) return false;
+    // local columns (bands, stencils: the mean column window of 256 rows is a small part of x): the panel kernel only
+    // sweeps what its groups touch, the model below does not apply (tools/sweep_sizes.py: a 20M x 16 band matrix took
+    // 1.89 ms through the two phases against 0.7 through the panel kernel)
+    if (m->win_avg_span < 0.5 * (double)m->ncol) return false;
     const double rounds = std::max(1.0, std::ceil((double)m->nrow / ((double)kNumCu * kTpGroupRows)));
     const double sweeps = 8.0 * (double)m->ncol * kNumXcd * rounds;
     const double runs   = (double)ceil_div(m->ncol, tp_panel_cols(m)) * (double)ceil_div(m->nrow, tp_groups_per(m));

@@ -434,6 +434,14 @@ def test_csr_twophase_kernel_on_wide_and_ragged_matrices(ctx, orc, pkg):
     del wide
     thin = ctx.gen_csr_uniform(0, 600_000, 40_000_000, 8, seed=3)
     assert thin.info.kernel == capi.CSR_PANEL
+    del thin
+    # few entries per row would pass the sweep model, but a band matrix only sweeps its band: the panel kernel stays
+    band = ctx.gen_csr_uniform(0, 3_000_000, 3_000_000, 4, band=4096, seed=3)
+    assert band.info.kernel == capi.CSR_PANEL
+    del band
+    sparse = ctx.gen_csr_uniform(0, 3_000_000, 3_000_000, 4, seed=3)  # the same shape with uniform columns takes the two phases
+    assert sparse.info.kernel == capi.CSR_TWOPHASE
+    del sparse
     square = ctx.gen_csr_uniform(0, 600_000, 600_000, 8, seed=3)
     assert square.info.kernel == capi.CSR_PANEL
 
