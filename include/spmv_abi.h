@@ -211,13 +211,19 @@ int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
  *                    (memory 2x -> 1x the matrix; download, other kernels, re-builds and conversions are then refused)
  *   "panel_trial"    1 / 0 = timing launches when the layout is built, yes / no (-1 = environment, default yes)
  *   "dia_col_bound"  DIA handles: columns >= this are skipped (row shards keep the bound of the whole matrix)
- *   "panel_trace", "panel_legacy", "panel_skew", "panel_pace_slack", "panel_two_per_cu", "panel_uncached", "panel_ablate"
- *                    diagnostics and experiments kept for the record (tools/trace_panel.py);
- *                    "panel_ablate" > 0 gives WRONG results by design (timing only) */
+ *   "twophase_panel_cols", "twophase_unroll"   two-phase CSR kernel: columns of x per panel (<= 20000; <= 10000 puts two
+ *                    workgroups on a CU) and pairs per lane in flight (6 or 4); take effect at the next
+ *                    spmv_mat_set_kernel(SPMV_CSR_TWOPHASE)
+ *   "symgs_order"    sweep order of spmv_symgs / SPMV_PRECOND_SYMGS: 1 multicolour (default), 0 the matrix's own row order
+ *   "panel_trace", "panel_legacy", "panel_two_per_cu"
+ *                    diagnostics and experiments kept for the record (tools/trace_panel.py) */
 int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value);
 /* What is in effect: "panel_rows", "panel_width", "panel_sort", "panel_groups", "panel_layout", "panel_unroll",
- * "panel_pipe", "panel_sync", "panel_stagger", "panel_pace_ns", "panel_pace_scale", "panel_pace_bumps", "panel_skew",
- * "panel_bytes", "panel_keep_csr", "device_bytes", "window_max_span", "window_avg_span". */
+ * "panel_pipe", "panel_sync", "panel_stagger", "panel_pace_ns", "panel_pace_scale", "panel_pace_bumps",
+ * "panel_bytes", "panel_keep_csr", "device_bytes", "window_max_span", "window_avg_span", "twophase_panel_cols",
+ * "twophase_padded" (entries of the two-phase layout with its padding), "ell_diagonal_slots" (1: the slots of an ELL
+ * handle were found to be diagonals and conforming rows read no column index), "symgs_order", "symgs_colours",
+ * "symgs_levels_forward", "symgs_levels_backward", "symgs_launches", "symgs_bytes". */
 int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value);
 /* Copy the arrays of a handle back to the host (any pointer may be NULL to skip it).
  *   CSR: a=row_ptr[nrow+1]  b=col_ind[nnz]      v=values[nnz]
