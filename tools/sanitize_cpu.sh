@@ -14,5 +14,5 @@ g++ -std=c++17 $SAN -fPIC -pthread -I"$R/include" -I"$R/arm-spmv_amd/host" -shar
 cd "$R"
 LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 \
     UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 SPMV_ORACLE_SO="$T/libspmv_oracle.so" SPMV_COMPAT_SO="$T/libarmspmv_compat.so" \
-    python3 -m pytest tests/test_oracle_golden.py tests/test_host_io.py -x -q 2>&1 | grep -E "passed|failed|ERROR|runtime error|Sanitizer"
+    python3 -m pytest tests/test_oracle_golden.py tests/test_oracle_symgs.py tests/test_host_io.py -x -q 2>&1 | grep -E "passed|failed|ERROR|runtime error|Sanitizer"
 rm -rf "$T"
