@@ -410,8 +410,13 @@ def main() -> None:
                         "csr": f"csr_n{int(inf.nrow)}_k{k}_band{65536 if int(inf.ncol) == int(inf.nrow) else 0}_ncol{int(inf.ncol)}"}[fmt]
                 tfile2 = ROOT / "profiles" / "pmc_traffic.json"
                 traffic2 = json.loads(tfile2.read_text()).get(tkey, {}).get("hbm_bytes_per_launch") if tfile2.exists() else None
+                note = None
+                if fmt == "ell" and M.get_param("ell_diagonal_slots"):
+                    note = ("the slots of this ELL matrix are diagonals (col = row + offset[slot] for all but the wrap-around rows): the "
+                            "kernel reads no column index for conforming rows, i.e. 8 instead of ELL's 12 algorithmic bytes per entry - "
+                            "frac (of the ALGORITHMIC bytes) can exceed what the bytes in `traffic` allow")
                 extra.append({
-                    "name": name, "format": fmt, "nrow": int(inf.nrow), "ncol": int(inf.ncol), "nnz": nnz2,
+                    "name": name, "format": fmt, **({"note": note} if note else {}), "nrow": int(inf.nrow), "ncol": int(inf.ncol), "nnz": nnz2,
                     "max_row_nnz": int(inf.max_row_nnz), "kernel_id": int(inf.kernel), "ms": round(ms, 5),
                     "value": round(2.0 * nnz2 / ms / 1e6, 2), "unit": "GFLOP/s", "setup_seconds": round(t_set, 3),
                     "roofline": {"bound": "hbm", "achieved": round(b / ms / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
