@@ -209,10 +209,11 @@ struct spmv_mat
     int64_t   tp_bytes   = 0;
 
     // ELL whose slots are diagonals (kernels_ell.hip: ell_detect_diagonals): slot s holds column i + off[s] in the row
-    // pairs whose bit is set; the product reads no column index there.  off[K]; mask[wavefront * K + s] = 64 row pairs
+    // pairs whose bit is set; the product reads no column index there.  ell_diag = off[K] | xbase[K] | clusters
+    // (kernels_ell.hip: stage_x_windows); mask[wavefront * K + s] = 64 row pairs
     int32_t* ell_diag      = nullptr;
     void*    ell_diag_mask = nullptr;
-    int32_t  ell_diag_min = 0, ell_diag_max = 0;  // smallest / largest offset (sizes the x window in LDS)
+    int32_t  ell_diag_lds = 0;  // doubles of LDS the x stretches of a block take (0: none, x from global memory)
 
     // COO / CSC / ELL: internal row-grouped copy in the panel layout (coo_build_panel, csc_analyse, ell_build_panel); owned
     spmv_mat* coo_csr = nullptr;

@@ -119,18 +119,44 @@ __global__ __launch_bounds__(kBlock) void ell_kernel_x2(int nrow, int k, const i
 using u64 = unsigned long long;
 
 // one lane per row pair; mask[wave * k + s] = ballot of "both rows of the pair hold column i + off[s] in slot s"
-__global__ __launch_bounds__(kBlock) void ell_diag_scan_kernel(int nrow, int k, const int32_t* __restrict__ col, int32_t* __restrict__ off,
+constexpr int kRefCandidates = 16, kRefSample = 2048;
+// candidate c for the reference row: 16 rows spread over the sampled stretch around the middle, at a spacing that does
+// not line up with round grid sizes (the middle row itself is often a boundary row of the grid, and so are its neighbours)
+__host__ __device__ inline int ref_candidate(int nrow, int c)
+{
+    const int count = nrow < kRefSample ? nrow : kRefSample, first = nrow / 2 - count / 2 > 0 ? nrow / 2 - count / 2 : 0;
+    const int r = first + (c * 131 + 17) % count;
+    return r < nrow ? r : nrow - 1;
+}
+
+// which row near the middle speaks for the most others?  hits[c] = entries of the sampled rows that sit where
+// candidate row c says
+__global__ __launch_bounds__(kBlock) void ell_ref_row_kernel(int nrow, int k, const int32_t* __restrict__ col, int first, int count,
+                                                             int32_t* __restrict__ hits)
+{
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= count) return;
+    const int i = first + t;
+    for (int c = 0; c < kRefCandidates; ++c)
+    {
+        const int ref = ref_candidate(nrow, c);
+        int       ok  = 0;
+        for (int s = 0; s < k; ++s) ok += (col[(size_t)i + (size_t)s * nrow] - i == col[(size_t)ref + (size_t)s * nrow] - ref) ? 1 : 0;
+        if (ok) atomicAdd(hits + c, ok);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void ell_diag_scan_kernel(int nrow, int k, int ref_row, const int32_t* __restrict__ col, int32_t* __restrict__ off,
                                                                u64* __restrict__ mask, u64* __restrict__ covered)
 {
     const int  pair = blockIdx.x * kBlock + threadIdx.x;
     const int  i    = 2 * pair;
     const int  wave = pair >> 6, lane = threadIdx.x & 63;
-    const int  mid  = nrow / 2;
     const bool on   = i + 1 < nrow;
     u64        mine = 0;
     for (int s = 0; s < k; ++s)
     {
-        const int o = col[(size_t)mid + (size_t)s * nrow] - mid;  // uniform: scalar load
+        const int o = col[(size_t)ref_row + (size_t)s * nrow] - ref_row;  // uniform: scalar load
         if (pair == 0) off[s] = o;
         bool conf = false;
         if (on)
@@ -148,39 +174,49 @@ __global__ __launch_bounds__(kBlock) void ell_diag_scan_kernel(int nrow, int k, 
     if (lane == 0 && mine) atomicAdd(covered, mine);
 }
 
+// The stretches of x a block of 2 * kBlock rows needs, one per CLUSTER of nearby offsets (a 7-point stencil on a grid:
+// {-m^2}, {-m}, {-1, 0, 1}, {m}, {m^2}), copied into LDS once per workgroup.  Descriptor array (int32, after off[K]):
+//   xbase[K]                       LDS index of x[r0 + off[s]] for slot s (r0 = first row of the block)
+//   ncl, then {lo, len, base} per cluster: x[r0 + lo .. r0 + lo + len) sits at xs[base ..)
+__device__ __forceinline__ void stage_x_windows(double* xs, const int32_t* __restrict__ desc, int k, const double* __restrict__ x, int r0, int ncol)
+{
+    const int ncl = desc[2 * k];
+    for (int c = 0; c < ncl; ++c)
+    {
+        const int     lo = desc[2 * k + 1 + 3 * c], len = desc[2 * k + 2 + 3 * c], base = desc[2 * k + 3 + 3 * c];
+        const int64_t j0 = (int64_t)r0 + lo;
+        if (j0 >= 0 && j0 + len <= ncol && ((j0 | base | len) & 1) == 0 && (((uintptr_t)x) & 15) == 0)
+        {
+            // whole stretch inside x, even start: 16-byte loads (half the vector-memory instructions)
+            const f64x2* __restrict__ x2 = reinterpret_cast<const f64x2*>(x + j0);
+            f64x2*                    s2 = reinterpret_cast<f64x2*>(xs + base);
+            for (int t = threadIdx.x; t < len / 2; t += kBlock) s2[t] = x2[t];
+        }
+        else
+            for (int t = threadIdx.x; t < len; t += kBlock)
+            {
+                const int64_t j = j0 + t;
+                xs[base + t]    = (j >= 0 && j < ncol) ? x[j] : 0.0;
+            }
+    }
+    __syncthreads();
+}
+
 template <int UNROLL, bool XWIN>
 __global__ __launch_bounds__(kBlock) void ell_diag_kernel_x2(int nrow, int k, const int32_t* __restrict__ col,
                                                              const double* __restrict__ val, const double* __restrict__ x,
                                                              double* __restrict__ y, const int32_t* __restrict__ off,
-                                                             const u64* __restrict__ mask, int ncol, int off_min, int off_max)
+                                                             const u64* __restrict__ mask, int ncol)
 {
-    extern __shared__ double xs[];  // XWIN: x[2 * kBlock * blockIdx.x + off_min ..  + 2 * kBlock - 1 + off_max]
-    const int     r0   = 2 * kBlock * (int)blockIdx.x;
-    const int64_t wlo  = (int64_t)r0 + off_min;
-    const int     span = XWIN ? 2 * kBlock + off_max - off_min : 0;
-    if constexpr (XWIN)
-    {
-        for (int t = threadIdx.x; t < span; t += kBlock)
-        {
-            const int64_t j = wlo + t;
-            xs[t]           = (j >= 0 && j < ncol) ? x[j] : 0.0;
-        }
-        __syncthreads();
-    }
+    extern __shared__ double xs[];  // XWIN: the stretches of x this block's conforming entries read (stage_x_windows)
+    const int r0 = 2 * kBlock * (int)blockIdx.x;
+    if constexpr (XWIN) stage_x_windows(xs, off, k, x, r0, ncol);
     const int i = r0 + 2 * (int)threadIdx.x;
     if (i >= nrow) return;  // nrow even: i+1 < nrow too
     const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * kBlock + threadIdx.x) >> 6));
     const u64* __restrict__ wm = mask + (size_t)wave * k;  // this wavefront's words: scalar loads
     const u64 bit = 1ull << (threadIdx.x & 63);
-    auto xat = [&](int c) {
-        if constexpr (XWIN)
-        {
-            const int64_t idx = (int64_t)c - wlo;
-            return (idx >= 0 && idx < span) ? xs[idx] : x[c];
-        }
-        else
-            return x[c];
-    };
+    const int32_t* __restrict__ xbase = off + k;
     f64x2        acc    = *reinterpret_cast<const f64x2*>(y + i);
     const size_t stride = (size_t)nrow;
     size_t       at     = (size_t)i;
@@ -195,20 +231,30 @@ __global__ __launch_bounds__(kBlock) void ell_diag_kernel_x2(int nrow, int k, co
             if (s0 + u < k)
             {
                 const int s = s0 + u;
-                int       c0, c1;
+                double    x0, x1;
                 if (wm[s] & bit)  // nearly always the whole wavefront
                 {
-                    c0 = i + off[s];
-                    c1 = c0 + 1;
+                    if constexpr (XWIN)
+                    {
+                        const int at_x = xbase[s] + 2 * (int)threadIdx.x;
+                        x0             = xs[at_x];
+                        x1             = xs[at_x + 1];
+                    }
+                    else
+                    {
+                        const int c0 = i + off[s];
+                        x0           = x[c0];
+                        x1           = x[c0 + 1];
+                    }
                 }
                 else
                 {
                     const i32x2 c = load_stream(reinterpret_cast<const i32x2*>(col + at + (size_t)u * stride));
-                    c0            = c.x;
-                    c1            = c.y;
+                    x0            = x[c.x];
+                    x1            = x[c.y];
                 }
-                acc.x = fma(v[u].x, xat(c0), acc.x);
-                acc.y = fma(v[u].y, xat(c1), acc.y);
+                acc.x = fma(v[u].x, x0, acc.x);
+                acc.y = fma(v[u].y, x1, acc.y);
             }
         at += (size_t)UNROLL * stride;
     }
@@ -324,7 +370,7 @@ int ell_build_panel(spmv_mat* m, bool only_if_worth)
 }
 
 // are the slots diagonals?  kept when at least half of the entries lie in conforming row pairs
-static int ell_detect_diagonals(spmv_mat* m)
+static int ell_detect_diagonals(spmv_mat* m, int64_t* covered_pairs = nullptr)
 {
     spmv_ctx* ctx = m->ctx;
     if (m->ell_diag || m->nrow < 4 * kBlock || m->nrow % 2 != 0 || m->k < 1 || m->k > 4096 || ((uintptr_t)m->b % 8) != 0) return SPMV_OK;
@@ -332,20 +378,40 @@ static int ell_detect_diagonals(spmv_mat* m)
     const int64_t npairs = m->nrow / 2, nwaves = ceil_div(npairs, 64);
     int32_t*      off    = nullptr;
     u64*          mask   = nullptr;
-    SPMV_TRY(ensure_scratch(ctx, 64));
-    u64* d_cov = (u64*)ctx->scratch;
-    u64  h_cov = 0;
+    SPMV_TRY(ensure_scratch(ctx, 256));
+    u64*     d_cov  = (u64*)ctx->scratch;
+    int32_t* d_hits = (int32_t*)((char*)ctx->scratch + 64);
+    u64      h_cov  = 0;
     if (hipMalloc(&off, sizeof(int32_t) * (size_t)k) != hipSuccess || hipMalloc(&mask, sizeof(u64) * (size_t)(nwaves * k)) != hipSuccess)
     {
         if (off) (void)hipFree(off);
         SPMV_FAIL(SPMV_ERR_ALLOC, "out of device memory for the slot descriptors of an ELL handle (%lld words)", (long long)(nwaves * k));
     }
     std::vector<int32_t> h_off((size_t)k);
+    // the reference row: of 16 rows from the middle on, the one most of 2048 sampled rows agree with
+    int ref_row = m->nrow / 2;
+    {
+        int32_t    h_hits[kRefCandidates] = {0};
+        const int  count = std::min(m->nrow, kRefSample), first = std::max(0, m->nrow / 2 - count / 2);
+        hipError_t e0    = hipMemsetAsync(d_hits, 0, sizeof(h_hits), ctx->stream);
+        hipLaunchKernelGGL(ell_ref_row_kernel, dim3((unsigned)ceil_div(count, kBlock)), dim3(kBlock), 0, ctx->stream, m->nrow, k, m->b, first, count, d_hits);
+        if (e0 == hipSuccess) e0 = hipMemcpyAsync(h_hits, d_hits, sizeof(h_hits), hipMemcpyDeviceToHost, ctx->stream);
+        if (e0 == hipSuccess) e0 = hipStreamSynchronize(ctx->stream);
+        if (e0 != hipSuccess)
+        {
+            (void)hipFree(off);
+            (void)hipFree(mask);
+            SPMV_FAIL(SPMV_ERR_HIP, "sampling the slots of an ELL handle failed: %s", hipGetErrorString(e0));
+        }
+        ref_row = ref_candidate(m->nrow, (int)(std::max_element(h_hits, h_hits + kRefCandidates) - h_hits));
+    }
     hipError_t           e = hipMemsetAsync(d_cov, 0, sizeof(u64), ctx->stream);
-    hipLaunchKernelGGL(ell_diag_scan_kernel, dim3((unsigned)ceil_div(nwaves * 64, kBlock)), dim3(kBlock), 0, ctx->stream, m->nrow, k, m->b, off, mask, d_cov);
+    hipLaunchKernelGGL(ell_diag_scan_kernel, dim3((unsigned)ceil_div(nwaves * 64, kBlock)), dim3(kBlock), 0, ctx->stream, m->nrow, k, ref_row, m->b, off, mask,
+                       d_cov);
     if (e == hipSuccess) e = hipMemcpyAsync(&h_cov, d_cov, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(h_off.data(), off, sizeof(int32_t) * (size_t)k, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (covered_pairs) *covered_pairs = (int64_t)h_cov;
     if (e != hipSuccess || (int64_t)h_cov * 2 < npairs * k)
     {
         (void)hipFree(off);
@@ -353,11 +419,45 @@ static int ell_detect_diagonals(spmv_mat* m)
         if (e != hipSuccess) SPMV_FAIL(SPMV_ERR_HIP, "scanning the slots of an ELL handle failed: %s", hipGetErrorString(e));
         return SPMV_OK;  // not a stencil / band: the column indices are needed
     }
-    m->ell_diag      = off;
+    // clusters of nearby offsets share one stretch of x in LDS (stage_x_windows); at most 40 KB in all, else no windows
+    std::vector<int> order((size_t)k);
+    for (int s2 = 0; s2 < k; ++s2) order[(size_t)s2] = s2;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return h_off[(size_t)a] < h_off[(size_t)b]; });
+    std::vector<int32_t> desc((size_t)2 * k + 1, 0);
+    for (int s2 = 0; s2 < k; ++s2) desc[(size_t)s2] = h_off[(size_t)s2];
+    std::vector<int32_t> cl;  // lo, len, base per cluster
+    int64_t total = 0;
+    for (int q = 0; q < k;)
+    {
+        int e2 = q;
+        while (e2 + 1 < k && (int64_t)h_off[(size_t)order[(size_t)e2 + 1]] - h_off[(size_t)order[(size_t)q]] <= 1024) ++e2;
+        const int lo  = h_off[(size_t)order[(size_t)q]] & ~1;  // even start and length: 16-byte staging loads
+        const int len = (2 * kBlock + (h_off[(size_t)order[(size_t)e2]] - lo) + 1) & ~1;
+        for (int t = q; t <= e2; ++t) desc[(size_t)k + order[(size_t)t]] = (int32_t)total + (h_off[(size_t)order[(size_t)t]] - lo);
+        cl.push_back(lo);
+        cl.push_back(len);
+        cl.push_back((int32_t)total);
+        total += len;
+        q = e2 + 1;
+    }
+    const bool windows = total * 8 <= 40 * 1024;
+    desc[(size_t)2 * k] = windows ? (int32_t)(cl.size() / 3) : 0;
+    if (windows) desc.insert(desc.end(), cl.begin(), cl.end());
+    int32_t* d_desc = nullptr;
+    if (hipMalloc(&d_desc, sizeof(int32_t) * desc.size()) != hipSuccess ||
+        hipMemcpyAsync(d_desc, desc.data(), sizeof(int32_t) * desc.size(), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess)
+    {
+        if (d_desc) (void)hipFree(d_desc);
+        (void)hipFree(off);
+        (void)hipFree(mask);
+        SPMV_FAIL(SPMV_ERR_ALLOC, "out of device memory for the slot descriptors of an ELL handle");
+    }
+    (void)hipFree(off);  // (the offsets live at the head of the descriptor)
+    m->ell_diag      = d_desc;
     m->ell_diag_mask = mask;
-    m->ell_diag_min  = *std::min_element(h_off.begin(), h_off.end());
-    m->ell_diag_max  = *std::max_element(h_off.begin(), h_off.end());
-    m->device_bytes += (int64_t)sizeof(int32_t) * k + (int64_t)sizeof(u64) * nwaves * k;
+    m->ell_diag_lds  = windows ? (int32_t)total : 0;
+    m->device_bytes += (int64_t)sizeof(int32_t) * (int64_t)desc.size() + (int64_t)sizeof(u64) * nwaves * k;
     return SPMV_OK;
 }
 
@@ -379,12 +479,11 @@ int ell_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
     if (x2 && A->ell_diag && A->ell_diag_mask && !(A->flags & SPMV_FLAG_ELL_READ_COLUMNS))
     {
         const unsigned grid = (unsigned)ceil_div(A->nrow / 2, kBlock);
-        const int64_t  band = (int64_t)A->ell_diag_max - A->ell_diag_min;
-        const bool     xwin = band >= 0 && band <= 3584;  // the x stretch of 512 rows fits 32 KB of LDS
-        const size_t   lds  = xwin ? sizeof(double) * (size_t)(2 * kBlock + band) : 0;
+        const bool     xwin = A->ell_diag_lds > 0 && A->ell_diag_lds <= 5120;  // the x stretches of 512 rows fit 40 KB of LDS
+        const size_t   lds  = xwin ? sizeof(double) * (size_t)A->ell_diag_lds : 0;
 #define SPMV_ELL_DIAG(U, W)                                                                                                                 \
     hipLaunchKernelGGL((ell_diag_kernel_x2<U, W>), dim3(grid), dim3(kBlock), lds, ctx->stream, A->nrow, A->k, A->b, A->v, x, y, A->ell_diag, \
-                       (const u64*)A->ell_diag_mask, A->ncol, xwin ? A->ell_diag_min : 0, xwin ? A->ell_diag_max : 0)
+                       (const u64*)A->ell_diag_mask, A->ncol)
         // slots in flight per lane: 4 by default; lanes_per_row 4 / 8 select 8 / 2 (tools/tune.py ell: A/B)
         if (A->lanes_per_row == 4)
         {

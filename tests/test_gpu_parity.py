@@ -119,7 +119,7 @@ def test_ell_slots_that_are_diagonals_need_no_column_stream(ctx, orc, pkg, shape
     if shape == "stencil":  # 5-point-like: offsets -70, -1, 0, 1, 70; boundary entries are padding
         nrow = ncol = 6000
         offs = np.array([-70, -1, 0, 1, 70])
-    elif shape == "wide_band":  # offsets too far apart for the LDS window: x from global memory
+    elif shape == "wide_band":  # offsets far apart: one stretch of x in LDS per cluster of nearby offsets (four here)
         nrow = ncol = 30_000
         offs = np.array([-9000, -3, 0, 3, 9000, 12_000])
     elif shape == "circulant":  # wraps around like C3; rectangular: more columns than rows
