@@ -370,7 +370,7 @@ int ell_build_panel(spmv_mat* m, bool only_if_worth)
 }
 
 // are the slots diagonals?  kept when at least half of the entries lie in conforming row pairs
-static int ell_detect_diagonals(spmv_mat* m, int64_t* covered_pairs = nullptr)
+static int ell_detect_diagonals(spmv_mat* m)
 {
     spmv_ctx* ctx = m->ctx;
     if (m->ell_diag || m->nrow < 4 * kBlock || m->nrow % 2 != 0 || m->k < 1 || m->k > 4096 || ((uintptr_t)m->b % 8) != 0) return SPMV_OK;
@@ -411,7 +411,6 @@ static int ell_detect_diagonals(spmv_mat* m, int64_t* covered_pairs = nullptr)
     if (e == hipSuccess) e = hipMemcpyAsync(&h_cov, d_cov, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(h_off.data(), off, sizeof(int32_t) * (size_t)k, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (covered_pairs) *covered_pairs = (int64_t)h_cov;
     if (e != hipSuccess || (int64_t)h_cov * 2 < npairs * k)
     {
         (void)hipFree(off);
