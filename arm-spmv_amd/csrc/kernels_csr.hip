@@ -247,6 +247,8 @@ int launch_vector(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, 
 {
     const int   nrow = A->nrow;
     hipStream_t s    = ctx->stream;
+    // one lane group per row: more than 2^32 lanes in a launch wrap around silently — fewer lanes per row then
+    while (lanes > 1 && (int64_t)nrow * lanes >= ((int64_t)1 << 32) - kBlock) lanes >>= 1;
 #define SPMV_LAUNCH_LPR(L)                                                                              \
     case L:                                                                                             \
         hipLaunchKernelGGL((csr_vector_kernel<L, USE_DPP, XCD_REMAP>), dim3((unsigned)ceil_div(nrow, kBlock / L)), \

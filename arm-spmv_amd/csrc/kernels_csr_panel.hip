@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void panel_scatter_kernel(const int32_t* __res
 
 // ---- build step 3: inside each (group, panel) tile, bucket the entries by 128-byte line of x --------------
 // counting sort with one bin per line of the panel (W/16 bins in LDS); src -> dst
-__global__ __launch_bounds__(256) void panel_line_sort_kernel(const int32_t* __restrict__ gstart, int W, int P,
+__global__ __launch_bounds__(256) void panel_line_sort_kernel(int64_t ntiles, const int32_t* __restrict__ gstart, int W, int P,
                                                               const int32_t* __restrict__ row_ptr,
                                                               const int32_t* __restrict__ tile_ptr,
                                                               const int32_t* __restrict__ src_col,
@@ -128,13 +128,17 @@ __global__ __launch_bounds__(256) void panel_line_sort_kernel(const int32_t* __r
                                                               double* __restrict__ dst_val)
 {
     extern __shared__ int32_t bins[];  // W/16 + 1
-    const int nb   = W / kLineDoubles;
-    const int g    = blockIdx.x / P;
-    const int p    = blockIdx.x % P;
+    const int nb = W / kLineDoubles;
+    // tiles beyond the grid are taken in turns: groups x panels can exceed what one launch may hold (a grid of more
+    // than 2^32 / 256 workgroups of 256 wraps around silently)
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
+    {
+    const int g    = (int)(tile / P);
+    const int p    = (int)(tile % P);
     const int base = row_ptr[gstart[g]];
     const int t0   = base + tile_ptr[(size_t)g * (P + 1) + p];
     const int t1   = base + tile_ptr[(size_t)g * (P + 1) + p + 1];
-    if (t0 == t1) return;
+    if (t0 == t1) continue;  // (uniform over the workgroup)
     const int c0 = p * W;
     for (int i = threadIdx.x; i <= nb; i += blockDim.x) bins[i] = 0;
     __syncthreads();
@@ -166,6 +170,8 @@ __global__ __launch_bounds__(256) void panel_line_sort_kernel(const int32_t* __r
         dst_col[pos]  = c;
         dst_row[pos]  = src_row[e];
         dst_val[pos]  = src_val[e];
+    }
+    __syncthreads();  // the bins are cleared for the next tile
     }
 }
 
@@ -704,6 +710,7 @@ int csr_panel_build(spmv_mat* m)
     if (m->nrow == 0 || m->nnz == 0) return SPMV_OK;
     constexpr int kCapRows = 20000;  // 160,000 B of the CU's 163,840 B LDS
     int G = m->pb_group_rows > 0 ? std::min(m->pb_group_rows, kCapRows) : pick_group_rows(m->nrow, kCapRows);
+    G     = std::max<int64_t>(G, ceil_div(m->nrow, (int64_t)1 << 21));  // at most 2M groups: one workgroup of 256 per group in the build kernels
     int W = m->pb_panel_width > 0 ? m->pb_panel_width : 128 * 1024;
     W     = std::max(kLineDoubles, (W / kLineDoubles) * kLineDoubles);
     while (ceil_div(m->ncol, W) > 8192) W *= 2;  // the per-group histogram lives in LDS
@@ -800,8 +807,8 @@ int csr_panel_build(spmv_mat* m)
         if (sort && sizeof(int32_t) * (W / kLineDoubles + 1) > 65536)  // one bin per x line of the panel, in LDS
             (void)hipFuncSetAttribute((const void*)panel_line_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160008);
         if (sort)
-            hipLaunchKernelGGL(panel_line_sort_kernel, dim3((unsigned)ngroups * P), dim3(256),
-                               sizeof(int32_t) * (W / kLineDoubles + 1), s, m->pb_gstart, W, P, m->a, tile_ptr, tcol, trow,
+            hipLaunchKernelGGL(panel_line_sort_kernel, dim3((unsigned)std::min<int64_t>((int64_t)ngroups * P, (int64_t)1 << 22)), dim3(256),
+                               sizeof(int32_t) * (W / kLineDoubles + 1), s, (int64_t)ngroups * P, m->pb_gstart, W, P, m->a, tile_ptr, tcol, trow,
                                tval, m->pb_col, m->pb_row, m->pb_val);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = SPMV_ERR_HIP;
     } while (0);
