@@ -163,3 +163,134 @@ def test_random_coo_in_file_order_with_duplicates(ctx, orc, pkg, seed):
     assert C.info.nnz == nnz
     got = C.download()
     assert np.array_equal(got[0], rp) and np.array_equal(got[1], cc) and np.array_equal(got[2], cv)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_dia_handles(ctx, orc, pkg, seed):
+    """row-major DIA with random offsets (narrow bands: x through LDS; far offsets: x from global memory), odd and even
+    diagonal counts, rectangular shapes: bit for bit the fma oracle (x padded with zeros where the reference over-reads)"""
+    rng = np.random.default_rng(4000 + seed)
+    nrow = int(rng.choice([1, 255, 256, 257, 5000, 70_001]))
+    ncol = int(rng.choice([nrow, max(1, nrow // 2), nrow + 300, 3 * nrow]))
+    nd = int(rng.integers(1, 20))
+    span = int(rng.choice([2, 40, 900, max(2, nrow)]))
+    offs = np.sort(rng.choice(np.arange(-span, span + 1), size=min(nd, 2 * span + 1), replace=False)).astype(np.int32)
+    val = rng.uniform(-1, 1, nrow * len(offs))
+    x = rng.uniform(-1, 1, ncol)
+    xpad = np.zeros(max(nrow, ncol) + 1)
+    xpad[:ncol] = x
+    y0 = rng.uniform(-1, 1, nrow)
+    ref = y0.copy()
+    ol.dia_spmv(orc, nrow, offs, val, xpad, ref, fma=True)
+    A = ctx.dia(nrow, ncol, offs, val)
+    dx = ctx.vector_from(x)
+    for flags in (0, 4):  # 4 = SPMV_FLAG_DIA_GLOBAL_X
+        A.set_flags(flags)
+        dy = ctx.vector_from(y0)
+        ctx.apply(A, dx, dy)
+        ctx.sync()
+        assert np.array_equal(dy.download(), ref), (seed, nrow, ncol, list(offs), flags)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_csc_handles(ctx, orc, pkg, seed):
+    capi = pkg.capi
+    rng = np.random.default_rng(5000 + seed)
+    nrow = int(rng.choice([1, 300, 40_000, 400_000]))
+    ncol = int(rng.choice([1, 77, 30_000, 500_000]))
+    nnz = int(rng.choice([0, 5, 20_000, 2_500_000]))
+    row = rng.integers(0, nrow, nnz).astype(np.int32)
+    col = np.sort(rng.integers(0, ncol, nnz)).astype(np.int32)
+    val = rng.uniform(-1, 1, nnz)
+    cp, cr, cw = ol.coo_to_csc(orc, ncol, row, col, val)
+    x = rng.uniform(-1, 1, ncol)
+    ref = np.zeros(nrow)
+    ol.csc_spmv(orc, cp, cr, cw, x, ref)
+    rp, cc, cv = ol.coo_to_csr(orc, nrow, row, col, val)
+    scale = np.zeros(nrow)
+    ol.csr_abs_row_sums(orc, rp, cc, cv, x, scale)
+    A = ctx.csc(nrow, ncol, cp, cr, cw)
+    dx, dy = ctx.vector_from(x), ctx.vector(nrow)
+    for kernel in (capi.CSR_AUTO, capi.CSR_VECTOR):
+        A.set_kernel(kernel)
+        dy.fill(0.0)
+        ctx.apply(A, dx, dy)
+        ctx.sync()
+        ol.assert_parity(dy.download(), ref, scale, f"csc seed {seed}: {nrow} x {ncol}, {nnz} entries, kernel {kernel}")
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_systems_through_the_gauss_seidel_sweep(ctx, orc, pkg, seed):
+    """random diagonally dominant matrices — symmetric or not in pattern, rows in random order, the diagonal entry
+    sometimes split in two — in both sweep orders, 1-3 sweeps, against the oracle's sweep over the sequence the engine
+    reports; the multicolour sequence against the oracle's sequential greedy colouring"""
+    rng = np.random.default_rng(6000 + seed)
+    n = int(rng.choice([2, 65, 1000, 20_000, 150_000]))
+    k = int(rng.integers(0, 9))
+    cols = rng.integers(0, n, (n, k))
+    if rng.uniform() < 0.5 and k:  # local couplings: long dependency chains in row order
+        cols = (np.arange(n)[:, None] + rng.integers(-3, 4, (n, k))) % n
+    vals = rng.uniform(-1, 1, (n, k))
+    rows = np.repeat(np.arange(n), k).reshape(n, k)
+    vals[cols == rows] = 0.0
+    r, c, v = rows.ravel(), cols.ravel(), vals.ravel()
+    if rng.uniform() < 0.5:  # symmetric pattern
+        r, c, v = np.concatenate([r, c]), np.concatenate([c, r]), np.concatenate([v, v])
+    dom = np.zeros(n)
+    np.add.at(dom, r, np.abs(v))
+    dom += 1.0
+    split = rng.uniform() < 0.5
+    dr = np.arange(n)
+    r = np.concatenate([r, dr] + ([dr] if split else []))
+    c = np.concatenate([c, dr] + ([dr] if split else []))
+    v = np.concatenate([v, dom * (0.6 if split else 1.0)] + ([dom * 0.4] if split else []))
+    o = np.lexsort((rng.uniform(size=len(r)), r))  # rows together, entries inside a row in random order
+    r, c, v = r[o], c[o], v[o]
+    rp = np.zeros(n + 1, np.int64)
+    np.add.at(rp, r + 1, 1)
+    rp, cc = np.cumsum(rp).astype(np.int32), c.astype(np.int32)
+    A = ctx.csr(n, n, rp, cc, v)
+    b_host, x0 = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    b = ctx.vector_from(b_host)
+    for order in (1, 0):
+        A.set_param("symgs_order", order)
+        seq = ctx.symgs_order(A)
+        if order == 1:
+            ncol, _, want_seq = ol.greedy_colour_order(orc, rp, cc)
+            assert np.array_equal(seq, want_seq) and A.get_param("symgs_colours") == ncol
+        else:
+            assert np.array_equal(seq, np.arange(n))
+        sweeps = int(rng.integers(1, 4))
+        want = x0.copy()
+        assert ol.symgs(orc, rp, cc, v, b_host, want, sweeps, order=seq) == 0
+        x = ctx.vector_from(x0)
+        ctx.symgs(A, b, x, sweeps)
+        ctx.sync()
+        err = np.max(np.abs(x.download() - want)) / max(np.max(np.abs(want)), 1e-300)
+        assert err <= ol.REL_TOL, (seed, n, k, order, sweeps, err)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_blas1(ctx, orc, seed):
+    """dot and the axpby branches on random lengths and coefficients (0, 1, -1 and general), w aliasing x or y"""
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.choice([1, 2, 3, 255, 1025, 100_003, 3_000_001]))
+    xh, yh = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    x, y = ctx.vector_from(xh), ctx.vector_from(yh)
+    d = ctx.dot(x, y)
+    assert abs(d - float(xh @ yh)) <= 1e-12 * float(np.abs(xh) @ np.abs(yh)) + 1e-300
+    for alpha in (0.0, 1.0, -1.0, float(rng.uniform(-2, 2))):
+        for beta in (0.0, 1.0, -1.0, float(rng.uniform(-2, 2))):
+            want = np.zeros(n)
+            ol.axpby(orc, alpha, xh, beta, yh, want, fma=True)
+            w = ctx.vector(n)
+            w.fill(np.nan)
+            ctx.axpby(alpha, x, beta, y, w)
+            ctx.sync()
+            assert np.array_equal(w.download(), want), (n, alpha, beta)
+    xa = ctx.vector_from(xh)  # w = x
+    ctx.axpby(0.5, xa, 2.0, y, xa)
+    want = np.zeros(n)
+    ol.axpby(orc, 0.5, xh, 2.0, yh, want, fma=True)
+    ctx.sync()
+    assert np.array_equal(xa.download(), want)
