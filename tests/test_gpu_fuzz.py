@@ -294,3 +294,61 @@ def test_random_blas1(ctx, orc, seed):
     ol.axpby(orc, 0.5, xh, 2.0, yh, want, fma=True)
     ctx.sync()
     assert np.array_equal(xa.download(), want)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_conversions_shards_and_column_splits(ctx, orc, pkg, seed):
+    """COO -> CSR / ELL on the device against the oracle's arrays (bit-exact, in-row order kept); row shards of the CSR
+    (the reference's equal-rows partition, src/mat_vec.cpp:245-246) concatenated; the split by a column range: inside
+    + outside = the whole product, inside rebased"""
+    capi = pkg.capi
+    rng = np.random.default_rng(8000 + seed)
+    nrow = int(rng.choice([1, 9, 500, 30_000, 200_000]))
+    ncol = int(rng.choice([1, 40, 9_000, 700_000]))
+    nnz = int(rng.choice([0, 3, 5_000, 900_000]))
+    row = rng.integers(0, nrow, nnz).astype(np.int32)
+    if rng.uniform() < 0.5:
+        row = np.sort(row)
+    col = rng.integers(0, ncol, nnz).astype(np.int32)
+    val = rng.uniform(-1, 1, nnz)
+    rp, cc, cv = ol.coo_to_csr(orc, nrow, row, col, val)
+    A = ctx.coo(nrow, ncol, row, col, val)
+    Cm = ctx.coo_to_csr(A)
+    a, b, v = Cm.download()
+    assert np.array_equal(a, rp) and np.array_equal(b, cc) and np.array_equal(v, cv)
+    if nrow * max(1, int(np.diff(rp).max())) <= 8_000_000:
+        k, ec, ev = ol.coo_to_ell(orc, nrow, row, col, val)
+        for E in (ctx.coo_to_ell(A), ctx.csr_to_ell(Cm)):
+            assert E.info.ell_k == k
+            _, gc, gv = E.download()
+            assert np.array_equal(gc, ec) and np.array_equal(gv, ev)
+    x = rng.uniform(-1, 1, ncol)
+    ref, scale = np.zeros(nrow), np.zeros(nrow)
+    ol.csr_spmv(orc, rp, cc, cv, x, ref)
+    ol.csr_abs_row_sums(orc, rp, cc, cv, x, scale)
+    dx = ctx.vector_from(x)
+    # row shards
+    nparts = int(rng.choice([1, 2, 3, 8, 17]))
+    rp64 = rp.astype(np.int64)
+    got = np.zeros(nrow)
+    for part in range(nparts):
+        r0, r1 = ol.partition_rows(orc, nrow, nparts, part)
+        S = ctx.csr_shard(r0, r1, ncol, rp64, cc, cv)
+        assert S.info.nrow == r1 - r0 and S.info.row_begin == r0
+        y = ctx.vector(r1 - r0)
+        y.fill(0.0)
+        ctx.apply(S, dx, y)
+        ctx.sync()
+        got[r0:r1] = y.download()
+    ol.assert_parity(got, ref, scale, f"seed {seed}: {nparts} row shards")
+    # column split
+    c0 = int(rng.integers(0, ncol))
+    c1 = int(rng.integers(c0, ncol + 1))
+    inside, outside = ctx.csr_split_columns(Cm, c0, c1)
+    assert inside.info.ncol == c1 - c0 and inside.info.nnz + outside.info.nnz == nnz
+    y = ctx.vector(nrow)
+    y.fill(0.0)
+    ctx.apply(inside, ctx.vector_from(x[c0:c1]), y)
+    ctx.apply(outside, dx, y)
+    ctx.sync()
+    ol.assert_parity(y.download(), ref, scale, f"seed {seed}: columns [{c0}, {c1}) split off")
