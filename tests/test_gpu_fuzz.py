@@ -352,3 +352,35 @@ def test_random_conversions_shards_and_column_splits(ctx, orc, pkg, seed):
     ctx.apply(outside, dx, y)
     ctx.sync()
     ol.assert_parity(y.download(), ref, scale, f"seed {seed}: columns [{c0}, {c1}) split off")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_large_csr_shapes(ctx, orc, pkg, seed):
+    """a few million rows: whole rounds of row groups, thousands of slices, ragged chunk tails, thousands of two-phase
+    panels; ragged row lengths; square, wide and tall"""
+    capi = pkg.capi
+    rng = np.random.default_rng(9000 + seed)
+    nrow = int(rng.choice([1_000_003, 2_500_000, 4_194_304]))
+    ncol = int(rng.choice([300_000, nrow, 31_000_000]))
+    lens = rng.poisson(rng.uniform(3, 14), nrow).astype(np.int64)
+    lens[rng.integers(0, nrow, 5)] = 3000  # a few long rows
+    rp = np.zeros(nrow + 1, np.int64)
+    rp[1:] = np.cumsum(lens)
+    nnz = int(rp[-1])
+    cc = rng.integers(0, ncol, nnz).astype(np.int32)
+    cv = rng.uniform(-1, 1, nnz)
+    rp = rp.astype(np.int32)
+    x = rng.uniform(-1, 1, ncol)
+    ref, scale = np.zeros(nrow), np.zeros(nrow)
+    ol.csr_spmv(orc, rp, cc, cv, x, ref)
+    ol.csr_abs_row_sums(orc, rp, cc, cv, x, scale)
+    A = ctx.csr(nrow, ncol, rp, cc, cv)
+    dx, dy = ctx.vector_from(x), ctx.vector(nrow)
+    runs = [("auto", lambda: None), ("vector", lambda: A.set_kernel(capi.CSR_VECTOR)), ("panel", lambda: A.set_kernel(capi.CSR_PANEL)),
+            ("two-phase", lambda: A.set_kernel(capi.CSR_TWOPHASE))]
+    for name, setup in runs:
+        setup()
+        dy.fill(0.0)
+        ctx.apply(A, dx, dy)
+        ctx.sync()
+        ol.assert_parity(dy.download(), ref, scale, f"seed {seed}: {nrow} x {ncol}, {nnz} entries, {name} (kernel {A.info.kernel})")
