@@ -343,6 +343,7 @@ bool csr_twophase_worth(const spmv_mat* m)
     const double sweeps = 8.0 * (double)m->ncol * kNumXcd * rounds;
     const double runs   = (double)ceil_div(m->ncol, tp_panel_cols(m)) * (double)ceil_div(m->nrow, tp_groups_per(m));
     if ((double)m->nnz < 64.0 * runs) return false;
+    if ((double)m->nnz + (kTpLine - 1) * runs >= 2147483648.0 || runs >= 134217728.0) return false;  // the padded layout must stay within int32
     return sweeps > 12.0 * (double)m->nnz;
 }
 

@@ -641,6 +641,41 @@ def test_full_size_csr_linearity_and_row_sample(ctx, orc, pkg):
     assert np.max(np.abs(y1.download() - 2.0 * h1)) <= 1e-12 * 32
 
 
+def test_csr_at_the_int32_limit_of_entries(ctx, orc, pkg):
+    """67.1M rows x 32 = 2,147,200,000 entries, 283,647 below 2^31: the largest shard the int32 offsets of the
+    reference's containers (and of this engine's shards) can hold.  Generated on the device (26 GB), multiplied through
+    the automatic choice (panel layout: another 26 GB) and the row-parallel kernel; rows at the start, in the middle
+    and at the very end are regenerated on the host and checked against the oracle; the two-phase layout, whose
+    padding would pass 2^31, is refused with a message and the handle keeps working"""
+    synth, capi = pkg.synth, pkg.capi
+    n, k = 67_100_000, 32
+    free, _ = ctx.mem_info()
+    if free < 80 * 2**30:
+        pytest.skip("needs ~60 GB of device memory")
+    A = ctx.gen_csr_uniform(0, n, n, k, band=0, seed=5)
+    assert A.info.nnz == n * k == 2_147_200_000 and A.info.kernel == capi.CSR_PANEL
+    x = ctx.gen_vector(n, seed=5)
+    hx = synth.vec_uniform(n, seed=5)
+    y = ctx.vector(n)
+
+    def check(what):
+        y.fill(0.0)
+        ctx.apply(A, x, y)
+        ctx.sync()
+        for r0 in (0, 33_554_000, n - 1500):
+            rp, cc, cv = synth.csr_uniform(r0, r0 + 1500, n, k, seed=5)
+            ref, scale = np.zeros(1500), np.zeros(1500)
+            ol.csr_spmv(orc, rp, cc, cv, hx, ref)
+            ol.csr_abs_row_sums(orc, rp, cc, cv, hx, scale)
+            ol.assert_parity(y.download(r0, 1500), ref, scale, f"{what}: rows {r0}..")
+
+    check("panel")
+    with pytest.raises(capi.SpmvError, match="too fine|int32|entries"):
+        A.set_kernel(capi.CSR_TWOPHASE)
+    A.set_kernel(capi.CSR_VECTOR)
+    check("row-parallel")
+
+
 # ---------------------------------------------------------------------------------- panel kernel (no locality)
 @pytest.mark.parametrize("make", cases.ALL_CASES, ids=lambda f: f.__name__)
 def test_csr_panel_kernel_matches_reference_golden(ctx, orc, pkg, make):
