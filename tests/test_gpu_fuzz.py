@@ -384,3 +384,56 @@ def test_random_large_csr_shapes(ctx, orc, pkg, seed):
         ctx.apply(A, dx, dy)
         ctx.sync()
         ol.assert_parity(dy.download(), ref, scale, f"seed {seed}: {nrow} x {ncol}, {nnz} entries, {name} (kernel {A.info.kernel})")
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_spd_systems_through_cg_and_the_fused_dot(ctx, orc, pkg, seed):
+    """random symmetric strictly diagonally dominant systems: apply_dot (overwrite or accumulate) through every CSR
+    kernel equals the product and the dot of its result; CG — plain, Jacobi, Gauss-Seidel in both orders — ends with
+    the residual it reports, checked through the oracle's product"""
+    capi = pkg.capi
+    rng = np.random.default_rng(10_000 + seed)
+    n = int(rng.choice([3, 200, 5_000, 120_000, 700_000]))
+    k = int(rng.integers(1, 7))
+    r = np.repeat(np.arange(n), k)
+    c = rng.integers(0, n, n * k) if rng.uniform() < 0.5 else (r + rng.integers(-50, 51, n * k)) % n
+    v = rng.uniform(-1, 1, n * k)
+    keep = r != c
+    r, c, v = r[keep], c[keep], v[keep]
+    rr, cc_, vv = np.concatenate([r, c]), np.concatenate([c, r]), np.concatenate([v, v])
+    diag = np.zeros(n)
+    np.add.at(diag, rr, np.abs(vv))
+    rr, cc_, vv = np.concatenate([rr, np.arange(n)]), np.concatenate([cc_, np.arange(n)]), np.concatenate([vv, diag + rng.uniform(0.05, 1.0, n)])
+    o = np.lexsort((cc_, rr))
+    rr, cc_, vv = rr[o], cc_[o], vv[o]
+    rp = np.zeros(n + 1, np.int64)
+    np.add.at(rp, rr + 1, 1)
+    rp, cc = np.cumsum(rp).astype(np.int32), cc_.astype(np.int32)
+    A = ctx.csr(n, n, rp, cc, vv)
+    xh, wh = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    ref, scale = np.zeros(n), np.zeros(n)
+    ol.csr_spmv(orc, rp, cc, vv, xh, ref)
+    ol.csr_abs_row_sums(orc, rp, cc, vv, xh, scale)
+    x, w, y = ctx.vector_from(xh), ctx.vector_from(wh), ctx.vector(n)
+    for kernel in (capi.CSR_AUTO, capi.CSR_VECTOR, capi.CSR_SCALAR, capi.CSR_PANEL, capi.CSR_TWOPHASE):
+        if kernel == capi.CSR_TWOPHASE and len(vv) < 1000:
+            continue
+        A.set_kernel(kernel)
+        for overwrite in (True, False):
+            y.fill(0.25 if overwrite else 0.0)
+            d = ctx.apply_dot(A, x, y, w, overwrite=overwrite)
+            got = y.download()
+            ol.assert_parity(got, ref, scale, f"seed {seed} n={n} kernel {kernel} overwrite={overwrite}")
+            assert abs(d - float(wh @ got)) <= 1e-11 * float(np.abs(wh) @ np.abs(got)) + 1e-300
+    A.set_kernel(capi.CSR_AUTO)
+    bh = rng.uniform(-1, 1, n)
+    b, sol = ctx.vector_from(bh), ctx.vector(n)
+    for kw in ({}, {"jacobi": True}, {"symgs": True}, {"symgs": True, "row_order": True}):
+        row_order = kw.pop("row_order", False)
+        A.set_param("symgs_order", 0 if row_order else 1)
+        sol.fill(0.0)
+        iters, relres = ctx.cg(A, b, sol, max_iter=500, rel_tol=1e-9, check_every=int(rng.integers(1, 9)), **kw)
+        ax = np.zeros(n)
+        ol.csr_spmv(orc, rp, cc, vv, sol.download(), ax)
+        true_res = np.linalg.norm(bh - ax) / np.linalg.norm(bh)
+        assert relres <= 1e-9 and true_res <= 1e-7, (seed, n, kw, row_order, iters, relres, true_res)
