@@ -225,6 +225,8 @@ struct spmv_mat
 
 namespace spmv
 {
+// a launch holds fewer than 2^32 work-items: beyond that the grid wraps around without an error
+inline bool launch_fits(int64_t items, int lanes_per_item) { return items * lanes_per_item < ((int64_t)1 << 32) - 4096; }
 int ensure_scratch(spmv_ctx* ctx, size_t bytes);
 
 // kernels_csr.hip

@@ -202,6 +202,12 @@ int coo_to_csr(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out)
             hipLaunchKernelGGL(claim_slot_kernel, dim3((unsigned)std::min<int64_t>(kMaxGrid, ceil_div(nnz, kBlock))),
                                dim3(kBlock), 0, s, nnz, coo->a, row_ptr, count, perm);
             constexpr int LPR = 8;
+            if (!launch_fits(nrow, LPR))
+            {
+                set_error("spmv_coo_to_csr: %d rows are more than one launch of the ordering step holds", nrow);
+                rc = SPMV_ERR_UNSUPPORTED;
+                break;
+            }
             hipLaunchKernelGGL(order_rows_kernel<LPR>, dim3((unsigned)ceil_div(nrow, kBlock / LPR)), dim3(kBlock), 0, s,
                                nrow, row_ptr, perm, coo->b, coo->v, out_col, out_val);
         }
@@ -241,6 +247,11 @@ int csr_to_ell(spmv_ctx* ctx, const spmv_mat* csr, spmv_mat** out)
         (void)hipMemsetAsync(const_cast<int32_t*>(ell->b), 0, sizeof(int32_t) * total, ctx->stream);
         (void)hipMemsetAsync(const_cast<double*>(ell->v), 0, sizeof(double) * total, ctx->stream);
         constexpr int LPR = 8;
+        if (!launch_fits(nrow, LPR))
+        {
+            mat_free(ell);
+            SPMV_FAIL(SPMV_ERR_UNSUPPORTED, "spmv_csr_to_ell: %d rows are more than one launch of the fill step holds", nrow);
+        }
         hipLaunchKernelGGL(csr_to_ell_kernel<LPR>, dim3((unsigned)ceil_div(nrow, kBlock / LPR)), dim3(kBlock), 0,
                            ctx->stream, nrow, csr->a, csr->b, csr->v, const_cast<int32_t*>(ell->b),
                            const_cast<double*>(ell->v));

@@ -190,6 +190,12 @@ int gen_coo_powerlaw(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t max_len,
         if ((rc = mat_alloc(ctx, SPMV_FMT_COO, nrow, ncol, nnz, 0, (size_t)nnz, (size_t)nnz, (size_t)nnz, &m)) != SPMV_OK)
             break;
         constexpr int LPR = 8;
+        if (!launch_fits(nrow, LPR))
+        {
+            set_error("spmv_gen_coo_powerlaw: %d rows are more than one launch of the fill step holds", nrow);
+            rc = SPMV_ERR_UNSUPPORTED;
+            break;
+        }
         if (nrow > 0)
             hipLaunchKernelGGL(gen_coo_fill_kernel<LPR>, dim3((unsigned)ceil_div(nrow, kBlock / LPR)), dim3(kBlock), 0,
                                ctx->stream, nrow, ncol, max_len, stream_key(seed, kStreamCol),

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void csc_expand_cols_kernel(int ncol, const
 int csc_analyse(spmv_mat* m)
 {
     const bool worth = m->nnz >= ((int64_t)2 << 20) && m->nrow > 0 && m->nnz / m->nrow >= 2 &&
-                       m->nnz <= (int64_t)INT32_MAX - 65536;
+                       m->nnz <= (int64_t)INT32_MAX - 65536 && launch_fits(m->ncol, 8);
     if (!worth || m->coo_csr) return SPMV_OK;
     spmv_ctx* ctx = m->ctx;
     int32_t*  cols = nullptr;
@@ -332,6 +332,7 @@ int csc_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
     if (A->ncol == 0 || A->nnz == 0) return SPMV_OK;
     if (A->coo_csr && !A->kernel_forced) return csr_panel_apply(ctx, A->coo_csr, x, y);
     constexpr int LPC = 8;
+    if (!launch_fits(A->ncol, LPC)) SPMV_FAIL(SPMV_ERR_UNSUPPORTED, "CSC product: %d columns are more than one launch holds", A->ncol);
     hipLaunchKernelGGL(csc_kernel<LPC>, dim3((unsigned)ceil_div(A->ncol, kBlock / LPC)), dim3(kBlock), 0, ctx->stream,
                        A->ncol, A->a, A->b, A->v, x, y);
     SPMV_HIP(hipGetLastError());
