@@ -6,12 +6,15 @@ clustered, every CSR kernel (row-parallel, one lane per row, LDS window where it
 chunk sizes, pipelines and wavefront syncs, two-phase with several panel widths), ELL handles from clean stencils to
 noise, COO in file order with duplicates.  Gate: SURVEY 8d's two tolerances for kernels that reorder sums, equality bit
 for bit with the fma oracle for the kernels that keep the reference's order (ELL, one lane per row)."""
+import os
+
 import numpy as np
 import pytest
 
 import oracle_lib as ol
 
 pytestmark = pytest.mark.gpu
+BASE = int(os.environ.get("SPMV_FUZZ_BASE", "0"))  # other seeds: SPMV_FUZZ_BASE=1000 pytest -m gpu tests/test_gpu_fuzz.py
 
 
 def _random_csr(rng):
@@ -46,7 +49,7 @@ def _random_csr(rng):
 @pytest.mark.parametrize("seed", range(40))
 def test_random_csr_shapes_through_every_kernel(ctx, orc, pkg, seed):
     capi = pkg.capi
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(BASE + 1000 + seed)
     nrow, ncol, rp, cc, cv = _random_csr(rng)
     nnz = len(cv)
     x = rng.uniform(-1, 1, ncol)
@@ -100,7 +103,7 @@ def test_random_csr_shapes_through_every_kernel(ctx, orc, pkg, seed):
 def test_random_ell_handles_from_stencils_to_noise(ctx, orc, pkg, seed):
     """column-major ELL with a random mix of diagonal slots, padding and arbitrary columns: the diagonal-slot kernel (when
     the analysis takes it) and the plain ones must equal the fma oracle exactly"""
-    rng = np.random.default_rng(2000 + seed)
+    rng = np.random.default_rng(BASE + 2000 + seed)
     nrow = int(rng.choice([1024, 1026, 5000, 33_334, 120_000]))
     ncol = int(rng.choice([nrow, nrow + 77, max(64, nrow // 3), 4 * nrow]))
     k = int(rng.integers(1, 12))
@@ -134,7 +137,7 @@ def test_random_ell_handles_from_stencils_to_noise(ctx, orc, pkg, seed):
 @pytest.mark.parametrize("seed", range(16))
 def test_random_coo_in_file_order_with_duplicates(ctx, orc, pkg, seed):
     capi = pkg.capi
-    rng = np.random.default_rng(3000 + seed)
+    rng = np.random.default_rng(BASE + 3000 + seed)
     nrow = int(rng.choice([1, 17, 3000, 90_000]))
     ncol = int(rng.choice([1, 100, 50_000, 2_000_000]))
     nnz = int(rng.choice([0, 1, 1000, 400_000, 3_000_000]))
@@ -169,7 +172,7 @@ def test_random_coo_in_file_order_with_duplicates(ctx, orc, pkg, seed):
 def test_random_dia_handles(ctx, orc, pkg, seed):
     """row-major DIA with random offsets (narrow bands: x through LDS; far offsets: x from global memory), odd and even
     diagonal counts, rectangular shapes: bit for bit the fma oracle (x padded with zeros where the reference over-reads)"""
-    rng = np.random.default_rng(4000 + seed)
+    rng = np.random.default_rng(BASE + 4000 + seed)
     nrow = int(rng.choice([1, 255, 256, 257, 5000, 70_001]))
     ncol = int(rng.choice([nrow, max(1, nrow // 2), nrow + 300, 3 * nrow]))
     nd = int(rng.integers(1, 20))
@@ -195,7 +198,7 @@ def test_random_dia_handles(ctx, orc, pkg, seed):
 @pytest.mark.parametrize("seed", range(10))
 def test_random_csc_handles(ctx, orc, pkg, seed):
     capi = pkg.capi
-    rng = np.random.default_rng(5000 + seed)
+    rng = np.random.default_rng(BASE + 5000 + seed)
     nrow = int(rng.choice([1, 300, 40_000, 400_000]))
     ncol = int(rng.choice([1, 77, 30_000, 500_000]))
     nnz = int(rng.choice([0, 5, 20_000, 2_500_000]))
@@ -224,7 +227,7 @@ def test_random_systems_through_the_gauss_seidel_sweep(ctx, orc, pkg, seed):
     """random diagonally dominant matrices — symmetric or not in pattern, rows in random order, the diagonal entry
     sometimes split in two — in both sweep orders, 1-3 sweeps, against the oracle's sweep over the sequence the engine
     reports; the multicolour sequence against the oracle's sequential greedy colouring"""
-    rng = np.random.default_rng(6000 + seed)
+    rng = np.random.default_rng(BASE + 6000 + seed)
     n = int(rng.choice([2, 65, 1000, 20_000, 150_000]))
     k = int(rng.integers(0, 9))
     cols = rng.integers(0, n, (n, k))
@@ -273,7 +276,7 @@ def test_random_systems_through_the_gauss_seidel_sweep(ctx, orc, pkg, seed):
 @pytest.mark.parametrize("seed", range(10))
 def test_random_blas1(ctx, orc, seed):
     """dot and the axpby branches on random lengths and coefficients (0, 1, -1 and general), w aliasing x or y"""
-    rng = np.random.default_rng(7000 + seed)
+    rng = np.random.default_rng(BASE + 7000 + seed)
     n = int(rng.choice([1, 2, 3, 255, 1025, 100_003, 3_000_001]))
     xh, yh = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
     x, y = ctx.vector_from(xh), ctx.vector_from(yh)
@@ -302,7 +305,7 @@ def test_random_conversions_shards_and_column_splits(ctx, orc, pkg, seed):
     (the reference's equal-rows partition, src/mat_vec.cpp:245-246) concatenated; the split by a column range: inside
     + outside = the whole product, inside rebased"""
     capi = pkg.capi
-    rng = np.random.default_rng(8000 + seed)
+    rng = np.random.default_rng(BASE + 8000 + seed)
     nrow = int(rng.choice([1, 9, 500, 30_000, 200_000]))
     ncol = int(rng.choice([1, 40, 9_000, 700_000]))
     nnz = int(rng.choice([0, 3, 5_000, 900_000]))
@@ -359,7 +362,7 @@ def test_random_large_csr_shapes(ctx, orc, pkg, seed):
     """a few million rows: whole rounds of row groups, thousands of slices, ragged chunk tails, thousands of two-phase
     panels; ragged row lengths; square, wide and tall"""
     capi = pkg.capi
-    rng = np.random.default_rng(9000 + seed)
+    rng = np.random.default_rng(BASE + 9000 + seed)
     nrow = int(rng.choice([1_000_003, 2_500_000, 4_194_304]))
     ncol = int(rng.choice([300_000, nrow, 31_000_000]))
     lens = rng.poisson(rng.uniform(3, 14), nrow).astype(np.int64)
@@ -392,7 +395,7 @@ def test_random_spd_systems_through_cg_and_the_fused_dot(ctx, orc, pkg, seed):
     kernel equals the product and the dot of its result; CG — plain, Jacobi, Gauss-Seidel in both orders — ends with
     the residual it reports, checked through the oracle's product"""
     capi = pkg.capi
-    rng = np.random.default_rng(10_000 + seed)
+    rng = np.random.default_rng(BASE + 10_000 + seed)
     n = int(rng.choice([3, 200, 5_000, 120_000, 700_000]))
     k = int(rng.integers(1, 7))
     r = np.repeat(np.arange(n), k)
