@@ -150,3 +150,38 @@ def test_spmv_main_on_a_stencil_matrix_file(tmp_path):
         assert mm and float(mm.group(1)) <= 1e-10, (name, res.stdout)
     mm = re.search(r"### DIA VERIFY \(informational\) .* = ([0-9.e+-]+)", res.stdout)
     assert mm and float(mm.group(1)) <= 1e-10, res.stdout  # no duplicate entries here: DIA agrees as well
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_spmv_main_on_random_files_shard_counts_and_x_slicings(tmp_path, pkg, seed):
+    """the whole drop-in flow (file -> COOMatrixRead -> constructors -> products -> sharded drivers) on random square
+    matrices with random row lengths, shard counts from 1 to more than there are rows, and x assembled from 1-5 slices"""
+    import os
+
+    rng = np.random.default_rng(500 + seed)
+    n = int(rng.choice([1, 2, 37, 800, 6000]))
+    lens = rng.integers(0, 12, n)
+    row = np.repeat(np.arange(n, dtype=np.int32), lens)
+    col = rng.integers(0, n, len(row)).astype(np.int32)
+    key = row.astype(np.int64) * n + col
+    _, first = np.unique(key, return_index=True)  # no duplicate (i, j): the reference's DIA would keep the last one only
+    first.sort()
+    row, col = row[first], col[first]
+    val = rng.uniform(-1, 1, len(row))
+    if len(row) == 0:
+        row, col, val = np.zeros(1, np.int32), np.zeros(1, np.int32), np.ones(1)
+    p = tmp_path / f"r{seed}.mtx"
+    _write_mtx(p, dict(nrow=n, ncol=n, row=row, col=col, val=val))
+    shards = int(rng.choice([1, 2, 3, 7, 16, 2 * n + 3]))
+    env = dict(os.environ)
+    parts = int(rng.choice([0, 2, 5]))
+    if parts:
+        env["SPMV_COMPAT_X_PARTS"] = str(parts)
+    fmts = "coo,csr,csc,ell" + (",dia" if n <= 800 else "")  # (DIA of a random matrix has ~n diagonals)
+    r = subprocess.run([str(BIN / "spmv_main"), str(p), str(shards), "--format", fmts, "--verify", "--reps", "3"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, (seed, n, shards, parts, r.stdout[-1500:] + r.stderr[-1500:])
+    names = ["CSR", "CSR NUMA", "CSC", "CSC NUMA", "ELL", "ELL NUMA", "COO NUMA"] + (["DIA NUMA"] if n <= 800 else [])
+    for name in names:
+        m = re.search(rf"### {name} VERIFY .* = ([0-9.e+-]+) OK", r.stdout)
+        assert m and float(m.group(1)) <= 1e-10, (seed, n, shards, parts, name, r.stdout[-1500:])
