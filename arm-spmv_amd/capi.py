@@ -407,8 +407,12 @@ class Comm:
         return self._lib.spmv_comm_backend(self.h).decode()
 
     def allgather(self, vecs, offsets) -> None:
-        arr = (_vp * len(vecs))(*[v.h for v in vecs])
+        n = len(self.ctxs)
         off = np.ascontiguousarray(offsets, dtype=np.int64)
+        # the C side reads vecs[0..n) and offsets[0..n]: a short array would be read out of bounds on the host
+        if len(vecs) != n or off.ndim != 1 or off.size != n + 1:
+            raise ValueError(f"Comm.allgather: {n} participants need {n} vectors and {n + 1} offsets, got {len(vecs)} and {off.size}")
+        arr = (_vp * n)(*[v.h for v in vecs])
         _check(self._lib.spmv_comm_allgather(self.h, arr, off.ctypes.data_as(_i64p)))
 
 

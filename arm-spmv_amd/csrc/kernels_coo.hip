@@ -158,6 +158,7 @@ int coo_build_panel(spmv_mat* m, bool only_if_worth)
     SPMV_TRY(coo_to_csr(m->ctx, m, &csr));  // csr_analyse inside picks (and builds) the panel layout when x is large
     if (csr->kernel != SPMV_CSR_PANEL)
     {
+        csr_twophase_free(csr);  // csr_analyse may have chosen (and built) the two-phase layout: not the one that runs here
         csr->kernel_forced = true;
         csr->kernel        = SPMV_CSR_PANEL;
         int rc             = csr_panel_build(csr);

@@ -437,14 +437,14 @@ int symgs_setup(spmv_mat* m)
     SPMV_REQUIRE(m->nnz == 0 || (m->b && m->v), "spmv_symgs: the CSR arrays are gone (panel_keep_csr = 0 released them)");
     const int   n = m->nrow;
     hipStream_t s = ctx->stream;
+    SPMV_TRY(ensure_scratch(ctx, 64));  // (before the plan is attached: a failure here leaves no half-built plan behind)
     symgs_plan* g = new symgs_plan();
+    g->mode       = m->gs_order != 0 ? 1 : 0;
     m->gs         = g;
     if (n == 0) return SPMV_OK;
     int32_t *lo_cnt = nullptr, *up_cnt = nullptr, *colour = nullptr, *pos = nullptr;
     int      rc     = SPMV_OK;
-    SPMV_TRY(ensure_scratch(ctx, 64));
     int* flag = (int*)ctx->scratch;
-    g->mode   = m->gs_order != 0 ? 1 : 0;
     do
     {
         if (g->mode == 1)

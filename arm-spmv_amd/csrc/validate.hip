@@ -35,6 +35,15 @@ inline unsigned grid_for(int64_t n) { return (unsigned)std::max<int64_t>(1, std:
 int mat_validate(const spmv_mat* m)
 {
     spmv_ctx* ctx = m->ctx;
+    // a handle that released its index arrays (panel_keep_csr = 0) has nothing left to check: refuse on the host, the
+    // kernels below would dereference a null pointer on the GPU
+    const int64_t entries = m->format == SPMV_FMT_ELL ? (int64_t)m->nrow * m->k : m->nnz;
+    if (m->format != SPMV_FMT_DIA)
+    {
+        const bool need_a = m->format != SPMV_FMT_ELL && (m->format != SPMV_FMT_COO || entries > 0);
+        SPMV_REQUIRE(!(need_a && !m->a) && !(entries > 0 && !m->b),
+                     "spmv_mat_validate: this handle gave up its index arrays (panel_keep_csr = 0): validate before releasing them");
+    }
     SPMV_TRY(ensure_scratch(ctx, 64));
     int32_t*    flags = (int32_t*)ctx->scratch;
     hipStream_t s     = ctx->stream;

@@ -707,11 +707,13 @@ void run_shards(const char* fmt_name, std::vector<Shard>& shards, const Vector& 
     for (int p = 0; p < parts; ++p) check(spmv_sync(pctx[(size_t)p]), "spmv_sync");
 
     const auto t0 = std::chrono::steady_clock::now();
+    // Every repetition of every shard is queued on its device's stream and the host waits ONCE at the end: the devices
+    // work through their queues side by side, and no launch latency is serialised between repetitions.  (The reference
+    // joins its threads in every repetition only because it re-creates them there, src/mat_vec.cpp:274-281; the timed
+    // quantity - NTESTS products of every shard - is the same.)
     for (int k = 0; k < g_numa_reps; ++k)
-    {
         for (Shard& s : shards) check(spmv_apply(E.ctx(s.device), s.mat, replica_of(s.device), s.y), "spmv_apply(shard)");
-        for (Shard& s : shards) check(spmv_sync(E.ctx(s.device)), "spmv_sync");  // the reference joins all threads per repetition
-    }
+    for (Shard& s : shards) check(spmv_sync(E.ctx(s.device)), "spmv_sync");
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     // same expression as src/mat_vec.cpp:284 (milliseconds per repetition; the "+ secs/1000" term is the reference's)
     const double t_avg = (secs * 1000.0 + secs / 1000.0) / g_numa_reps;

@@ -7,11 +7,22 @@
 //
 //   spmv_main <file.mtx> <nshards> [options]          nshards plays the role of main.cpp's nthreads (argv[2])
 //   spmv_main --synthetic uniform|band --n N [--k K] [--band W] [--seed S] <nshards> [options]
+//   spmv_main --synthetic uniform|band --n ROWS_PER_SHARD [--k K] [--band W] [--seed S] --sharded --gpus P [--reps R]
+//             [--check-rows C --check-out FILE]
+//        the sharded driver at BASELINE sizes (configs[4]: --n 10000000 --k 32 --gpus 8): P row shards of a
+//        (P*n x P*n) matrix, every shard GENERATED ON ITS DEVICE (no host container, so no int32 entry count in the way:
+//        the reference's CSRMatrixMatVectorNuma cannot hold 2.56e9 entries, src/mat_vec.cpp:260-263 rebases per shard for
+//        that reason), x slices drawn on the devices and all-gathered through spmv_comm_allgather (RCCL / peer copies),
+//        the timed loop of src/mat_vec.cpp:270-282 with one host thread queueing on every device's stream, then
+//        "### CSR NUMA GFLOPS" and one JSON line.  Shard i lives on GPU i % (GPUs present).
 // options: --format coo,csr,csc,ell,dia   (default coo,csr,ell)     --reps R (default 50)
 //          --no-dropin   skip the host-vector timing       --no-numa  skip the sharded drivers
 //          --verify      compare every format's y with the COO result (norm-wise 1e-10)
+#include <algorithm>
 #include <chrono>
+#include <climits>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -29,7 +40,9 @@ struct Options
     std::string file, synthetic, formats = "coo,csr,ell";
     int         shards = 1, reps = 50, n = 0, k = 32, band = 0;
     unsigned long long seed = 1;
-    bool dropin = true, numa = true, verify = false;
+    bool dropin = true, numa = true, verify = false, sharded = false;
+    int         gpus = 1, check_rows = 0;
+    std::string check_out;
     bool has(const char* f) const { return ("," + formats + ",").find(std::string(",") + f + ",") != std::string::npos; }
 };
 
@@ -84,10 +97,156 @@ void dropin(const char* name, double nnz, Vector& y, int reps, Fn product)
     printf("### %s GPU GFLOPS = %.5f   (drop-in call: x and y cross PCIe every product)\n", name, gflops(nnz, dt, reps));
 }
 
+
+// ---- the sharded driver on device-generated shards (BASELINE configs[4]) ------------------------------------------
+// CSRMatrixMatVectorNuma's protocol (src/mat_vec.cpp:230-297) without a host matrix: partition the rows (:245-246),
+// build every shard where it will run (:254-265: here spmv_gen_csr_uniform draws rows [row0, row1) of the global matrix
+// on the shard's GPU, rebased row_ptr + global columns), give every participant a full x (:257,:266: here each
+// participant draws ITS slice and spmv_comm_allgather assembles the replicas on the devices), zero the y slices (:267),
+// time NTESTS products of every shard (:270-282), print the reference's line (:285).
+int run_sharded_synthetic(const Options& o)
+{
+    int ndev = 0;
+    check(spmv_device_count(&ndev), "spmv_device_count");
+    if (ndev < 1) armspmv::die("spmv_device_count: no GPU");
+    const int     P    = o.gpus;
+    const int64_t ncol64 = (int64_t)o.n * P;
+    if (ncol64 > INT32_MAX)
+    {
+        printf("spmv_main: %lld columns exceed the int32 column indices of the reference's containers\n", (long long)ncol64);
+        return 2;
+    }
+    const int  ncol = (int)ncol64;
+    const int  band = o.synthetic == "band" ? o.band : 0;
+    std::vector<spmv_ctx*> ctx((size_t)P, nullptr);
+    std::vector<spmv_mat*> mat((size_t)P, nullptr);
+    std::vector<spmv_vec*> xs((size_t)P, nullptr), ys((size_t)P, nullptr);
+    std::vector<int64_t>   off((size_t)P + 1, 0);
+    std::vector<spmv_mat_info> info((size_t)P);
+    int64_t      nnz_total = 0, bytes_total = 0;
+    const double t_build0  = now_s();
+    for (int i = 0; i < P; ++i)
+    {
+        check(spmv_ctx_create(i % ndev, &ctx[(size_t)i]), "spmv_ctx_create");
+        int64_t r0 = 0, r1 = 0;
+        check(spmv_partition_rows(ncol64, P, i, &r0, &r1), "spmv_partition_rows");
+        off[(size_t)i]     = r0;
+        off[(size_t)i + 1] = r1;
+        check(spmv_gen_csr_uniform(ctx[(size_t)i], r0, r1, ncol, o.k, band, o.seed, &mat[(size_t)i]), "spmv_gen_csr_uniform(shard)");
+        check(spmv_mat_get_info(mat[(size_t)i], &info[(size_t)i]), "spmv_mat_get_info");
+        if (info[(size_t)i].kernel == SPMV_CSR_PANEL || info[(size_t)i].kernel == SPMV_CSR_TWOPHASE)
+            check(spmv_mat_set_param(mat[(size_t)i], "panel_keep_csr", 0), "panel_keep_csr");  // the product's own layout only: 1x the matrix
+        int64_t held = 0;
+        check(spmv_mat_get_param(mat[(size_t)i], "device_bytes", &held), "device_bytes");
+        bytes_total += held;
+        nnz_total += info[(size_t)i].nnz;
+        // x: the participant's own slice, drawn in place inside its full-length vector
+        check(spmv_vec_create(ctx[(size_t)i], ncol, &xs[(size_t)i]), "spmv_vec_create(x)");
+        check(spmv_vec_fill(xs[(size_t)i], -1.0), "spmv_vec_fill(x)");  // whatever is not the own slice must come from the others
+        double* xp = nullptr;
+        check(spmv_vec_device_ptr(xs[(size_t)i], &xp), "spmv_vec_device_ptr");
+        if (r1 > r0)
+        {
+            spmv_vec* own = nullptr;
+            check(spmv_vec_wrap_device(ctx[(size_t)i], r1 - r0, xp + r0, &own), "spmv_vec_wrap_device(x slice)");
+            check(spmv_gen_vec_uniform(ctx[(size_t)i], own, r0, o.seed), "spmv_gen_vec_uniform(x slice)");
+            check(spmv_vec_destroy(own), "spmv_vec_destroy");
+        }
+        check(spmv_vec_create(ctx[(size_t)i], r1 - r0, &ys[(size_t)i]), "spmv_vec_create(y)");
+        check(spmv_vec_fill(ys[(size_t)i], 0.0), "spmv_vec_fill(y)");
+    }
+    auto sync_all = [&] {
+        for (int i = 0; i < P; ++i) check(spmv_sync(ctx[(size_t)i]), "spmv_sync");
+    };
+    sync_all();
+    const double build_s = now_s() - t_build0;
+    printf("### ROW=%lld, COL=%d, NNZ=%lld   (%d shards of %d rows, generated on %d GPU%s)\n", (long long)ncol64, ncol, (long long)nnz_total, P, o.n,
+           std::min(P, ndev), std::min(P, ndev) > 1 ? "s" : "");
+
+    spmv_comm* comm = nullptr;
+    check(spmv_comm_create(ctx.data(), P, &comm), "spmv_comm_create");
+    const std::string backend = spmv_comm_backend(comm);
+    double t0 = now_s();
+    check(spmv_comm_allgather(comm, xs.data(), off.data()), "spmv_comm_allgather(x)");
+    sync_all();
+    const double first_gather_ms = (now_s() - t0) * 1e3;
+
+    auto products = [&] {
+        for (int i = 0; i < P; ++i) check(spmv_apply(ctx[(size_t)i], mat[(size_t)i], xs[(size_t)i], ys[(size_t)i]), "spmv_apply(shard)");
+    };
+    for (int w = 0; w < 3; ++w) products();  // warm-up
+    sync_all();
+    // the timed loop (src/mat_vec.cpp:270-282).  One host thread queues every repetition on every participant's stream;
+    // the devices run their queues side by side and the host waits once at the end (the reference joins its threads in
+    // every repetition because it re-creates them there, :274-281).
+    t0 = now_s();
+    for (int r = 0; r < o.reps; ++r) products();
+    const double queued_s = now_s() - t0;
+    sync_all();
+    const double secs = now_s() - t0;
+    // the same loop with the exchange charged to every repetition (x changes per iteration in a solver)
+    t0 = now_s();
+    for (int r = 0; r < o.reps; ++r)
+    {
+        check(spmv_comm_allgather(comm, xs.data(), off.data()), "spmv_comm_allgather(x)");
+        products();
+    }
+    sync_all();
+    const double secs_x = now_s() - t0;
+    t0 = now_s();
+    for (int r = 0; r < 10; ++r) check(spmv_comm_allgather(comm, xs.data(), off.data()), "spmv_comm_allgather(x)");
+    sync_all();
+    const double gather_ms = (now_s() - t0) * 1e3 / 10;
+
+    const double t_avg = (secs * 1000.0 + secs / 1000.0) / o.reps;  // src/mat_vec.cpp:284, its stray term included
+    printf("### CSR NUMA GFLOPS = %.5f\n", 2.0 * (double)nnz_total / t_avg / 1e6);
+
+    // rows for an outside check: y of ONE product from y = 0 for the first, middle and last `check_rows` rows of every shard
+    if (o.check_rows > 0 && !o.check_out.empty())
+    {
+        FILE* f = fopen(o.check_out.c_str(), "w");
+        if (!f) armspmv::die("fopen(--check-out)");
+        for (int i = 0; i < P; ++i)
+        {
+            check(spmv_vec_fill(ys[(size_t)i], 0.0), "spmv_vec_fill(y)");
+            check(spmv_apply(ctx[(size_t)i], mat[(size_t)i], xs[(size_t)i], ys[(size_t)i]), "spmv_apply(shard)");
+            const int64_t rows = off[(size_t)i + 1] - off[(size_t)i];
+            const int64_t c    = std::min<int64_t>(o.check_rows, rows);
+            std::vector<double> buf((size_t)c);
+            for (int64_t start : {(int64_t)0, (rows - c) / 2, rows - c})
+            {
+                if (c == 0) break;
+                check(spmv_vec_download(ys[(size_t)i], start, c, buf.data()), "spmv_vec_download(y rows)");
+                for (int64_t j = 0; j < c; ++j) fprintf(f, "%lld %a\n", (long long)(off[(size_t)i] + start + j), buf[(size_t)j]);
+            }
+        }
+        fclose(f);
+    }
+    const double ms = secs * 1e3 / o.reps;
+    printf("{\"harness\": \"spmv_main --sharded\", \"participants\": %d, \"gpus_present\": %d, \"exchange\": \"%s\", \"rows_per_shard\": %d, "
+           "\"ncol\": %d, \"nnz_per_row\": %d, \"band\": %d, \"nnz_total\": %lld, \"reps\": %d, \"ms_per_product\": %.5f, \"gflops\": %.3f, "
+           "\"host_queueing_ms_per_product\": %.5f, \"with_x_allgather_each_step\": {\"ms_per_product\": %.5f, \"gflops\": %.3f, "
+           "\"allgather_ms\": %.4f, \"first_allgather_ms\": %.3f, \"bytes_per_participant\": %lld}, \"kernel_of_shard_0\": %d, "
+           "\"device_bytes_held\": %lld, \"build_seconds\": %.3f}\n",
+           P, ndev, backend.c_str(), o.n, ncol, o.k, band, (long long)nnz_total, o.reps, ms, 2.0 * (double)nnz_total / ms / 1e6,
+           queued_s * 1e3 / o.reps, secs_x * 1e3 / o.reps, 2.0 * (double)nnz_total / (secs_x * 1e3 / o.reps) / 1e6, gather_ms, first_gather_ms,
+           (long long)(8 * (int64_t)o.n), (int)info[0].kernel, (long long)bytes_total, build_s);
+    spmv_comm_destroy(comm);
+    for (int i = 0; i < P; ++i)
+    {
+        spmv_vec_destroy(xs[(size_t)i]);
+        spmv_vec_destroy(ys[(size_t)i]);
+        spmv_mat_destroy(mat[(size_t)i]);
+        spmv_ctx_destroy(ctx[(size_t)i]);
+    }
+    return 0;
+}
+
 int usage()
 {
     printf("Usage: spmv_main <file.mtx> <nshards> [--format coo,csr,csc,ell,dia] [--reps R] [--verify] [--no-dropin] [--no-numa]\n"
-           "       spmv_main --synthetic uniform|band --n N [--k K] [--band W] [--seed S] <nshards> [...]\n");
+           "       spmv_main --synthetic uniform|band --n N [--k K] [--band W] [--seed S] <nshards> [...]\n"
+           "       spmv_main --synthetic uniform|band --n ROWS_PER_SHARD [--k K] [--band W] --sharded --gpus P [--reps R] [--check-rows C --check-out FILE]\n");
     return -1;
 }
 }  // namespace
@@ -108,6 +267,10 @@ int main(int argc, char* argv[])
         else if (a == "--band") o.band = atoi(next());
         else if (a == "--seed") o.seed = strtoull(next(), 0, 10);
         else if (a == "--verify") o.verify = true;
+        else if (a == "--sharded") o.sharded = true;
+        else if (a == "--gpus") o.gpus = atoi(next());
+        else if (a == "--check-rows") o.check_rows = atoi(next());
+        else if (a == "--check-out") o.check_out = next();
         else if (a == "--no-dropin") o.dropin = false;
         else if (a == "--no-numa") o.numa = false;
         else pos.push_back(a);
@@ -117,6 +280,12 @@ int main(int argc, char* argv[])
         if (pos.size() < 2) return usage();  // main.cpp:20-24
         o.file   = pos[0];
         o.shards = atoi(pos[1].c_str());
+    }
+    else if (o.sharded)
+    {
+        if (o.n <= 0 || o.gpus < 1) return usage();
+        if (o.reps < 1) o.reps = 1;
+        return run_sharded_synthetic(o);
     }
     else
     {

@@ -43,6 +43,50 @@ def algorithmic_bytes(fmt: str, nrow: int, ncol: int, nnz: int, k: int = 0) -> i
     raise ValueError(fmt)
 
 
+L2_PEAK_GBS = 34500.0  # the eight L2s together, 128-byte line operations (same guide, "L2 (per XCD)")
+
+
+def required_bytes(kind: str, nrow: int, ncol: int, nnz: int, k: int = 0) -> int:
+    """Bytes the kernel that actually ran HAS to move (its own storage, x once, y read + written) — what `roofline.frac`
+    of an extra line is measured against, so that no fraction can exceed 1.  `kind`:
+      csr / panel      12 B per entry + row_ptr          (the panel layout packs an entry into 12 bytes: CSR's own cost)
+      ell_columns      12 B per slot                      (one lane per row, column indices read)
+      ell_diagonals    8 B per slot                       (slots recognised as diagonals: no index stream)
+      coo_segscan      16 B per entry                     (row, column, value)"""
+    if kind in ("csr", "panel"):
+        return 12 * nnz + 4 * (nrow + 1) + 8 * ncol + 16 * nrow
+    if kind == "ell_columns":
+        return 12 * nrow * k + 8 * ncol + 16 * nrow
+    if kind == "ell_diagonals":
+        return 8 * nrow * k + 8 * ncol + 16 * nrow
+    if kind == "coo_segscan":
+        return 16 * nnz + 8 * ncol + 16 * nrow
+    raise ValueError(kind)
+
+
+def measured_counters(key: str, kernel: str, layout: dict | None) -> dict:
+    """HBM bytes and L2 line operations per launch from the committed PMC passes (profiles/pmc_traffic.json), or nulls
+    when that file's entry was measured on another kernel or panel layout than the one that just ran — a stale
+    constant must not pass for a measurement."""
+    none = {"traffic": None, "l2_line_ops": None, "measured_on": None}
+    tfile = ROOT / "profiles" / "pmc_traffic.json"
+    if not tfile.exists():
+        return none
+    e = json.loads(tfile.read_text()).get(key)
+    if not e:
+        return none
+    want = e.get("match", {})
+    if want.get("kernel") and want["kernel"] not in kernel:
+        return dict(none, measured_on=f"stale: counters are for {want['kernel']}, this run used {kernel}")
+    for name, val in (want.get("panel_layout") or {}).items():
+        if layout is None or int(layout.get(name, -1)) != int(val):
+            return dict(none, measured_on=f"stale: counters are for panel {name}={val}, this run has {None if layout is None else layout.get(name)}")
+    ops = None
+    if e.get("tcp_tcc_read_req") and e.get("tcc_miss"):
+        ops = int(e["tcp_tcc_read_req"]) + int(e["tcc_miss"])  # L1->L2 read requests + fills from the fabric
+    return {"traffic": e.get("hbm_bytes_per_launch"), "l2_line_ops": ops, "measured_on": e.get("kernel")}
+
+
 def host_topology() -> dict:
     """sockets / NUMA nodes / physical cores of the host and of the CPUs this process may run on"""
     import subprocess
@@ -79,6 +123,52 @@ def host_topology() -> dict:
     }
 
 
+def host_limits() -> dict:
+    """what bounds the CPU leg besides the core count: the cgroup's CPU quota (a container may see 256 CPUs and be
+    allowed 16 CPUs' worth of time), its cpuset, and the NUMA nodes the allowed CPUs sit on (no numactl on the box:
+    read from sysfs)"""
+    out = {}
+    for name, path in (("cgroup_cpu_max", "/sys/fs/cgroup/cpu.max"), ("cgroup_cpuset_effective", "/sys/fs/cgroup/cpuset.cpus.effective"),
+                       ("cgroup_cpu_stat", "/sys/fs/cgroup/cpu.stat")):
+        try:
+            out[name] = Path(path).read_text().strip().replace("\n", "; ")[:300]
+        except OSError:
+            out[name] = None
+    quota = None
+    try:
+        q, period = (out.get("cgroup_cpu_max") or "max 100000").split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except ValueError:
+        pass
+    if quota is None:  # cgroup v1
+        try:
+            q = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+            per = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            if q > 0:
+                quota = q / per
+                out["cgroup_cpu_max"] = f"{q} {per} (v1 cfs_quota_us cfs_period_us)"
+        except (OSError, ValueError):
+            pass
+    out["cgroup_cpu_quota_cpus"] = round(quota, 2) if quota else None
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = []
+    nodes = {}
+    for node in sorted(Path("/sys/devices/system/node").glob("node[0-9]*")):
+        try:
+            cpus = set()
+            for part in (node / "cpulist").read_text().strip().split(","):
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+            nodes[node.name] = len(cpus & set(allowed))
+        except (OSError, ValueError):
+            pass
+    out["allowed_cpus_per_numa_node"] = nodes or None
+    return out
+
+
 def cpu_baseline_child(args) -> dict:
     """The CPU leg of the report, in a process of its own (no torch: its OpenMP runtime and thread pools would be in
     the way; OMP_PROC_BIND / OMP_PLACES have to be in the environment before libgomp starts).  Times, on the GPU box's
@@ -104,6 +194,7 @@ def cpu_baseline_child(args) -> dict:
     import oracle_lib as ol  # the checker / baseline only — never on the product path
 
     topo = host_topology()
+    facts = host_limits()  # (before libgomp starts: OMP_PROC_BIND pins the initial thread, and with it sched_getaffinity)
     threads = max(1, min(topo["allowed_physical_cores"], args.cpu_threads if args.cpu_threads > 0 else 1 << 30))
     nrow_total = args.n * max(args.gpus, 1)
     m = min(args.cpu_sample_rows, args.n)
@@ -132,17 +223,44 @@ def cpu_baseline_child(args) -> dict:
         return reps, total
 
     modes = []
-    # ---- OpenMP mode
-    y = np.zeros(m)
-    gomp.omp_set_num_threads(threads)
-    if ref is not None:
-        reps, total = timed(lambda: ref.ref_csr_spmv(m, nrow_total, p(row_ptr), p(col), p(val), p(x), p(y)))
+    # ---- OpenMP mode: CSRMatrixMatVector with the arrays first-touched inside the OpenMP team, a sweep over team sizes
+    quota = facts.get("cgroup_cpu_quota_cpus")
+    cap = topo["allowed_physical_cores"]
+    if args.cpu_threads > 0:
+        sweep = [threads]
     else:
-        reps, total = timed(lambda: ol.csr_spmv_omp(orc, row_ptr, col, val, x, y))
+        sweep = sorted({t for t in (8, 16, 32, 64, 128, cap, int(quota) if quota else 0) if 0 < t <= cap})
+    orc.orc_csr_first_touch_copy.restype = None
+    per_point = max(1.0, budget / max(len(sweep), 1))
+    sweep_out = []
+    for t_n in sweep:
+        gomp.omp_set_num_threads(t_n)
+        # fresh, never-written destinations: their pages are placed by the team's first touch (same static row schedule)
+        d_rp, d_col, d_val = np.empty(m + 1, np.int32), np.empty(nnz, np.int32), np.empty(nnz, np.float64)
+        d_x, y = np.empty(nrow_total, np.float64), np.empty(m, np.float64)
+        orc.orc_csr_first_touch_copy(C.c_int32(m), C.c_int64(nrow_total), p(row_ptr), p(col), p(val), p(x), p(d_rp), p(d_col), p(d_val), p(d_x), p(y))
+        if ref is not None:
+            run = lambda: ref.ref_csr_spmv(m, nrow_total, p(d_rp), p(d_col), p(d_val), p(d_x), p(y))
+        else:
+            run = lambda: ol.csr_spmv_omp(orc, d_rp, d_col, d_val, d_x, y)
+        run()  # warm-up
+        reps, total = 0, 0.0
+        while reps < 50 and total < per_point:
+            t = time.perf_counter()
+            run()
+            total += time.perf_counter() - t
+            reps += 1
+        sweep_out.append({"threads": t_n, "value": round(2.0 * nnz * reps / total / 1e9, 4), "ms_per_apply": round(1e3 * total / reps, 3), "reps": reps})
+        del d_rp, d_col, d_val, d_x, y
+    best = max(sweep_out, key=lambda e: e["value"])
+    threads = best["threads"]
     openmp = {"mode": "openmp", "kind": "reference" if ref is not None else "port", "threads": threads,
               "bind": f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} OMP_PLACES={os.environ.get('OMP_PLACES')}",
-              "value": round(2.0 * nnz * reps / total / 1e9, 4), "unit": "GFLOP/s", "ms_per_apply": round(1e3 * total / reps, 3), "reps": reps}
+              "first_touch": "matrix, x and y copied into fresh arrays inside the OpenMP team (static row schedule of the product) before timing",
+              "value": best["value"], "unit": "GFLOP/s", "ms_per_apply": best["ms_per_apply"], "reps": best["reps"],
+              "thread_sweep": sweep_out}
     modes.append(openmp)
+    budget = min(budget, 10.0)
     # ---- the reference's NUMA driver as it is (prints its own line; 50 repetitions inside)
     if ref is not None:
         y = np.zeros(m)
@@ -222,11 +340,13 @@ def cpu_baseline_child(args) -> dict:
         "unit": "GFLOP/s",
         "cores": threads,
         "kind": openmp["kind"],
-        "sample": f"rows [0,{m}) of the benchmark matrix ({nnz} entries, full x of {nrow_total}); headline value = the OpenMP mode "
-                  f"({openmp['reps']} reps of CSRMatrixMatVector, {threads} threads = the physical cores this process may use); "
-                  f"{gen_s:.1f}s to regenerate the rows on the host",
+        "sample": f"rows [0,{m}) of the benchmark matrix ({nnz} entries, full x of {nrow_total}); headline value = the OpenMP mode, best of a "
+                  f"sweep over team sizes {[e['threads'] for e in sweep_out]} ({openmp['reps']} reps of CSRMatrixMatVector with {threads} threads; "
+                  f"{topo['allowed_physical_cores']} physical cores allowed, cgroup CPU quota {facts.get('cgroup_cpu_max')}); arrays first-touched inside "
+                  f"the OpenMP team; {gen_s:.1f}s to regenerate the rows on the host",
         "ms_per_apply": openmp["ms_per_apply"],
         "host": topo,
+        "host_limits": facts,
         "compiler": "g++ -O2 -fopenmp -DUSE_OPENMP (the reference's flags, oracle/Makefile); restatement: gcc -O2 -fopenmp -ffp-contract=off",
         "modes": modes,
     }
@@ -301,7 +421,11 @@ def main() -> None:
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # Under torch.distributed.run the process group exists at EVERY world size, 1 included: `torchrun --nproc-per-node 1
+    # bench.py --gpus 1` runs the same RCCL calls (all-gather of x, barrier, all-reduce of the times) as the 8-GPU job,
+    # which is how a one-GPU box exercises them.  A plain `python bench.py` (no RANK in the environment) has no group.
+    grouped = world > 1 or "RANK" in os.environ
+    if grouped:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -344,7 +468,7 @@ def main() -> None:
         vx_own = ctx.wrap_vector(x_own, n)
         capi._check(ctx._lib.spmv_gen_vec_uniform(ctx.h, vx_own.h, row_begin, args.seed))
         allgather_ms = None
-        if world > 1:
+        if grouped:
             x_send = x_own.clone()
             shard.allgather_x(x_full, x_send, ncol)
         y = torch.zeros(n, dtype=torch.float64, device=dev)
@@ -352,9 +476,15 @@ def main() -> None:
 
         def barrier():
             torch.cuda.synchronize()
-            if world > 1:
+            if grouped:
                 dist.barrier()
             torch.cuda.synchronize()
+
+        def max_over_ranks(*vals):
+            t = torch.tensor(list(vals), dtype=torch.float64, device=dev)
+            if grouped:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return [float(v) for v in t.tolist()]
 
         for _ in range(args.warmup):
             ctx.apply(A, vx, vy)
@@ -371,7 +501,7 @@ def main() -> None:
 
         # secondary: the same loop with the x exchange charged to every step (solver-realistic)
         exch_s = None
-        if world > 1:
+        if grouped:
             barrier()
             t1 = time.perf_counter()
             for _ in range(args.steps):
@@ -387,63 +517,110 @@ def main() -> None:
             torch.cuda.synchronize()
             allgather_ms = e0.elapsed_time(e1) / 10
 
-        # N = 1 only, after the headline loop: the other single-GPU configurations of BASELINE.json (C3: ELL, C4: COO) and
-        # the band-random variant of C2, each 5 warm-up + 50 applications between HIP events on the
-        # engine's stream.  Reported in "extra"; they never enter "value".
+        panel_names = ("rows", "width", "groups", "layout", "unroll", "pipe", "sync", "stagger", "pace_ns", "bytes")
+
+        def panel_of(M):
+            try:
+                return {name: M.get_param("panel_" + name) for name in panel_names}
+            except capi.SpmvError:
+                return None
+
+        def describe(fmt, M, inf, flags):
+            """(kernel that runs, which bytes it has to move) of a handle"""
+            kid = int(inf.kernel)
+            if fmt == "ell":
+                if kid == 4:
+                    return "csr_panel_kernel on the row-grouped copy of the ELL slots", "panel"
+                if M.get_param("ell_diagonal_slots") and not (flags & 8):  # 8 = SPMV_FLAG_ELL_READ_COLUMNS
+                    return "ell_diag_kernel_x2 (slots recognised as diagonals: conforming rows read no column index)", "ell_diagonals"
+                return "ell_kernel_x2 (one lane per two rows, column-major slots, every column index read)", "ell_columns"
+            if fmt == "coo":
+                if kid == 4:
+                    return "csr_panel_kernel on the row-grouped copy (12-byte packed entries)", "panel"
+                return "coo_segscan_kernel (wavefront segmented scan over the entries in file order)", "coo_segscan"
+            names = {1: "csr_vector_kernel", 2: "csr_ldswin_kernel", 3: "csr_scalar_kernel", 4: "csr_panel_kernel",
+                     5: "tp_expand_kernel + tp_reduce_kernel (two-phase)"}
+            return names.get(kid, str(kid)), "csr"
+
+        # After the headline loop: the other single-GPU configurations of BASELINE.json (C3: ELL, C4: COO), each once with
+        # the kernel the engine picks and once with the kernel the config NAMES (column-reading ELL, COO segmented scan),
+        # the band-random variant of C2 (SURVEY.md section 7; at every world size: each rank generates its band shard) and,
+        # at N = 1, the shard shape of C5.  5 warm-up + 50 applications between HIP events on the engine's stream.
+        # Reported in "extra"; they never enter "value".
         extra = []
-        if world == 1 and not args.no_extra:
-            def one(name, fmt, make):
+        if not args.no_extra:
+            def one(name, fmt, make, tkey=None, x_vec=None, sharded=False, flags=0):
                 t = time.perf_counter()
                 M = make()
+                if flags:
+                    M.set_flags(flags)
                 inf = M.info
                 ctx.sync()
                 t_set = time.perf_counter() - t
-                vx2, vy2 = ctx.gen_vector(int(inf.ncol), seed=args.seed), ctx.vector(int(inf.nrow))
+                vx2 = x_vec if x_vec is not None else ctx.gen_vector(int(inf.ncol), seed=args.seed)
+                vy2 = ctx.vector(int(inf.nrow))
                 vy2.fill(0.0)
                 for _ in range(5):
                     ctx.apply(M, vx2, vy2)
+                barrier()
                 ms = ctx.apply_timed(M, vx2, vy2, 50)
+                (ms,) = max_over_ranks(ms)
                 nnz2 = int(inf.nnz)
                 kk = int(inf.ell_k) if fmt == "ell" else 0
-                b = algorithmic_bytes(fmt, int(inf.nrow), int(inf.ncol), nnz2, kk)
-                tkey = {"ell": f"ell_n{int(inf.nrow)}_k{kk}", "coo": f"coo_n{int(inf.nrow)}_nnz{nnz2}",
-                        "csr": f"csr_n{int(inf.nrow)}_k{k}_band{65536 if int(inf.ncol) == int(inf.nrow) else 0}_ncol{int(inf.ncol)}"}[fmt]
-                tfile2 = ROOT / "profiles" / "pmc_traffic.json"
-                traffic2 = json.loads(tfile2.read_text()).get(tkey, {}).get("hbm_bytes_per_launch") if tfile2.exists() else None
-                note = None
-                if fmt == "ell" and M.get_param("ell_diagonal_slots"):
-                    note = ("the slots of this ELL matrix are diagonals (col = row + offset[slot] for all but the wrap-around rows): the "
-                            "kernel reads no column index for conforming rows, i.e. 8 instead of ELL's 12 algorithmic bytes per entry - "
-                            "frac (of the ALGORITHMIC bytes) can exceed what the bytes in `traffic` allow")
+                kernel, kind = describe(fmt, M, inf, flags)
+                b_fmt = algorithmic_bytes(fmt, int(inf.nrow), int(inf.ncol), nnz2, kk)
+                b_req = required_bytes(kind, int(inf.nrow), int(inf.ncol), nnz2, kk)
+                layout = panel_of(M) if int(inf.kernel) == 4 else None
+                counters = measured_counters(tkey, kernel, layout) if tkey else {"traffic": None, "l2_line_ops": None, "measured_on": None}
+                parts = world if sharded else 1
                 extra.append({
-                    "name": name, "format": fmt, **({"note": note} if note else {}), "nrow": int(inf.nrow), "ncol": int(inf.ncol), "nnz": nnz2,
-                    "max_row_nnz": int(inf.max_row_nnz), "kernel_id": int(inf.kernel), "ms": round(ms, 5),
-                    "value": round(2.0 * nnz2 / ms / 1e6, 2), "unit": "GFLOP/s", "setup_seconds": round(t_set, 3),
-                    "roofline": {"bound": "hbm", "achieved": round(b / ms / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": round(b / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": traffic2, "algorithmic_bytes_per_launch": b},
+                    "name": name, "format": fmt, "kernel": kernel, "nrow": int(inf.nrow), "ncol": int(inf.ncol), "nnz": nnz2 * parts,
+                    "n_gpus": parts, "max_row_nnz": int(inf.max_row_nnz), "kernel_id": int(inf.kernel), "ms": round(ms, 5),
+                    "value": round(2.0 * nnz2 * parts / ms / 1e6, 2), "unit": "GFLOP/s", "setup_seconds": round(t_set, 3),
+                    "roofline": {"bound": "hbm", "achieved": round(b_req / ms / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(b_req / ms / 1e6 / HBM_PEAK_GBS, 4), "bytes_required": b_req, "bytes_required_kind": kind,
+                                 "frac_of_format_bytes": round(b_fmt / ms / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": b_fmt,
+                                 "traffic": counters["traffic"], "traffic_measured_on": counters["measured_on"],
+                                 "per": "rank" if sharded else "launch"},
                 })
-                del M, vx2, vy2
+                del M, vy2
 
-            one("C3: ELL N=4M, 64 per row, circulant band (BASELINE configs[2])", "ell",
-                lambda: ctx.gen_ell_banded(4_000_000, 4_000_000, 64, seed=args.seed))
-            one("C4: COO N=2M, power-law rows up to 4096, row-sorted (BASELINE configs[3]; realised nnz reported)", "coo",
-                lambda: ctx.gen_coo_powerlaw(2_000_000, 2_000_000, 4096, seed=args.seed))
+            if world == 1:
+                def c3():
+                    return ctx.gen_ell_banded(4_000_000, 4_000_000, 64, seed=args.seed)
+                one("C3: ELL N=4M, 64 per row, circulant band (BASELINE configs[2]) - the kernel the engine picks", "ell", c3,
+                    tkey="ell_n4000000_k64")
+                one("C3 with the kernel configs[2] names: coalesced column-major ELL, every column index read (SPMV_FLAG_ELL_READ_COLUMNS)",
+                    "ell", c3, tkey="ell_n4000000_k64_columns", flags=8)
+
+                def c4(kernel):
+                    M = ctx.gen_coo_powerlaw(2_000_000, 2_000_000, 4096, seed=args.seed)
+                    if kernel:
+                        M.set_kernel(kernel, 0)
+                    return M
+                one("C4: COO N=2M, power-law rows up to 4096, row-sorted (BASELINE configs[3]; realised nnz reported) - the kernel the engine picks",
+                    "coo", lambda: c4(0), tkey="coo_n2000000_nnz115008628")
+                one("C4 with the kernel configs[3] names: COO segmented scan over the entries as stored (spmv_mat_set_kernel VECTOR)",
+                    "coo", lambda: c4(1), tkey="coo_n2000000_nnz115008628_segscan")
             if args.band == 0:
-                one(f"C2 shape, columns random in a band of 65536 (CSR N={n}, {k} per row)", "csr",
-                    lambda: ctx.gen_csr_uniform(0, n, n, k, band=65536, seed=args.seed))
-
+                def band_shard():
+                    M = ctx.gen_csr_uniform(row_begin, row_end, ncol, k, band=65536, seed=args.seed)
+                    if int(M.info.kernel) in (4, 5):
+                        M.set_param("panel_keep_csr", 0)
+                    return M
+                one(f"C2 shape, columns random in a band of 65536 around the diagonal (CSR, {n} rows per GPU x {k}, {ncol} columns"
+                    + (f"; rank r holds rows r*{n}..: the band keeps its locality under sharding)" if world > 1 else ")"),
+                    "csr", band_shard, tkey=f"csr_n{n}_k{k}_band65536_ncol{ncol}", x_vec=vx, sharded=world > 1)
+            if world == 1 and args.band == 0:
                 def c5_shard():
                     M = ctx.gen_csr_uniform(7 * n, 8 * n, 8 * n, k, band=0, seed=args.seed)
                     if int(M.info.kernel) in (4, 5):
                         M.set_param("panel_keep_csr", 0)
                     return M
                 one(f"C5 shard: what the last rank of 8 holds in BASELINE configs[4] (rows {7 * n}-{8 * n} of {8 * n} x {8 * n}, {k} per row; "
-                    "x = 640 MB resident)", "csr", c5_shard)
+                    "x = 640 MB resident)", "csr", c5_shard, tkey=f"csr_n{n}_k{k}_band0_ncol{8 * n}")
 
-        times = torch.tensor([wall_s, kernel_ms, exch_s or 0.0], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(times, op=dist.ReduceOp.MAX)
-        wall_s, kernel_ms, exch_max = (float(t) for t in times.tolist())
+        wall_s, kernel_ms, exch_max = max_over_ranks(wall_s, kernel_ms, exch_s or 0.0)
 
     if rank == 0:
         nnz_rank = int(info.nnz)
@@ -451,16 +628,18 @@ def main() -> None:
         gflops = 2.0 * nnz_total * args.steps / wall_s / 1e9
         bytes_launch = algorithmic_bytes("csr", n, ncol, nnz_rank)
         achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tfile = ROOT / "profiles" / "pmc_traffic.json"
-        wl_key = f"csr_n{n}_k{k}_band{args.band}_ncol{ncol}"
-        if tfile.exists():
-            traffic = json.loads(tfile.read_text()).get(wl_key, {}).get("hbm_bytes_per_launch")
         kernel_names = {1: "csr_vector_kernel", 2: "csr_ldswin_kernel", 3: "csr_scalar_kernel", 4: "csr_panel_kernel",
                         5: "tp_expand_kernel + tp_reduce_kernel (two-phase)"}
-        panel = None
-        if int(info.kernel) == 4:
-            panel = {k: A.get_param("panel_" + k) for k in ("rows", "width", "groups", "layout", "unroll", "pipe", "sync", "stagger", "pace_ns", "bytes")}
+        kernel_name = kernel_names.get(int(info.kernel), str(info.kernel))
+        panel = panel_of(A) if int(info.kernel) == 4 else None
+        counters = measured_counters(f"csr_n{n}_k{k}_band{args.band}_ncol{ncol}", kernel_name, panel)
+        l2 = None
+        if counters["l2_line_ops"]:
+            # what bounds the panel kernel on scattered columns is the L2's line rate, not HBM: 128-byte line
+            # operations per launch (L1->L2 read requests + fills, PMC) over this run's kernel time, against the L2s' peak
+            l2_gbs = counters["l2_line_ops"] * 128 / (kernel_ms * 1e-3) / 1e9
+            l2 = {"l2_line_ops": counters["l2_line_ops"], "l2_achieved": round(l2_gbs, 1), "l2_peak": L2_PEAK_GBS, "l2_unit": "GB/s",
+                  "l2_frac": round(l2_gbs / L2_PEAK_GBS, 4)}
         out = {
             "metric": "SpMV GFLOP/s + achieved HBM GB/s (% roofline), fp64 CSR, 1/2/4/8 MI355X",
             "value": round(gflops, 3),
@@ -486,7 +665,8 @@ def main() -> None:
                 "seed": args.seed,
                 "partition": f"row-range x{world}, full x replica per GPU (src/mat_vec.cpp:240-268)",
                 "x_exchange": "static replica, all-gathered once before the timed loop (as src/mat_vec.cpp:266 vs :271)",
-                "kernel": kernel_names.get(int(info.kernel), str(info.kernel)),
+                "process_group": (f"{backend} (torch.distributed, world {world})" if grouped else "none (plain single-process run)"),
+                "kernel": kernel_name,
                 "lanes_per_row": int(info.lanes_per_row),
                 "setup_seconds": round(setup_s, 3),
                 "setup_seconds_without_trials": round(setup_no_trial_s, 3) if setup_no_trial_s is not None else None,
@@ -501,12 +681,16 @@ def main() -> None:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic,
+                "traffic": counters["traffic"],
+                "traffic_measured_on": counters["measured_on"],
                 "algorithmic_bytes_per_launch": bytes_launch,
                 "kernel_ms": round(kernel_ms, 5),
+                **(l2 or {}),
+                **({"limiter": "the L2s' 128-byte line rate (one line operation per gathered x line: ~0.63 per entry with 20000 fp64 "
+                               "accumulators per CU), not HBM: see l2_frac"} if l2 and l2["l2_frac"] > 0.75 else {}),
             },
         }
-        if world > 1:
+        if grouped:
             out["with_x_allgather_each_step"] = {
                 "value": round(2.0 * nnz_total * args.steps / exch_max / 1e9, 3),
                 "unit": "GFLOP/s",
@@ -519,7 +703,7 @@ def main() -> None:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -131,6 +131,33 @@ void orc_csr_spmv_omp(int32_t nrow, const int32_t* row_ptr, const int32_t* col,
     }
 }
 
+/* First-touch placement for the OpenMP baseline ("first-touch initialisation"): copies a CSR
+ * matrix and its vectors into destination arrays the caller has allocated but never written, inside an OpenMP team with
+ * the SAME static row schedule as the product loop above (src/mat_vec.cpp:54-57: `omp parallel for` over rows, default
+ * static schedule) — so every page of a row's entries and of its y lands on the NUMA node of the thread that will
+ * multiply that row.  x is gathered from by every thread: its pages are spread over the team in equal stretches. */
+void orc_csr_first_touch_copy(int32_t nrow, int64_t ncol, const int32_t* row_ptr, const int32_t* col, const double* val,
+                              const double* x, int32_t* d_row_ptr, int32_t* d_col, double* d_val, double* d_x, double* d_y)
+{
+#pragma omp parallel
+    {
+#pragma omp for schedule(static) nowait
+        for (int32_t i = 0; i < nrow; i++)
+        {
+            d_row_ptr[i] = row_ptr[i];
+            for (int32_t j = row_ptr[i]; j < row_ptr[i + 1]; j++)
+            {
+                d_col[j] = col[j];
+                d_val[j] = val[j];
+            }
+            d_y[i] = 0.0;
+        }
+#pragma omp for schedule(static)
+        for (int64_t c = 0; c < ncol; c++) d_x[c] = x[c];
+    }
+    d_row_ptr[nrow] = row_ptr[nrow];
+}
+
 /* src/mat_vec.cpp:230-297 + :507-530, the NUMA driver's protocol with PERSISTENT workers (cpu_baseline "port" leg,
  * BASELINE.md section 4): equal-row shards (last takes the remainder, :245-246), every shard a private copy of its
  * rebased row_ptr (:260-263), its col/val slices and a FULL replica of x (:257,:266), a local y slice (:258,:267) —

@@ -41,6 +41,10 @@ void orc_csr_spmv_fma(int32_t nrow, const int32_t* row_ptr, const int32_t* col,
 /* same loop with `#pragma omp parallel for` as in src/mat_vec.cpp:54-57 (cpu_baseline "port") */
 void orc_csr_spmv_omp(int32_t nrow, const int32_t* row_ptr, const int32_t* col,
                       const double* val, const double* x, double* y);
+/* first-touch copy of a CSR matrix, x and a zeroed y inside an OpenMP team with the product's static row schedule
+ * (cpu_baseline leg: BASELINE.md section 4 "first-touch initialisation") */
+void orc_csr_first_touch_copy(int32_t nrow, int64_t ncol, const int32_t* row_ptr, const int32_t* col, const double* val,
+                              const double* x, int32_t* d_row_ptr, int32_t* d_col, double* d_val, double* d_x, double* d_y);
 /* NUMA-driver protocol with persistent pinned workers (src/mat_vec.cpp:230-297); returns ms per repetition */
 double orc_csr_spmv_sharded(int32_t nrow, int32_t ncol, const int32_t* row_ptr, const int32_t* col, const double* val,
                             const double* x, double* y, int32_t nshards, int32_t reps);

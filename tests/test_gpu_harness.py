@@ -106,7 +106,14 @@ def test_bench_contract_one_rank_and_two_rank_rehearsal(tmp_path):
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["steps"] == 4 and line["unit"] == "GFLOP/s" and line["value"] > 0
     assert line["dtype"] == "f64" and line["scaling"] == "weak" and line["vs_baseline"] is None
-    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1.2
+    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1.0
+    assert line["config"]["process_group"].startswith("none")
+    names = " | ".join(e["name"] for e in line["extra"])
+    assert "configs[2] names" in names and "configs[3] names" in names and "band of 65536" in names
+    for e in line["extra"]:  # a fraction of the bytes the kernel has to move can never exceed 1
+        assert 0 < e["roofline"]["frac"] <= 1.0 and e["roofline"]["bytes_required"] > 0, e
+    kernels = {e["name"]: e["kernel"] for e in line["extra"]}
+    assert any("ell_kernel_x2" in v for v in kernels.values()) and any("coo_segscan_kernel" in v for v in kernels.values())
     assert line["cpu_baseline"]["kind"] in ("reference", "port") and line["cpu_baseline"]["value"] > 0
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -121,6 +128,132 @@ def test_bench_contract_one_rank_and_two_rank_rehearsal(tmp_path):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["ncol"] == 800000 and line["config"]["nnz_total"] == 2 * 400000 * 32
     assert line["value"] > 0 and "with_x_allgather_each_step" in line
+    band = [e for e in line["extra"] if "band of 65536" in e["name"]]  # the band-random variant is reported at every world size
+    assert len(band) == 1 and band[0]["n_gpus"] == 2 and band[0]["nnz"] == 2 * 400000 * 32 and 0 < band[0]["roofline"]["frac"] <= 1.0
+
+
+def _check_sharded_rows(pkg, orc, path, n, parts, k, band, seed):
+    """y rows written by `spmv_main --sharded --check-rows` against the oracle on the same rows, regenerated from the seed"""
+    import oracle_lib as ol
+
+    ncol = n * parts
+    x = pkg.synth.vec_uniform(ncol, seed=seed)
+    rows, vals = [], []
+    for ln in open(path):
+        r, v = ln.split()
+        rows.append(int(r))
+        vals.append(float.fromhex(v))
+    rows, vals = np.array(rows), np.array(vals)
+    assert len(rows) > 0
+    worst = 0.0
+    # the file holds runs of consecutive rows (first / middle / last of every shard)
+    cuts = np.flatnonzero(np.diff(rows) != 1) + 1
+    for seg_r, seg_v in zip(np.split(rows, cuts), np.split(vals, cuts)):
+        r0, r1 = int(seg_r[0]), int(seg_r[-1]) + 1
+        rp, col, val = pkg.synth.csr_uniform(r0, r1, ncol, k, band=band, seed=seed)
+        ref, scale = np.zeros(r1 - r0), np.zeros(r1 - r0)
+        ol.csr_spmv(orc, rp, col, val, x, ref, fma=True)
+        ol.csr_abs_row_sums(orc, rp, col, val, x, scale)
+        worst = max(worst, float(np.max(np.abs(seg_v - ref) / np.maximum(scale, 1e-300))))
+    assert worst <= 1e-10, worst
+    return len(rows)
+
+
+@pytest.mark.parametrize("parts,n,k,band", [(3, 50_000, 12, 0), (8, 250_000, 32, 0), (4, 300_000, 32, 4096)])
+def test_native_sharded_harness_on_device_generated_shards(tmp_path, pkg, orc, parts, n, k, band):
+    """`spmv_main --synthetic ... --sharded --gpus P`: the C++ driver of BASELINE configs[4] - shards generated on their
+    devices, x slices all-gathered by spmv_comm_*, the reference's timed loop and print-out, one JSON line - with P
+    participants on however many GPUs the box has.  Sampled rows of every shard are checked against the oracle."""
+    import json
+
+    out = tmp_path / "rows.txt"
+    r = subprocess.run([str(BIN / "spmv_main"), "--synthetic", "band" if band else "uniform", "--n", str(n), "--k", str(k), "--band", str(band),
+                        "--seed", "5", "--sharded", "--gpus", str(parts), "--reps", "10", "--check-rows", "700", "--check-out", str(out)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert re.search(rf"### ROW={n * parts}, COL={n * parts}, NNZ={n * parts * k} ", r.stdout), r.stdout
+    assert re.search(r"### CSR NUMA GFLOPS = [0-9.]+", r.stdout)
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["participants"] == parts and line["nnz_total"] == n * parts * k and line["exchange"] in ("rccl", "peer-copy")
+    assert line["gflops"] > 0 and line["with_x_allgather_each_step"]["gflops"] > 0
+    assert _check_sharded_rows(pkg, orc, out, n, parts, k, band, 5) == 3 * 700 * parts
+
+
+def test_native_sharded_harness_at_the_full_shard_shape_of_config_5(tmp_path, pkg, orc):
+    """two of the eight shards of BASELINE configs[4] as the native driver builds them is what one GPU's time allows here:
+    `--n 10000000 --gpus 2` = shards of 10M rows x 20M columns, 6.4e8 entries in all, no host container anywhere"""
+    import json
+
+    out = tmp_path / "rows.txt"
+    r = subprocess.run([str(BIN / "spmv_main"), "--synthetic", "uniform", "--n", "10000000", "--k", "32", "--seed", "1", "--sharded", "--gpus", "2",
+                        "--reps", "10", "--check-rows", "1000", "--check-out", str(out)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["nnz_total"] == 640_000_000 and line["ncol"] == 20_000_000
+    assert _check_sharded_rows(pkg, orc, out, 10_000_000, 2, 32, 0, 1) == 6000
+
+
+def test_bench_under_torchrun_with_one_rank_runs_the_rccl_collectives(tmp_path):
+    """`torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`: the launcher starts before anything touches the GPU,
+    the process group is backend nccl (= RCCL) with world size 1, and the run makes the same collective calls as the
+    8-GPU job - all_gather_into_tensor of the x slices, barriers, the all-reduce of the times."""
+    import json
+    import os
+    import socket
+    import sys
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SPMV_BENCH_BACKEND", None)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "1", "--rows", "400000",
+                        "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-extra"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["config"]["process_group"].startswith("nccl")
+    assert line["with_x_allgather_each_step"]["value"] > 0 and line["with_x_allgather_each_step"]["allgather_ms"] > 0
+
+
+def test_allgather_x_over_nccl_world_one():
+    """arm-spmv_amd/dist.py on backend nccl with one rank, in a child process (its process group must not leak into the
+    test session): the equal-slice all-gather, concatenate_y, the max / sum reductions of the timing and solver paths"""
+    import os
+    import socket
+    import sys
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    code = f"""
+import sys, torch, torch.distributed as dist
+sys.path.insert(0, {str(ROOT)!r})
+from __graft_entry__ import load_package
+load_package()
+import importlib
+shard = importlib.import_module("arm_spmv_amd.dist")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == "nccl"
+n = 1_000_003
+own = torch.rand(n, dtype=torch.float64, device=dev)
+full = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
+shard.allgather_x(full, own, n)
+torch.cuda.synchronize()
+assert torch.equal(full, own)
+assert torch.equal(shard.concatenate_y(own, n), own)
+assert shard.max_over_ranks(3.5, dev) == 3.5 and shard.sum_over_ranks(2.25, dev) == 2.25
+dist.barrier()
+dist.destroy_process_group()
+print("nccl world 1 OK")
+"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "nccl world 1 OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_spmv_main_on_a_stencil_matrix_file(tmp_path):

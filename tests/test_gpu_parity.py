@@ -362,6 +362,8 @@ def test_csr_handle_can_give_up_its_arrays_once_the_panel_layout_is_built(ctx, p
         A.set_kernel(capi.CSR_VECTOR)
     with pytest.raises(Err, match="gave up"):
         ctx.csr_to_ell(A)
+    with pytest.raises(Err, match="gave up"):
+        A.validate()  # refused on the host: the check kernels would read the released index array
     A.set_param("panel_rows", 5000)
     with pytest.raises(Err, match="gave up"):
         A.set_kernel(capi.CSR_PANEL)  # a re-build with other parameters needs the CSR arrays
@@ -481,6 +483,81 @@ def test_native_exchange_allgather_and_vec_copy(pkg):
     assert np.array_equal(got[10:30], np.full(20, 7.0)) and not got[:10].any() and not got[30:].any()
     with pytest.raises(capi.SpmvError):
         dst.copy_from(vecs[0], 60)
+
+
+def test_rccl_transport_runs_with_one_participant_on_one_gpu(pkg, monkeypatch):
+    """SPMV_COMM=rccl forces the RCCL transport of spmv_comm_* (the default takes it only with two or more GPUs): on a
+    one-GPU box that is ncclCommInitAll(1), the self-check of the fresh communicator (an ncclAllGather and a group of
+    ncclBroadcast calls through the prototypes of rccl.h) and the all-gather itself - every RCCL call the multi-GPU path
+    makes, with one rank.  Two participants on ONE device are refused (RCCL has one communicator per device)."""
+    capi = pkg.capi
+    monkeypatch.setenv("SPMV_COMM", "rccl")
+    ctx0 = capi.Context(0)
+    comm = capi.Comm([ctx0])
+    assert comm.backend == "rccl"
+    n = 1_000_003
+    full = np.random.default_rng(5).uniform(-1, 1, n)
+    v = ctx0.vector_from(full)
+    for _ in range(3):
+        comm.allgather([v], np.array([0, n], dtype=np.int64))
+    ctx0.sync()
+    assert np.array_equal(v.download(), full)
+    # the current device of the calling thread is left alone (callers share the process with torch)
+    with pytest.raises(ValueError):
+        comm.allgather([v], np.array([0], dtype=np.int64))  # n + 1 offsets are needed: checked before the C side reads them
+    with pytest.raises(capi.SpmvError, match="one GPU per participant"):
+        capi.Comm([ctx0, capi.Context(0)])
+    monkeypatch.setenv("SPMV_COMM", "peer")
+    assert capi.Comm([ctx0]).backend == "peer-copy"
+
+
+def test_rccl_and_peer_copy_transports_agree_bit_for_bit_across_gpus(pkg, monkeypatch):
+    """needs two GPUs (skipped on the one-GPU box): the same ragged all-gather, one empty slice included, through RCCL
+    and through peer copies"""
+    capi = pkg.capi
+    ndev = capi.device_count()
+    if ndev < 2:
+        pytest.skip("one GPU visible: the RCCL transport between devices needs two")
+    ndev = min(ndev, 4)
+    n = 2_000_003
+    cuts = sorted(np.random.default_rng(9).integers(0, n, ndev - 2).tolist()) if ndev > 2 else []
+    offsets = np.array([0, *cuts, n, n], dtype=np.int64)[: ndev + 1]
+    offsets[-1] = n
+    full = np.random.default_rng(6).uniform(-1, 1, n)
+    got = {}
+    for transport in ("rccl", "peer"):
+        monkeypatch.setenv("SPMV_COMM", transport)
+        ctxs = [capi.Context(d) for d in range(ndev)]
+        comm = capi.Comm(ctxs)
+        assert comm.backend == ("rccl" if transport == "rccl" else "peer-copy")
+        vecs = [c.vector(n) for c in ctxs]
+        for i, v in enumerate(vecs):
+            v.fill(float("nan"))
+            if offsets[i + 1] > offsets[i]:
+                v.upload(full[offsets[i]:offsets[i + 1]], offset=int(offsets[i]))
+        comm.allgather(vecs, offsets)
+        for c in ctxs:
+            c.sync()
+        got[transport] = [v.download() for v in vecs]
+        del comm, vecs, ctxs
+    for a, b in zip(got["rccl"], got["peer"]):
+        assert np.array_equal(a, full) and np.array_equal(b, full)
+
+
+def test_large_coo_handle_keeps_one_layout_only(ctx, pkg):
+    """a scattered COO handle with few entries per row: its row-grouped copy satisfies the two-phase policy, the handle
+    runs the panel product - the two-phase layout (20 bytes per entry) must not stay allocated beside the panel one"""
+    capi = pkg.capi
+    n, k = 2_500_000, 4
+    C = ctx.gen_csr_uniform(0, n, n, k, seed=41)
+    assert C.info.kernel == capi.CSR_TWOPHASE  # (what the policy picks for this shape as CSR)
+    rp, col, val = C.download()
+    del C
+    rows = np.repeat(np.arange(n, dtype=np.int32), k)
+    A = ctx.coo(n, n, rows, col, val)
+    nnz = n * k
+    assert A.info.kernel == capi.CSR_PANEL
+    assert A.get_param("device_bytes") <= 16 * nnz + 15 * nnz + 8 * (n + 1), A.get_param("device_bytes")
 
 
 # ---------------------------------------------------------------------------------- BLAS-1
