@@ -673,7 +673,27 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         m->tp_pcols_req = (int32_t)value;
     else if (!strcmp(name, "twophase_unroll"))
         m->tp_unroll = (int32_t)value;
-
+    else if (!strcmp(name, "twophase_realloc"))
+    {
+        // experiment (tools/probe_twophase_placement.py): move streams of the two-phase layout to fresh allocations, the
+        // old ones freed only afterwards so that other memory is handed out.  Bits: 1 products, 2 values, 4 columns, 8 rows
+        SPMV_REQUIRE(m->tp_val && m->tp_padded > 0, "twophase_realloc: the two-phase layout is not built");
+        SPMV_HIP(hipSetDevice(m->ctx->device));
+        SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
+        auto move = [&](void** slot, size_t bytes) -> int {
+            void* fresh = nullptr;
+            if (hipMalloc(&fresh, bytes) != hipSuccess) SPMV_FAIL(SPMV_ERR_ALLOC, "twophase_realloc: out of device memory");
+            SPMV_HIP(hipMemcpy(fresh, *slot, bytes, hipMemcpyDeviceToDevice));
+            (void)hipFree(*slot);
+            *slot = fresh;
+            return SPMV_OK;
+        };
+        const size_t np = (size_t)m->tp_padded;
+        if (value & 1) SPMV_TRY(move((void**)&m->tp_xg, sizeof(double) * np));
+        if (value & 2) SPMV_TRY(move((void**)&m->tp_val, sizeof(double) * np));
+        if (value & 4) SPMV_TRY(move((void**)&m->tp_col, sizeof(uint16_t) * np));
+        if (value & 8) SPMV_TRY(move((void**)&m->tp_row, sizeof(uint16_t) * np));
+    }
     else
         SPMV_FAIL(SPMV_ERR_INVALID, "unknown parameter '%s'", name);
     return SPMV_OK;
@@ -730,6 +750,10 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         *value = m->ell_diag ? 1 : 0;
     else if (!strcmp(name, "twophase_panel_cols"))
         *value = m->tp_pcols;
+    else if (!strcmp(name, "twophase_placements_timed"))
+        *value = m->tp_place_seen;
+    else if (!strcmp(name, "twophase_placement_spread"))  // slowest / kept placement of the product stream, in 1/1000
+        *value = m->tp_place_gain;
     else if (!strcmp(name, "twophase_padded"))
         *value = m->tp_padded;
     else if (!strcmp(name, "window_max_span"))

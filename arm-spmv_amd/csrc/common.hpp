@@ -199,12 +199,13 @@ struct spmv_mat
     uint16_t* tp_col       = nullptr;  // [padded] column - panel base, same order
     uint16_t* tp_row       = nullptr;  // [padded] row - group base, (group, panel) order; 0xFFFF = padding
     double*   tp_xg        = nullptr;  // [padded] the stream between the two phases, (group, panel) order
-    int32_t*  tp_blk       = nullptr;  // [padded / 16] destination line of every source line
+    int32_t*  tp_blk       = nullptr;  // [2 * ceil(padded / 16)] two table words per source line: source pair -> destination pair
     int32_t*  tp_panel_ptr = nullptr;  // [panels + 1]
     int32_t*  tp_group_ptr = nullptr;  // [groups + 1]
     int32_t*  tp_gstart    = nullptr;  // [groups + 1] first row of every group
     int32_t   tp_ngroups = 0, tp_panels = 0, tp_pcols = 0, tp_max_rows = 0;
     int32_t   tp_pcols_req = 0, tp_unroll = 0;  // requested panel width / pairs per lane in flight (0 = default)
+    int32_t   tp_place_seen = 0, tp_place_gain = 0;  // placements of the product stream timed at build; slowest / kept, in 1/1000
     int64_t   tp_padded = 0;
     int64_t   tp_bytes   = 0;
 

@@ -9,23 +9,38 @@
 //            every line of x exactly once per product) and writes, for every matrix entry whose column lies in the
 //            panel, the PRODUCT value * x[col] to a stream `xg`.  It READS the entries in (panel, row group) order — a
 //            flat pass: 2-byte index + 8-byte value — and WRITES the products in (row group, panel) order: the entries
-//            of one RUN (panel p, group g) are contiguous in both, runs are padded to whole 128-byte lines of
-//            products (16 entries), and a table holds the destination line of every source line;
+//            of one RUN (panel p, group g) are contiguous in both;
 //   phase B (reduce, y-stationary)  one workgroup owns a row GROUP (<= 20000 rows, accumulators in LDS) and streams
 //            its stretch of xg with a 2-byte local row per entry, flat from the first entry to the last; products go
 //            into LDS with ds_add_f64 and y is touched once at the end.
-// Bytes per entry: A reads 2 + 8 (+ 0.25 for the table), writes 8; B reads 8 + 2: 28.25, times the padding (the C5
-// shard: runs of 160 entries, +5 %), against the panel kernel's 12 + x sweeps.  No gather ever leaves LDS, so there
-// is nothing to keep in step and no dependence on where the columns fall; x is read once.  The scatter between the
-// two orders is carried by phase A's stores (whole lines, nothing waits for them), so both phases read flat streams.
-// Worth it when the sweeps would cost more than the 16 extra bytes per entry: see csr_twophase_worth().
+// Bytes per entry: A reads 2 + 8 (+ 0.5 for the table), writes 8; B reads 8 + 2: 28.5.  No gather ever leaves LDS, so
+// there is nothing to keep in step and no dependence on where the columns fall; x is read once.  The scatter between
+// the two orders is carried by phase A's stores (16-byte pairs, consecutive lanes consecutive pairs inside a run), so
+// both phases read flat streams.  Worth it when the sweeps would cost more than the 16 extra bytes per entry: see
+// csr_twophase_worth().
+//
+// Runs and padding (round 3).  Both phases move PAIRS of entries (16-byte values / products, 4-byte index pairs).  A run
+// is padded to a multiple of 8 entries - whole 64-byte pieces of the product stream, the size of the write requests the
+// L2 sends to memory - and to at least 16, which puts at most one run boundary into any 16 entries (a LINE of the source
+// order).  Round 2 padded to whole 128-byte lines (+7.5 entries per run: 4.8 % of every stream on the C5 shard, whose
+// runs hold 156 entries); 8 costs 2.2 %.  Padding to pairs only (0.3 %) was built and measured too: slower by 0.15 ms in
+// phase A - run ends then share 64-byte pieces with their neighbours, which other workgroups write at other times, and
+// partial pieces cost the memory side a read-modify-write (profiles/r03_tune_twophase_run_padding.txt).
+// What the coarser padding bought was a one-word table (destination line of a source line); the table is now two words
+// per source line:
+//   word 0 = (delta0 << 3) | bpos     word 1 = delta1
+// destination pair = source pair + delta0 for the pairs of the line before position bpos, + delta1 from bpos on (bpos = 0:
+// no boundary inside the line).  Eight lanes share one 8-byte load.  delta0 has 29 bits: the layout holds < 2^29 entries.
+// Every wavefront access of either phase covers whole 128-byte lines of the arrays it reads: panels and group stretches
+// are walked from the line that holds their first pair.
 //
 // Layout (built once per handle, like the reference's shard construction before its timed loop, src/mat_vec.cpp:240-268):
-//   tp_val[e], tp_col[e] (uint16: column - panel base)     e in (panel, group) order, runs padded to 16 (value 0)
+//   tp_val[e], tp_col[e] (uint16: column - panel base)     e in (panel, group) order, padding: value 0, column 0
 //   tp_row[e'] (uint16: row - group base; 0xFFFF = padding) e' in (group, panel) order
-//   tp_blk[e / 16]            destination line e' / 16 of source line e / 16
+//   tp_blk[2 * (e / 16) + {0, 1}]  the two table words of every source line
 //   tp_panel_ptr[P + 1], tp_group_ptr[G + 1]     first entry of every panel in e, of every group in e'
 //   tp_xg[padded nnz]         the stream between the phases (scratch owned by the handle), in e' order
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
@@ -40,10 +55,14 @@ namespace
 {
 constexpr int kTpPanelCols = 20000;  // 160,000 B of x in LDS
 constexpr int kTpGroupRows = 20000;  // 160,000 B of accumulators in LDS
-constexpr int kTpLine      = 16;     // products per 128-byte line: the unit runs are padded to
+constexpr int kTpMinRun    = 16;     // entries: a non-empty run is at least one source line long
+constexpr int kTpPad       = 8;      // entries: runs are padded to whole 64-byte pieces of the product stream
+constexpr int kTpLine      = 16;     // entries per source line (8 pairs: what one table entry describes)
 constexpr unsigned kTpPadRow = 0xFFFFu;
+constexpr int64_t kTpMaxPadded = (int64_t)1 << 29;  // delta0 keeps 29 bits
 
 using u16x2 = unsigned short __attribute__((ext_vector_type(2)));
+using i32x2 = int __attribute__((ext_vector_type(2)));
 
 // ---- build ----------------------------------------------------------------------------------------------------
 // one lane per row: group of the row by binary search in gstart, then one key per entry
@@ -86,8 +105,9 @@ __global__ __launch_bounds__(kBlock) void tp_place_kernel(int nrow, int ngroups,
     }
 }
 
-// run lengths padded to whole lines, in both orders
-__global__ __launch_bounds__(kBlock) void tp_pad_kernel(int ngroups, int P, int32_t* __restrict__ count_pg /* [P*G + 1], in place */,
+// run lengths with their padding (even, at least kTpMinRun; an empty run stays empty), in both orders
+__global__ __launch_bounds__(kBlock) void tp_pad_kernel(int ngroups, int P, int pad /* 2, 8 or 16 */,
+                                                        int32_t* __restrict__ count_pg /* [P*G + 1], in place */,
                                                         int32_t* __restrict__ count_gp /* [G*P + 1] */)
 {
     const int64_t total = (int64_t)ngroups * P;
@@ -100,25 +120,38 @@ __global__ __launch_bounds__(kBlock) void tp_pad_kernel(int ngroups, int P, int3
             continue;
         }
         const int p = (int)(i / ngroups), g = (int)(i % ngroups);
-        const int c = (count_pg[i] + kTpLine - 1) / kTpLine * kTpLine;
+        const int n = count_pg[i];
+        const int c = n == 0 ? 0 : max(kTpMinRun, (n + pad - 1) / pad * pad);
         count_pg[i] = c;
         count_gp[(size_t)g * P + p] = c;
     }
 }
 
-// destination line of every source line + where panels (source order) and groups (destination order) begin
+// per run: the table words of the source lines it touches (delta of the run covering a line's first pair -> word 0;
+// a run that begins inside a line -> its position and delta, packed by tp_pack_kernel) + where panels (source order)
+// and groups (destination order) begin
 __global__ __launch_bounds__(kBlock) void tp_tables_kernel(int ngroups, int P, const int32_t* __restrict__ start_pg /* [P*G + 1] */,
                                                            const int32_t* __restrict__ start_gp /* [G*P + 1] */,
-                                                           int32_t* __restrict__ blk /* [padded / 16] */,
+                                                           int32_t* __restrict__ tbl /* 2 per line */, int32_t* __restrict__ bpos /* per line */,
                                                            int32_t* __restrict__ panel_ptr /* [P+1] */, int32_t* __restrict__ group_ptr /* [G+1] */)
 {
     const int64_t total = (int64_t)ngroups * P;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock)
     {
         const int p = (int)(i / ngroups), g = (int)(i % ngroups);
-        const int s = start_pg[i] / kTpLine, n = (start_pg[i + 1] - start_pg[i]) / kTpLine;
-        const int d = start_gp[(size_t)g * P + p] / kTpLine;
-        for (int b = 0; b < n; ++b) blk[s + b] = d + b;
+        const int sp = start_pg[i] / 2, np = (start_pg[i + 1] - start_pg[i]) / 2;  // pairs
+        const int delta = start_gp[(size_t)g * P + p] / 2 - sp;
+        if (np > 0)
+            for (int L = sp >> 3; L <= (sp + np - 1) >> 3; ++L)
+            {
+                if ((L << 3) >= sp)
+                    tbl[2 * (size_t)L] = delta;
+                else
+                {
+                    bpos[L]                = sp - (L << 3);  // 1..7
+                    tbl[2 * (size_t)L + 1] = delta;
+                }
+            }
         if (g == 0) panel_ptr[p] = start_pg[i];
         if (p == 0) group_ptr[g] = start_gp[(size_t)g * P];
         if (i == total - 1)
@@ -128,15 +161,22 @@ __global__ __launch_bounds__(kBlock) void tp_tables_kernel(int ngroups, int P, c
         }
     }
 }
+__global__ __launch_bounds__(kBlock) void tp_pack_kernel(int64_t nlines, int32_t* __restrict__ tbl, const int32_t* __restrict__ bpos)
+{
+    for (int64_t L = (int64_t)blockIdx.x * kBlock + threadIdx.x; L < nlines; L += (int64_t)gridDim.x * kBlock)
+        tbl[2 * L] = (int32_t)(((uint32_t)tbl[2 * L] << 3) | (uint32_t)bpos[L]);
+}
 
 // ---- phase A: xg[dst(e)] = tp_val[e] * x[panel base + tp_col[e]] ----------------------------------------------------
-// Two entries per lane: 4-byte index loads, 16-byte value loads and 16-byte product stores; eight lanes fill one
-// 128-byte line of products, whose destination line comes from tp_blk (one 4-byte load shared by the eight).  The
-// loads of the next set of UNROLL pairs per lane are issued before this set is multiplied and stored, and the first
-// set of a panel before its x is fetched, so the HBM latency is paid once per panel (UNROLL 6: 114 VGPRs; 8 spills).
-// THREADS = 1024: one workgroup
-// per CU with a panel of up to 20000 columns; 512: two per CU with up to 10000 each, one streaming while the other
-// changes its panel.
+// Two entries per lane: 4-byte index loads, 16-byte value loads and 16-byte product stores, the table words of a source
+// line in one 8-byte load shared by its eight lanes.  A workgroup treats its panels as ONE stream of sets of
+// THREADS x UNROLL pairs: the set that follows the one being multiplied is always in flight, also when it belongs to the
+// next panel, and the next panel's x waits in registers (XR 16-byte pairs per lane, loaded when the current panel starts)
+// until the barrier pair that swaps it into LDS - so neither the HBM latency nor the 160 KB of x is waited for at a panel
+// change (round 2 stopped the stream there: 1.31 -> 1.27 ms on the C5 shard, profiles/r03_tune_twophase_phases.txt).
+// rotate: workgroup b starts b / 256 of the way through each panel and wraps around, so that at any moment the
+// workgroups write into different row groups' stretches of xg instead of all into the same one.
+// Control flow is workgroup-uniform throughout.
 template <int THREADS, int UNROLL>
 __global__ __launch_bounds__(THREADS) void tp_expand_kernel(int P, int pcols, int ncol, const int32_t* __restrict__ panel_ptr,
                                                             const unsigned short* __restrict__ tp_col, const double* __restrict__ tp_val,
@@ -146,93 +186,154 @@ __global__ __launch_bounds__(THREADS) void tp_expand_kernel(int P, int pcols, in
     extern __shared__ double xs[];  // pcols entries of x
     const u16x2* __restrict__ c2 = reinterpret_cast<const u16x2*>(tp_col);
     const f64x2* __restrict__ v2 = reinterpret_cast<const f64x2*>(tp_val);
+    const i32x2* __restrict__ b2 = reinterpret_cast<const i32x2*>(tp_blk);
     f64x2* __restrict__ o2       = reinterpret_cast<f64x2*>(xg);
+    f64x2*              s2       = reinterpret_cast<f64x2*>(xs);
     constexpr int SET = THREADS * UNROLL;
-    for (int p = blockIdx.x; p < P; p += gridDim.x)
+    constexpr int XR  = (kTpPanelCols / 2 + THREADS - 1) / THREADS;  // 16-byte pairs of x per lane
+    struct Pan
     {
-        const int c0 = p * pcols;
-        const int n  = min(pcols, ncol - c0);
-        const int t_begin = panel_ptr[p] / 2, t_end = panel_ptr[p + 1] / 2;  // pairs: runs are padded to 16 entries
-        const int len = t_end - t_begin;
-        // rotate: workgroup b starts b / 256 of the way through its panel and wraps around, so that at any moment the
-        // workgroups write into different row groups' stretches of xg instead of all into the same one (4-5 % on
-        // average over allocations: profiles/r02_probe_twophase_placement.txt)
-        const int rot = rotate ? (int)(((int64_t)len * (int)(blockIdx.x % 256u) / 256) & ~7) : 0;
-        auto      phys = [&](int u) { return t_begin + (u + rot >= len ? u + rot - len : u + rot); };
-        u16x2 c[2][UNROLL];
-        f64x2 v[2][UNROLL];
-        int   d[2][UNROLL];
-        auto  fetch = [&](int u0, u16x2(&cc)[UNROLL], f64x2(&vv)[UNROLL], int(&dd)[UNROLL]) {
-#pragma unroll
-            for (int k = 0; k < UNROLL; ++k)
-            {
-                const int t = phys(min(u0 + k * THREADS + (int)threadIdx.x, len - 1));  // past the end: re-read the last pair
-                cc[k]       = __builtin_nontemporal_load(c2 + t);
-                vv[k]       = __builtin_nontemporal_load(v2 + t);
-                dd[k]       = __builtin_nontemporal_load(tp_blk + (t >> 3));
-            }
-        };
-        auto emit = [&](int u0, const u16x2(&cc)[UNROLL], const f64x2(&vv)[UNROLL], const int(&dd)[UNROLL]) {
-#pragma unroll
-            for (int k = 0; k < UNROLL; ++k)
-            {
-                const int u = u0 + k * THREADS + (int)threadIdx.x;
-                if (u < len)
-                {
-                    const int t = phys(u);
-                    f64x2     o;
-                    o.x = vv[k].x * xs[cc[k].x];
-                    o.y = vv[k].y * xs[cc[k].y];
-                    __builtin_nontemporal_store(o, o2 + ((size_t)dd[k] * 8 + (t & 7)));  // read again only 2.7 GB later: 2-3 %
-                }
-            }
-        };
-        if (len > 0) fetch(0, c[0], v[0], d[0]);  // (workgroup-uniform)
-        // the panel: 16-byte loads when x allows (panel bases are multiples of pcols entries)
-        const double* __restrict__ xp = x + c0;
-        if ((reinterpret_cast<uintptr_t>(xp) & 15) == 0)
+        int p, t_begin, len, skip, rot;  // panel, first pair of its first line, pairs from there, pairs of the line before the panel, rotation
+    };
+    const int  tid     = (int)threadIdx.x;
+    const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0;  // panel bases are even: x + p * pcols keeps x's alignment
+    // the next panel of this workgroup that holds entries, from q on (panels without entries need no x either)
+    // A panel's pairs are walked from the 128-byte line that holds its first pair (pairs before it are skipped in emit),
+    // and the rotation is a whole number of lines: every wavefront load covers whole lines of the source arrays.
+    auto find = [&](int q) -> Pan {
+        for (; q < P; q += (int)gridDim.x)
         {
-            const int    pairs = n / 2;
-            const f64x2* x2    = reinterpret_cast<const f64x2*>(xp);
-            f64x2*       s2    = reinterpret_cast<f64x2*>(xs);
-            constexpr int XU   = 5;
-            for (int i0 = 0; i0 < pairs; i0 += THREADS * XU)
+            const int tb = panel_ptr[q] / 2, te = panel_ptr[q + 1] / 2;
+            if (te > tb)
             {
-                f64x2 t[XU];
-#pragma unroll
-                for (int k = 0; k < XU; ++k)
-                {
-                    const int i = i0 + k * THREADS + (int)threadIdx.x;
-                    if (i < pairs) t[k] = x2[i];
-                }
-#pragma unroll
-                for (int k = 0; k < XU; ++k)
-                {
-                    const int i = i0 + k * THREADS + (int)threadIdx.x;
-                    if (i < pairs) s2[i] = t[k];
-                }
+                const int t0  = tb & ~7;
+                const int len = te - t0;
+                return Pan{q, t0, len, tb - t0, rotate ? (int)(((int64_t)len * (int)(blockIdx.x % 256u) / 256) & ~7) : 0};
             }
-            if ((n & 1) && threadIdx.x == 0) xs[n - 1] = xp[n - 1];
+        }
+        return Pan{P, 0, 0, 0, 0};
+    };
+    f64x2  xr[XR];
+    double xr_last = 0.0;
+    auto   load_x  = [&](int p) {
+        const int     c0 = p * pcols, n = min(pcols, ncol - c0), pairs = n / 2;
+        const double* xp = x + c0;
+        if (aligned)
+        {
+            const f64x2* x2 = reinterpret_cast<const f64x2*>(xp);
+#pragma unroll
+            for (int k = 0; k < XR; ++k)
+            {
+                const int i = k * THREADS + tid;
+                if (i < pairs) xr[k] = x2[i];
+            }
         }
         else
-            for (int i = threadIdx.x; i < n; i += THREADS) xs[i] = xp[i];
-        __syncthreads();
-        for (int u0 = 0; u0 < len; u0 += 2 * SET)
         {
-            fetch(u0 + SET, c[1], v[1], d[1]);  // (clamped when past the end)
-            emit(u0, c[0], v[0], d[0]);
-            fetch(u0 + 2 * SET, c[0], v[0], d[0]);
-            emit(u0 + SET, c[1], v[1], d[1]);
+#pragma unroll
+            for (int k = 0; k < XR; ++k)
+            {
+                const int i = k * THREADS + tid;
+                if (i < pairs)
+                {
+                    xr[k].x = xp[2 * i];
+                    xr[k].y = xp[2 * i + 1];
+                }
+            }
         }
-        __syncthreads();  // the panel is replaced next
+        if ((n & 1) && tid == 0) xr_last = xp[n - 1];
+    };
+    auto store_x = [&](int p) {
+        const int c0 = p * pcols, n = min(pcols, ncol - c0), pairs = n / 2;
+#pragma unroll
+        for (int k = 0; k < XR; ++k)
+        {
+            const int i = k * THREADS + tid;
+            if (i < pairs) s2[i] = xr[k];
+        }
+        if ((n & 1) && tid == 0) xs[n - 1] = xr_last;
+    };
+    u16x2 c[2][UNROLL];
+    f64x2 v[2][UNROLL];
+    i32x2 d[2][UNROLL];
+    auto  phys  = [](const Pan& a, int u) { return a.t_begin + (u + a.rot >= a.len ? u + a.rot - a.len : u + a.rot); };
+    auto  fetch = [&](const Pan& a, int u0, u16x2(&cc)[UNROLL], f64x2(&vv)[UNROLL], i32x2(&dd)[UNROLL]) {
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k)
+        {
+            const int t = phys(a, min(u0 + k * THREADS + tid, a.len - 1));  // past the end: re-read the last pair
+            cc[k]       = __builtin_nontemporal_load(c2 + t);
+            vv[k]       = __builtin_nontemporal_load(v2 + t);
+            dd[k]       = __builtin_nontemporal_load(b2 + (t >> 3));
+        }
+    };
+    auto emit = [&](const Pan& a, int u0, const u16x2(&cc)[UNROLL], const f64x2(&vv)[UNROLL], const i32x2(&dd)[UNROLL]) {
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k)
+        {
+            const int u = u0 + k * THREADS + tid;
+            const int t = phys(a, u);
+            if (u < a.len && t >= a.t_begin + a.skip)
+            {
+                const int bpos = dd[k].x & 7;
+                const int dst  = t + ((bpos != 0 && (t & 7) >= bpos) ? dd[k].y : (dd[k].x >> 3));
+                f64x2     o;
+                o.x = vv[k].x * xs[cc[k].x];
+                o.y = vv[k].y * xs[cc[k].y];
+                __builtin_nontemporal_store(o, o2 + dst);  // read again only 2.7 GB later: 2-3 %
+            }
+        }
+    };
+    Pan cur = find((int)blockIdx.x);
+    if (cur.p >= P) return;
+    fetch(cur, 0, c[0], v[0], d[0]);
+    load_x(cur.p);
+    store_x(cur.p);
+    Pan nxt = find(cur.p + (int)gridDim.x);
+    if (nxt.p < P) load_x(nxt.p);
+    __syncthreads();
+    int u = 0;
+    // one step: the set after (cur, u) goes into `f*`, (cur, u) is multiplied out of `e*`; false when nothing follows
+    auto step = [&](const u16x2(&ec)[UNROLL], const f64x2(&ev)[UNROLL], const i32x2(&ed)[UNROLL], u16x2(&fc)[UNROLL], f64x2(&fv)[UNROLL],
+                    i32x2(&fd)[UNROLL]) -> bool {
+        const bool cross = u + SET >= cur.len;
+        const bool last  = cross && nxt.p >= P;
+        if (!last)
+        {
+            if (cross)
+                fetch(nxt, 0, fc, fv, fd);
+            else
+                fetch(cur, u + SET, fc, fv, fd);
+        }
+        emit(cur, u, ec, ev, ed);
+        if (last) return false;
+        if (cross)
+        {
+            __syncthreads();  // every wavefront is done with the current panel's x
+            store_x(nxt.p);
+            cur = nxt;
+            nxt = find(cur.p + (int)gridDim.x);
+            if (nxt.p < P) load_x(nxt.p);
+            __syncthreads();
+            u = 0;
+        }
+        else
+            u += SET;
+        return true;
+    };
+    for (;;)
+    {
+        if (!step(c[0], v[0], d[0], c[1], v[1], d[1])) break;
+        if (!step(c[1], v[1], d[1], c[0], v[0], d[0])) break;
     }
 }
 
 // ---- phase B: y[group] += the group's stretch of the product stream ---------------------------------------------------
 // Flat: a lane takes pairs t, t + 1024, ... of the stretch; 16-byte product loads, 4-byte row loads, the next set in
-// flight while this one goes into LDS.
-constexpr int kTpThreads     = 1024;
-constexpr int kReduceUnroll  = 8;
+// flight while this one goes into LDS.  Runs at the rate of its reads (3.5 GB in 0.57-0.60 ms on the C5 shard; with the
+// LDS atomics replaced by plain adds, a timing experiment, it takes the same time: profiles/r03_tune_twophase_phases.txt).
+constexpr int kTpThreads    = 1024;
+constexpr int kReduceUnroll = 8;
 __global__ __launch_bounds__(kTpThreads) void tp_reduce_kernel(const int32_t* __restrict__ gstart, int ngroups,
                                                                const int32_t* __restrict__ group_ptr,
                                                                const unsigned short* __restrict__ tp_row, const double* __restrict__ xg,
@@ -248,7 +349,10 @@ __global__ __launch_bounds__(kTpThreads) void tp_reduce_kernel(const int32_t* __
     {
         const int r0   = gstart[g];
         const int rows = gstart[g + 1] - r0;
-        const int t_begin = group_ptr[g] / 2, t_end = group_ptr[g + 1] / 2;
+        // the stretch is walked from the 128-byte line of products that holds its first pair (the pairs before it belong to
+        // the previous group and are skipped): every wavefront load covers whole lines
+        const int t_first = group_ptr[g] / 2, t_end = group_ptr[g + 1] / 2;
+        const int t_begin = t_first & ~7;
         u16x2 r[2][U];
         f64x2 v[2][U];
         auto  fetch = [&](int t0, u16x2(&rr)[U], f64x2(&vv)[U]) {
@@ -265,17 +369,17 @@ __global__ __launch_bounds__(kTpThreads) void tp_reduce_kernel(const int32_t* __
             for (int k = 0; k < U; ++k)
             {
                 const int t = t0 + k * kTpThreads + (int)threadIdx.x;
-                if (t < t_end)
+                if (t < t_end && t >= t_first)
                 {
                     if (rr[k].x != kTpPadRow) atomicAdd(&acc[rr[k].x], vv[k].x);  // ds_add_f64
                     if (rr[k].y != kTpPadRow) atomicAdd(&acc[rr[k].y], vv[k].y);
                 }
             }
         };
-        if (t_begin < t_end) fetch(t_begin, r[0], v[0]);
+        if (t_first < t_end) fetch(t_begin, r[0], v[0]);
         for (int i = threadIdx.x; i < rows; i += kTpThreads) acc[i] = 0.0;
         __syncthreads();
-        for (int t0 = t_begin; t0 < t_end; t0 += 2 * SET)
+        for (int t0 = t_begin; t0 < t_end && t_first < t_end; t0 += 2 * SET)
         {
             fetch(t0 + SET, r[1], v[1]);
             add(t0, r[0], v[0]);
@@ -324,14 +428,17 @@ int tp_groups_per(const spmv_mat* m)  // rows per group: whole rounds of 256 wor
         if (per <= kTpGroupRows) return std::max(per, 1);
     }
 }
-int tp_panel_cols(const spmv_mat* m) { return m->tp_pcols_req > 0 ? std::min(m->tp_pcols_req, kTpPanelCols) : kTpPanelCols; }
+int tp_panel_cols(const spmv_mat* m)  // even: the panels of x are moved in 16-byte pairs
+{
+    return m->tp_pcols_req > 0 ? std::max(2, std::min(m->tp_pcols_req, kTpPanelCols) & ~1) : kTpPanelCols;
+}
 }  // namespace
 
 // The panel kernel sweeps x once per XCD and round (8 x rounds x 8 ncol bytes over the fabric); the two phases move
 // ~20 more bytes per entry than it and read x once.  Measured on 10M rows x 32 (profiles/r02_tune_csr_c5_*): panel
 // 1.13 / 1.63 / 1.98 / 2.37 ms at ncol = 10M / 20M / 40M / 80M against a flat 1.8-1.9 ms: the two phases win from
 // ~3x more columns than rows on, i.e. when the sweeps exceed 12 bytes per entry.  And the runs (panel x row group)
-// must be long enough that padding them to whole lines costs little.
+// must be long enough that their padding (to an even count, at least 16) costs little.
 bool csr_twophase_worth(const spmv_mat* m)
 {
     if (m->nnz < ((int64_t)8 << 20) || m->nrow <= 0) return false;
@@ -342,10 +449,136 @@ bool csr_twophase_worth(const spmv_mat* m)
     const double rounds = std::max(1.0, std::ceil((double)m->nrow / ((double)kNumCu * kTpGroupRows)));
     const double sweeps = 8.0 * (double)m->ncol * kNumXcd * rounds;
     const double runs   = (double)ceil_div(m->ncol, tp_panel_cols(m)) * (double)ceil_div(m->nrow, tp_groups_per(m));
-    if ((double)m->nnz < 64.0 * runs) return false;
-    if ((double)m->nnz + (kTpLine - 1) * runs >= 2147483648.0 || runs >= 134217728.0) return false;  // the padded layout must stay within int32
+    if ((double)m->nnz < 48.0 * runs) return false;
+    if ((double)m->nnz + kTpMinRun * runs >= (double)kTpMaxPadded || runs >= 134217728.0) return false;  // the table's delta keeps 29 bits
     return sweeps > 12.0 * (double)m->nnz;
 }
+
+namespace
+{
+void tp_grant_lds(spmv_ctx* ctx)
+{
+    static std::atomic<unsigned long long> granted{0};  // bit per device
+    if ((granted.load(std::memory_order_relaxed) >> ctx->device) & 1ull) return;
+    (void)hipFuncSetAttribute((const void*)tp_expand_kernel<1024, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160008);
+    (void)hipFuncSetAttribute((const void*)tp_expand_kernel<1024, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160008);
+    (void)hipFuncSetAttribute((const void*)tp_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160008);
+    granted.fetch_or(1ull << ctx->device, std::memory_order_relaxed);
+}
+
+void tp_launch_expand(spmv_ctx* ctx, const spmv_mat* A, const double* x)
+{
+    const size_t xlds = sizeof(double) * (size_t)A->tp_pcols;
+    const dim3   grid((unsigned)std::min(A->tp_panels, kNumCu));
+    static const int rotate = [] { const char* e = getenv("SPMV_TP_ROTATE"); return e ? atoi(e) : 1; }();  // (0: A/B)
+    // 3 pairs per lane in flight: 124 registers, nothing spilled (the default); 4 spills 24 and measured 5-10 % slower
+    if (A->tp_unroll == 4)
+        hipLaunchKernelGGL((tp_expand_kernel<1024, 4>), grid, dim3(1024), xlds, ctx->stream, A->tp_panels, A->tp_pcols, A->ncol, A->tp_panel_ptr,
+                           (const unsigned short*)A->tp_col, (const double*)A->tp_val, (const int32_t*)A->tp_blk, x, A->tp_xg, rotate);
+    else
+        hipLaunchKernelGGL((tp_expand_kernel<1024, 3>), grid, dim3(1024), xlds, ctx->stream, A->tp_panels, A->tp_pcols, A->ncol, A->tp_panel_ptr,
+                           (const unsigned short*)A->tp_col, (const double*)A->tp_val, (const int32_t*)A->tp_blk, x, A->tp_xg, rotate);
+}
+
+void tp_launch_reduce(spmv_ctx* ctx, const spmv_mat* A, double* y, const apply_extra& ex)
+{
+    hipLaunchKernelGGL(tp_reduce_kernel, dim3((unsigned)std::min(A->tp_ngroups, kNumCu)), dim3(kTpThreads), sizeof(double) * (size_t)A->tp_max_rows,
+                       ctx->stream, A->tp_gstart, A->tp_ngroups, A->tp_group_ptr, (const unsigned short*)A->tp_row, (const double*)A->tp_xg, y,
+                       ex.overwrite ? 1 : 0, ex.dot_w, ex.dot_out);
+}
+
+// Where the PRODUCT stream lies in physical memory decides a tenth of the product: with everything else in place, moving
+// tp_xg alone to another allocation switches phase A between ~1.18 and ~1.33 ms on the C5 shard (and phase B, which reads
+// it back, between 0.55 and 0.61), while moving the values, columns or rows changes nothing
+// (profiles/r03_probe_twophase_placement.txt; round 2 had seen the spread and not its owner).  The same virtual address is
+// fast in one build and slow in the next, and allocations made one after the other tend to share their mode: it is the
+// physical memory behind the allocation.  The engine cannot ask for a placement, but it can look: candidate allocations are
+// made one after the other and all held (so that each is other memory), both phases are timed on each (1 warm-up + 2
+// launches, zeroed scratch x and y), the fastest is kept and the rest returned.  The search stops when a fast and a slow
+// candidate have both been seen and the last one is among the fast, or after `SPMV_TP_PLACEMENT_TRIES` (12) candidates
+// or when less than a quarter of the device's free memory would be left.  Like the panel kernel's trial: a few dozen
+// launches when the layout is built, none afterwards; SPMV_PANEL_TRIAL=0 / "panel_trial" 0 switch both off.  Only for
+// streams of 512 MB or more, where the spread was seen.
+int tp_choose_placement(spmv_mat* m)
+{
+    spmv_ctx* ctx = m->ctx;
+    const char* e_tries = getenv("SPMV_TP_PLACEMENT_TRIES");
+    int         tries   = e_tries ? atoi(e_tries) : 12;
+    const char* e_trial = getenv("SPMV_PANEL_TRIAL");
+    if (m->pb_trial == 0 || (m->pb_trial < 0 && e_trial && e_trial[0] == '0')) tries = 0;
+    const size_t bytes = sizeof(double) * (size_t)m->tp_padded;
+    if (tries <= 1 || bytes < ((size_t)512 << 20)) return SPMV_OK;
+    hipStream_t s = ctx->stream;
+    double *    x = nullptr, *y = nullptr;
+    hipEvent_t  e0 = nullptr, e1 = nullptr;
+    bool        ok = hipMalloc(&x, sizeof(double) * (size_t)m->ncol) == hipSuccess && hipMalloc(&y, sizeof(double) * (size_t)m->nrow) == hipSuccess &&
+              hipMemsetAsync(x, 0, sizeof(double) * (size_t)m->ncol, s) == hipSuccess &&
+              hipMemsetAsync(y, 0, sizeof(double) * (size_t)m->nrow, s) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
+              hipEventCreate(&e1) == hipSuccess;
+    std::vector<double*> cand{m->tp_xg};
+    std::vector<float>   ms;
+    if (ok)
+    {
+        tp_grant_lds(ctx);
+        apply_extra plain;
+        size_t free0 = 0, total_b = 0;
+        (void)hipMemGetInfo(&free0, &total_b);
+        for (int t = 0; t < tries; ++t)
+        {
+            if (t > 0)
+            {
+                size_t  free_b = 0;
+                double* fresh  = nullptr;
+                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + free0 / 4 || hipMalloc(&fresh, bytes) != hipSuccess)
+                {
+                    (void)hipGetLastError();
+                    break;
+                }
+                cand.push_back(fresh);
+                m->tp_xg = fresh;
+            }
+            tp_launch_expand(ctx, m, x);  // warm-up (first touch of the candidate)
+            tp_launch_reduce(ctx, m, y, plain);
+            (void)hipEventRecord(e0, s);
+            for (int r = 0; r < 2; ++r)
+            {
+                tp_launch_expand(ctx, m, x);
+                tp_launch_reduce(ctx, m, y, plain);
+            }
+            (void)hipEventRecord(e1, s);
+            float t_ms = 0.f;
+            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t_ms, e0, e1) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                t_ms = 1e30f;
+            }
+            ms.push_back(t_ms);
+            const float best = *std::min_element(ms.begin(), ms.end()), worst = *std::max_element(ms.begin(), ms.end());
+            if (t >= 1 && t_ms <= best * 1.015f && worst >= best * 1.05f) break;  // both modes seen, this one is the fast one
+        }
+    }
+    size_t keep = 0;
+    for (size_t i = 1; i < ms.size(); ++i)
+        if (ms[i] < ms[keep]) keep = i;
+    if (const char* e_v = getenv("SPMV_TP_PLACEMENT_VERBOSE"); e_v && e_v[0] == '1')
+    {
+        fprintf(stderr, "two-phase product stream, ms per product for every candidate placement:");
+        for (size_t i = 0; i < ms.size(); ++i) fprintf(stderr, " %.4f%s", ms[i] / 2, i == keep ? "*" : "");
+        fprintf(stderr, "\n");
+    }
+    for (size_t i = 0; i < cand.size(); ++i)
+        if (i != keep) (void)hipFree(cand[i]);
+    m->tp_xg         = cand[keep];
+    m->tp_place_seen = (int32_t)ms.size();
+    m->tp_place_gain = ms.empty() || ms[keep] <= 0.f ? 0 : (int32_t)(1000.0f * (*std::max_element(ms.begin(), ms.end())) / ms[keep]);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (x) (void)hipFree(x);
+    if (y) (void)hipFree(y);
+    (void)hipGetLastError();
+    return SPMV_OK;
+}
+}  // namespace
 
 int csr_twophase_build(spmv_mat* m)
 {
@@ -362,9 +595,10 @@ int csr_twophase_build(spmv_mat* m)
     for (int g = 0; g <= ngroups; ++g) gstart[(size_t)g] = (int32_t)std::min<int64_t>((int64_t)g * per, m->nrow);
     const int     P    = (int)ceil_div(m->ncol, pcols);
     const int64_t keys = (int64_t)P * ngroups;
-    SPMV_REQUIRE(keys < ((int64_t)1 << 27) && m->nnz + keys * (kTpLine - 1) < ((int64_t)1 << 31),
-                 "two-phase layout: %d panels x %d groups is too fine for %lld entries", P, ngroups, (long long)m->nnz);
-    int32_t *cnt_pg = nullptr, *cnt_gp = nullptr, *start_pg = nullptr, *start_gp = nullptr;
+    SPMV_REQUIRE(keys < ((int64_t)1 << 27) && m->nnz + keys * kTpMinRun < kTpMaxPadded,
+                 "two-phase layout: %d panels x %d groups is too fine for %lld entries (or the layout would pass 2^29 entries)", P, ngroups,
+                 (long long)m->nnz);
+    int32_t *cnt_pg = nullptr, *cnt_gp = nullptr, *start_pg = nullptr, *start_gp = nullptr, *bpos = nullptr;
     int      rc     = SPMV_OK;
     const size_t kbytes = sizeof(int32_t) * (size_t)(keys + 1);
     do
@@ -388,7 +622,11 @@ int csr_twophase_build(spmv_mat* m)
         hipLaunchKernelGGL(tp_place_kernel<true>, dim3(rgrid), dim3(kBlock), 0, s, m->nrow, ngroups, P, pcols, m->tp_gstart, m->a, m->b, m->v,
                            cnt_pg, (const int32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr, (unsigned short*)nullptr,
                            (unsigned short*)nullptr, (double*)nullptr);
-        hipLaunchKernelGGL(tp_pad_kernel, dim3(kgrid), dim3(kBlock), 0, s, ngroups, P, cnt_pg, cnt_gp);
+        // runs are padded to whole 64-byte pieces of the product stream (8 entries); SPMV_TP_PAD = 2 / 16: to pairs / to whole
+        // 128-byte lines instead (A/B switch, see the header of this file)
+        const char* e_pad = getenv("SPMV_TP_PAD");
+        const int   pad   = e_pad && (atoi(e_pad) == 2 || atoi(e_pad) == 16) ? atoi(e_pad) : kTpPad;
+        hipLaunchKernelGGL(tp_pad_kernel, dim3(kgrid), dim3(kBlock), 0, s, ngroups, P, pad, cnt_pg, cnt_gp);
         if ((rc = exclusive_scan_i32(ctx, cnt_pg, start_pg, keys + 1)) != SPMV_OK) break;
         if ((rc = exclusive_scan_i32(ctx, cnt_gp, start_gp, keys + 1)) != SPMV_OK) break;
         int32_t padded = 0;
@@ -397,33 +635,38 @@ int csr_twophase_build(spmv_mat* m)
             rc = SPMV_ERR_HIP;
             break;
         }
-        if (padded < m->nnz || padded % kTpLine != 0 || (int64_t)padded > m->nnz + keys * (kTpLine - 1))
+        if (padded < m->nnz || padded % 2 != 0 || (int64_t)padded > m->nnz + keys * kTpMinRun)
         {
             rc = SPMV_ERR_HIP;  // (the scan disagrees with the counts)
             break;
         }
-        const size_t np = (size_t)padded;
+        const size_t np     = (size_t)padded;
+        const size_t nlines = (np + kTpLine - 1) / kTpLine;
         if (hipMalloc(&m->tp_val, sizeof(double) * np) != hipSuccess || hipMalloc(&m->tp_col, sizeof(unsigned short) * np) != hipSuccess ||
             hipMalloc(&m->tp_row, sizeof(unsigned short) * np) != hipSuccess || hipMalloc(&m->tp_xg, sizeof(double) * np) != hipSuccess ||
-            hipMalloc(&m->tp_blk, sizeof(int32_t) * (np / kTpLine)) != hipSuccess)
+            hipMalloc(&m->tp_blk, sizeof(int32_t) * 2 * nlines) != hipSuccess || hipMalloc(&bpos, sizeof(int32_t) * nlines) != hipSuccess)
         {
             rc = SPMV_ERR_ALLOC;
             break;
         }
         // padding: value 0 at column 0 of the panel on the source side, row 0xFFFF on the destination side; cnt_pg becomes the cursors
         if (hipMemsetAsync(m->tp_val, 0, sizeof(double) * np, s) != hipSuccess || hipMemsetAsync(m->tp_col, 0, sizeof(unsigned short) * np, s) != hipSuccess ||
-            hipMemsetAsync(m->tp_row, 0xFF, sizeof(unsigned short) * np, s) != hipSuccess || hipMemsetAsync(cnt_pg, 0, kbytes, s) != hipSuccess)
+            hipMemsetAsync(m->tp_row, 0xFF, sizeof(unsigned short) * np, s) != hipSuccess || hipMemsetAsync(cnt_pg, 0, kbytes, s) != hipSuccess ||
+            hipMemsetAsync(m->tp_blk, 0, sizeof(int32_t) * 2 * nlines, s) != hipSuccess || hipMemsetAsync(bpos, 0, sizeof(int32_t) * nlines, s) != hipSuccess)
         {
             rc = SPMV_ERR_HIP;
             break;
         }
         hipLaunchKernelGGL(tp_place_kernel<false>, dim3(rgrid), dim3(kBlock), 0, s, m->nrow, ngroups, P, pcols, m->tp_gstart, m->a, m->b, m->v,
                            (int32_t*)nullptr, start_pg, start_gp, cnt_pg, m->tp_col, m->tp_row, m->tp_val);
-        hipLaunchKernelGGL(tp_tables_kernel, dim3(kgrid), dim3(kBlock), 0, s, ngroups, P, start_pg, start_gp, m->tp_blk, m->tp_panel_ptr, m->tp_group_ptr);
+        hipLaunchKernelGGL(tp_tables_kernel, dim3(kgrid), dim3(kBlock), 0, s, ngroups, P, start_pg, start_gp, m->tp_blk, bpos, m->tp_panel_ptr,
+                           m->tp_group_ptr);
+        hipLaunchKernelGGL(tp_pack_kernel, dim3((unsigned)std::min<int64_t>(kMaxGrid, ceil_div((int64_t)nlines, kBlock))), dim3(kBlock), 0, s,
+                           (int64_t)nlines, m->tp_blk, bpos);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = SPMV_ERR_HIP;  // gstart (host) is done with
         m->tp_padded = padded;
     } while (0);
-    for (int32_t* p : {cnt_pg, cnt_gp, start_pg, start_gp})
+    for (int32_t* p : {cnt_pg, cnt_gp, start_pg, start_gp, bpos})
         if (p) (void)hipFree(p);
     if (rc != SPMV_OK)
     {
@@ -435,9 +678,9 @@ int csr_twophase_build(spmv_mat* m)
     m->tp_panels    = P;
     m->tp_pcols     = pcols;
     m->tp_max_rows  = per;
-    m->tp_bytes     = m->tp_padded * 20 + m->tp_padded / kTpLine * 4 + (int64_t)(P + 1 + 2 * (ngroups + 1)) * 4;
+    m->tp_bytes     = m->tp_padded * 20 + (m->tp_padded + kTpLine - 1) / kTpLine * 8 + (int64_t)(P + 1 + 2 * (ngroups + 1)) * 4;
     m->device_bytes += m->tp_bytes;
-    return SPMV_OK;
+    return tp_choose_placement(m);
 }
 
 int csr_twophase_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, const apply_extra& ex)
@@ -449,39 +692,15 @@ int csr_twophase_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, dou
     }
     // the kernels dereference exactly these: refuse on the host rather than fault on the GPU
     if (!A->tp_val || !A->tp_col || !A->tp_row || !A->tp_xg || !A->tp_blk || !A->tp_panel_ptr || !A->tp_group_ptr || !A->tp_gstart || !x || !y ||
-        A->tp_panels <= 0 || A->tp_pcols <= 0 || A->tp_pcols > kTpPanelCols || A->tp_max_rows > kTpGroupRows || A->tp_padded % kTpLine != 0)
+        A->tp_panels <= 0 || A->tp_pcols <= 0 || A->tp_pcols > kTpPanelCols || A->tp_pcols % 2 != 0 || A->tp_max_rows > kTpGroupRows ||
+        A->tp_padded % 2 != 0)
         SPMV_FAIL(SPMV_ERR_INVALID, "two-phase kernel selected but its layout was not built");
-    static std::atomic<unsigned long long> granted{0};  // bit per device
-    if (!((granted.load(std::memory_order_relaxed) >> ctx->device) & 1ull))
-    {
-        SPMV_HIP(hipFuncSetAttribute((const void*)tp_expand_kernel<1024, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160008));
-        SPMV_HIP(hipFuncSetAttribute((const void*)tp_expand_kernel<1024, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160008));
-        SPMV_HIP(hipFuncSetAttribute((const void*)tp_expand_kernel<512, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 80008));
-        SPMV_HIP(hipFuncSetAttribute((const void*)tp_expand_kernel<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80008));
-        SPMV_HIP(hipFuncSetAttribute((const void*)tp_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160008));
-        granted.fetch_or(1ull << ctx->device, std::memory_order_relaxed);
-    }
-    // a panel of at most 10000 columns: two workgroups of 512 share a CU
-    const bool   half  = A->tp_pcols * 2 <= kTpPanelCols;
-    const int    unr   = A->tp_unroll == 4 ? 4 : 6;
-    const size_t xlds  = sizeof(double) * (size_t)A->tp_pcols;
-    const dim3   egrid((unsigned)std::min(A->tp_panels, half ? 2 * kNumCu : kNumCu));
-    static const int rotate = [] { const char* e = getenv("SPMV_TP_ROTATE"); return e ? atoi(e) : 1; }();  // (0: A/B)
-#define SPMV_TP_EXPAND(T, U)                                                                                                                  \
-    hipLaunchKernelGGL((tp_expand_kernel<T, U>), egrid, dim3(T), xlds, ctx->stream, A->tp_panels, A->tp_pcols, A->ncol, A->tp_panel_ptr,       \
-                       (const unsigned short*)A->tp_col, (const double*)A->tp_val, (const int32_t*)A->tp_blk, x, A->tp_xg, rotate)
-    if (half && unr == 6)
-        SPMV_TP_EXPAND(512, 6);
-    else if (half)
-        SPMV_TP_EXPAND(512, 4);
-    else if (unr == 6)
-        SPMV_TP_EXPAND(1024, 6);
-    else
-        SPMV_TP_EXPAND(1024, 4);
-#undef SPMV_TP_EXPAND
-    hipLaunchKernelGGL(tp_reduce_kernel, dim3((unsigned)std::min(A->tp_ngroups, kNumCu)), dim3(kTpThreads), sizeof(double) * (size_t)A->tp_max_rows,
-                       ctx->stream, A->tp_gstart, A->tp_ngroups, A->tp_group_ptr, (const unsigned short*)A->tp_row, (const double*)A->tp_xg, y,
-                       ex.overwrite ? 1 : 0, ex.dot_w, ex.dot_out);
+    tp_grant_lds(ctx);
+    // SPMV_TP_ONLY = 1 / 2: one phase alone, read per call (tools/tune_twophase.py times the phases; the result is then wrong)
+    const char* e_only = getenv("SPMV_TP_ONLY");
+    const int   only   = e_only ? atoi(e_only) : 0;
+    if (only != 2) tp_launch_expand(ctx, A, x);
+    if (only != 1) tp_launch_reduce(ctx, A, y, ex);
     SPMV_HIP(hipGetLastError());
     return SPMV_OK;
 }

@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
-"""tools/probe_twophase_placement.py — the two-phase product of the C5 shard shape, its layout built several times in
-one process (alternating two panel widths forces a re-build: every stream is freed and allocated again).  Measured
-(profiles/r02_probe_twophase_placement.txt): the streams come back at the SAME device addresses, filling the same
-memory again with the entries in another order changes nothing, and yet a re-build lands anywhere from 1.79 to 2.03 ms
-per product (phase A: 1.22 or 1.38 ms) — what differs is the physical memory behind the addresses."""
+"""tools/probe_twophase_placement.py — which stream's PLACEMENT decides the time of the two-phase product?
+
+Round 2 found (profiles/r02_probe_twophase_placement.txt) that re-building the layout of the C5 shard shape in one
+process gives the same device addresses and yet 1.82-1.88 or 1.95-2.03 ms per product.  Here single streams are moved to
+fresh allocations (spmv_mat_set_param "twophase_realloc": bit 1 products, 2 values, 4 columns, 8 rows; contents copied,
+the old allocation freed afterwards) and each phase is timed alone after every move."""
+import os
+import statistics
 import sys
 from pathlib import Path
 
@@ -18,17 +21,28 @@ def main():
     n, ncol, k = 10_000_000, int(sys.argv[1]) if len(sys.argv) > 1 else 80_000_000, 32
     ctx = capi.Context(0)
     A = ctx.gen_csr_uniform(0, n, ncol, k, band=0, seed=1)
+    A.set_kernel(capi.CSR_TWOPHASE)
     x, y = ctx.gen_vector(ncol, seed=1), ctx.vector(n)
     y.fill(0.0)
-    for build in range(8):
-        for cols in (10_000, 20_000):  # the first forces the re-build of the second
-            A.set_param("twophase_panel_cols", cols)
-            A.set_kernel(capi.CSR_TWOPHASE)
-        ts = []
-        for _ in range(3):
+
+    def phases():
+        out = []
+        for only in ("1", "2", None):
+            if only:
+                os.environ["SPMV_TP_ONLY"] = only
+            else:
+                os.environ.pop("SPMV_TP_ONLY", None)
             ctx.apply(A, x, y)
-            ts.append(ctx.apply_timed(A, x, y, 5))
-        print(f"build {build}: " + " ".join(f"{t:.4f}" for t in ts) + " ms per product", flush=True)
+            out.append(statistics.median(ctx.apply_timed(A, x, y, 5) for _ in range(3)))
+        return out
+
+    a, b, ab = phases()
+    print(f"as built:                 A {a:.4f}  B {b:.4f}  both {ab:.4f}", flush=True)
+    for name, bits in (("products", 1), ("values", 2), ("columns", 4), ("rows", 8)):
+        for rep in range(5):
+            A.set_param("twophase_realloc", bits)
+            a, b, ab = phases()
+            print(f"moved {name:9s} (#{rep}):   A {a:.4f}  B {b:.4f}  both {ab:.4f}", flush=True)
 
 
 if __name__ == "__main__":
