@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--builds", type=int, default=1, help="re-build the layout this many times (placement lottery)")
     ap.add_argument("--pads", type=lambda v: [int(t) for t in v.split(",")], default=[8], help="run padding per build, cycled: 2, 8 or 16 entries")
-    ap.add_argument("--tries", type=int, default=6, help="placements of the product stream timed per build (1 = none)")
+    ap.add_argument("--tries", type=int, default=12, help="placements of the product stream timed per build (1 = none)")
     a = ap.parse_args()
     ctx = capi.Context(0)
     A = ctx.gen_csr_uniform(0, a.n, a.ncol, a.k, band=0, seed=1)
