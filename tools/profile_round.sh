@@ -39,7 +39,7 @@ if cur:
 with open(O + "/timed_region.txt", "w") as out:
     for run in runs:
         name = run[0]["Kernel_Name"]
-        if len(run) < 50 or is_trial(name) or not any(k in name for k in ("csr_panel_kernel", "ell_kernel", "ell_diag_kernel", "tp_expand_kernel", "tp_reduce_kernel")):
+        if len(run) < 50 or is_trial(name) or not any(k in name for k in ("csr_panel_kernel", "ell_kernel", "ell_diag_kernel", "coo_segscan_kernel", "tp_expand_kernel", "tp_reduce_kernel")):
             continue
         d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in run]
         tail = d[-50:]
@@ -56,5 +56,5 @@ with open(O + "/timed_region.txt", "a") as out:
 print(open(O + "/timed_region.txt").read())
 PY
 # product launches only (the trial launches carry `true` as their fourth template argument); per workload: 1 warm-up + 5
-for d in pmc_fetch pmc_write pmc_tcc pmc_req; do echo "== $d"; python3 tools/pmc_summary.py "$O/$d" csr_panel --runs | grep -v ", true," ; python3 tools/pmc_summary.py "$O/$d" ell_ --runs; python3 tools/pmc_summary.py "$O/$d" tp_ | tail -4; done > "$O/pmc_summary.txt" 2>&1
+for d in pmc_fetch pmc_write pmc_tcc pmc_req; do echo "== $d"; python3 tools/pmc_summary.py "$O/$d" csr_panel --runs | grep -v ", true," ; python3 tools/pmc_summary.py "$O/$d" ell_ --runs; python3 tools/pmc_summary.py "$O/$d" coo_segscan --runs; python3 tools/pmc_summary.py "$O/$d" tp_ | tail -4; done > "$O/pmc_summary.txt" 2>&1
 cat "$O/pmc_summary.txt"
