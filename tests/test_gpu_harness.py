@@ -31,7 +31,7 @@ def test_spmv_main_verifies_every_format_and_the_sharded_drivers(tmp_path, pkg):
     assert r.returncode == 0, r.stdout + r.stderr
     out = r.stdout
     assert "### ROW=3000, COL=3000, NNZ=36000" in out
-    for name in ("CSR", "CSR EDIT-IN-PLACE", r"CSR \(edit undone\)", "CSR NUMA", "CSC", "CSC NUMA", "ELL", "ELL NUMA", "COO NUMA"):
+    for name in ("COO", "CSR", "CSR EDIT-IN-PLACE", r"CSR \(edit undone\)", "CSR NUMA", "CSC", "CSC NUMA", "ELL", "ELL NUMA", "COO NUMA"):
         m = re.search(rf"### {name} VERIFY .* = ([0-9.e+-]+) OK", out)
         assert m and float(m.group(1)) <= 1e-10, (name, out)
     # the generated matrix has duplicate (i,j) entries in some rows: the reference's DIA keeps the last one
