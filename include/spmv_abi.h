@@ -137,9 +137,12 @@ int spmv_vec_copy(spmv_vec* dst, int64_t dst_offset, const spmv_vec* src, int64_
  * src/mat_vec.cpp:257,266 — by an all-gather on the devices: participant i holds slice [offsets[i], offsets[i+1]) of x
  * in its own (full-length) vector; afterwards every participant's vector holds all of [0, offsets[n]).  Asynchronous:
  * ordered by events behind the work queued on the participants' streams, and the streams continue behind it.
- * Transport: RCCL (ncclCommInitAll + a group of broadcasts, one per slice; loaded with dlopen) when every participant
- * has a GPU of its own, else — or with SPMV_COMM=peer — concurrent hipMemcpyPeerAsync pulls, one stream per peer link.
- * Participants may share a GPU (several shards on one device): then the copies are device-to-device.
+ * Transport: RCCL (ncclCommInitAll; one in-place ncclAllGather when the slices are equal, else a group of broadcasts, one
+ * per slice; loaded with dlopen and called through rccl.h's own prototypes; fresh communicators pass a self-check first) when
+ * there are two or more participants, each with a GPU of its own, else — or with SPMV_COMM=peer — concurrent
+ * hipMemcpyPeerAsync pulls, one stream per peer link.  SPMV_COMM=rccl: RCCL or SPMV_ERR_*, also with ONE participant (a
+ * one-GPU box exercising the RCCL calls).  Participants may share a GPU (several shards on one device): then the copies
+ * are device-to-device.  The calling thread's current HIP device is left as it was found.
  * (One process per GPU instead: arm-spmv_amd/dist.py does the same exchange through torch.distributed.) */
 typedef struct spmv_comm spmv_comm;
 int         spmv_comm_create(spmv_ctx* const* ctxs, int32_t n, spmv_comm** out);
@@ -211,9 +214,11 @@ int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
  *                    (memory 2x -> 1x the matrix; download, other kernels, re-builds and conversions are then refused)
  *   "panel_trial"    1 / 0 = timing launches when the layout is built, yes / no (-1 = environment, default yes)
  *   "dia_col_bound"  DIA handles: columns >= this are skipped (row shards keep the bound of the whole matrix)
- *   "twophase_panel_cols", "twophase_unroll"   two-phase CSR kernel: columns of x per panel (<= 20000; <= 10000 puts two
- *                    workgroups on a CU) and pairs per lane in flight (6 or 4); take effect at the next
- *                    spmv_mat_set_kernel(SPMV_CSR_TWOPHASE)
+ *   "twophase_panel_cols", "twophase_unroll"   two-phase CSR kernel: columns of x per panel (<= 20000, even) and pairs per lane
+ *                    in flight in the expand phase (3, the default, or 4); take effect at the next
+ *                    spmv_mat_set_kernel(SPMV_CSR_TWOPHASE) / at the next product
+ *   "twophase_realloc"  experiment (tools/probe_twophase_placement.py): move streams of the built two-phase layout to fresh
+ *                    allocations; bits 1 products, 2 values, 4 columns, 8 rows
  *   "symgs_order"    sweep order of spmv_symgs / SPMV_PRECOND_SYMGS: 1 multicolour (default), 0 the matrix's own row order
  *   "panel_trace", "panel_legacy", "panel_two_per_cu"
  *                    diagnostics and experiments kept for the record (tools/trace_panel.py) */
@@ -221,7 +226,8 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value);
 /* What is in effect: "panel_rows", "panel_width", "panel_sort", "panel_groups", "panel_layout", "panel_unroll",
  * "panel_pipe", "panel_sync", "panel_stagger", "panel_pace_ns", "panel_pace_scale", "panel_pace_bumps",
  * "panel_bytes", "panel_keep_csr", "device_bytes", "window_max_span", "window_avg_span", "twophase_panel_cols",
- * "twophase_padded" (entries of the two-phase layout with its padding), "ell_diagonal_slots" (1: the slots of an ELL
+ * "twophase_padded" (entries of the two-phase layout with its padding), "twophase_placements_timed" / "twophase_placement_spread"
+ * (candidate allocations of the product stream timed when the layout was built; slowest / kept in 1/1000), "ell_diagonal_slots" (1: the slots of an ELL
  * handle were found to be diagonals and conforming rows read no column index), "symgs_order", "symgs_colours",
  * "symgs_levels_forward", "symgs_levels_backward", "symgs_launches", "symgs_bytes". */
 int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value);
