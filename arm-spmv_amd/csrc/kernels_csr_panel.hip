@@ -923,11 +923,12 @@ int panel_choose_pace(spmv_mat* m)
     {
         int unroll, pipe, sync;
     };
-    // ({4, stream-first, barrier} is what the shard shapes with x 2-4x the rows take: 1.50 against 1.60 ms at N = 2)
-    const Try packed_tries[] = {{8, 2, 3}, {8, 2, 1}, {4, 2, 1}, {4, 1, 1}, {4, 1, 0}, {8, 1, 0}};
+    // (stream-first with a barrier is what the shard shapes with x 2-4x the rows take: at N = 2, 10M x 20M, {8, stream-first,
+    // barrier} 1.46 ms, {4, ...} 1.51, the best gather-first candidate 1.62: profiles/r03_tune_csr_shard_shapes_n2_n4.txt)
+    const Try packed_tries[] = {{8, 2, 3}, {8, 2, 1}, {4, 2, 1}, {4, 1, 1}, {8, 1, 1}, {4, 1, 0}, {8, 1, 0}};
     const Try plain_tries[]  = {{8, 1, 1}, {8, 1, 0}, {4, 1, 0}, {2, 1, 0}};
     const Try* tries  = m->pb_pack ? packed_tries : plain_tries;
-    const int  ntries = m->pb_pack ? 6 : 4;
+    const int  ntries = m->pb_pack ? 7 : 4;
     Try    best{m->pb_unroll > 0 ? m->pb_unroll : 8, m->pb_pipe >= 0 ? m->pb_pipe : 1, m->pb_sync >= 0 ? m->pb_sync : 0};
     double best_ms = 1e30;
     int    tried   = 0;
