@@ -373,7 +373,11 @@ int csr_split_columns(spmv_ctx* ctx, const spmv_mat* csr, int32_t c0, int32_t c1
         if (A_out) mat_free(A_out);
         SPMV_FAIL(rc, "spmv_csr_split_columns failed: %s", hipGetErrorString(hipGetLastError()));
     }
-    A_in->row_begin = A_out->row_begin = csr->row_begin;
+    // `inside` has its columns rebased to c0: its row i (global row row_begin + i) meets its own diagonal at column
+    // row_begin + i - c0.  For the block of a shard's own rows (c0 = row_begin) that is a square matrix starting at 0, which
+    // is what the Jacobi diagonal and the Gauss-Seidel sweep of the sharded solver work on.
+    A_out->row_begin = csr->row_begin;
+    A_in->row_begin  = csr->row_begin - c0;
     *out_in  = A_in;
     *out_out = A_out;
     return SPMV_OK;

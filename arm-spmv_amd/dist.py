@@ -110,6 +110,19 @@ class HipShardOps:
         v.fill(0.0)
         return v
 
+    # ---- block-Jacobi preconditioner: symmetric Gauss-Seidel inside the rank's own diagonal block -------------
+    def enable_symgs(self, col_begin: int, col_end: int, sweeps: int = 1) -> None:
+        """z = M^-1 r with M = one symmetric Gauss-Seidel sweep (spmv_symgs, multicolour) on the square block of the shard
+        whose columns are the rank's own rows [col_begin, col_end) - block Jacobi across the ranks, Gauss-Seidel inside,
+        no exchange.  The block is the `inside` part of spmv_csr_split_columns (columns rebased to 0)."""
+        if not hasattr(self, "A_in"):
+            self.enable_overlap(col_begin, col_end)
+        self._gs_sweeps = sweeps
+        self.ctx.symgs_order(self.A_in)  # set-up now (colouring, split, levels), outside the iteration
+
+    def precondition(self, r_own, z_own) -> None:
+        self.ctx.symgs(self.A_in, self._v(r_own), self._fill0(z_own), self._gs_sweeps)
+
     def axpby(self, alpha, x, beta, y, w) -> None:  # w = alpha x + beta y (w may be x or y)
         self.ctx.axpby(alpha, self._v(x), beta, self._v(y), self._v(w))
 
@@ -127,27 +140,35 @@ def cg_sharded(ops, b_own: torch.Tensor, x_own: torch.Tensor, nrow: int, max_ite
     Per iteration: ONE all-gather (the search direction p, which every shard needs in full — the x exchange of
     SURVEY.md 8e) and two scalar all-reduces (p.Ap and r.r).  When `ops` was split by column range
     (HipShardOps.enable_overlap), the product of the rank's own columns is queued on the engine's stream BEFORE the
-    all-gather is issued on torch's, so the two run side by side; the remaining columns follow the exchange.  Vectors stay sharded by rows and device-resident;
+    all-gather is issued on torch's, so the two run side by side; the remaining columns follow the exchange.  When `ops`
+    has a `precondition(r_own, z_own)` (HipShardOps.enable_symgs: one symmetric Gauss-Seidel sweep on the rank's own diagonal
+    block - block Jacobi across the ranks, so it needs no exchange) the iteration is preconditioned CG with one more scalar
+    all-reduce (r.z).  Vectors stay sharded by rows and device-resident;
     `ops` does the local work (HipShardOps on a GPU; the CPU tests plug the oracle in).  Every rank returns the same
     (iterations, ||r|| / ||b||)."""
     dev = b_own.device
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     lo, hi = all_bounds(nrow, world)[rank]
+    precond = hasattr(ops, "precondition") and getattr(ops, "_gs_sweeps", 0) > 0  # (enable_symgs was called)
     p_full = torch.empty(nrow, dtype=torch.float64, device=dev)
     q_own, r_own, p_own = torch.empty_like(b_own), torch.empty_like(b_own), torch.empty_like(b_own)
-    # r = b - A x0, p = r
+    z_own = torch.empty_like(b_own) if precond else r_own
+    # r = b - A x0, z = M^-1 r, p = z
     allgather_x(p_full, x_own, nrow, group)
     if dev.type == "cuda":
         torch.cuda.current_stream(dev).synchronize()
     ops.product_dot(p_full, b_own, q_own)
     ops.axpby(1.0, b_own, -1.0, q_own, r_own)
-    ops.axpby(1.0, r_own, 0.0, r_own, p_own)
+    if precond:
+        ops.precondition(r_own, z_own)
+    ops.axpby(1.0, z_own, 0.0, z_own, p_own)
     bb = sum_over_ranks(ops.dot(b_own, b_own), dev, group)
     rr = sum_over_ranks(ops.dot(r_own, r_own), dev, group)
+    rz = sum_over_ranks(ops.dot(r_own, z_own), dev, group) if precond else rr
     if bb == 0.0 or rr <= rel_tol * rel_tol * bb:
         return 0, (rr / bb) ** 0.5 if bb > 0.0 else 0.0
     k = 0
-    overlap = hasattr(ops, "A_in") or getattr(ops, "overlap", False)
+    overlap = (hasattr(ops, "A_in") or getattr(ops, "overlap", False)) and getattr(ops, "use_overlap", True)
     while k < max_iter:
         ops.sync()  # the collective runs on torch's stream: p_own must be complete
         if overlap:
@@ -164,14 +185,18 @@ def cg_sharded(ops, b_own: torch.Tensor, x_own: torch.Tensor, nrow: int, max_ite
             pq = sum_over_ranks(ops.product_dot(p_full, p_own, q_own), dev, group)
         if not pq > 0.0:
             raise ArithmeticError(f"cg_sharded: p.Ap = {pq} at iteration {k}: the matrix is not positive definite")
-        alpha = rr / pq
+        alpha = rz / pq
         ops.axpby(alpha, p_own, 1.0, x_own, x_own)
         ops.axpby(-alpha, q_own, 1.0, r_own, r_own)
-        rr_new = sum_over_ranks(ops.dot(r_own, r_own), dev, group)
+        rr = sum_over_ranks(ops.dot(r_own, r_own), dev, group)
         k += 1
-        if rr_new <= rel_tol * rel_tol * bb:
-            rr = rr_new
+        if rr <= rel_tol * rel_tol * bb:
             break
-        ops.axpby(1.0, r_own, rr_new / rr, p_own, p_own)
-        rr = rr_new
+        if precond:
+            ops.precondition(r_own, z_own)  # local: block Jacobi across the ranks, no exchange
+            rz_new = sum_over_ranks(ops.dot(r_own, z_own), dev, group)
+        else:
+            rz_new = rr
+        ops.axpby(1.0, z_own, rz_new / rz, p_own, p_own)
+        rz = rz_new
     return k, (rr / bb) ** 0.5

@@ -121,8 +121,22 @@ class _OracleOps:
     def sync(self):
         pass
 
+    # block-Jacobi preconditioner (dist.HipShardOps.enable_symgs): the oracle's symmetric Gauss-Seidel sweep, in the
+    # matrix's own row order, on the rank's own diagonal block
+    def enable_symgs(self, c0, c1, sweeps=1):
+        if not hasattr(self, "m_in"):
+            self.enable_overlap(c0, c1)
+        self.use_overlap = False
+        self._gs_sweeps = sweeps
+        self.precondition = self._precondition
 
-def _cg_worker(rank, world, port, m, q, overlap=False):
+    def _precondition(self, r_own, z_own):
+        z = z_own.numpy()
+        z[:] = 0.0
+        assert self.ol.symgs(self.orc, *self.m_in, r_own.numpy(), z, self._gs_sweeps) == 0
+
+
+def _cg_worker(rank, world, port, m, q, overlap=False, symgs=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import sys
     from pathlib import Path
@@ -152,6 +166,8 @@ def _cg_worker(rank, world, port, m, q, overlap=False):
         ops = _OracleOps(orc, ol, srp, np.ascontiguousarray(col[rp[b]:rp[e]]), np.ascontiguousarray(val[rp[b]:rp[e]]))
         if overlap:
             ops.enable_overlap(b, e)
+        if symgs:
+            ops.enable_symgs(b, e)
         x_own = torch.zeros(e - b, dtype=torch.float64)
         iters, relres = dmod.cg_sharded(ops, torch.from_numpy(bvec[b:e].copy()), x_own, n, max_iter=500, rel_tol=1e-10)
         x_full = dmod.concatenate_y(x_own, n).numpy()
@@ -163,13 +179,16 @@ def _cg_worker(rank, world, port, m, q, overlap=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,m,overlap", [(2, 600, False), (3, 601, False), (2, 600, True), (3, 601, True)])
-def test_sharded_cg_over_gloo(world, m, overlap):
-    """dist.cg_sharded: one all-gather of the direction + two scalar all-reduces per iteration"""
+@pytest.mark.parametrize("world,m,overlap,symgs", [(2, 600, False, False), (3, 601, False, False), (2, 600, True, False), (3, 601, True, False),
+                                                   (2, 600, False, True), (3, 601, False, True)])
+def test_sharded_cg_over_gloo(world, m, overlap, symgs):
+    """dist.cg_sharded: one all-gather of the direction + two scalar all-reduces per iteration; with
+    `symgs` the block-Jacobi preconditioner (a symmetric Gauss-Seidel sweep on every rank's own diagonal block, no
+    exchange) and one more all-reduce"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_cg_worker, args=(r, world, port, m, q, overlap)) for r in range(world)]
+    procs = [ctx.Process(target=_cg_worker, args=(r, world, port, m, q, overlap, symgs)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=180) for _ in range(world)]
@@ -178,3 +197,5 @@ def test_sharded_cg_over_gloo(world, m, overlap):
         assert p.exitcode == 0
     assert len({(r[1], r[2]) for r in results}) == 1, "ranks disagree on iterations / residual"
     assert all(0 < r[1] < 500 and r[2] <= 1e-10 and r[3] <= 1e-9 for r in results), results
+    if symgs:  # (1-D Laplacian with diagonal 2.5: plain CG needs ~30 iterations to 1e-10, the sweep about half)
+        assert results[0][1] <= 20, results
