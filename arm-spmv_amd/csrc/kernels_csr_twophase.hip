@@ -696,9 +696,11 @@ int csr_twophase_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, dou
         A->tp_padded % 2 != 0)
         SPMV_FAIL(SPMV_ERR_INVALID, "two-phase kernel selected but its layout was not built");
     tp_grant_lds(ctx);
-    // SPMV_TP_ONLY = 1 / 2: one phase alone, read per call (tools/tune_twophase.py times the phases; the result is then wrong)
+    // SPMV_TP_ONLY = 1 / 2 together with SPMV_EXPERIMENTS = 1: one phase alone, read per call (tools/tune_twophase.py times
+    // the phases; the RESULT IS THEN WRONG, hence the second switch)
     const char* e_only = getenv("SPMV_TP_ONLY");
-    const int   only   = e_only ? atoi(e_only) : 0;
+    const char* e_exp  = getenv("SPMV_EXPERIMENTS");
+    const int   only   = e_only && e_exp && e_exp[0] == '1' ? atoi(e_only) : 0;
     if (only != 2) tp_launch_expand(ctx, A, x);
     if (only != 1) tp_launch_reduce(ctx, A, y, ex);
     SPMV_HIP(hipGetLastError());

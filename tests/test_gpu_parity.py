@@ -410,12 +410,26 @@ def test_csr_twophase_kernel_on_wide_and_ragged_matrices(ctx, orc, pkg):
     got = dy.download()
     ol.assert_parity(got, ref, scale, "twophase overwrite")
     assert abs(d - float(w @ got)) <= 1e-9 * float(np.abs(w) @ np.abs(got))
-    # a narrower panel (two workgroups per CU in the expand phase) and the shorter pipeline: same sums
-    for cols, unroll in ((10_000, 6), (7_000, 4), (20_000, 4)):
+    # x that is only 8-byte aligned (a view one entry into a vector): the expand phase then loads its panels of x with
+    # 8-byte instead of 16-byte loads
+    big = ctx.vector(ncol + 1)
+    big.upload(np.concatenate(([123.0], x)))
+    dx_odd = ctx.wrap_vector(big.device_ptr + 8, ncol)
+    dy.fill(0.0)
+    ctx.apply(A, dx_odd, dy)
+    ctx.sync()
+    ol.assert_parity(dy.download(), ref, scale, "twophase, x not 16-byte aligned")
+    # narrower panels (an odd request is rounded down to even: x moves in pairs), both pipeline depths, and every run padding
+    # (pairs / 64-byte pieces / 128-byte lines: boundaries at any pair of a source line, at half lines, at lines only)
+    import os
+
+    for cols, unroll, pad in ((10_000, 3, 8), (7_001, 4, 8), (20_000, 4, 2), (333, 3, 2), (20_000, 3, 16), (4_000, 3, 16)):
+        os.environ["SPMV_TP_PAD"] = str(pad)
         A.set_param("twophase_panel_cols", cols)
         A.set_param("twophase_unroll", unroll)
         A.set_kernel(capi.CSR_TWOPHASE)
-        assert A.get_param("twophase_panel_cols") == cols and A.get_param("twophase_padded") % 2 == 0
+        os.environ.pop("SPMV_TP_PAD")
+        assert A.get_param("twophase_panel_cols") == cols - cols % 2 and A.get_param("twophase_padded") % pad == 0
         dy.fill(0.0)
         ctx.apply(A, dx, dy)
         ctx.sync()

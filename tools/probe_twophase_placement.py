@@ -15,6 +15,7 @@ sys.path.insert(0, str(ROOT))
 from __graft_entry__ import load_package  # noqa: E402
 
 capi = load_package().capi
+os.environ["SPMV_EXPERIMENTS"] = "1"  # SPMV_TP_ONLY (one phase alone, wrong results) is honoured only with this
 
 
 def main():
