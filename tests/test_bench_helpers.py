@@ -1,0 +1,40 @@
+"""CPU tests of bench.py's bookkeeping: the bytes a kernel has to move (`roofline.bytes_required` of the extra lines) and
+the stamp check that keeps stale PMC constants out of the line (`roofline.traffic`, `l2_line_ops`)."""
+import json
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import bench  # noqa: E402
+
+
+def test_required_bytes_per_kernel_kind():
+    n, k = 4_000_000, 64
+    # C3: ELL's algorithmic figure is the column-reading kernel's requirement; diagonal slots drop the 4-byte index
+    assert bench.algorithmic_bytes("ell", n, n, n * k, k) == 3_168_000_000 == bench.required_bytes("ell_columns", n, n, n * k, k)
+    assert bench.required_bytes("ell_diagonals", n, n, n * k, k) == 8 * n * k + 8 * n + 16 * n == 2_144_000_000
+    # C2: CSR
+    assert bench.required_bytes("csr", 10_000_000, 10_000_000, 320_000_000) == 4_120_000_004 == bench.algorithmic_bytes("csr", 10_000_000, 10_000_000, 320_000_000)
+    # C4: the panel path moves 12 bytes per entry, the segmented scan COO's 16
+    nnz = 115_008_628
+    assert bench.required_bytes("coo_segscan", 2_000_000, 2_000_000, nnz) == bench.algorithmic_bytes("coo", 2_000_000, 2_000_000, nnz)
+    assert bench.required_bytes("panel", 2_000_000, 2_000_000, nnz) < bench.algorithmic_bytes("coo", 2_000_000, 2_000_000, nnz)
+
+
+def test_counters_are_reported_only_for_the_kernel_and_layout_they_were_measured_on():
+    table = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+    key = "csr_n10000000_k32_band0_ncol10000000"
+    layout = dict(table[key]["match"]["panel_layout"])
+    got = bench.measured_counters(key, "csr_panel_kernel", layout)
+    assert got["traffic"] == table[key]["hbm_bytes_per_launch"] and got["l2_line_ops"] == table[key]["tcp_tcc_read_req"] + table[key]["tcc_miss"]
+    assert 270e6 < got["l2_line_ops"] < 280e6
+    other = dict(layout, unroll=4)
+    stale = bench.measured_counters(key, "csr_panel_kernel", other)
+    assert stale["traffic"] is None and stale["l2_line_ops"] is None and "stale" in stale["measured_on"]
+    assert bench.measured_counters(key, "tp_expand_kernel + tp_reduce_kernel (two-phase)", None)["traffic"] is None
+    assert bench.measured_counters("no_such_workload", "csr_panel_kernel", layout) == {"traffic": None, "l2_line_ops": None, "measured_on": None}
+    # every entry of the table that carries a stamp names a kernel
+    for name, e in table.items():
+        if isinstance(e, dict) and "match" in e:
+            assert e["match"].get("kernel"), name
