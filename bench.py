@@ -620,6 +620,18 @@ def main() -> None:
                 one(f"C5 shard: what the last rank of 8 holds in BASELINE configs[4] (rows {7 * n}-{8 * n} of {8 * n} x {8 * n}, {k} per row; "
                     "x = 640 MB resident)", "csr", c5_shard, tkey=f"csr_n{n}_k{k}_band0_ncol{8 * n}")
 
+        # every rank's own kernel time (the headline takes the slowest): shows whether one rank's placement / layout lags
+        per_rank_ms = [round(kernel_ms, 5)]
+        if grouped:
+            everyone = torch.zeros(world, dtype=torch.float64, device=dev)
+            everyone[rank] = kernel_ms
+            dist.all_reduce(everyone, op=dist.ReduceOp.SUM)  # (a one-hot sum: the same collective the times already use)
+            per_rank_ms = [round(float(v), 5) for v in everyone.tolist()]
+        twophase = None
+        if int(info.kernel) == 5:
+            twophase = {"panel_cols": A.get_param("twophase_panel_cols"), "padded_entries": A.get_param("twophase_padded"),
+                        "placements_timed": A.get_param("twophase_placements_timed"),
+                        "slowest_over_kept_placement": A.get_param("twophase_placement_spread") / 1000.0}
         wall_s, kernel_ms, exch_max = max_over_ranks(wall_s, kernel_ms, exch_s or 0.0)
 
     if rank == 0:
@@ -674,6 +686,8 @@ def main() -> None:
                                  "matrix_csr": 12 * nnz_rank + 4 * (n + 1),
                                  "ratio_to_matrix": round(bytes_held / (12 * nnz_rank + 4 * (n + 1)), 3)},
                 "panel_layout": panel,
+                "twophase_layout": twophase,
+                "kernel_ms_per_rank": per_rank_ms,
             },
             "roofline": {
                 "bound": "hbm",
