@@ -32,7 +32,8 @@
 // destination pair = source pair + delta0 for the pairs of the line before position bpos, + delta1 from bpos on (bpos = 0:
 // no boundary inside the line).  Eight lanes share one 8-byte load.  delta0 has 29 bits: the layout holds < 2^29 entries.
 // Every wavefront access of either phase covers whole 128-byte lines of the arrays it reads: panels and group stretches
-// are walked from the line that holds their first pair.
+// are walked from the 512-byte stretch (32 pairs) that holds their first pair, so that the loads of the 4-byte index pairs
+// cover whole lines too (phase B 0.58 -> 0.545 ms against walks aligned to the products' lines only).
 //
 // Layout (built once per handle, like the reference's shard construction before its timed loop, src/mat_vec.cpp:240-268):
 //   tp_val[e], tp_col[e] (uint16: column - panel base)     e in (panel, group) order, padding: value 0, column 0
@@ -206,9 +207,9 @@ __global__ __launch_bounds__(THREADS) void tp_expand_kernel(int P, int pcols, in
             const int tb = panel_ptr[q] / 2, te = panel_ptr[q + 1] / 2;
             if (te > tb)
             {
-                const int t0  = tb & ~7;
+                const int t0  = tb & ~31;
                 const int len = te - t0;
-                return Pan{q, t0, len, tb - t0, rotate ? (int)(((int64_t)len * (int)(blockIdx.x % 256u) / 256) & ~7) : 0};
+                return Pan{q, t0, len, tb - t0, rotate ? (int)(((int64_t)len * (int)(blockIdx.x % 256u) / 256) & ~31) : 0};
             }
         }
         return Pan{P, 0, 0, 0, 0};
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(kTpThreads) void tp_reduce_kernel(const int32_t* __
         // the stretch is walked from the 128-byte line of products that holds its first pair (the pairs before it belong to
         // the previous group and are skipped): every wavefront load covers whole lines
         const int t_first = group_ptr[g] / 2, t_end = group_ptr[g + 1] / 2;
-        const int t_begin = t_first & ~7;
+        const int t_begin = t_first & ~31;
         u16x2 r[2][U];
         f64x2 v[2][U];
         auto  fetch = [&](int t0, u16x2(&rr)[U], f64x2(&vv)[U]) {
@@ -387,6 +388,7 @@ __global__ __launch_bounds__(kTpThreads) void tp_reduce_kernel(const int32_t* __
             add(t0 + SET, r[1], v[1]);
         }
         __syncthreads();
+        // (batching the loads of y here was measured: 0.5 % of the phase, profiles/r03_tune_writeback_batches.txt - not kept)
         double part = 0.0;
         for (int i = threadIdx.x; i < rows; i += kTpThreads)
         {
@@ -470,7 +472,8 @@ void tp_launch_expand(spmv_ctx* ctx, const spmv_mat* A, const double* x)
 {
     const size_t xlds = sizeof(double) * (size_t)A->tp_pcols;
     const dim3   grid((unsigned)std::min(A->tp_panels, kNumCu));
-    static const int rotate = [] { const char* e = getenv("SPMV_TP_ROTATE"); return e ? atoi(e) : 1; }();  // (0: A/B)
+    const char* e_rot  = getenv("SPMV_TP_ROTATE");  // (A/B switch, read per call)
+    const int   rotate = e_rot ? atoi(e_rot) : 1;
     // 3 pairs per lane in flight: 124 registers, nothing spilled (the default); 4 spills 24 and measured 5-10 % slower
     if (A->tp_unroll == 4)
         hipLaunchKernelGGL((tp_expand_kernel<1024, 4>), grid, dim3(1024), xlds, ctx->stream, A->tp_panels, A->tp_pcols, A->ncol, A->tp_panel_ptr,
@@ -496,7 +499,8 @@ void tp_launch_reduce(spmv_ctx* ctx, const spmv_mat* A, double* y, const apply_e
 // made one after the other and all held (so that each is other memory), both phases are timed on each (1 warm-up + 2
 // launches, zeroed scratch x and y), the fastest is kept and the rest returned.  The search stops when a fast and a slow
 // candidate have both been seen and the last one is among the fast, or after `SPMV_TP_PLACEMENT_TRIES` (12) candidates
-// or when less than a quarter of the device's free memory would be left.  Like the panel kernel's trial: a few dozen
+// or when less than a quarter of the device's free memory would be left.  Spacers of 1-8 GB between the later candidates
+// (held, then freed) make them differ in where they lie.  Like the panel kernel's trial: a few dozen
 // launches when the layout is built, none afterwards; SPMV_PANEL_TRIAL=0 / "panel_trial" 0 switch both off.  Only for
 // streams of 512 MB or more, where the spread was seen.
 int tp_choose_placement(spmv_mat* m)
@@ -516,6 +520,7 @@ int tp_choose_placement(spmv_mat* m)
               hipMemsetAsync(y, 0, sizeof(double) * (size_t)m->nrow, s) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
               hipEventCreate(&e1) == hipSuccess;
     std::vector<double*> cand{m->tp_xg};
+    std::vector<void*>   spacers;  // held until the search ends: they move the following candidates further along in memory
     std::vector<float>   ms;
     if (ok)
     {
@@ -527,9 +532,26 @@ int tp_choose_placement(spmv_mat* m)
         {
             if (t > 0)
             {
-                size_t  free_b = 0;
-                double* fresh  = nullptr;
-                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + free0 / 4 || hipMalloc(&fresh, bytes) != hipSuccess)
+                // Neighbours in allocation order tend to share their mode (whole searches of 12 back-to-back candidates came
+                // out slow), and the mode changes on the scale of gigabytes (tools/probe_twophase_regions.py): from the third
+                // candidate on a spacer of 1, 2, ... 8 GB is allocated first and held.
+                size_t       free_b = 0;
+                const size_t gap    = t >= 2 ? (size_t)std::min(t - 1, 8) << 30 : 0;
+                double*      fresh  = nullptr;
+                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + free0 / 4)
+                {
+                    (void)hipGetLastError();
+                    break;
+                }
+                if (gap && free_b >= bytes + gap + free0 / 4)
+                {
+                    void* sp = nullptr;
+                    if (hipMalloc(&sp, gap) == hipSuccess)
+                        spacers.push_back(sp);
+                    else
+                        (void)hipGetLastError();
+                }
+                if (hipMalloc(&fresh, bytes) != hipSuccess)
                 {
                     (void)hipGetLastError();
                     break;
@@ -557,6 +579,7 @@ int tp_choose_placement(spmv_mat* m)
             if (t >= 1 && t_ms <= best * 1.015f && worst >= best * 1.05f) break;  // both modes seen, this one is the fast one
         }
     }
+    for (void* sp : spacers) (void)hipFree(sp);
     size_t keep = 0;
     for (size_t i = 1; i < ms.size(); ++i)
         if (ms[i] < ms[keep]) keep = i;

@@ -37,7 +37,7 @@ def main():
     A = ctx.gen_csr_uniform(0, a.n, a.ncol, a.k, band=0, seed=1)
     x, y = ctx.gen_vector(a.ncol, seed=1), ctx.vector(a.n)
     y.fill(0.0)
-    keys = ("SPMV_TP_ONLY",)
+    keys = ("SPMV_TP_ONLY", "SPMV_TP_ROTATE")
     for build in range(a.builds):
         pad = a.pads[build % len(a.pads)]
         os.environ["SPMV_TP_PAD"] = str(pad)
@@ -45,8 +45,8 @@ def main():
         for cols in (10_000, 20_000):  # the first forces the re-build of the second: every stream is allocated again
             A.set_param("twophase_panel_cols", cols)
             A.set_kernel(capi.CSR_TWOPHASE)
-        variants = [("A U4", dict(SPMV_TP_ONLY="1"), 4), ("A U3", dict(SPMV_TP_ONLY="1"), 3), ("B", dict(SPMV_TP_ONLY="2"), 4),
-                    ("both U4", {}, 4), ("both U3", {}, 3)]
+        variants = [("A U3, every workgroup from its panel's start", dict(SPMV_TP_ONLY="1", SPMV_TP_ROTATE="0"), 3), ("A U3", dict(SPMV_TP_ONLY="1"), 3),
+                    ("A U4", dict(SPMV_TP_ONLY="1"), 4), ("B", dict(SPMV_TP_ONLY="2"), 3), ("both U3", {}, 3)]
         res = {name: [] for name, _, _ in variants}
         for _ in range(a.rounds):
             for name, env, unroll in variants:
