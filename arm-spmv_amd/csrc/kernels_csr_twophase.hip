@@ -194,13 +194,14 @@ __global__ __launch_bounds__(THREADS) void tp_expand_kernel(int P, int pcols, in
     constexpr int XR  = (kTpPanelCols / 2 + THREADS - 1) / THREADS;  // 16-byte pairs of x per lane
     struct Pan
     {
-        int p, t_begin, len, skip, rot;  // panel, first pair of its first line, pairs from there, pairs of the line before the panel, rotation
+        int p, t_begin, len, skip, rot;  // panel, where its walk starts (a 32-pair boundary), pairs from there, pairs walked before the panel's first, rotation
     };
     const int  tid     = (int)threadIdx.x;
     const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0;  // panel bases are even: x + p * pcols keeps x's alignment
     // the next panel of this workgroup that holds entries, from q on (panels without entries need no x either)
-    // A panel's pairs are walked from the 128-byte line that holds its first pair (pairs before it are skipped in emit),
-    // and the rotation is a whole number of lines: every wavefront load covers whole lines of the source arrays.
+    // A panel's pairs are walked from the 32-pair boundary before its first pair (512 bytes of values, 128 of column pairs;
+    // the pairs before the panel are skipped in emit), and the rotation is a multiple of 32 pairs too: every wavefront load
+    // covers whole 128-byte lines of all three source arrays.
     auto find = [&](int q) -> Pan {
         for (; q < P; q += (int)gridDim.x)
         {
@@ -350,8 +351,8 @@ __global__ __launch_bounds__(kTpThreads) void tp_reduce_kernel(const int32_t* __
     {
         const int r0   = gstart[g];
         const int rows = gstart[g + 1] - r0;
-        // the stretch is walked from the 128-byte line of products that holds its first pair (the pairs before it belong to
-        // the previous group and are skipped): every wavefront load covers whole lines
+        // the stretch is walked from the 32-pair boundary before its first pair (the pairs before it belong to the previous
+        // group and are skipped): every wavefront load covers whole lines of the products AND of the 4-byte row pairs
         const int t_first = group_ptr[g] / 2, t_end = group_ptr[g + 1] / 2;
         const int t_begin = t_first & ~31;
         u16x2 r[2][U];
