@@ -147,3 +147,25 @@ def test_oracle_live_against_compiled_reference():
         assert np.array_equal(a, b)
         n = min(nrow, ncol)
         assert ol.dot(orc, x[:n], x[:n]) == ref.ref_dot(n, p(x[:n].copy()), p(x[:n].copy()))
+
+
+def test_first_touch_copy_of_the_cpu_baseline_is_a_faithful_copy(orc):
+    """orc_csr_first_touch_copy (bench.py's cpu_baseline leg: arrays placed by the OpenMP team that multiplies them) must
+    hand the reference's loop exactly the matrix and x it was given, and a zeroed y"""
+    import ctypes as C
+
+    rng = np.random.default_rng(12)
+    nrow, ncol = 5003, 7001
+    lens = rng.integers(0, 9, nrow)
+    rp = np.zeros(nrow + 1, np.int32)
+    rp[1:] = np.cumsum(lens)
+    nnz = int(rp[-1])
+    col = rng.integers(0, ncol, nnz).astype(np.int32)
+    val, x = rng.uniform(-1, 1, nnz), rng.uniform(0, 1, ncol)
+    d_rp, d_col, d_val = np.full(nrow + 1, -7, np.int32), np.full(nnz, -7, np.int32), np.full(nnz, np.nan)
+    d_x, d_y = np.full(ncol, np.nan), np.full(nrow, np.nan)
+    orc.orc_csr_first_touch_copy.restype = None
+    p = ol._p
+    orc.orc_csr_first_touch_copy(C.c_int32(nrow), C.c_int64(ncol), p(rp), p(col), p(val), p(x), p(d_rp), p(d_col), p(d_val), p(d_x), p(d_y))
+    assert np.array_equal(d_rp, rp) and np.array_equal(d_col, col) and np.array_equal(d_val, val) and np.array_equal(d_x, x)
+    assert not d_y.any()
