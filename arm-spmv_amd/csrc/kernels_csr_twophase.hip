@@ -498,9 +498,9 @@ void tp_launch_reduce(spmv_ctx* ctx, const spmv_mat* A, double* y, const apply_e
 // fast in one build and slow in the next, and allocations made one after the other tend to share their mode: it is the
 // physical memory behind the allocation.  The engine cannot ask for a placement, but it can look: candidate allocations are
 // made one after the other and all held (so that each is other memory), both phases are timed on each (1 warm-up + 2
-// launches, zeroed scratch x and y), the fastest is kept and the rest returned.  The search stops when a fast and a slow
-// candidate have both been seen and the last one is among the fast, or after `SPMV_TP_PLACEMENT_TRIES` (12) candidates
-// or when less than a quarter of the device's free memory would be left.  Spacers of 1-8 GB between the later candidates
+// launches, zeroed scratch x and y), the fastest is kept and the rest returned.  The search stops after six candidates or more
+// when the last one is the best seen and a clearly slower one has been seen, or after `SPMV_TP_PLACEMENT_TRIES` (12) candidates
+// or when less than a quarter of the device's free memory would be left.  Spacers of 1-4 GB between the later candidates
 // (held, then freed) make them differ in where they lie.  Like the panel kernel's trial: a few dozen
 // launches when the layout is built, none afterwards; SPMV_PANEL_TRIAL=0 / "panel_trial" 0 switch both off.  Only for
 // streams of 512 MB or more, where the spread was seen.
@@ -535,9 +535,9 @@ int tp_choose_placement(spmv_mat* m)
             {
                 // Neighbours in allocation order tend to share their mode (whole searches of 12 back-to-back candidates came
                 // out slow), and the mode changes on the scale of gigabytes (tools/probe_twophase_regions.py): from the third
-                // candidate on a spacer of 1, 2, ... 8 GB is allocated first and held.
+                // candidate on a spacer of 1, 2, 3, 4, 4, ... GB is allocated first and held.
                 size_t       free_b = 0;
-                const size_t gap    = t >= 2 ? (size_t)std::min(t - 1, 8) << 30 : 0;
+                const size_t gap    = t >= 2 ? (size_t)std::min(t - 1, 4) << 30 : 0;
                 double*      fresh  = nullptr;
                 if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + free0 / 4)
                 {
@@ -577,7 +577,9 @@ int tp_choose_placement(spmv_mat* m)
             }
             ms.push_back(t_ms);
             const float best = *std::min_element(ms.begin(), ms.end()), worst = *std::max_element(ms.begin(), ms.end());
-            if (t >= 1 && t_ms <= best * 1.015f && worst >= best * 1.05f) break;  // both modes seen, this one is the fast one
+            // at least six candidates (the times form a range, 1.73-1.95 ms on the C5 shard, not two values: the second-best
+            // of two is often 3 % off the best of twelve); then stop once this one is the best seen and slow ones were seen
+            if (t >= 5 && t_ms <= best * 1.005f && worst >= best * 1.05f) break;
         }
     }
     for (void* sp : spacers) (void)hipFree(sp);
