@@ -499,7 +499,7 @@ void tp_launch_reduce(spmv_ctx* ctx, const spmv_mat* A, double* y, const apply_e
 // physical memory behind the allocation.  The engine cannot ask for a placement, but it can look: candidate allocations are
 // made one after the other and all held (so that each is other memory), both phases are timed on each (1 warm-up + 2
 // launches, zeroed scratch x and y), the fastest is kept and the rest returned.  The search stops after six candidates or more
-// when the last one is the best seen and a clearly slower one has been seen, or after `SPMV_TP_PLACEMENT_TRIES` (12) candidates
+// when the last one is the best seen and a clearly slower one has been seen, or after `SPMV_TP_PLACEMENT_TRIES` (16) candidates
 // or when less than a quarter of the device's free memory would be left.  Spacers of 1-4 GB between the later candidates
 // (held, then freed) make them differ in where they lie.  Like the panel kernel's trial: a few dozen
 // launches when the layout is built, none afterwards; SPMV_PANEL_TRIAL=0 / "panel_trial" 0 switch both off.  Only for
@@ -508,7 +508,7 @@ int tp_choose_placement(spmv_mat* m)
 {
     spmv_ctx* ctx = m->ctx;
     const char* e_tries = getenv("SPMV_TP_PLACEMENT_TRIES");
-    int         tries   = e_tries ? atoi(e_tries) : 12;
+    int         tries   = e_tries ? atoi(e_tries) : 16;
     const char* e_trial = getenv("SPMV_PANEL_TRIAL");
     if (m->pb_trial == 0 || (m->pb_trial < 0 && e_trial && e_trial[0] == '0')) tries = 0;
     const size_t bytes = sizeof(double) * (size_t)m->tp_padded;
