@@ -22,9 +22,14 @@ $(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/common.hpp $(CSRC)/wave.hpp include/spmv_ab
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIBDIR)/libspmv_hip.so: $(ENGINE_OBJS)
+# The link is gated: no kernel on a measured path may use scratch memory or spill registers (tools/hot_kernels.txt lists
+# them; the check reads the code objects' metadata notes, no GPU needed).  `make engine NOSCRATCH_GATE=0` links anyway.
+NOSCRATCH_GATE ?= 1
+$(LIBDIR)/libspmv_hip.so: $(ENGINE_OBJS) tools/hot_kernels.txt tools/kernel_resources.py
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^
+	@if [ "$(NOSCRATCH_GATE)" = "1" ]; then python3 tools/kernel_resources.py --check tools/hot_kernels.txt $(ENGINE_OBJS) > $(OBJDIR)/kernel_resources.txt \
+	    || { cat $(OBJDIR)/kernel_resources.txt; echo "make engine: a hot kernel uses scratch (see above)"; exit 1; }; tail -1 $(OBJDIR)/kernel_resources.txt; fi
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(ENGINE_OBJS)
 
 host: engine
 	@if [ -f $(PKG)/host/Makefile ]; then $(MAKE) -C $(PKG)/host; fi

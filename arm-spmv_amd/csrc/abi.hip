@@ -671,25 +671,60 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
     }
     else if (!strcmp(name, "twophase_panel_cols"))  // takes effect at the next spmv_mat_set_kernel(TWOPHASE)
         m->tp_pcols_req = (int32_t)value;
-    else if (!strcmp(name, "twophase_unroll"))
+    else if (!strcmp(name, "twophase_unroll"))  // pairs per lane in flight of the expand kernel: 3 (default) or 4; with 512 threads 6 or 8
         m->tp_unroll = (int32_t)value;
+    else if (!strcmp(name, "twophase_threads"))  // threads per workgroup of the expand kernel: 0 / 1024 (default) or 512
+    {
+        SPMV_REQUIRE(value == 0 || value == 512 || value == 1024, "twophase_threads: 0, 512 or 1024, got %lld", (long long)value);
+        m->tp_threads = (int32_t)value;
+    }
+    else if (!strcmp(name, "twophase_alloc_mode"))  // experiment: 0 hipMalloc, 1 / 2 mapped physical memory (next build / realloc)
+    {
+        SPMV_REQUIRE(value >= 0 && value <= 2, "twophase_alloc_mode: 0, 1 or 2");
+        m->tp_alloc_mode = (int32_t)value;
+    }
+    else if (!strcmp(name, "twophase_rotate"))  // 1 (default): workgroup b starts b / 256 of the way through each of its panels
+        m->tp_rotate = value ? 1 : 0;
+    else if (!strcmp(name, "twophase_only"))
+    {
+        // experiment (tools/tune_twophase.py): run phase A (1) or phase B (2) alone.  THE PRODUCT IS THEN WRONG, so the
+        // switch exists only under SPMV_EXPERIMENTS=1 (read here, once, not on the product's path).
+        const char* e_exp = getenv("SPMV_EXPERIMENTS");
+        SPMV_REQUIRE(value == 0 || (e_exp && e_exp[0] == '1'), "twophase_only is an experiment: set SPMV_EXPERIMENTS=1");
+        SPMV_REQUIRE(value >= 0 && value <= 2, "twophase_only: 0, 1 (phase A alone) or 2 (phase B alone)");
+        m->tp_only = (int32_t)value;
+    }
     else if (!strcmp(name, "twophase_realloc"))
     {
         // experiment (tools/probe_twophase_placement.py): move streams of the two-phase layout to fresh allocations, the
         // old ones freed only afterwards so that other memory is handed out.  Bits: 1 products, 2 values, 4 columns, 8 rows
+        const char* e_exp = getenv("SPMV_EXPERIMENTS");
+        SPMV_REQUIRE(e_exp && e_exp[0] == '1', "twophase_realloc is an experiment: set SPMV_EXPERIMENTS=1");
         SPMV_REQUIRE(m->tp_val && m->tp_padded > 0, "twophase_realloc: the two-phase layout is not built");
         SPMV_HIP(hipSetDevice(m->ctx->device));
         SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
         auto move = [&](void** slot, size_t bytes) -> int {
             void* fresh = nullptr;
             if (hipMalloc(&fresh, bytes) != hipSuccess) SPMV_FAIL(SPMV_ERR_ALLOC, "twophase_realloc: out of device memory");
-            SPMV_HIP(hipMemcpy(fresh, *slot, bytes, hipMemcpyDeviceToDevice));
+            if (const hipError_t e = hipMemcpy(fresh, *slot, bytes, hipMemcpyDeviceToDevice); e != hipSuccess)
+            {
+                (void)hipFree(fresh);
+                SPMV_FAIL(SPMV_ERR_HIP, "twophase_realloc: copy failed: %s", hipGetErrorString(e));
+            }
             (void)hipFree(*slot);
             *slot = fresh;
             return SPMV_OK;
         };
         const size_t np = (size_t)m->tp_padded;
-        if (value & 1) SPMV_TRY(move((void**)&m->tp_xg, sizeof(double) * np));
+        if (value & 1)  // the product stream: allocated by the handle's twophase_alloc_mode; its contents need no copy
+        {
+            double* fresh    = nullptr;
+            void*   fresh_vm = nullptr;
+            SPMV_TRY(csr_twophase_products_alloc(m, &fresh, &fresh_vm));
+            csr_twophase_products_free(m->tp_xg, m->tp_xg_vm);
+            m->tp_xg    = fresh;
+            m->tp_xg_vm = fresh_vm;
+        }
         if (value & 2) SPMV_TRY(move((void**)&m->tp_val, sizeof(double) * np));
         if (value & 4) SPMV_TRY(move((void**)&m->tp_col, sizeof(uint16_t) * np));
         if (value & 8) SPMV_TRY(move((void**)&m->tp_row, sizeof(uint16_t) * np));

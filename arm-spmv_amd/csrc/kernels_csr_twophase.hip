@@ -178,8 +178,10 @@ __global__ __launch_bounds__(kBlock) void tp_pack_kernel(int64_t nlines, int32_t
 // rotate: workgroup b starts b / 256 of the way through each panel and wraps around, so that at any moment the
 // workgroups write into different row groups' stretches of xg instead of all into the same one.
 // Control flow is workgroup-uniform throughout.
-template <int THREADS, int UNROLL>
-__global__ __launch_bounds__(THREADS) void tp_expand_kernel(int P, int pcols, int ncol, const int32_t* __restrict__ panel_ptr,
+// ALIGNED: x is 16-byte aligned (every vector the engine allocates is; a wrapped device pointer may not be) - its own
+// instance, so that the aligned kernel carries neither the 8-byte path nor its hoisted index arithmetic.
+template <int THREADS, int UNROLL, bool ALIGNED>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS / 256, THREADS / 256))) void tp_expand_kernel(int P, int pcols, int ncol, const int32_t* __restrict__ panel_ptr,
                                                             const unsigned short* __restrict__ tp_col, const double* __restrict__ tp_val,
                                                             const int32_t* __restrict__ tp_blk, const double* __restrict__ x,
                                                             double* __restrict__ xg, int rotate)
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(THREADS) void tp_expand_kernel(int P, int pcols, in
         int p, t_begin, len, skip, rot;  // panel, where its walk starts (a 32-pair boundary), pairs from there, pairs walked before the panel's first, rotation
     };
     const int  tid     = (int)threadIdx.x;
-    const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0;  // panel bases are even: x + p * pcols keeps x's alignment
+    // (panel bases are even: x + p * pcols keeps x's alignment)
     // the next panel of this workgroup that holds entries, from q on (panels without entries need no x either)
     // A panel's pairs are walked from the 32-pair boundary before its first pair (512 bytes of values, 128 of column pairs;
     // the pairs before the panel are skipped in emit), and the rotation is a multiple of 32 pairs too: every wavefront load
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(THREADS) void tp_expand_kernel(int P, int pcols, in
     auto   load_x  = [&](int p) {
         const int     c0 = p * pcols, n = min(pcols, ncol - c0), pairs = n / 2;
         const double* xp = x + c0;
-        if (aligned)
+        if constexpr (ALIGNED)
         {
             const f64x2* x2 = reinterpret_cast<const f64x2*>(xp);
 #pragma unroll
@@ -259,14 +261,21 @@ __global__ __launch_bounds__(THREADS) void tp_expand_kernel(int P, int pcols, in
     f64x2 v[2][UNROLL];
     i32x2 d[2][UNROLL];
     auto  phys  = [](const Pan& a, int u) { return a.t_begin + (u + a.rot >= a.len ? u + a.rot - a.len : u + a.rot); };
+    // Addresses are an SGPR base + a 32-bit BYTE offset per lane (the layout holds < 2^28 pairs: 16 B x pair < 2^32), so a
+    // load costs one address register instead of a 64-bit pair and no 64-bit adds (round 3's 64-bit addressing spilled 24
+    // registers at the panel change; tools/kernel_resources.py --check now fails the build when this kernel uses scratch).
+    const char* cb = reinterpret_cast<const char*>(c2);
+    const char* vb = reinterpret_cast<const char*>(v2);
+    const char* bb = reinterpret_cast<const char*>(b2);
+    char*       ob = reinterpret_cast<char*>(o2);
     auto  fetch = [&](const Pan& a, int u0, u16x2(&cc)[UNROLL], f64x2(&vv)[UNROLL], i32x2(&dd)[UNROLL]) {
 #pragma unroll
         for (int k = 0; k < UNROLL; ++k)
         {
-            const int t = phys(a, min(u0 + k * THREADS + tid, a.len - 1));  // past the end: re-read the last pair
-            cc[k]       = __builtin_nontemporal_load(c2 + t);
-            vv[k]       = __builtin_nontemporal_load(v2 + t);
-            dd[k]       = __builtin_nontemporal_load(b2 + (t >> 3));
+            const uint32_t t = (uint32_t)phys(a, min(u0 + k * THREADS + tid, a.len - 1));  // past the end: re-read the last pair
+            cc[k]            = __builtin_nontemporal_load(reinterpret_cast<const u16x2*>(cb + (t << 2)));
+            vv[k]            = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(vb + (t << 4)));
+            dd[k]            = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(bb + ((t >> 3) << 3)));
         }
     };
     auto emit = [&](const Pan& a, int u0, const u16x2(&cc)[UNROLL], const f64x2(&vv)[UNROLL], const i32x2(&dd)[UNROLL]) {
@@ -277,12 +286,12 @@ __global__ __launch_bounds__(THREADS) void tp_expand_kernel(int P, int pcols, in
             const int t = phys(a, u);
             if (u < a.len && t >= a.t_begin + a.skip)
             {
-                const int bpos = dd[k].x & 7;
-                const int dst  = t + ((bpos != 0 && (t & 7) >= bpos) ? dd[k].y : (dd[k].x >> 3));
-                f64x2     o;
+                const int      bpos = dd[k].x & 7;
+                const uint32_t dst  = (uint32_t)(t + ((bpos != 0 && (t & 7) >= bpos) ? dd[k].y : (dd[k].x >> 3)));
+                f64x2          o;
                 o.x = vv[k].x * xs[cc[k].x];
                 o.y = vv[k].y * xs[cc[k].y];
-                __builtin_nontemporal_store(o, o2 + dst);  // read again only 2.7 GB later: 2-3 %
+                __builtin_nontemporal_store(o, reinterpret_cast<f64x2*>(ob + (dst << 4)));  // read again only 2.7 GB later: 2-3 %
             }
         }
     };
@@ -407,10 +416,128 @@ __global__ __launch_bounds__(kTpThreads) void tp_reduce_kernel(const int32_t* __
 }
 }  // namespace
 
+// ---- where the product stream lives -------------------------------------------------------------------------------------
+// mode 0: hipMalloc.  mode 1 / 2 (experiment, "twophase_alloc_mode"): HIP's virtual memory management - physical memory
+// created explicitly (1: one piece, 2: pieces of 1 GB) and mapped at a 1 GB-aligned virtual address.
+struct tp_vm_block
+{
+    void*                                        va = nullptr;
+    size_t                                       size = 0;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+    std::vector<size_t>                          sizes;
+};
+namespace
+{
+void tp_vm_release(tp_vm_block* b)
+{
+    if (!b) return;
+    if (b->va)
+    {
+        size_t off = 0;
+        for (size_t i = 0; i < b->handles.size(); ++i)
+        {
+            (void)hipMemUnmap((char*)b->va + off, b->sizes[i]);
+            (void)hipMemRelease(b->handles[i]);
+            off += b->sizes[i];
+        }
+        (void)hipMemAddressFree(b->va, b->size);
+    }
+    (void)hipGetLastError();
+    delete b;
+}
+tp_vm_block* tp_vm_alloc(int device, size_t bytes, size_t piece)
+{
+    hipMemAllocationProp prop{};
+    prop.type          = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id   = device;
+    size_t gran        = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) return nullptr;
+    auto up = [](size_t v, size_t g) { return (v + g - 1) / g * g; };
+    auto* b = new tp_vm_block;
+    b->size = up(bytes, gran);
+    if (hipMemAddressReserve(&b->va, b->size, (size_t)1 << 30, nullptr, 0) != hipSuccess)
+    {
+        b->va = nullptr;
+        tp_vm_release(b);
+        return nullptr;
+    }
+    piece = piece ? up(piece, gran) : b->size;
+    bool ok = true;
+    for (size_t off = 0; off < b->size && ok; off += piece)
+    {
+        const size_t                    n = std::min(piece, b->size - off);
+        hipMemGenericAllocationHandle_t h{};
+        if (hipMemCreate(&h, n, &prop, 0) != hipSuccess)
+        {
+            ok = false;
+            break;
+        }
+        if (hipMemMap((char*)b->va + off, n, 0, h, 0) != hipSuccess)
+        {
+            (void)hipMemRelease(h);
+            ok = false;
+            break;
+        }
+        b->handles.push_back(h);
+        b->sizes.push_back(n);
+    }
+    if (ok)
+    {
+        hipMemAccessDesc acc{};
+        acc.location = prop.location;
+        acc.flags    = hipMemAccessFlagsProtReadWrite;
+        ok           = hipMemSetAccess(b->va, b->size, &acc, 1) == hipSuccess;
+    }
+    if (!ok)
+    {
+        // only what was mapped is unmapped
+        size_t mapped = 0;
+        for (size_t n : b->sizes) mapped += n;
+        (void)mapped;
+        tp_vm_release(b);
+        return nullptr;
+    }
+    return b;
+}
+}  // namespace
+
+// allocate / release the product stream of a handle by its tp_alloc_mode
+int csr_twophase_products_alloc(spmv_mat* m, double** out, void** out_vm)
+{
+    const size_t bytes = sizeof(double) * (size_t)m->tp_padded;
+    *out               = nullptr;
+    *out_vm            = nullptr;
+    if (m->tp_alloc_mode == 0)
+    {
+        if (hipMalloc(out, bytes) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            SPMV_FAIL(SPMV_ERR_ALLOC, "two-phase layout: no memory for the product stream (%zu bytes)", bytes);
+        }
+        return SPMV_OK;
+    }
+    tp_vm_block* b = tp_vm_alloc(m->ctx->device, bytes, m->tp_alloc_mode == 2 ? (size_t)1 << 30 : 0);
+    if (!b) SPMV_FAIL(SPMV_ERR_ALLOC, "two-phase layout: mapping %zu bytes for the product stream failed", bytes);
+    *out    = (double*)b->va;
+    *out_vm = b;
+    return SPMV_OK;
+}
+void csr_twophase_products_free(double* p, void* vm)
+{
+    if (vm)
+        tp_vm_release((tp_vm_block*)vm);
+    else if (p)
+        (void)hipFree(p);
+}
+
 void csr_twophase_free(spmv_mat* m)
 {
-    for (void** p : {(void**)&m->tp_val, (void**)&m->tp_col, (void**)&m->tp_row, (void**)&m->tp_xg, (void**)&m->tp_blk,
-                     (void**)&m->tp_panel_ptr, (void**)&m->tp_group_ptr, (void**)&m->tp_gstart})
+    csr_twophase_products_free(m->tp_xg, m->tp_xg_vm);
+    m->tp_xg    = nullptr;
+    m->tp_xg_vm = nullptr;
+    for (void** p : {(void**)&m->tp_val, (void**)&m->tp_col, (void**)&m->tp_row, (void**)&m->tp_blk, (void**)&m->tp_panel_ptr,
+                     (void**)&m->tp_group_ptr, (void**)&m->tp_gstart})
         if (*p)
         {
             (void)hipFree(*p);
@@ -459,29 +586,55 @@ bool csr_twophase_worth(const spmv_mat* m)
 
 namespace
 {
+// the expand instances that can be launched: {threads, pairs per lane in flight}; the first is the default
+template <int THREADS, int UNROLL>
+void tp_expand_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x)
+{
+    const size_t xlds = sizeof(double) * (size_t)A->tp_pcols;
+    const dim3   grid((unsigned)std::min(A->tp_panels, kNumCu));
+    if ((reinterpret_cast<uintptr_t>(x) & 15) == 0)
+        hipLaunchKernelGGL((tp_expand_kernel<THREADS, UNROLL, true>), grid, dim3(THREADS), xlds, ctx->stream, A->tp_panels, A->tp_pcols, A->ncol,
+                           A->tp_panel_ptr, (const unsigned short*)A->tp_col, (const double*)A->tp_val, (const int32_t*)A->tp_blk, x, A->tp_xg,
+                           (int)A->tp_rotate);
+    else
+        hipLaunchKernelGGL((tp_expand_kernel<THREADS, UNROLL, false>), grid, dim3(THREADS), xlds, ctx->stream, A->tp_panels, A->tp_pcols, A->ncol,
+                           A->tp_panel_ptr, (const unsigned short*)A->tp_col, (const double*)A->tp_val, (const int32_t*)A->tp_blk, x, A->tp_xg,
+                           (int)A->tp_rotate);
+}
+template <int THREADS, int UNROLL>
+void tp_expand_grant()
+{
+    (void)hipFuncSetAttribute((const void*)tp_expand_kernel<THREADS, UNROLL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160008);
+    (void)hipFuncSetAttribute((const void*)tp_expand_kernel<THREADS, UNROLL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160008);
+}
+
 void tp_grant_lds(spmv_ctx* ctx)
 {
     static std::atomic<unsigned long long> granted{0};  // bit per device
     if ((granted.load(std::memory_order_relaxed) >> ctx->device) & 1ull) return;
-    (void)hipFuncSetAttribute((const void*)tp_expand_kernel<1024, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160008);
-    (void)hipFuncSetAttribute((const void*)tp_expand_kernel<1024, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160008);
+    tp_expand_grant<1024, 3>();
+    tp_expand_grant<1024, 4>();
+    tp_expand_grant<512, 6>();
+    tp_expand_grant<512, 8>();
     (void)hipFuncSetAttribute((const void*)tp_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160008);
     granted.fetch_or(1ull << ctx->device, std::memory_order_relaxed);
 }
 
+// Which instance runs is a field of the handle ("twophase_unroll", "twophase_threads", "twophase_rotate"), set when the
+// layout is built or by spmv_mat_set_param: nothing is read from the environment on the product's path.
 void tp_launch_expand(spmv_ctx* ctx, const spmv_mat* A, const double* x)
 {
-    const size_t xlds = sizeof(double) * (size_t)A->tp_pcols;
-    const dim3   grid((unsigned)std::min(A->tp_panels, kNumCu));
-    const char* e_rot  = getenv("SPMV_TP_ROTATE");  // (A/B switch, read per call)
-    const int   rotate = e_rot ? atoi(e_rot) : 1;
-    // 3 pairs per lane in flight: 124 registers, nothing spilled (the default); 4 spills 24 and measured 5-10 % slower
-    if (A->tp_unroll == 4)
-        hipLaunchKernelGGL((tp_expand_kernel<1024, 4>), grid, dim3(1024), xlds, ctx->stream, A->tp_panels, A->tp_pcols, A->ncol, A->tp_panel_ptr,
-                           (const unsigned short*)A->tp_col, (const double*)A->tp_val, (const int32_t*)A->tp_blk, x, A->tp_xg, rotate);
+    if (A->tp_threads == 512)
+    {
+        if (A->tp_unroll == 8)
+            tp_expand_launch<512, 8>(ctx, A, x);
+        else
+            tp_expand_launch<512, 6>(ctx, A, x);
+    }
+    else if (A->tp_unroll == 4)
+        tp_expand_launch<1024, 4>(ctx, A, x);
     else
-        hipLaunchKernelGGL((tp_expand_kernel<1024, 3>), grid, dim3(1024), xlds, ctx->stream, A->tp_panels, A->tp_pcols, A->ncol, A->tp_panel_ptr,
-                           (const unsigned short*)A->tp_col, (const double*)A->tp_val, (const int32_t*)A->tp_blk, x, A->tp_xg, rotate);
+        tp_expand_launch<1024, 3>(ctx, A, x);
 }
 
 void tp_launch_reduce(spmv_ctx* ctx, const spmv_mat* A, double* y, const apply_extra& ex)
@@ -512,7 +665,7 @@ int tp_choose_placement(spmv_mat* m)
     const char* e_trial = getenv("SPMV_PANEL_TRIAL");
     if (m->pb_trial == 0 || (m->pb_trial < 0 && e_trial && e_trial[0] == '0')) tries = 0;
     const size_t bytes = sizeof(double) * (size_t)m->tp_padded;
-    if (tries <= 1 || bytes < ((size_t)512 << 20)) return SPMV_OK;
+    if (tries <= 1 || bytes < ((size_t)512 << 20) || m->tp_alloc_mode != 0) return SPMV_OK;
     hipStream_t s = ctx->stream;
     double *    x = nullptr, *y = nullptr;
     hipEvent_t  e0 = nullptr, e1 = nullptr;
@@ -669,8 +822,14 @@ int csr_twophase_build(spmv_mat* m)
         const size_t np     = (size_t)padded;
         const size_t nlines = (np + kTpLine - 1) / kTpLine;
         if (hipMalloc(&m->tp_val, sizeof(double) * np) != hipSuccess || hipMalloc(&m->tp_col, sizeof(unsigned short) * np) != hipSuccess ||
-            hipMalloc(&m->tp_row, sizeof(unsigned short) * np) != hipSuccess || hipMalloc(&m->tp_xg, sizeof(double) * np) != hipSuccess ||
+            hipMalloc(&m->tp_row, sizeof(unsigned short) * np) != hipSuccess ||
             hipMalloc(&m->tp_blk, sizeof(int32_t) * 2 * nlines) != hipSuccess || hipMalloc(&bpos, sizeof(int32_t) * nlines) != hipSuccess)
+        {
+            rc = SPMV_ERR_ALLOC;
+            break;
+        }
+        m->tp_padded = padded;
+        if (csr_twophase_products_alloc(m, &m->tp_xg, &m->tp_xg_vm) != SPMV_OK)
         {
             rc = SPMV_ERR_ALLOC;
             break;
@@ -722,11 +881,9 @@ int csr_twophase_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, dou
         A->tp_padded % 2 != 0)
         SPMV_FAIL(SPMV_ERR_INVALID, "two-phase kernel selected but its layout was not built");
     tp_grant_lds(ctx);
-    // SPMV_TP_ONLY = 1 / 2 together with SPMV_EXPERIMENTS = 1: one phase alone, read per call (tools/tune_twophase.py times
-    // the phases; the RESULT IS THEN WRONG, hence the second switch)
-    const char* e_only = getenv("SPMV_TP_ONLY");
-    const char* e_exp  = getenv("SPMV_EXPERIMENTS");
-    const int   only   = e_only && e_exp && e_exp[0] == '1' ? atoi(e_only) : 0;
+    // tp_only = 1 / 2: one phase alone ("twophase_only", accepted by spmv_mat_set_param only under SPMV_EXPERIMENTS=1:
+    // tools/tune_twophase.py times the phases; the RESULT IS THEN WRONG)
+    const int only = A->tp_only;
     if (only != 2) tp_launch_expand(ctx, A, x);
     if (only != 1) tp_launch_reduce(ctx, A, y, ex);
     SPMV_HIP(hipGetLastError());

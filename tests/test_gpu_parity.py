@@ -695,6 +695,38 @@ def test_row_shards_concatenate_to_unsharded_result(ctx, orc, pkg):
 
 
 # ---------------------------------------------------------------------------------- full-size properties
+
+def _abs_row_scale(ctx, pkg, A, x):
+    """(|A||x|)_i for every row of a device-resident CSR handle, computed on the device: the values come to the host once,
+    go back as |a_ij| in a second handle (row-parallel kernel: no layout, no trial launches), and one product gives the
+    scale of the parity gate for ALL rows — what the whole-vector comparisons below divide by."""
+    rp, cc, cv = A.download()
+    np.abs(cv, out=cv)
+    B = ctx.csr(A.info.nrow, A.info.ncol, rp, cc, cv)  # (a shard's row_ptr comes back rebased: the product does not care)
+    del rp, cc, cv
+    B.set_kernel(pkg.capi.CSR_VECTOR)
+    xa = ctx.vector(A.info.ncol)
+    ctx.axpby(1.0, x, 0.0, x, xa)  # the tests' x is U(0,1): |x| = x; copied so that the caller's vector is not aliased
+    s = ctx.vector(A.info.nrow)
+    s.fill(0.0)
+    ctx.apply(B, xa, s)
+    ctx.sync()
+    return s.download()
+
+
+def _check_boundary_rows(orc, synth, hy, row0, nglob, k, seed, hx, starts, what, halo=2):
+    """rows start - halo .. start + halo - 1 around every given row-group start against the oracle (regenerated from the seed)"""
+    n = len(hy)
+    for g0 in starts:
+        lo, hi = max(0, g0 - halo), min(n, g0 + halo)
+        if lo >= hi:
+            continue
+        rp, cc, cv = synth.csr_uniform(row0 + lo, row0 + hi, nglob, k, seed=seed)
+        ref, scale = np.zeros(hi - lo), np.zeros(hi - lo)
+        ol.csr_spmv(orc, rp, cc, cv, hx, ref)
+        ol.csr_abs_row_sums(orc, rp, cc, cv, hx, scale)
+        ol.assert_parity(hy[lo:hi], ref, scale, f"{what}: rows {row0 + lo}..{row0 + hi} (a row-group boundary)")
+
 def test_full_size_csr_linearity_and_row_sample(ctx, orc, pkg):
     """BASELINE config 2 shape at reduced N would not exercise int32 limits; run the real N = 10M, 32/row.
     Size-independent checks: (i) a sample of rows recomputed by the oracle from the regenerated rows,
@@ -730,6 +762,26 @@ def test_full_size_csr_linearity_and_row_sample(ctx, orc, pkg):
     ctx.apply(A, x1, y1)
     ctx.sync()
     assert np.max(np.abs(y1.download() - 2.0 * h1)) <= 1e-12 * 32
+    # (iv) the rows on both sides of row-group boundaries of the panel layout (where a group's accumulators are written
+    # back and the next group's slices begin) against the oracle: every 37th group and the last ones
+    assert A.info.kernel == pkg.capi.CSR_PANEL
+    groups, rows_per = A.get_param("panel_groups"), A.get_param("panel_rows")
+    starts = [g * rows_per for g in list(range(1, groups, 37)) + [groups - 2, groups - 1]]
+    _check_boundary_rows(orc, synth, h1, 0, n, k, 1, hx1, starts, "C2 panel")
+    # (v) ALL 10M rows: the panel product against the row-parallel kernel (an independent code path: no re-ordered
+    # layout, one wavefront slice per row), scaled by (|A||x|)_i computed on the device - a defect confined to one row
+    # group, one slice or one run of the layout cannot hide between the oracle's samples
+    scale = _abs_row_scale(ctx, pkg, A, x1)
+    assert scale.min() > 0.0
+    A.set_kernel(pkg.capi.CSR_VECTOR)
+    y2.fill(0.0)
+    ctx.apply(A, x1, y2)
+    ctx.sync()
+    hv = y2.download()
+    err = np.abs(h1 - hv) / scale
+    worst = int(np.argmax(err))
+    assert err[worst] <= ol.REL_TOL, f"panel vs row-parallel kernel: row {worst}: {h1[worst]!r} vs {hv[worst]!r}, scaled {err[worst]:.3e}"
+    assert np.max(np.abs(h1 - hv)) / np.max(np.abs(hv)) <= ol.REL_TOL
 
 
 def test_csr_at_the_int32_limit_of_entries(ctx, orc, pkg):
@@ -1254,15 +1306,35 @@ def test_full_size_c5_last_shard_row_sample(ctx, orc, pkg):
     x = ctx.gen_vector(nglob, seed=1)
     hx = synth.vec_uniform(nglob, seed=1)
     y = ctx.vector(e - b)
+    got = {}
     for kernel in (pkg.capi.CSR_TWOPHASE, pkg.capi.CSR_PANEL):  # both at full size
         A.set_kernel(kernel)
         y.fill(0.0)
         ctx.apply(A, x, y)
         ctx.sync()
         hy = y.download()
+        got[kernel] = hy
         for r0 in (b, b + 4_321_000, e - 2000):
             rp, cc, cv = synth.csr_uniform(r0, r0 + 2000, nglob, k, seed=1)
             ref, scale = np.zeros(2000), np.zeros(2000)
             ol.csr_spmv(orc, rp, cc, cv, hx, ref)
             ol.csr_abs_row_sums(orc, rp, cc, cv, hx, scale)
             ol.assert_parity(hy[r0 - b:r0 - b + 2000], ref, scale, f"C5 shard rows {r0}.. kernel {kernel}")
+        # rows on both sides of row-group boundaries (two-phase: equal groups of ceil(10M / 512) rows, a group's stretch of
+        # the product stream ends and the next begins; panel: the groups of its own layout) against the oracle
+        if kernel == pkg.capi.CSR_PANEL:
+            groups, per = A.get_param("panel_groups"), A.get_param("panel_rows")
+        else:
+            per = -(-(e - b) // 512)
+            groups = -(-(e - b) // per)
+        starts = [g * per for g in list(range(1, groups, 41)) + [groups - 2, groups - 1]]
+        _check_boundary_rows(orc, synth, hy, b, nglob, k, 1, hx, starts, f"C5 shard kernel {kernel}")
+    # ALL 10M rows: the two products come from layouts that share nothing (product stream in (group, panel) runs against
+    # line-sorted packed slices) - compared row by row, scaled by (|A||x|)_i computed on the device
+    scale = _abs_row_scale(ctx, pkg, A, x)
+    assert scale.min() > 0.0
+    ya, yb = got[pkg.capi.CSR_TWOPHASE], got[pkg.capi.CSR_PANEL]
+    err = np.abs(ya - yb) / scale
+    worst = int(np.argmax(err))
+    assert err[worst] <= ol.REL_TOL, f"two-phase vs panel: row {b + worst}: {ya[worst]!r} vs {yb[worst]!r}, scaled {err[worst]:.3e}"
+    assert np.max(np.abs(ya - yb)) / np.max(np.abs(yb)) <= ol.REL_TOL

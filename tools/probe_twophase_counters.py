@@ -22,7 +22,7 @@ def main():
     A.set_kernel(capi.CSR_TWOPHASE)
     x, y = ctx.gen_vector(ncol, seed=1), ctx.vector(n)
     y.fill(0.0)
-    os.environ["SPMV_TP_ONLY"] = "1"
+    A.set_param("twophase_only", 1)
     held = []
     for move, spacer_gb in enumerate((0, 0, 1, 2, 4, 4, 8, 8, 2, 1, 0, 4)):
         if spacer_gb:

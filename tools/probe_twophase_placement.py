@@ -15,7 +15,7 @@ sys.path.insert(0, str(ROOT))
 from __graft_entry__ import load_package  # noqa: E402
 
 capi = load_package().capi
-os.environ["SPMV_EXPERIMENTS"] = "1"  # SPMV_TP_ONLY (one phase alone, wrong results) is honoured only with this
+os.environ["SPMV_EXPERIMENTS"] = "1"  # "twophase_only" (one phase alone, wrong results) and "twophase_realloc" exist only with this
 
 
 def main():
@@ -28,11 +28,8 @@ def main():
 
     def phases():
         out = []
-        for only in ("1", "2", None):
-            if only:
-                os.environ["SPMV_TP_ONLY"] = only
-            else:
-                os.environ.pop("SPMV_TP_ONLY", None)
+        for only in (1, 2, 0):
+            A.set_param("twophase_only", only)
             ctx.apply(A, x, y)
             out.append(statistics.median(ctx.apply_timed(A, x, y, 5) for _ in range(3)))
         return out

@@ -24,7 +24,7 @@ def main():
     A.set_kernel(capi.CSR_TWOPHASE)
     x, y = ctx.gen_vector(ncol, seed=1), ctx.vector(n)
     y.fill(0.0)
-    os.environ["SPMV_TP_ONLY"] = "1"
+    A.set_param("twophase_only", 1)
 
     def phase_a():
         ctx.apply(A, x, y)

@@ -4,9 +4,9 @@
 
     python tools/tune_twophase.py [--ncol 80000000] [--rounds 4] [--builds 1]
 
-Switches of the engine (kernels_csr_twophase.hip): SPMV_TP_ONLY=1|2 one phase alone (per call; timing only), SPMV_TP_PAD=2|8|16
-run padding and SPMV_TP_PLACEMENT_TRIES (at build); spmv_mat_set_param "twophase_unroll" picks the pairs per lane in flight
-of the expand kernel.
+Switches of the engine (kernels_csr_twophase.hip), all per handle through spmv_mat_set_param: "twophase_only" 1|2 one phase
+alone (timing only: needs SPMV_EXPERIMENTS=1), "twophase_threads" / "twophase_unroll" the expand instance, "twophase_rotate";
+SPMV_TP_PAD=2|8|16 run padding and SPMV_TP_PLACEMENT_TRIES are read when the layout is built.
 """
 import argparse
 import os
@@ -19,7 +19,7 @@ sys.path.insert(0, str(ROOT))
 from __graft_entry__ import load_package  # noqa: E402
 
 capi = load_package().capi
-os.environ["SPMV_EXPERIMENTS"] = "1"  # SPMV_TP_ONLY (one phase alone, wrong results) is honoured only with this
+os.environ["SPMV_EXPERIMENTS"] = "1"  # "twophase_only" (one phase alone, wrong results) exists only with this
 
 
 def main():
@@ -37,7 +37,6 @@ def main():
     A = ctx.gen_csr_uniform(0, a.n, a.ncol, a.k, band=0, seed=1)
     x, y = ctx.gen_vector(a.ncol, seed=1), ctx.vector(a.n)
     y.fill(0.0)
-    keys = ("SPMV_TP_ONLY", "SPMV_TP_ROTATE")
     for build in range(a.builds):
         pad = a.pads[build % len(a.pads)]
         os.environ["SPMV_TP_PAD"] = str(pad)
@@ -45,19 +44,20 @@ def main():
         for cols in (10_000, 20_000):  # the first forces the re-build of the second: every stream is allocated again
             A.set_param("twophase_panel_cols", cols)
             A.set_kernel(capi.CSR_TWOPHASE)
-        variants = [("A U3, every workgroup from its panel's start", dict(SPMV_TP_ONLY="1", SPMV_TP_ROTATE="0"), 3), ("A U3", dict(SPMV_TP_ONLY="1"), 3),
-                    ("A U4", dict(SPMV_TP_ONLY="1"), 4), ("B", dict(SPMV_TP_ONLY="2"), 3), ("both U3", {}, 3)]
-        res = {name: [] for name, _, _ in variants}
+        # name, phase alone (0 = both), threads, pairs per lane in flight, rotate
+        variants = [("A 1024 x 3, every workgroup from its panel's start", 1, 1024, 3, 0), ("A 1024 x 3", 1, 1024, 3, 1), ("A 1024 x 4", 1, 1024, 4, 1),
+                    ("A 512 x 6", 1, 512, 6, 1), ("A 512 x 8", 1, 512, 8, 1), ("B", 2, 1024, 3, 1), ("both 1024 x 3", 0, 1024, 3, 1),
+                    ("both 1024 x 4", 0, 1024, 4, 1), ("both 512 x 6", 0, 512, 6, 1)]
+        res = {v[0]: [] for v in variants}
         for _ in range(a.rounds):
-            for name, env, unroll in variants:
-                for k in keys:
-                    os.environ.pop(k, None)
-                os.environ.update(env)
+            for name, only, threads, unroll, rotate in variants:
+                A.set_param("twophase_only", only)
+                A.set_param("twophase_threads", threads)
                 A.set_param("twophase_unroll", unroll)
+                A.set_param("twophase_rotate", rotate)
                 ctx.apply(A, x, y)
                 res[name].append(ctx.apply_timed(A, x, y, a.reps))
-        for k in keys:
-            os.environ.pop(k, None)
+        A.set_param("twophase_only", 0)
         print(f"# build {build}: run padding {pad}, padded entries {A.get_param('twophase_padded')} ({A.get_param('twophase_padded') / A.info.nnz - 1:.2%} padding), "
               f"placements timed {A.get_param('twophase_placements_timed')}, slowest / kept {A.get_param('twophase_placement_spread') / 1000:.3f}")
         for name, ts in res.items():
