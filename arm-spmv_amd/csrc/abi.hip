@@ -678,6 +678,23 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         SPMV_REQUIRE(value == 0 || value == 512 || value == 1024, "twophase_threads: 0, 512 or 1024, got %lld", (long long)value);
         m->tp_threads = (int32_t)value;
     }
+    else if (!strcmp(name, "twophase_products_push") || !strcmp(name, "twophase_products_rotate"))  // experiments
+    {
+        const char* e_exp = getenv("SPMV_EXPERIMENTS");
+        SPMV_REQUIRE(e_exp && e_exp[0] == '1', "%s is an experiment: set SPMV_EXPERIMENTS=1", name);
+        SPMV_HIP(hipSetDevice(m->ctx->device));
+        if (!strcmp(name, "twophase_products_push"))
+            SPMV_TRY(csr_twophase_products_push(m, (int)value));
+        else
+            SPMV_TRY(csr_twophase_products_rotate(m));
+    }
+    else if (!strcmp(name, "twophase_place_again"))  // experiment: run the placement search of the product stream again
+    {
+        const char* e_exp = getenv("SPMV_EXPERIMENTS");
+        SPMV_REQUIRE(e_exp && e_exp[0] == '1', "twophase_place_again is an experiment: set SPMV_EXPERIMENTS=1");
+        SPMV_HIP(hipSetDevice(m->ctx->device));
+        SPMV_TRY(csr_twophase_place_again(m));
+    }
     else if (!strcmp(name, "twophase_alloc_mode"))  // experiment: 0 hipMalloc, 1 / 2 mapped physical memory (next build / realloc)
     {
         SPMV_REQUIRE(value >= 0 && value <= 2, "twophase_alloc_mode: 0, 1 or 2");
@@ -728,6 +745,7 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         if (value & 2) SPMV_TRY(move((void**)&m->tp_val, sizeof(double) * np));
         if (value & 4) SPMV_TRY(move((void**)&m->tp_col, sizeof(uint16_t) * np));
         if (value & 8) SPMV_TRY(move((void**)&m->tp_row, sizeof(uint16_t) * np));
+        if (value & 16) SPMV_TRY(move((void**)&m->tp_blk, sizeof(int32_t) * 2 * ((np + 15) / 16)));
     }
     else
         SPMV_FAIL(SPMV_ERR_INVALID, "unknown parameter '%s'", name);

@@ -205,6 +205,8 @@ struct spmv_mat
     int32_t*  tp_gstart    = nullptr;  // [groups + 1] first row of every group
     int32_t   tp_ngroups = 0, tp_panels = 0, tp_pcols = 0, tp_max_rows = 0;
     int32_t   tp_pcols_req = 0, tp_unroll = 0;  // requested panel width / pairs per lane in flight (0 = default)
+    void*     tp_vm_more[4] = {nullptr, nullptr, nullptr, nullptr};  // experiment: values / columns / rows / table in mapped pieces
+    void*     tp_held = nullptr;                // experiments: further product streams held (kernels_csr_twophase.hip: tp_held_list)
     void*     tp_xg_vm = nullptr;               // set when tp_xg is mapped memory (tp_alloc_mode 1 / 2): what to release
     int32_t   tp_alloc_mode = 0;                // product stream: 0 hipMalloc, 1 / 2 mapped physical memory (one piece / 1 GB pieces)
     int32_t   tp_threads = 0;                   // expand kernel: threads per workgroup (0 = default 1024; 512)
@@ -248,6 +250,9 @@ int  csr_panel_read_trace(spmv_ctx* ctx, int64_t index, int64_t* value);
 int  csr_twophase_build(spmv_mat* m);
 void csr_twophase_free(spmv_mat* m);
 bool csr_twophase_worth(const spmv_mat* m);
+int  csr_twophase_place_again(spmv_mat* m);
+int  csr_twophase_products_push(spmv_mat* m, int mode);
+int  csr_twophase_products_rotate(spmv_mat* m);
 int  csr_twophase_products_alloc(spmv_mat* m, double** out, void** out_vm);
 void csr_twophase_products_free(double* p, void* vm);
 // A sum that thousands of wavefronts add into is kept as kDotSlots partial sums on different 128-byte lines (an

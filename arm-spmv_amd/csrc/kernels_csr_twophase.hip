@@ -416,13 +416,18 @@ __global__ __launch_bounds__(kTpThreads) void tp_reduce_kernel(const int32_t* __
 }
 }  // namespace
 
+struct tp_held_list  // experiments: product streams held besides the current one
+{
+    std::vector<std::pair<double*, void*>> v;
+};
 // ---- where the product stream lives -------------------------------------------------------------------------------------
 // mode 0: hipMalloc.  mode 1 / 2 (experiment, "twophase_alloc_mode"): HIP's virtual memory management - physical memory
 // created explicitly (1: one piece, 2: pieces of 1 GB) and mapped at a 1 GB-aligned virtual address.
 struct tp_vm_block
 {
-    void*                                        va = nullptr;
-    size_t                                       size = 0;
+    void*                                        va = nullptr;   // the reserved address range
+    size_t                                       size = 0;       // its length
+    size_t                                       map_off = 0;    // where inside it the pieces are mapped
     std::vector<hipMemGenericAllocationHandle_t> handles;
     std::vector<size_t>                          sizes;
 };
@@ -436,7 +441,7 @@ void tp_vm_release(tp_vm_block* b)
         size_t off = 0;
         for (size_t i = 0; i < b->handles.size(); ++i)
         {
-            (void)hipMemUnmap((char*)b->va + off, b->sizes[i]);
+            (void)hipMemUnmap((char*)b->va + b->map_off + off, b->sizes[i]);
             (void)hipMemRelease(b->handles[i]);
             off += b->sizes[i];
         }
@@ -531,11 +536,45 @@ void csr_twophase_products_free(double* p, void* vm)
         (void)hipFree(p);
 }
 
+// experiment (SPMV_TP_STREAMS_VM=<piece MB>): the layout's read streams (values, columns, rows, table) in mapped pieces too
+namespace
+{
+int tp_stream_alloc(spmv_mat* m, void** out, size_t bytes, int slot)
+{
+    const char* e = getenv("SPMV_TP_STREAMS_VM");
+    if (e && atoll(e) >= 2)
+    {
+        tp_vm_block* b = tp_vm_alloc(m->ctx->device, bytes, (size_t)atoll(e) << 20);
+        if (!b) return SPMV_ERR_ALLOC;
+        *out               = b->va;
+        m->tp_vm_more[slot] = b;
+        return SPMV_OK;
+    }
+    return hipMalloc(out, bytes) == hipSuccess ? SPMV_OK : SPMV_ERR_ALLOC;
+}
+}  // namespace
+
 void csr_twophase_free(spmv_mat* m)
 {
+    {
+        void** slots[4] = {(void**)&m->tp_val, (void**)&m->tp_col, (void**)&m->tp_row, (void**)&m->tp_blk};
+        for (int i = 0; i < 4; ++i)
+            if (m->tp_vm_more[i])
+            {
+                tp_vm_release((tp_vm_block*)m->tp_vm_more[i]);
+                m->tp_vm_more[i] = nullptr;
+                *slots[i]        = nullptr;
+            }
+    }
     csr_twophase_products_free(m->tp_xg, m->tp_xg_vm);
     m->tp_xg    = nullptr;
     m->tp_xg_vm = nullptr;
+    if (m->tp_held)
+    {
+        for (auto& e : ((tp_held_list*)m->tp_held)->v) csr_twophase_products_free(e.first, e.second);
+        delete (tp_held_list*)m->tp_held;
+        m->tp_held = nullptr;
+    }
     for (void** p : {(void**)&m->tp_val, (void**)&m->tp_col, (void**)&m->tp_row, (void**)&m->tp_blk, (void**)&m->tp_panel_ptr,
                      (void**)&m->tp_group_ptr, (void**)&m->tp_gstart})
         if (*p)
@@ -645,75 +684,153 @@ void tp_launch_reduce(spmv_ctx* ctx, const spmv_mat* A, double* y, const apply_e
 }
 
 // Where the PRODUCT stream lies in physical memory decides a tenth of the product: with everything else in place, moving
-// tp_xg alone to another allocation switches phase A between ~1.18 and ~1.33 ms on the C5 shard (and phase B, which reads
-// it back, between 0.55 and 0.61), while moving the values, columns or rows changes nothing
-// (profiles/r03_probe_twophase_placement.txt; round 2 had seen the spread and not its owner).  The same virtual address is
-// fast in one build and slow in the next, and allocations made one after the other tend to share their mode: it is the
-// physical memory behind the allocation.  The engine cannot ask for a placement, but it can look: candidate allocations are
-// made one after the other and all held (so that each is other memory), both phases are timed on each (1 warm-up + 2
-// launches, zeroed scratch x and y), the fastest is kept and the rest returned.  The search stops after six candidates or more
-// when the last one is the best seen and a clearly slower one has been seen, or after `SPMV_TP_PLACEMENT_TRIES` (16) candidates
-// or when less than a quarter of the device's free memory would be left.  Spacers of 1-4 GB between the later candidates
-// (held, then freed) make them differ in where they lie.  Like the panel kernel's trial: a few dozen
-// launches when the layout is built, none afterwards; SPMV_PANEL_TRIAL=0 / "panel_trial" 0 switch both off.  Only for
-// streams of 512 MB or more, where the spread was seen.
+// tp_xg alone switches phase A between ~1.16 and ~1.33 ms on the C5 shard, while moving the values, columns or rows changes
+// nothing (profiles/r03_probe_twophase_placement.txt).  Round 4 looked for the cause (profiles/r04_pmc_twophase_placement.txt):
+// the address translation is innocent (the same 2.4e5 UTCL1 misses of 1.5e8 requests in fast and slow placements) and so is
+// the allocator (hipMalloc, one mapped piece, mapped 1 GB pieces: the same two modes); what differs is how readily the
+// MEMORY takes requests - 5.0-5.4M cycles of "read request stalled: out of DRAM credits" in slow placements against
+// 1.7-2.5M in fast ones, and 2.0M against 1.2M for the writes: a property of the DRAM region the stream occupies (next to
+// the regions of the streams read at the same time), which the engine cannot ask for.
+// It can choose, though, and within a fixed budget: the stream is backed by PIECES of physical memory (HIP's virtual memory
+// management: hipMemCreate / hipMemMap) inside ONE reserved address range.  `extra` more pieces than the stream needs are
+// created (at most kTpArenaExtra = 8 GB, never more than a quarter of the free memory), every WINDOW of consecutive pieces
+// is mapped under the stream in turn and both phases are timed on it (1 warm-up + 2 products, zeroed scratch x and y), the
+// fastest window stays mapped and every other piece is released before the function returns.  Transient footprint: the
+// stream + 8 GB + scratch x and y; afterwards exactly the stream.  Round 3 held up to 16 whole candidate streams with 1-4 GB
+// spacers between them (up to 3/4 of the free memory for seconds).  SPMV_PANEL_TRIAL=0 / "panel_trial" 0 / SPMV_TP_PLACEMENT_TRIES=1:
+// no search (one hipMalloc).  Only for streams of 512 MB or more, where the spread was seen.  Failures of the mapping calls
+// fall back to the plain allocation the build made; failures of a timing launch are reported (SPMV_ERR_HIP).
+constexpr size_t kTpArenaPiece = (size_t)256 << 20;  // physical pieces: the stream's mapping is rounded up to this
+constexpr size_t kTpArenaStep  = (size_t)1 << 30;    // distance between the windows that are tried
+constexpr size_t kTpArenaExtra = (size_t)8 << 30;    // pieces created beyond the stream: the search's whole transient cost
+
 int tp_choose_placement(spmv_mat* m)
 {
-    spmv_ctx* ctx = m->ctx;
-    const char* e_tries = getenv("SPMV_TP_PLACEMENT_TRIES");
-    int         tries   = e_tries ? atoi(e_tries) : 16;
+    spmv_ctx*   ctx     = m->ctx;
+    const char* e_tries = getenv("SPMV_TP_PLACEMENT_TRIES");  // (read when the layout is built, never on the product's path)
+    int         tries   = e_tries ? atoi(e_tries) : 9;
     const char* e_trial = getenv("SPMV_PANEL_TRIAL");
     if (m->pb_trial == 0 || (m->pb_trial < 0 && e_trial && e_trial[0] == '0')) tries = 0;
     const size_t bytes = sizeof(double) * (size_t)m->tp_padded;
     if (tries <= 1 || bytes < ((size_t)512 << 20) || m->tp_alloc_mode != 0) return SPMV_OK;
+    const char* e_piece = getenv("SPMV_TP_ARENA_PIECE_MB");  // experiments: piece size and budget
+    const char* e_extra = getenv("SPMV_TP_ARENA_EXTRA_MB");
+    size_t      piece   = e_piece && atoll(e_piece) >= 2 ? (size_t)atoll(e_piece) << 20 : kTpArenaPiece;
+    size_t      extra_b = e_extra && atoll(e_extra) >= 0 ? std::min((size_t)atoll(e_extra) << 20, (size_t)64 << 30) : kTpArenaExtra;
+
+    hipMemAllocationProp prop{};
+    prop.type          = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id   = ctx->device;
+    size_t gran        = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0)
+    {
+        (void)hipGetLastError();
+        return SPMV_OK;  // no virtual memory management here: the plain allocation stays
+    }
+    piece               = (piece + gran - 1) / gran * gran;
+    const size_t need   = (bytes + piece - 1) / piece;  // pieces under the stream
+    const char*  e_step = getenv("SPMV_TP_ARENA_STEP_MB");
+    const size_t step_b = e_step && atoll(e_step) >= 2 ? (size_t)atoll(e_step) << 20 : kTpArenaStep;
+    const size_t stride = std::max<size_t>(1, step_b / piece);  // pieces between two windows
+    size_t       free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return SPMV_OK;
+    // the plain allocation is given back first: the pieces take its place (memory is never held twice)
+    const size_t budget = std::min(extra_b, (free_b + bytes) / 4);
+    size_t       extra  = std::min(budget / piece, (size_t)std::max(tries - 1, 0) * stride) / stride * stride;
+    if (extra == 0) return SPMV_OK;
+    // experiment (SPMV_TP_VA_STEP_MB): the SAME physical pieces mapped at different virtual addresses instead
+    const char*  e_va    = getenv("SPMV_TP_VA_STEP_MB");
+    const size_t va_step = e_va && atoll(e_va) >= 2 ? ((size_t)atoll(e_va) << 20) / gran * gran : 0;
+    const size_t windows = (size_t)std::max(tries, 2);
+    if (va_step) extra = 0;
+
     hipStream_t s = ctx->stream;
     double *    x = nullptr, *y = nullptr;
     hipEvent_t  e0 = nullptr, e1 = nullptr;
-    bool        ok = hipMalloc(&x, sizeof(double) * (size_t)m->ncol) == hipSuccess && hipMalloc(&y, sizeof(double) * (size_t)m->nrow) == hipSuccess &&
-              hipMemsetAsync(x, 0, sizeof(double) * (size_t)m->ncol, s) == hipSuccess &&
-              hipMemsetAsync(y, 0, sizeof(double) * (size_t)m->nrow, s) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
-              hipEventCreate(&e1) == hipSuccess;
-    std::vector<double*> cand{m->tp_xg};
-    std::vector<void*>   spacers;  // held until the search ends: they move the following candidates further along in memory
-    std::vector<float>   ms;
-    if (ok)
+    auto*       blk = new tp_vm_block;
+    int         rc  = SPMV_OK;
+    bool        mapped_any = false;
+    std::vector<float> ms;
+    size_t      keep = 0;
+    char*       base = nullptr;  // where the mapped window begins (the reservation's start unless the experiment moves it)
+    const char* e_each = getenv("SPMV_TP_RESERVE_EACH");  // experiment: with SPMV_TP_VA_STEP_MB, every window in a reservation of its own
+    const bool  each   = e_each && e_each[0] == '1';
+    std::vector<void*> own;  // those reservations (leaked at the end of the experiment: address space only)
+    auto        map_window = [&](size_t w) -> bool {
+        base            = (char*)blk->va + (va_step ? w * va_step : 0);
+        if (each)
+        {
+            const size_t ri = va_step ? w : w / stride;
+            while (own.size() <= ri)
+            {
+                void* r = nullptr;
+                if (hipMemAddressReserve(&r, need * piece, (size_t)1 << 30, nullptr, 0) != hipSuccess) return false;
+                own.push_back(r);
+            }
+            base = (char*)own[ri];
+        }
+        const size_t p0 = va_step ? 0 : w;
+        for (size_t i = 0; i < need; ++i)
+            if (hipMemMap(base + i * piece, piece, 0, blk->handles[p0 + i], 0) != hipSuccess)
+            {
+                for (size_t j = 0; j < i; ++j) (void)hipMemUnmap(base + j * piece, piece);
+                return false;
+            }
+        hipMemAccessDesc acc{};
+        acc.location = prop.location;
+        acc.flags    = hipMemAccessFlagsProtReadWrite;
+        if (hipMemSetAccess(base, need * piece, &acc, 1) != hipSuccess)
+        {
+            for (size_t j = 0; j < need; ++j) (void)hipMemUnmap(base + j * piece, piece);
+            return false;
+        }
+        return true;
+    };
+    auto unmap_window = [&]() {
+        for (size_t j = 0; j < need; ++j) (void)hipMemUnmap(base + j * piece, piece);
+    };
+    do
     {
+        if (hipMalloc(&x, sizeof(double) * (size_t)m->ncol) != hipSuccess || hipMalloc(&y, sizeof(double) * (size_t)m->nrow) != hipSuccess ||
+            hipMemsetAsync(x, 0, sizeof(double) * (size_t)m->ncol, s) != hipSuccess || hipMemsetAsync(y, 0, sizeof(double) * (size_t)m->nrow, s) != hipSuccess ||
+            hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+            break;  // no room for the scratch vectors: keep the plain allocation
+        blk->size = need * piece + (va_step ? (windows - 1) * va_step : 0);
+        if (hipMemAddressReserve(&blk->va, blk->size, (size_t)1 << 30, nullptr, 0) != hipSuccess)
+        {
+            blk->va = nullptr;
+            break;
+        }
+        // the stream's plain allocation goes; its memory is what the first pieces are made of
+        if (hipStreamSynchronize(s) != hipSuccess) break;
+        csr_twophase_products_free(m->tp_xg, m->tp_xg_vm);
+        m->tp_xg    = nullptr;
+        m->tp_xg_vm = nullptr;
+        for (size_t i = 0; i < need + extra; ++i)
+        {
+            hipMemGenericAllocationHandle_t h{};
+            if (hipMemCreate(&h, piece, &prop, 0) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                break;
+            }
+            blk->handles.push_back(h);
+        }
+        if (blk->handles.size() < need) break;  // (cannot happen unless somebody else took the memory meanwhile)
+        extra = (blk->handles.size() - need) / stride * stride;
         tp_grant_lds(ctx);
         apply_extra plain;
-        size_t free0 = 0, total_b = 0;
-        (void)hipMemGetInfo(&free0, &total_b);
-        for (int t = 0; t < tries; ++t)
+        for (size_t w = 0; va_step ? w < windows : w <= extra; w += va_step ? 1 : stride)
         {
-            if (t > 0)
+            if (!map_window(w))
             {
-                // Neighbours in allocation order tend to share their mode (whole searches of 12 back-to-back candidates came
-                // out slow), and the mode changes on the scale of gigabytes (tools/probe_twophase_regions.py): from the third
-                // candidate on a spacer of 1, 2, 3, 4, 4, ... GB is allocated first and held.
-                size_t       free_b = 0;
-                const size_t gap    = t >= 2 ? (size_t)std::min(t - 1, 4) << 30 : 0;
-                double*      fresh  = nullptr;
-                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + free0 / 4)
-                {
-                    (void)hipGetLastError();
-                    break;
-                }
-                if (gap && free_b >= bytes + gap + free0 / 4)
-                {
-                    void* sp = nullptr;
-                    if (hipMalloc(&sp, gap) == hipSuccess)
-                        spacers.push_back(sp);
-                    else
-                        (void)hipGetLastError();
-                }
-                if (hipMalloc(&fresh, bytes) != hipSuccess)
-                {
-                    (void)hipGetLastError();
-                    break;
-                }
-                cand.push_back(fresh);
-                m->tp_xg = fresh;
+                (void)hipGetLastError();
+                break;
             }
-            tp_launch_expand(ctx, m, x);  // warm-up (first touch of the candidate)
+            mapped_any = true;
+            m->tp_xg   = (double*)base;
+            tp_launch_expand(ctx, m, x);  // warm-up (first touch of the window)
             tp_launch_reduce(ctx, m, y, plain);
             (void)hipEventRecord(e0, s);
             for (int r = 0; r < 2; ++r)
@@ -723,41 +840,149 @@ int tp_choose_placement(spmv_mat* m)
             }
             (void)hipEventRecord(e1, s);
             float t_ms = 0.f;
-            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t_ms, e0, e1) != hipSuccess)
+            if (hipGetLastError() != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t_ms, e0, e1) != hipSuccess)
             {
-                (void)hipGetLastError();
-                t_ms = 1e30f;
+                set_error("two-phase layout: a timing launch of the placement search failed: %s", hipGetErrorString(hipGetLastError()));
+                rc = SPMV_ERR_HIP;
             }
-            ms.push_back(t_ms);
-            const float best = *std::min_element(ms.begin(), ms.end()), worst = *std::max_element(ms.begin(), ms.end());
-            // at least six candidates (the times form a range, 1.73-1.95 ms on the C5 shard, not two values: the second-best
-            // of two is often 3 % off the best of twelve); then stop once this one is the best seen and slow ones were seen
-            if (t >= 5 && t_ms <= best * 1.005f && worst >= best * 1.05f) break;
+            unmap_window();
+            m->tp_xg = nullptr;
+            if (rc != SPMV_OK) break;
+            ms.push_back(t_ms / 2);
         }
-    }
-    for (void* sp : spacers) (void)hipFree(sp);
-    size_t keep = 0;
-    for (size_t i = 1; i < ms.size(); ++i)
-        if (ms[i] < ms[keep]) keep = i;
+        if (rc != SPMV_OK || ms.empty()) break;
+        for (size_t i = 1; i < ms.size(); ++i)
+            if (ms[i] < ms[keep]) keep = i;
+        if (!map_window(va_step ? keep : keep * stride))
+        {
+            (void)hipGetLastError();
+            ms.clear();
+            break;
+        }
+        m->tp_xg = (double*)base;
+        if (const char* e_v = getenv("SPMV_TP_PLACEMENT_VERBOSE"); e_v && e_v[0] == '1')
+        {
+            // the kept window timed again after its final mapping, the same way and with 20 products in a row
+            for (int reps : {2, 20, 2})
+            {
+                tp_launch_expand(ctx, m, x);
+                tp_launch_reduce(ctx, m, y, plain);
+                (void)hipEventRecord(e0, s);
+                for (int r = 0; r < reps; ++r)
+                {
+                    tp_launch_expand(ctx, m, x);
+                    tp_launch_reduce(ctx, m, y, plain);
+                }
+                (void)hipEventRecord(e1, s);
+                float t_ms = 0.f;
+                (void)hipEventSynchronize(e1);
+                (void)hipEventElapsedTime(&t_ms, e0, e1);
+                fprintf(stderr, "kept window mapped again, %d products: %.4f ms each\n", reps, t_ms / reps);
+            }
+        }
+    } while (0);
     if (const char* e_v = getenv("SPMV_TP_PLACEMENT_VERBOSE"); e_v && e_v[0] == '1')
     {
-        fprintf(stderr, "two-phase product stream, ms per product for every candidate placement:");
-        for (size_t i = 0; i < ms.size(); ++i) fprintf(stderr, " %.4f%s", ms[i] / 2, i == keep ? "*" : "");
+        fprintf(stderr, "addresses: reservation %p (+%zu MB per window), values %p, columns %p, rows %p, table %p, scratch x %p, y %p\n", blk->va, va_step >> 20,
+                (void*)m->tp_val, (void*)m->tp_col, (void*)m->tp_row, (void*)m->tp_blk, (void*)x, (void*)y);
+        fprintf(stderr, "two-phase product stream: %zu pieces of %zu MB under the stream, %zu more, windows %zu pieces apart; ms per product by window:",
+                need, piece >> 20, extra, stride);
+        for (size_t i = 0; i < ms.size(); ++i) fprintf(stderr, " %.4f%s", ms[i], i == keep && m->tp_xg ? "*" : "");
         fprintf(stderr, "\n");
     }
-    for (size_t i = 0; i < cand.size(); ++i)
-        if (i != keep) (void)hipFree(cand[i]);
-    m->tp_xg         = cand[keep];
-    m->tp_place_seen = (int32_t)ms.size();
-    m->tp_place_gain = ms.empty() || ms[keep] <= 0.f ? 0 : (int32_t)(1000.0f * (*std::max_element(ms.begin(), ms.end())) / ms[keep]);
+    if (m->tp_xg)
+    {
+        // the kept window's pieces stay with the handle, every other piece goes back now
+        std::vector<hipMemGenericAllocationHandle_t> kept;
+        for (size_t i = 0; i < blk->handles.size(); ++i)
+        {
+            if (va_step || (i >= keep * stride && i < keep * stride + need))
+                kept.push_back(blk->handles[i]);
+            else
+                (void)hipMemRelease(blk->handles[i]);
+        }
+        blk->handles = kept;
+        blk->sizes.assign(need, piece);
+        blk->map_off = each ? 0 : (size_t)(base - (char*)blk->va);
+        if (each)
+        {
+            (void)hipMemAddressFree(blk->va, blk->size);
+            blk->va   = base;
+            blk->size = need * piece;
+        }
+        m->tp_xg_vm      = blk;
+        m->tp_bytes += (int64_t)(need * piece - bytes);  // the mapping is rounded up to whole pieces: counted
+        m->device_bytes += (int64_t)(need * piece - bytes);
+        m->tp_place_seen = (int32_t)ms.size();
+        m->tp_place_gain = ms[keep] > 0.f ? (int32_t)(1000.0f * (*std::max_element(ms.begin(), ms.end())) / ms[keep]) : 0;
+    }
+    else
+    {
+        // nothing mapped: release whatever was created and go back to one plain allocation
+        (void)mapped_any;
+        for (auto h : blk->handles) (void)hipMemRelease(h);
+        if (blk->va) (void)hipMemAddressFree(blk->va, blk->size);
+        delete blk;
+        (void)hipGetLastError();
+        if (!m->tp_xg && csr_twophase_products_alloc(m, &m->tp_xg, &m->tp_xg_vm) != SPMV_OK && rc == SPMV_OK) rc = SPMV_ERR_ALLOC;
+    }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     if (x) (void)hipFree(x);
     if (y) (void)hipFree(y);
     (void)hipGetLastError();
-    return SPMV_OK;
+    return rc;
 }
 }  // namespace
+
+// experiments ("twophase_products_push" / "_rotate"): several product streams held at once, one of them current
+int csr_twophase_products_push(spmv_mat* m, int mode)
+{
+    SPMV_REQUIRE(m->tp_val && m->tp_padded > 0, "the two-phase layout is not built");
+    SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
+    if (!m->tp_held) m->tp_held = new tp_held_list;
+    const int32_t saved = m->tp_alloc_mode;
+    m->tp_alloc_mode    = mode;
+    double* fresh       = nullptr;
+    void*   fresh_vm    = nullptr;
+    const int rc        = csr_twophase_products_alloc(m, &fresh, &fresh_vm);
+    m->tp_alloc_mode    = saved;
+    if (rc != SPMV_OK) return rc;
+    ((tp_held_list*)m->tp_held)->v.emplace_back(m->tp_xg, m->tp_xg_vm);
+    m->tp_xg    = fresh;
+    m->tp_xg_vm = fresh_vm;
+    return SPMV_OK;
+}
+int csr_twophase_products_rotate(spmv_mat* m)
+{
+    SPMV_REQUIRE(m->tp_held && !((tp_held_list*)m->tp_held)->v.empty(), "no product streams are held");
+    SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
+    auto& v = ((tp_held_list*)m->tp_held)->v;
+    v.emplace_back(m->tp_xg, m->tp_xg_vm);
+    m->tp_xg    = v.front().first;
+    m->tp_xg_vm = v.front().second;
+    v.erase(v.begin());
+    return SPMV_OK;
+}
+
+// experiment ("twophase_place_again"): give the product stream back and run the placement search again
+int csr_twophase_place_again(spmv_mat* m)
+{
+    SPMV_REQUIRE(m->tp_val && m->tp_padded > 0, "the two-phase layout is not built");
+    SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
+    if (m->tp_xg_vm)
+    {
+        int64_t slack = -(int64_t)sizeof(double) * m->tp_padded;
+        for (size_t n : ((tp_vm_block*)m->tp_xg_vm)->sizes) slack += (int64_t)n;
+        m->tp_bytes -= slack;
+        m->device_bytes -= slack;
+    }
+    csr_twophase_products_free(m->tp_xg, m->tp_xg_vm);
+    m->tp_xg    = nullptr;
+    m->tp_xg_vm = nullptr;
+    SPMV_TRY(csr_twophase_products_alloc(m, &m->tp_xg, &m->tp_xg_vm));
+    return tp_choose_placement(m);
+}
 
 int csr_twophase_build(spmv_mat* m)
 {
@@ -821,9 +1046,10 @@ int csr_twophase_build(spmv_mat* m)
         }
         const size_t np     = (size_t)padded;
         const size_t nlines = (np + kTpLine - 1) / kTpLine;
-        if (hipMalloc(&m->tp_val, sizeof(double) * np) != hipSuccess || hipMalloc(&m->tp_col, sizeof(unsigned short) * np) != hipSuccess ||
-            hipMalloc(&m->tp_row, sizeof(unsigned short) * np) != hipSuccess ||
-            hipMalloc(&m->tp_blk, sizeof(int32_t) * 2 * nlines) != hipSuccess || hipMalloc(&bpos, sizeof(int32_t) * nlines) != hipSuccess)
+        if (tp_stream_alloc(m, (void**)&m->tp_val, sizeof(double) * np, 0) != SPMV_OK ||
+            tp_stream_alloc(m, (void**)&m->tp_col, sizeof(unsigned short) * np, 1) != SPMV_OK ||
+            tp_stream_alloc(m, (void**)&m->tp_row, sizeof(unsigned short) * np, 2) != SPMV_OK ||
+            tp_stream_alloc(m, (void**)&m->tp_blk, sizeof(int32_t) * 2 * nlines, 3) != SPMV_OK || hipMalloc(&bpos, sizeof(int32_t) * nlines) != hipSuccess)
         {
             rc = SPMV_ERR_ALLOC;
             break;
@@ -865,7 +1091,9 @@ int csr_twophase_build(spmv_mat* m)
     m->tp_max_rows  = per;
     m->tp_bytes     = m->tp_padded * 20 + (m->tp_padded + kTpLine - 1) / kTpLine * 8 + (int64_t)(P + 1 + 2 * (ngroups + 1)) * 4;
     m->device_bytes += m->tp_bytes;
-    return tp_choose_placement(m);
+    rc = tp_choose_placement(m);
+    if (rc != SPMV_OK) csr_twophase_free(m);
+    return rc;
 }
 
 int csr_twophase_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, const apply_extra& ex)

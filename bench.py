@@ -29,6 +29,12 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
+# Multi-process GPU work on this platform shares device memory through dmabuf handles only: with the legacy IPC mode
+# RCCL's (and torch's) cross-process buffer registration fails with `hipIpcGetMemHandle: invalid argument`.  The image
+# exports HSA_ENABLE_IPC_MODE_LEGACY=0 already; bench.py sets it itself (before anything touches the GPU) so that an
+# 8-rank launch does not depend on the caller's environment.  INTEGRATION.md section 4 says the same for applications.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
@@ -372,6 +378,92 @@ def cpu_baseline(args) -> dict:
         return {"value": None, "unit": "GFLOP/s", "cores": 0, "kind": "reference", "sample": f"the CPU leg failed: {e}"}
 
 
+def pmc_child(args) -> None:
+    """What the counter passes profile (`rocprofv3 --pmc ... -- python3 bench.py --pmc-child`): the headline matrix built the
+    same way, one warm-up and three products through the engine, nothing else (no torch: the engine allocates its own
+    vectors).  Prints the kernel and panel layout that ran, so that the parent can tell a child whose trial picked another
+    instance from one that measured its own."""
+    from __graft_entry__ import load_package
+
+    capi = load_package().capi
+    ctx = capi.Context(0)
+    A = ctx.gen_csr_uniform(0, args.n, args.n, args.k, band=args.band, seed=args.seed)
+    if args.kernel or args.lanes:
+        A.set_kernel(args.kernel, args.lanes)
+    if args.flags:
+        A.set_flags(args.flags)
+    x, y = ctx.gen_vector(args.n, seed=args.seed), ctx.vector(args.n)
+    y.fill(0.0)
+    for _ in range(4):
+        ctx.apply(A, x, y)
+    ctx.sync()
+    layout = None
+    if int(A.info.kernel) == 4:
+        layout = {name: A.get_param("panel_" + name) for name in ("layout", "unroll", "pipe", "sync")}
+    print(json.dumps({"pmc_child": True, "kernel_id": int(A.info.kernel), "panel_layout": layout}), flush=True)
+
+
+def live_counters(args) -> dict:
+    """HBM-side traffic of the dominant kernel measured NOW, by this very bench.py: two rocprofv3 --pmc passes (FETCH_SIZE
+    and WRITE_SIZE separately: they do not fit one pass, MI355X_MICROARCH.md 'rocprofv3 PMC slots') over `--pmc-child`,
+    run before this process touches the GPU.  Per launch: 2 x FETCH_SIZE (gfx950 tallies its 128-byte fabric reads at
+    64 B: the guide's correction) + WRITE_SIZE, both KB x 1024, from the product launches only (trial launches of the
+    panel kernel carry `true` as their fourth template argument).  Returns {"traffic": bytes or None, ...}; on any failure
+    the caller falls back to the stamped constants of profiles/pmc_traffic.json."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    out = {"traffic": None, "source": None, "kernel": None, "child": None, "error": None}
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return dict(out, error="rocprofv3 not found")
+    if any(k.startswith(("ROCPROF", "ROCPROFILER", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return dict(out, error="bench.py itself runs under a profiler: no nested counter passes")
+    child = [sys.executable, str(Path(__file__).resolve()), "--pmc-child", "--rows", str(args.n), "--per-row", str(args.k), "--band", str(args.band),
+             "--seed", str(args.seed), "--kernel", str(args.kernel), "--lanes", str(args.lanes), "--flags", str(args.flags)]
+    sums = {}
+    t0 = time.perf_counter()
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            try:
+                r = subprocess.run([rocprof, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
+                                   capture_output=True, text=True, timeout=240)
+            except (OSError, subprocess.SubprocessError) as e:
+                return dict(out, error=f"{counter} pass: {e}")
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and "pmc_child" in ln]
+            if r.returncode != 0 or not line:
+                return dict(out, error=f"{counter} pass failed (rc {r.returncode}): " + (r.stderr or r.stdout)[-300:])
+            out["child"] = json.loads(line[-1])
+            rows = []
+            for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
+                rows += [row for row in csv.DictReader(open(f)) if row["Counter_Name"] == counter]
+            kid = out["child"]["kernel_id"]
+            want = {4: ("csr_panel_kernel",), 5: ("tp_expand_kernel", "tp_reduce_kernel"), 1: ("csr_vector_kernel",), 2: ("csr_ldswin_kernel",),
+                    3: ("csr_scalar_kernel",)}.get(kid, ())
+            per_kernel = {}
+            for name in want:
+                mine = [row for row in rows if name in row["Kernel_Name"]]
+                if name == "csr_panel_kernel":  # product launches only: template <U, LAYOUT, PIPE, TRIAL, TRACE, SYNC>
+                    mine = [row for row in mine if row["Kernel_Name"].split("csr_panel_kernel<")[1].split(">")[0].split(",")[3].strip() == "false"]
+                mine.sort(key=lambda row: int(row["Dispatch_Id"]))
+                last = mine[-3:]  # the three products after the warm-up
+                if len(last) < 3:
+                    return dict(out, error=f"{counter} pass: fewer than 3 dispatches of {name}")
+                per_kernel[name] = sum(float(row["Counter_Value"]) for row in last) / len(last)
+                out["kernel"] = last[-1]["Kernel_Name"].split("(anonymous namespace)::")[-1].split("(")[0]
+            sums[counter] = sum(per_kernel.values())
+    out["traffic"] = int(round((2.0 * sums["FETCH_SIZE"] + sums["WRITE_SIZE"]) * 1024))
+    out["fetch_size_kb"], out["write_size_kb"] = round(sums["FETCH_SIZE"], 1), round(sums["WRITE_SIZE"], 1)
+    out["source"] = "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --pmc-child`, mean of 3 product launches"
+    out["seconds"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -392,10 +484,19 @@ def main() -> None:
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--keep-csr", action="store_true", help="keep col_ind / values of the CSR copy next to the panel layout")
     ap.add_argument("--no-extra", action="store_true", help="skip the C3 / C4 / band lines after the headline loop")
+    ap.add_argument("--no-live-counters", action="store_true", help="do not run the two rocprofv3 --pmc passes; use profiles/pmc_traffic.json")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
         print(json.dumps(cpu_baseline_child(args)), flush=True)
         return
+    if args.pmc_child:
+        pmc_child(args)
+        return
+    # N = 1: the counter passes run first, while this process has not touched the GPU (one GPU process at a time)
+    live = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and not args.no_live_counters:
+        live = live_counters(args)
 
     import torch
     import torch.distributed as dist
@@ -517,6 +618,19 @@ def main() -> None:
             torch.cuda.synchronize()
             allgather_ms = e0.elapsed_time(e1) / 10
 
+        # the optional last step of the sharded product: every rank's y slice gathered into the full y on every rank
+        # (the reference does it for DIA only, src/mat_vec.cpp:474-477); timed by itself, never part of `value`
+        y_concat_ms = None
+        if grouped:
+            y_full = shard.concatenate_y(y, ncol)  # warm-up (allocates the result)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                y_full = shard.concatenate_y(y, ncol)
+            barrier()
+            (y_concat_ms,) = max_over_ranks(1e3 * (time.perf_counter() - t1) / 10)
+            del y_full
+
         panel_names = ("rows", "width", "groups", "layout", "unroll", "pipe", "sync", "stagger", "pace_ns", "bytes")
 
         def panel_of(M):
@@ -580,7 +694,9 @@ def main() -> None:
                     "roofline": {"bound": "hbm", "achieved": round(b_req / ms / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(b_req / ms / 1e6 / HBM_PEAK_GBS, 4), "bytes_required": b_req, "bytes_required_kind": kind,
                                  "frac_of_format_bytes": round(b_fmt / ms / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": b_fmt,
-                                 "traffic": counters["traffic"], "traffic_measured_on": counters["measured_on"],
+                                 "traffic": counters["traffic"],
+                                 "traffic_gbs": round(counters["traffic"] / ms / 1e6, 1) if counters["traffic"] else None,
+                                 "traffic_measured_on": counters["measured_on"],
                                  "per": "rank" if sharded else "launch"},
                 })
                 del M, vy2
@@ -632,6 +748,19 @@ def main() -> None:
             twophase = {"panel_cols": A.get_param("twophase_panel_cols"), "padded_entries": A.get_param("twophase_padded"),
                         "placements_timed": A.get_param("twophase_placements_timed"),
                         "slowest_over_kept_placement": A.get_param("twophase_placement_spread") / 1000.0}
+        # every rank's kernel choice, set-up time and (two-phase) placement search, so that a rank that lags is visible in
+        # rank 0's line: one all-gather of five numbers per rank
+        mine = [float(int(info.kernel)), setup_s, float(A.get_param("twophase_placements_timed")) if int(info.kernel) == 5 else 0.0,
+                A.get_param("twophase_placement_spread") / 1000.0 if int(info.kernel) == 5 else 0.0, kernel_ms]
+        per_rank_layout = [mine]
+        if grouped:
+            table = torch.zeros(world, len(mine), dtype=torch.float64, device=dev)
+            table[rank] = torch.tensor(mine, dtype=torch.float64, device=dev)
+            dist.all_reduce(table, op=dist.ReduceOp.SUM)
+            per_rank_layout = table.tolist()
+        per_rank_layout = [{"rank": r, "kernel_id": int(v[0]), "setup_seconds": round(v[1], 3), "twophase_placements_timed": int(v[2]),
+                            "twophase_slowest_over_kept_placement": round(v[3], 3), "kernel_ms": round(v[4], 5)}
+                           for r, v in enumerate(per_rank_layout)]
         wall_s, kernel_ms, exch_max = max_over_ranks(wall_s, kernel_ms, exch_s or 0.0)
 
     if rank == 0:
@@ -645,6 +774,16 @@ def main() -> None:
         kernel_name = kernel_names.get(int(info.kernel), str(info.kernel))
         panel = panel_of(A) if int(info.kernel) == 4 else None
         counters = measured_counters(f"csr_n{n}_k{k}_band{args.band}_ncol{ncol}", kernel_name, panel)
+        traffic_source = "profiles/pmc_traffic.json (stamped constants of an earlier run)" if counters["traffic"] else None
+        if live and live.get("traffic"):
+            # measured minutes ago by this command; kept only if the child ran the instance this process ran
+            same = live["child"]["kernel_id"] == int(info.kernel) and (panel is None or all(
+                int(panel.get(name, -1)) == int(val) for name, val in (live["child"]["panel_layout"] or {}).items()))
+            if same:
+                counters = dict(counters, traffic=live["traffic"], measured_on=live["kernel"])
+                traffic_source = live["source"]
+            else:
+                live["error"] = f"the counter passes ran {live['child']}, this process {int(info.kernel)} / {panel}: not used"
         l2 = None
         if counters["l2_line_ops"]:
             # what bounds the panel kernel on scattered columns is the L2's line rate, not HBM: 128-byte line
@@ -688,6 +827,7 @@ def main() -> None:
                 "panel_layout": panel,
                 "twophase_layout": twophase,
                 "kernel_ms_per_rank": per_rank_ms,
+                "per_rank": per_rank_layout,
             },
             "roofline": {
                 "bound": "hbm",
@@ -696,7 +836,13 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": counters["traffic"],
+                # the counters' bytes over THIS run's kernel time: north_star's "FETCH_SIZE/WRITE_SIZE counters reported as
+                # achieved HBM GB/s" (the L2s' traffic with memory, what the chip's ~8 TB/s bound)
+                "traffic_gbs": round(counters["traffic"] / (kernel_ms * 1e-3) / 1e9, 1) if counters["traffic"] else None,
+                "traffic_frac": round(counters["traffic"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if counters["traffic"] else None,
                 "traffic_measured_on": counters["measured_on"],
+                "traffic_source": traffic_source,
+                "traffic_live": ({k_: live.get(k_) for k_ in ("fetch_size_kb", "write_size_kb", "seconds", "error")} if live else None),
                 "algorithmic_bytes_per_launch": bytes_launch,
                 "kernel_ms": round(kernel_ms, 5),
                 **(l2 or {}),
@@ -711,6 +857,7 @@ def main() -> None:
                 "allgather_ms": round(allgather_ms, 4) if allgather_ms else None,
                 "bytes_per_rank": 8 * n,
             }
+            out["y_concatenate_ms"] = round(y_concat_ms, 4) if y_concat_ms is not None else None
         if extra:
             out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
