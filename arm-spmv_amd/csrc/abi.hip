@@ -671,34 +671,18 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
     }
     else if (!strcmp(name, "twophase_panel_cols"))  // takes effect at the next spmv_mat_set_kernel(TWOPHASE)
         m->tp_pcols_req = (int32_t)value;
-    else if (!strcmp(name, "twophase_unroll"))  // pairs per lane in flight of the expand kernel: 3 (default) or 4; with 512 threads 6 or 8
-        m->tp_unroll = (int32_t)value;
-    else if (!strcmp(name, "twophase_threads"))  // threads per workgroup of the expand kernel: 0 / 1024 (default) or 512
+    else if (!strcmp(name, "twophase_placement_budget_mb"))
     {
-        SPMV_REQUIRE(value == 0 || value == 512 || value == 1024, "twophase_threads: 0, 512 or 1024, got %lld", (long long)value);
-        m->tp_threads = (int32_t)value;
+        // memory (MB) the piece search of the two-phase layout may hold beyond the product stream while it runs; 0 = no
+        // search; -1 = the default (SPMV_TP_PLACEMENT_BUDGET_MB or 8192).  Takes effect at the next spmv_mat_set_kernel(TWOPHASE)
+        // that builds the layout.
+        SPMV_REQUIRE(value >= -1 && value <= (1 << 20), "twophase_placement_budget_mb: -1 (default), 0 (no search) or megabytes");
+        m->tp_place_budget_mb = (int32_t)value;
     }
-    else if (!strcmp(name, "twophase_products_push") || !strcmp(name, "twophase_products_rotate"))  // experiments
+    else if (!strcmp(name, "twophase_choose_pieces"))  // run the piece search of a built two-phase layout (again) with the current budget
     {
-        const char* e_exp = getenv("SPMV_EXPERIMENTS");
-        SPMV_REQUIRE(e_exp && e_exp[0] == '1', "%s is an experiment: set SPMV_EXPERIMENTS=1", name);
         SPMV_HIP(hipSetDevice(m->ctx->device));
-        if (!strcmp(name, "twophase_products_push"))
-            SPMV_TRY(csr_twophase_products_push(m, (int)value));
-        else
-            SPMV_TRY(csr_twophase_products_rotate(m));
-    }
-    else if (!strcmp(name, "twophase_place_again"))  // experiment: run the placement search of the product stream again
-    {
-        const char* e_exp = getenv("SPMV_EXPERIMENTS");
-        SPMV_REQUIRE(e_exp && e_exp[0] == '1', "twophase_place_again is an experiment: set SPMV_EXPERIMENTS=1");
-        SPMV_HIP(hipSetDevice(m->ctx->device));
-        SPMV_TRY(csr_twophase_place_again(m));
-    }
-    else if (!strcmp(name, "twophase_alloc_mode"))  // experiment: 0 hipMalloc, 1 / 2 mapped physical memory (next build / realloc)
-    {
-        SPMV_REQUIRE(value >= 0 && value <= 2, "twophase_alloc_mode: 0, 1 or 2");
-        m->tp_alloc_mode = (int32_t)value;
+        SPMV_TRY(csr_twophase_choose_again(m));
     }
     else if (!strcmp(name, "twophase_rotate"))  // 1 (default): workgroup b starts b / 256 of the way through each of its panels
         m->tp_rotate = value ? 1 : 0;
@@ -733,15 +717,14 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
             return SPMV_OK;
         };
         const size_t np = (size_t)m->tp_padded;
-        if (value & 1)  // the product stream: allocated by the handle's twophase_alloc_mode; its contents need no copy
-        {
-            double* fresh    = nullptr;
-            void*   fresh_vm = nullptr;
-            SPMV_TRY(csr_twophase_products_alloc(m, &fresh, &fresh_vm));
-            csr_twophase_products_free(m->tp_xg, m->tp_xg_vm);
-            m->tp_xg    = fresh;
-            m->tp_xg_vm = fresh_vm;
-        }
+        if (value & 1)  // the product stream's pieces: fresh allocations (its contents need no copy: phase A rewrites all of it)
+            for (int i = 0; i < m->tp_npieces; ++i)
+            {
+                double* fresh = nullptr;
+                if (hipMalloc(&fresh, i + 1 < m->tp_npieces ? (size_t)1 << 30 : (size_t)m->tp_last_piece_bytes) != hipSuccess) SPMV_FAIL(SPMV_ERR_ALLOC, "twophase_realloc: out of device memory");
+                (void)hipFree(m->tp_piece[i]);
+                m->tp_piece[i] = fresh;
+            }
         if (value & 2) SPMV_TRY(move((void**)&m->tp_val, sizeof(double) * np));
         if (value & 4) SPMV_TRY(move((void**)&m->tp_col, sizeof(uint16_t) * np));
         if (value & 8) SPMV_TRY(move((void**)&m->tp_row, sizeof(uint16_t) * np));
@@ -809,6 +792,12 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         *value = m->tp_place_gain;
     else if (!strcmp(name, "twophase_padded"))
         *value = m->tp_padded;
+    else if (!strcmp(name, "twophase_pieces"))  // 1 GB pieces the product stream consists of
+        *value = m->tp_npieces;
+    else if (!strcmp(name, "twophase_pieces_exchanged"))  // of them: exchanged for other pieces by the search
+        *value = m->tp_pieces_exchanged;
+    else if (!strcmp(name, "twophase_placement_budget_mb"))
+        *value = m->tp_place_budget_mb;
     else if (!strcmp(name, "window_max_span"))
         *value = m->win_max_span;
     else if (!strcmp(name, "window_avg_span"))

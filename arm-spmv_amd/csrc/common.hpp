@@ -198,18 +198,17 @@ struct spmv_mat
     double*   tp_val       = nullptr;  // [padded] (panel, group) order, runs padded to 16 entries
     uint16_t* tp_col       = nullptr;  // [padded] column - panel base, same order
     uint16_t* tp_row       = nullptr;  // [padded] row - group base, (group, panel) order; 0xFFFF = padding
-    double*   tp_xg        = nullptr;  // [padded] the stream between the two phases, (group, panel) order
+    double*   tp_piece[4] = {};        // the stream between the two phases, (group, panel) order, in pieces of 2^26 pairs (1 GB)
+    int32_t   tp_npieces   = 0;
+    int64_t   tp_last_piece_bytes = 0;  // the last piece: a whole one when the piece search ran, else what the stream needs of it
     int32_t*  tp_blk       = nullptr;  // [2 * ceil(padded / 16)] two table words per source line: source pair -> destination pair
     int32_t*  tp_panel_ptr = nullptr;  // [panels + 1]
     int32_t*  tp_group_ptr = nullptr;  // [groups + 1]
     int32_t*  tp_gstart    = nullptr;  // [groups + 1] first row of every group
     int32_t   tp_ngroups = 0, tp_panels = 0, tp_pcols = 0, tp_max_rows = 0;
-    int32_t   tp_pcols_req = 0, tp_unroll = 0;  // requested panel width / pairs per lane in flight (0 = default)
-    void*     tp_vm_more[4] = {nullptr, nullptr, nullptr, nullptr};  // experiment: values / columns / rows / table in mapped pieces
-    void*     tp_held = nullptr;                // experiments: further product streams held (kernels_csr_twophase.hip: tp_held_list)
-    void*     tp_xg_vm = nullptr;               // set when tp_xg is mapped memory (tp_alloc_mode 1 / 2): what to release
-    int32_t   tp_alloc_mode = 0;                // product stream: 0 hipMalloc, 1 / 2 mapped physical memory (one piece / 1 GB pieces)
-    int32_t   tp_threads = 0;                   // expand kernel: threads per workgroup (0 = default 1024; 512)
+    int32_t   tp_pcols_req = 0;  // requested panel width (0 = default)
+    int32_t   tp_place_budget_mb = -1;          // memory the piece search may hold beyond the stream (-1: SPMV_TP_PLACEMENT_BUDGET_MB or 8192; 0: no search)
+    int32_t   tp_pieces_exchanged = 0;               // pieces of the stream the search exchanged for others
     int32_t   tp_rotate = 1;                    // expand kernel: workgroup b starts b / 256 of the way through its panels
     int32_t   tp_only = 0;                      // experiment (SPMV_EXPERIMENTS=1): 1 / 2 = run phase A / B alone - wrong results
     int32_t   tp_place_seen = 0, tp_place_gain = 0;  // placements of the product stream timed at build; slowest / kept, in 1/1000
@@ -250,11 +249,9 @@ int  csr_panel_read_trace(spmv_ctx* ctx, int64_t index, int64_t* value);
 int  csr_twophase_build(spmv_mat* m);
 void csr_twophase_free(spmv_mat* m);
 bool csr_twophase_worth(const spmv_mat* m);
-int  csr_twophase_place_again(spmv_mat* m);
-int  csr_twophase_products_push(spmv_mat* m, int mode);
-int  csr_twophase_products_rotate(spmv_mat* m);
-int  csr_twophase_products_alloc(spmv_mat* m, double** out, void** out_vm);
-void csr_twophase_products_free(double* p, void* vm);
+int  csr_twophase_choose_again(spmv_mat* m);
+
+
 // A sum that thousands of wavefronts add into is kept as kDotSlots partial sums on different 128-byte lines (an
 // atomic on ONE word costs ~12 ns each at the L2, serialised: 8192 of them are 100 us); readers add the slots up.
 constexpr int kDotSlots   = 32;

@@ -61,6 +61,16 @@ constexpr int kTpPad       = 8;      // entries: runs are padded to whole 64-byt
 constexpr int kTpLine      = 16;     // entries per source line (8 pairs: what one table entry describes)
 constexpr unsigned kTpPadRow = 0xFFFFu;
 constexpr int64_t kTpMaxPadded = (int64_t)1 << 29;  // delta0 keeps 29 bits
+// The product stream lives in PIECES: plain allocations of 2^kTpPieceShift pairs (1 GB), at most kTpMaxPieces of them
+// (the layout holds < 2^28 pairs).  Both phases look the piece of a pair up in a table of base addresses that sits in
+// front of the x panel / the accumulators in LDS.  Why pieces: see tp_choose_pieces().
+constexpr int kTpPieceShift = 26;  // pairs per piece, log2: 2^26 x 16 B = 1 GB
+constexpr int kTpMaxPieces  = 4;
+constexpr int kTpTabDoubles = 16;  // the table's place in LDS: 128 bytes, so that what follows keeps its 16-byte alignment
+struct tp_piece_tab
+{
+    double* base[kTpMaxPieces];
+};
 
 using u16x2 = unsigned short __attribute__((ext_vector_type(2)));
 using i32x2 = int __attribute__((ext_vector_type(2)));
@@ -184,14 +194,16 @@ template <int THREADS, int UNROLL, bool ALIGNED>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS / 256, THREADS / 256))) void tp_expand_kernel(int P, int pcols, int ncol, const int32_t* __restrict__ panel_ptr,
                                                             const unsigned short* __restrict__ tp_col, const double* __restrict__ tp_val,
                                                             const int32_t* __restrict__ tp_blk, const double* __restrict__ x,
-                                                            double* __restrict__ xg, int rotate)
+                                                            const tp_piece_tab pieces, int rotate)
 {
-    extern __shared__ double xs[];  // pcols entries of x
+    extern __shared__ double lds_a[];  // [kTpTabDoubles] piece table | [pcols] entries of x
+    char**  tab = reinterpret_cast<char**>(lds_a);
+    double* xs  = lds_a + kTpTabDoubles;
     const u16x2* __restrict__ c2 = reinterpret_cast<const u16x2*>(tp_col);
     const f64x2* __restrict__ v2 = reinterpret_cast<const f64x2*>(tp_val);
     const i32x2* __restrict__ b2 = reinterpret_cast<const i32x2*>(tp_blk);
-    f64x2* __restrict__ o2       = reinterpret_cast<f64x2*>(xg);
     f64x2*              s2       = reinterpret_cast<f64x2*>(xs);
+    if (threadIdx.x < kTpMaxPieces) tab[threadIdx.x] = reinterpret_cast<char*>(pieces.base[threadIdx.x]);  // (before the first barrier)
     constexpr int SET = THREADS * UNROLL;
     constexpr int XR  = (kTpPanelCols / 2 + THREADS - 1) / THREADS;  // 16-byte pairs of x per lane
     struct Pan
@@ -267,7 +279,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
     const char* cb = reinterpret_cast<const char*>(c2);
     const char* vb = reinterpret_cast<const char*>(v2);
     const char* bb = reinterpret_cast<const char*>(b2);
-    char*       ob = reinterpret_cast<char*>(o2);
     auto  fetch = [&](const Pan& a, int u0, u16x2(&cc)[UNROLL], f64x2(&vv)[UNROLL], i32x2(&dd)[UNROLL]) {
 #pragma unroll
         for (int k = 0; k < UNROLL; ++k)
@@ -291,7 +302,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
                 f64x2          o;
                 o.x = vv[k].x * xs[cc[k].x];
                 o.y = vv[k].y * xs[cc[k].y];
-                __builtin_nontemporal_store(o, reinterpret_cast<f64x2*>(ob + (dst << 4)));  // read again only 2.7 GB later: 2-3 %
+                // the pair's piece from the table in LDS, its place inside the piece in 28 bits
+                char* const ob = tab[dst >> kTpPieceShift];
+                __builtin_nontemporal_store(o, reinterpret_cast<f64x2*>(ob + ((dst & ((1u << kTpPieceShift) - 1u)) << 4)));  // read again only 2.7 GB later: 2-3 %
             }
         }
     };
@@ -347,14 +360,17 @@ constexpr int kTpThreads    = 1024;
 constexpr int kReduceUnroll = 8;
 __global__ __launch_bounds__(kTpThreads) void tp_reduce_kernel(const int32_t* __restrict__ gstart, int ngroups,
                                                                const int32_t* __restrict__ group_ptr,
-                                                               const unsigned short* __restrict__ tp_row, const double* __restrict__ xg,
+                                                               const unsigned short* __restrict__ tp_row, const tp_piece_tab pieces,
                                                                double* __restrict__ y, int overwrite, const double* __restrict__ dot_w,
                                                                double* __restrict__ dot_out)
 {
-    extern __shared__ double acc[];
+    extern __shared__ double lds_b[];  // [kTpTabDoubles] piece table | accumulators
+    const char** tab = reinterpret_cast<const char**>(lds_b);
+    double*      acc = lds_b + kTpTabDoubles;
     const int lane = threadIdx.x & 63;
     const u16x2* __restrict__ r2 = reinterpret_cast<const u16x2*>(tp_row);
-    const f64x2* __restrict__ p2 = reinterpret_cast<const f64x2*>(xg);
+    if (threadIdx.x < kTpMaxPieces) tab[threadIdx.x] = reinterpret_cast<const char*>(pieces.base[threadIdx.x]);
+    __syncthreads();
     constexpr int U = kReduceUnroll, SET = kTpThreads * U;
     for (int g = blockIdx.x; g < ngroups; g += gridDim.x)
     {
@@ -372,7 +388,7 @@ __global__ __launch_bounds__(kTpThreads) void tp_reduce_kernel(const int32_t* __
             {
                 const int t = min(t0 + k * kTpThreads + (int)threadIdx.x, t_end - 1);
                 rr[k]       = __builtin_nontemporal_load(r2 + t);
-                vv[k]       = __builtin_nontemporal_load(p2 + t);
+                vv[k]       = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(tab[(unsigned)t >> kTpPieceShift] + (((unsigned)t & ((1u << kTpPieceShift) - 1u)) << 4)));
             }
         };
         auto add = [&](int t0, const u16x2(&rr)[U], const f64x2(&vv)[U]) {
@@ -416,165 +432,15 @@ __global__ __launch_bounds__(kTpThreads) void tp_reduce_kernel(const int32_t* __
 }
 }  // namespace
 
-struct tp_held_list  // experiments: product streams held besides the current one
-{
-    std::vector<std::pair<double*, void*>> v;
-};
-// ---- where the product stream lives -------------------------------------------------------------------------------------
-// mode 0: hipMalloc.  mode 1 / 2 (experiment, "twophase_alloc_mode"): HIP's virtual memory management - physical memory
-// created explicitly (1: one piece, 2: pieces of 1 GB) and mapped at a 1 GB-aligned virtual address.
-struct tp_vm_block
-{
-    void*                                        va = nullptr;   // the reserved address range
-    size_t                                       size = 0;       // its length
-    size_t                                       map_off = 0;    // where inside it the pieces are mapped
-    std::vector<hipMemGenericAllocationHandle_t> handles;
-    std::vector<size_t>                          sizes;
-};
-namespace
-{
-void tp_vm_release(tp_vm_block* b)
-{
-    if (!b) return;
-    if (b->va)
-    {
-        size_t off = 0;
-        for (size_t i = 0; i < b->handles.size(); ++i)
-        {
-            (void)hipMemUnmap((char*)b->va + b->map_off + off, b->sizes[i]);
-            (void)hipMemRelease(b->handles[i]);
-            off += b->sizes[i];
-        }
-        (void)hipMemAddressFree(b->va, b->size);
-    }
-    (void)hipGetLastError();
-    delete b;
-}
-tp_vm_block* tp_vm_alloc(int device, size_t bytes, size_t piece)
-{
-    hipMemAllocationProp prop{};
-    prop.type          = hipMemAllocationTypePinned;
-    prop.location.type = hipMemLocationTypeDevice;
-    prop.location.id   = device;
-    size_t gran        = 0;
-    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) return nullptr;
-    auto up = [](size_t v, size_t g) { return (v + g - 1) / g * g; };
-    auto* b = new tp_vm_block;
-    b->size = up(bytes, gran);
-    if (hipMemAddressReserve(&b->va, b->size, (size_t)1 << 30, nullptr, 0) != hipSuccess)
-    {
-        b->va = nullptr;
-        tp_vm_release(b);
-        return nullptr;
-    }
-    piece = piece ? up(piece, gran) : b->size;
-    bool ok = true;
-    for (size_t off = 0; off < b->size && ok; off += piece)
-    {
-        const size_t                    n = std::min(piece, b->size - off);
-        hipMemGenericAllocationHandle_t h{};
-        if (hipMemCreate(&h, n, &prop, 0) != hipSuccess)
-        {
-            ok = false;
-            break;
-        }
-        if (hipMemMap((char*)b->va + off, n, 0, h, 0) != hipSuccess)
-        {
-            (void)hipMemRelease(h);
-            ok = false;
-            break;
-        }
-        b->handles.push_back(h);
-        b->sizes.push_back(n);
-    }
-    if (ok)
-    {
-        hipMemAccessDesc acc{};
-        acc.location = prop.location;
-        acc.flags    = hipMemAccessFlagsProtReadWrite;
-        ok           = hipMemSetAccess(b->va, b->size, &acc, 1) == hipSuccess;
-    }
-    if (!ok)
-    {
-        // only what was mapped is unmapped
-        size_t mapped = 0;
-        for (size_t n : b->sizes) mapped += n;
-        (void)mapped;
-        tp_vm_release(b);
-        return nullptr;
-    }
-    return b;
-}
-}  // namespace
-
-// allocate / release the product stream of a handle by its tp_alloc_mode
-int csr_twophase_products_alloc(spmv_mat* m, double** out, void** out_vm)
-{
-    const size_t bytes = sizeof(double) * (size_t)m->tp_padded;
-    *out               = nullptr;
-    *out_vm            = nullptr;
-    if (m->tp_alloc_mode == 0)
-    {
-        if (hipMalloc(out, bytes) != hipSuccess)
-        {
-            (void)hipGetLastError();
-            SPMV_FAIL(SPMV_ERR_ALLOC, "two-phase layout: no memory for the product stream (%zu bytes)", bytes);
-        }
-        return SPMV_OK;
-    }
-    tp_vm_block* b = tp_vm_alloc(m->ctx->device, bytes, m->tp_alloc_mode == 2 ? (size_t)1 << 30 : 0);
-    if (!b) SPMV_FAIL(SPMV_ERR_ALLOC, "two-phase layout: mapping %zu bytes for the product stream failed", bytes);
-    *out    = (double*)b->va;
-    *out_vm = b;
-    return SPMV_OK;
-}
-void csr_twophase_products_free(double* p, void* vm)
-{
-    if (vm)
-        tp_vm_release((tp_vm_block*)vm);
-    else if (p)
-        (void)hipFree(p);
-}
-
-// experiment (SPMV_TP_STREAMS_VM=<piece MB>): the layout's read streams (values, columns, rows, table) in mapped pieces too
-namespace
-{
-int tp_stream_alloc(spmv_mat* m, void** out, size_t bytes, int slot)
-{
-    const char* e = getenv("SPMV_TP_STREAMS_VM");
-    if (e && atoll(e) >= 2)
-    {
-        tp_vm_block* b = tp_vm_alloc(m->ctx->device, bytes, (size_t)atoll(e) << 20);
-        if (!b) return SPMV_ERR_ALLOC;
-        *out               = b->va;
-        m->tp_vm_more[slot] = b;
-        return SPMV_OK;
-    }
-    return hipMalloc(out, bytes) == hipSuccess ? SPMV_OK : SPMV_ERR_ALLOC;
-}
-}  // namespace
-
 void csr_twophase_free(spmv_mat* m)
 {
-    {
-        void** slots[4] = {(void**)&m->tp_val, (void**)&m->tp_col, (void**)&m->tp_row, (void**)&m->tp_blk};
-        for (int i = 0; i < 4; ++i)
-            if (m->tp_vm_more[i])
-            {
-                tp_vm_release((tp_vm_block*)m->tp_vm_more[i]);
-                m->tp_vm_more[i] = nullptr;
-                *slots[i]        = nullptr;
-            }
-    }
-    csr_twophase_products_free(m->tp_xg, m->tp_xg_vm);
-    m->tp_xg    = nullptr;
-    m->tp_xg_vm = nullptr;
-    if (m->tp_held)
-    {
-        for (auto& e : ((tp_held_list*)m->tp_held)->v) csr_twophase_products_free(e.first, e.second);
-        delete (tp_held_list*)m->tp_held;
-        m->tp_held = nullptr;
-    }
+    for (int i = 0; i < kTpMaxPieces; ++i)
+        if (m->tp_piece[i])
+        {
+            (void)hipFree(m->tp_piece[i]);
+            m->tp_piece[i] = nullptr;
+        }
+    m->tp_npieces = 0;
     for (void** p : {(void**)&m->tp_val, (void**)&m->tp_col, (void**)&m->tp_row, (void**)&m->tp_blk, (void**)&m->tp_panel_ptr,
                      (void**)&m->tp_group_ptr, (void**)&m->tp_gstart})
         if (*p)
@@ -627,24 +493,24 @@ namespace
 {
 // the expand instances that can be launched: {threads, pairs per lane in flight}; the first is the default
 template <int THREADS, int UNROLL>
-void tp_expand_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x)
+void tp_expand_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, const tp_piece_tab& tab)
 {
-    const size_t xlds = sizeof(double) * (size_t)A->tp_pcols;
+    const size_t xlds = sizeof(double) * ((size_t)A->tp_pcols + kTpTabDoubles);
     const dim3   grid((unsigned)std::min(A->tp_panels, kNumCu));
     if ((reinterpret_cast<uintptr_t>(x) & 15) == 0)
         hipLaunchKernelGGL((tp_expand_kernel<THREADS, UNROLL, true>), grid, dim3(THREADS), xlds, ctx->stream, A->tp_panels, A->tp_pcols, A->ncol,
-                           A->tp_panel_ptr, (const unsigned short*)A->tp_col, (const double*)A->tp_val, (const int32_t*)A->tp_blk, x, A->tp_xg,
+                           A->tp_panel_ptr, (const unsigned short*)A->tp_col, (const double*)A->tp_val, (const int32_t*)A->tp_blk, x, tab,
                            (int)A->tp_rotate);
     else
         hipLaunchKernelGGL((tp_expand_kernel<THREADS, UNROLL, false>), grid, dim3(THREADS), xlds, ctx->stream, A->tp_panels, A->tp_pcols, A->ncol,
-                           A->tp_panel_ptr, (const unsigned short*)A->tp_col, (const double*)A->tp_val, (const int32_t*)A->tp_blk, x, A->tp_xg,
+                           A->tp_panel_ptr, (const unsigned short*)A->tp_col, (const double*)A->tp_val, (const int32_t*)A->tp_blk, x, tab,
                            (int)A->tp_rotate);
 }
 template <int THREADS, int UNROLL>
 void tp_expand_grant()
 {
-    (void)hipFuncSetAttribute((const void*)tp_expand_kernel<THREADS, UNROLL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160008);
-    (void)hipFuncSetAttribute((const void*)tp_expand_kernel<THREADS, UNROLL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160008);
+    (void)hipFuncSetAttribute((const void*)tp_expand_kernel<THREADS, UNROLL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160008 + 8 * kTpTabDoubles);
+    (void)hipFuncSetAttribute((const void*)tp_expand_kernel<THREADS, UNROLL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160008 + 8 * kTpTabDoubles);
 }
 
 void tp_grant_lds(spmv_ctx* ctx)
@@ -652,280 +518,218 @@ void tp_grant_lds(spmv_ctx* ctx)
     static std::atomic<unsigned long long> granted{0};  // bit per device
     if ((granted.load(std::memory_order_relaxed) >> ctx->device) & 1ull) return;
     tp_expand_grant<1024, 3>();
-    tp_expand_grant<1024, 4>();
-    tp_expand_grant<512, 6>();
-    tp_expand_grant<512, 8>();
-    (void)hipFuncSetAttribute((const void*)tp_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160008);
+    (void)hipFuncSetAttribute((const void*)tp_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160008 + 8 * kTpTabDoubles);
     granted.fetch_or(1ull << ctx->device, std::memory_order_relaxed);
 }
 
-// Which instance runs is a field of the handle ("twophase_unroll", "twophase_threads", "twophase_rotate"), set when the
-// layout is built or by spmv_mat_set_param: nothing is read from the environment on the product's path.
-void tp_launch_expand(spmv_ctx* ctx, const spmv_mat* A, const double* x)
+// One instance: 1024 threads, 3 pairs per lane in flight.  Round 4 measured 1024 x 4, 512 x 6 and 512 x 8 (all without
+// scratch once the addressing was 32-bit) on the C5 shard: 1.31-1.35 ms where this one takes 1.32 in the same slow
+// placement - the phase runs at the memory's rate whatever the shape (profiles/r04_tune_twophase_expand_shapes.txt).
+tp_piece_tab tp_table_of(const spmv_mat* A)
 {
-    if (A->tp_threads == 512)
-    {
-        if (A->tp_unroll == 8)
-            tp_expand_launch<512, 8>(ctx, A, x);
-        else
-            tp_expand_launch<512, 6>(ctx, A, x);
-    }
-    else if (A->tp_unroll == 4)
-        tp_expand_launch<1024, 4>(ctx, A, x);
-    else
-        tp_expand_launch<1024, 3>(ctx, A, x);
+    tp_piece_tab t{};
+    for (int i = 0; i < kTpMaxPieces; ++i) t.base[i] = A->tp_piece[i];
+    return t;
+}
+void tp_launch_expand(spmv_ctx* ctx, const spmv_mat* A, const double* x, const tp_piece_tab& tab)
+{
+    tp_expand_launch<1024, 3>(ctx, A, x, tab);
 }
 
-void tp_launch_reduce(spmv_ctx* ctx, const spmv_mat* A, double* y, const apply_extra& ex)
+void tp_launch_reduce(spmv_ctx* ctx, const spmv_mat* A, double* y, const apply_extra& ex, const tp_piece_tab& tab)
 {
-    hipLaunchKernelGGL(tp_reduce_kernel, dim3((unsigned)std::min(A->tp_ngroups, kNumCu)), dim3(kTpThreads), sizeof(double) * (size_t)A->tp_max_rows,
-                       ctx->stream, A->tp_gstart, A->tp_ngroups, A->tp_group_ptr, (const unsigned short*)A->tp_row, (const double*)A->tp_xg, y,
-                       ex.overwrite ? 1 : 0, ex.dot_w, ex.dot_out);
+    hipLaunchKernelGGL(tp_reduce_kernel, dim3((unsigned)std::min(A->tp_ngroups, kNumCu)), dim3(kTpThreads),
+                       sizeof(double) * ((size_t)A->tp_max_rows + kTpTabDoubles), ctx->stream, A->tp_gstart, A->tp_ngroups, A->tp_group_ptr,
+                       (const unsigned short*)A->tp_row, tab, y, ex.overwrite ? 1 : 0, ex.dot_w, ex.dot_out);
 }
 
-// Where the PRODUCT stream lies in physical memory decides a tenth of the product: with everything else in place, moving
-// tp_xg alone switches phase A between ~1.16 and ~1.33 ms on the C5 shard, while moving the values, columns or rows changes
-// nothing (profiles/r03_probe_twophase_placement.txt).  Round 4 looked for the cause (profiles/r04_pmc_twophase_placement.txt):
-// the address translation is innocent (the same 2.4e5 UTCL1 misses of 1.5e8 requests in fast and slow placements) and so is
-// the allocator (hipMalloc, one mapped piece, mapped 1 GB pieces: the same two modes); what differs is how readily the
-// MEMORY takes requests - 5.0-5.4M cycles of "read request stalled: out of DRAM credits" in slow placements against
-// 1.7-2.5M in fast ones, and 2.0M against 1.2M for the writes: a property of the DRAM region the stream occupies (next to
-// the regions of the streams read at the same time), which the engine cannot ask for.
-// It can choose, though, and within a fixed budget: the stream is backed by PIECES of physical memory (HIP's virtual memory
-// management: hipMemCreate / hipMemMap) inside ONE reserved address range.  `extra` more pieces than the stream needs are
-// created (at most kTpArenaExtra = 8 GB, never more than a quarter of the free memory), every WINDOW of consecutive pieces
-// is mapped under the stream in turn and both phases are timed on it (1 warm-up + 2 products, zeroed scratch x and y), the
-// fastest window stays mapped and every other piece is released before the function returns.  Transient footprint: the
-// stream + 8 GB + scratch x and y; afterwards exactly the stream.  Round 3 held up to 16 whole candidate streams with 1-4 GB
-// spacers between them (up to 3/4 of the free memory for seconds).  SPMV_PANEL_TRIAL=0 / "panel_trial" 0 / SPMV_TP_PLACEMENT_TRIES=1:
-// no search (one hipMalloc).  Only for streams of 512 MB or more, where the spread was seen.  Failures of the mapping calls
-// fall back to the plain allocation the build made; failures of a timing launch are reported (SPMV_ERR_HIP).
-constexpr size_t kTpArenaPiece = (size_t)256 << 20;  // physical pieces: the stream's mapping is rounded up to this
-constexpr size_t kTpArenaStep  = (size_t)1 << 30;    // distance between the windows that are tried
-constexpr size_t kTpArenaExtra = (size_t)8 << 30;    // pieces created beyond the stream: the search's whole transient cost
-
-int tp_choose_placement(spmv_mat* m)
+// Where the PRODUCT stream lies in PHYSICAL memory decides a tenth of the product.  With everything else in place, phase A
+// takes 1.14-1.17 ms on the C5 shard when the stream lies in some regions of the device's memory and 1.32-1.34 ms in others
+// (phase B, which reads it back, 0.565 against 0.548: the opposite way, a fifth as much); nothing else matters - not where the
+// values, columns, rows, table, x or y lie, not the virtual address, not how the memory was allocated (plain, one mapped piece,
+// mapped 1 GB pieces), not the translation (the same 2.4e5 UTCL1 misses of 1.5e8 requests either way).  What differs is how
+// readily the MEMORY takes requests: 5.0-5.4M cycles of "read request stalled: out of DRAM credits" in slow regions against
+// 1.7-2.5M in fast ones, 2.0M against 1.2M for the writes (profiles/r04_pmc_twophase_placement.txt,
+// r04_probe_twophase_placement_cause.txt).  A region keeps its mode for as long as it is held; twelve streams held at once
+// showed four fast and eight slow ones; streams cut from mixed regions land in between in proportion (1.70 / 1.78 / 1.835 /
+// 1.89 ms per product with 3 / 2 / 1 / 0 of three 1 GB pieces fast).  The engine cannot see physical addresses, let alone ask
+// for them.  (Round 4 also tried HIP's virtual memory management - one reserved range, windows of physical pieces mapped in
+// turn - and found that on this ROCm (7.2) a virtual address keeps reaching the FIRST piece ever mapped there, after
+// hipMemUnmap, hipMemAddressFree and a new reservation alike: tools/probe_vm_remap.hip.  Nothing here re-maps anything.)
+//
+// So the stream is not one allocation but PIECES of 1 GB (kernels: a table of base addresses in LDS), and which pieces it
+// consists of is CHOSEN by measurement: `extra` more pieces than the stream needs are allocated (plain hipMalloc; the budget
+// is m->tp_place_budget_mb, 8 GB by default, never more than a quarter of the free memory) and configurations of pieces are
+// timed as they are (1 warm-up + 2 products of both phases on zeroed scratch vectors): coordinate descent - for every slot of
+// the stream in turn, every piece outside the current configuration is tried in that slot and the best configuration seen
+// replaces the current one when it wins by more than the noise; two rounds at most (3 slots x 8 pieces x 2 = 48 configurations
+// of 6 ms each on the C5 shard: 0.3 s).  Nothing is inferred about single pieces: the time of a configuration is NOT a sum over
+// its pieces (a piece that is fast beside two others can be slow beside a third, and the whole stream aliased onto one piece
+// behaves differently again - profiles/r04_tune_twophase_piece_search.txt).  Every piece not kept is freed before the
+// function returns.
+// Transient footprint: the stream + the budget (8 GB) + scratch x and y.  Afterwards: the stream rounded up to whole pieces.
+// Round 3 held up to 16 whole candidate streams with 1-4 GB spacers between them - up to 3/4 of the free memory.
+// The outcome is still a draw from what the allocator hands out, and it is recorded: "twophase_placements_timed"
+// (configurations timed), "twophase_placement_spread" (as built / kept, in 1/1000), "twophase_pieces_exchanged".
+// "panel_trial" 0 / SPMV_PANEL_TRIAL=0 / a budget of 0: no search, no timing launches.  Streams below 512 MB: no search.
+// A failing timing launch is an error (SPMV_ERR_HIP), not a silent 1e30.
+// how many pieces beyond the stream's own the search may hold (0: no search; the last piece is then allocated at its exact size)
+int tp_search_extra(const spmv_mat* m)
 {
-    spmv_ctx*   ctx     = m->ctx;
-    const char* e_tries = getenv("SPMV_TP_PLACEMENT_TRIES");  // (read when the layout is built, never on the product's path)
-    int         tries   = e_tries ? atoi(e_tries) : 9;
-    const char* e_trial = getenv("SPMV_PANEL_TRIAL");
-    if (m->pb_trial == 0 || (m->pb_trial < 0 && e_trial && e_trial[0] == '0')) tries = 0;
-    const size_t bytes = sizeof(double) * (size_t)m->tp_padded;
-    if (tries <= 1 || bytes < ((size_t)512 << 20) || m->tp_alloc_mode != 0) return SPMV_OK;
-    const char* e_piece = getenv("SPMV_TP_ARENA_PIECE_MB");  // experiments: piece size and budget
-    const char* e_extra = getenv("SPMV_TP_ARENA_EXTRA_MB");
-    size_t      piece   = e_piece && atoll(e_piece) >= 2 ? (size_t)atoll(e_piece) << 20 : kTpArenaPiece;
-    size_t      extra_b = e_extra && atoll(e_extra) >= 0 ? std::min((size_t)atoll(e_extra) << 20, (size_t)64 << 30) : kTpArenaExtra;
+    const size_t bytes   = sizeof(double) * (size_t)m->tp_padded;
+    const size_t piece   = (size_t)16 << kTpPieceShift;
+    const char*  e_trial = getenv("SPMV_PANEL_TRIAL");  // (read when the layout is built, never on the product's path)
+    const char*  e_mb    = getenv("SPMV_TP_PLACEMENT_BUDGET_MB");
+    int64_t      budget_mb = m->tp_place_budget_mb >= 0 ? m->tp_place_budget_mb : (e_mb ? atoll(e_mb) : 8192);
+    if (m->pb_trial == 0 || (m->pb_trial < 0 && e_trial && e_trial[0] == '0')) budget_mb = 0;
+    if (budget_mb <= 0 || bytes < ((size_t)512 << 20)) return 0;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+    const size_t budget = std::min((size_t)budget_mb << 20, free_b / 4);
+    const int    extra  = (int)std::min<size_t>(budget / piece, 256);
+    return extra >= 2 ? extra : 0;  // two reference pieces besides the stream's own are the least the scheme needs
+}
 
-    hipMemAllocationProp prop{};
-    prop.type          = hipMemAllocationTypePinned;
-    prop.location.type = hipMemLocationTypeDevice;
-    prop.location.id   = ctx->device;
-    size_t gran        = 0;
-    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0)
-    {
-        (void)hipGetLastError();
-        return SPMV_OK;  // no virtual memory management here: the plain allocation stays
-    }
-    piece               = (piece + gran - 1) / gran * gran;
-    const size_t need   = (bytes + piece - 1) / piece;  // pieces under the stream
-    const char*  e_step = getenv("SPMV_TP_ARENA_STEP_MB");
-    const size_t step_b = e_step && atoll(e_step) >= 2 ? (size_t)atoll(e_step) << 20 : kTpArenaStep;
-    const size_t stride = std::max<size_t>(1, step_b / piece);  // pieces between two windows
-    size_t       free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return SPMV_OK;
-    // the plain allocation is given back first: the pieces take its place (memory is never held twice)
-    const size_t budget = std::min(extra_b, (free_b + bytes) / 4);
-    size_t       extra  = std::min(budget / piece, (size_t)std::max(tries - 1, 0) * stride) / stride * stride;
-    if (extra == 0) return SPMV_OK;
-    // experiment (SPMV_TP_VA_STEP_MB): the SAME physical pieces mapped at different virtual addresses instead
-    const char*  e_va    = getenv("SPMV_TP_VA_STEP_MB");
-    const size_t va_step = e_va && atoll(e_va) >= 2 ? ((size_t)atoll(e_va) << 20) / gran * gran : 0;
-    const size_t windows = (size_t)std::max(tries, 2);
-    if (va_step) extra = 0;
+int tp_choose_pieces(spmv_mat* m)
+{
+    spmv_ctx*    ctx   = m->ctx;
+    const size_t piece = (size_t)16 << kTpPieceShift;
+    const int    need  = m->tp_npieces;
+    const int    extra = tp_search_extra(m);
+    m->tp_place_seen   = 0;
+    m->tp_place_gain   = 0;
+    m->tp_pieces_exchanged  = 0;
+    if (extra < 2 || need <= 0 || m->tp_last_piece_bytes != (int64_t)piece) return SPMV_OK;  // (pieces must be interchangeable)
 
     hipStream_t s = ctx->stream;
     double *    x = nullptr, *y = nullptr;
     hipEvent_t  e0 = nullptr, e1 = nullptr;
-    auto*       blk = new tp_vm_block;
-    int         rc  = SPMV_OK;
-    bool        mapped_any = false;
-    std::vector<float> ms;
-    size_t      keep = 0;
-    char*       base = nullptr;  // where the mapped window begins (the reservation's start unless the experiment moves it)
-    const char* e_each = getenv("SPMV_TP_RESERVE_EACH");  // experiment: with SPMV_TP_VA_STEP_MB, every window in a reservation of its own
-    const bool  each   = e_each && e_each[0] == '1';
-    std::vector<void*> own;  // those reservations (leaked at the end of the experiment: address space only)
-    auto        map_window = [&](size_t w) -> bool {
-        base            = (char*)blk->va + (va_step ? w * va_step : 0);
-        if (each)
+    int         rc = SPMV_OK;
+    std::vector<double*> cand(m->tp_piece, m->tp_piece + need);  // the stream's own pieces are candidates like the others
+    apply_extra plain;
+    // ms per product of the configuration `slots` (piece index per slot; slots past `need` repeat the last: never addressed)
+    auto time_config = [&](const std::vector<int>& slots, float* out) -> bool {
+        tp_piece_tab t{};
+        for (int i = 0; i < kTpMaxPieces; ++i) t.base[i] = cand[(size_t)slots[(size_t)std::min(i, need - 1)]];
+        tp_launch_expand(ctx, m, x, t);  // warm-up
+        tp_launch_reduce(ctx, m, y, plain, t);
+        (void)hipEventRecord(e0, s);
+        for (int r = 0; r < 2; ++r)
         {
-            const size_t ri = va_step ? w : w / stride;
-            while (own.size() <= ri)
-            {
-                void* r = nullptr;
-                if (hipMemAddressReserve(&r, need * piece, (size_t)1 << 30, nullptr, 0) != hipSuccess) return false;
-                own.push_back(r);
-            }
-            base = (char*)own[ri];
+            tp_launch_expand(ctx, m, x, t);
+            tp_launch_reduce(ctx, m, y, plain, t);
         }
-        const size_t p0 = va_step ? 0 : w;
-        for (size_t i = 0; i < need; ++i)
-            if (hipMemMap(base + i * piece, piece, 0, blk->handles[p0 + i], 0) != hipSuccess)
-            {
-                for (size_t j = 0; j < i; ++j) (void)hipMemUnmap(base + j * piece, piece);
-                return false;
-            }
-        hipMemAccessDesc acc{};
-        acc.location = prop.location;
-        acc.flags    = hipMemAccessFlagsProtReadWrite;
-        if (hipMemSetAccess(base, need * piece, &acc, 1) != hipSuccess)
+        (void)hipEventRecord(e1, s);
+        float t_ms = 0.f;
+        if (hipGetLastError() != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t_ms, e0, e1) != hipSuccess)
         {
-            for (size_t j = 0; j < need; ++j) (void)hipMemUnmap(base + j * piece, piece);
+            set_error("two-phase layout: a timing launch of the piece search failed: %s", hipGetErrorString(hipGetLastError()));
             return false;
         }
+        *out = t_ms / 2;
         return true;
     };
-    auto unmap_window = [&]() {
-        for (size_t j = 0; j < need; ++j) (void)hipMemUnmap(base + j * piece, piece);
-    };
+    const char*        e_v     = getenv("SPMV_TP_PLACEMENT_VERBOSE");
+    const bool         verbose = e_v && e_v[0] == '1';
+    float              t_first = 0.f, t_kept = 0.f;
+    bool               searched = false;
     do
     {
         if (hipMalloc(&x, sizeof(double) * (size_t)m->ncol) != hipSuccess || hipMalloc(&y, sizeof(double) * (size_t)m->nrow) != hipSuccess ||
             hipMemsetAsync(x, 0, sizeof(double) * (size_t)m->ncol, s) != hipSuccess || hipMemsetAsync(y, 0, sizeof(double) * (size_t)m->nrow, s) != hipSuccess ||
             hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
-            break;  // no room for the scratch vectors: keep the plain allocation
-        blk->size = need * piece + (va_step ? (windows - 1) * va_step : 0);
-        if (hipMemAddressReserve(&blk->va, blk->size, (size_t)1 << 30, nullptr, 0) != hipSuccess)
+            break;  // no room for the scratch vectors: the pieces stay as they are
+        for (int i = 0; i < extra; ++i)
         {
-            blk->va = nullptr;
-            break;
-        }
-        // the stream's plain allocation goes; its memory is what the first pieces are made of
-        if (hipStreamSynchronize(s) != hipSuccess) break;
-        csr_twophase_products_free(m->tp_xg, m->tp_xg_vm);
-        m->tp_xg    = nullptr;
-        m->tp_xg_vm = nullptr;
-        for (size_t i = 0; i < need + extra; ++i)
-        {
-            hipMemGenericAllocationHandle_t h{};
-            if (hipMemCreate(&h, piece, &prop, 0) != hipSuccess)
+            double* p = nullptr;
+            if (hipMalloc(&p, piece) != hipSuccess)
             {
                 (void)hipGetLastError();
                 break;
             }
-            blk->handles.push_back(h);
+            cand.push_back(p);
         }
-        if (blk->handles.size() < need) break;  // (cannot happen unless somebody else took the memory meanwhile)
-        extra = (blk->handles.size() - need) / stride * stride;
+        const int n = (int)cand.size();
+        if (n < need + 2) break;
         tp_grant_lds(ctx);
-        apply_extra plain;
-        for (size_t w = 0; va_step ? w < windows : w <= extra; w += va_step ? 1 : stride)
+        // the configuration the layout was built with
+        std::vector<int> slots((size_t)need);
+        for (int i = 0; i < need; ++i) slots[(size_t)i] = i;
+        if (!time_config(slots, &t_first))
         {
-            if (!map_window(w))
-            {
-                (void)hipGetLastError();
-                break;
-            }
-            mapped_any = true;
-            m->tp_xg   = (double*)base;
-            tp_launch_expand(ctx, m, x);  // warm-up (first touch of the window)
-            tp_launch_reduce(ctx, m, y, plain);
-            (void)hipEventRecord(e0, s);
-            for (int r = 0; r < 2; ++r)
-            {
-                tp_launch_expand(ctx, m, x);
-                tp_launch_reduce(ctx, m, y, plain);
-            }
-            (void)hipEventRecord(e1, s);
-            float t_ms = 0.f;
-            if (hipGetLastError() != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t_ms, e0, e1) != hipSuccess)
-            {
-                set_error("two-phase layout: a timing launch of the placement search failed: %s", hipGetErrorString(hipGetLastError()));
-                rc = SPMV_ERR_HIP;
-            }
-            unmap_window();
-            m->tp_xg = nullptr;
-            if (rc != SPMV_OK) break;
-            ms.push_back(t_ms / 2);
-        }
-        if (rc != SPMV_OK || ms.empty()) break;
-        for (size_t i = 1; i < ms.size(); ++i)
-            if (ms[i] < ms[keep]) keep = i;
-        if (!map_window(va_step ? keep : keep * stride))
-        {
-            (void)hipGetLastError();
-            ms.clear();
+            rc = SPMV_ERR_HIP;
             break;
         }
-        m->tp_xg = (double*)base;
-        if (const char* e_v = getenv("SPMV_TP_PLACEMENT_VERBOSE"); e_v && e_v[0] == '1')
+        // Coordinate descent over REAL configurations (the time of a configuration is not a sum over its pieces - a piece that
+        // is fast beside two others can be slow beside a third - so nothing is inferred, only measured): for every slot in
+        // turn, every piece outside the configuration is tried in that slot; the best configuration seen replaces the
+        // current one when it wins by more than the noise; two rounds, or until a round changes nothing.
+        float t_cur = t_first;
+        int   tried = 0;
+        bool  ok    = true;
+        for (int round = 0; ok && round < 2; ++round)
         {
-            // the kept window timed again after its final mapping, the same way and with 20 products in a row
-            for (int reps : {2, 20, 2})
+            bool changed = false;
+            for (int slot = 0; ok && slot < need; ++slot)
             {
-                tp_launch_expand(ctx, m, x);
-                tp_launch_reduce(ctx, m, y, plain);
-                (void)hipEventRecord(e0, s);
-                for (int r = 0; r < reps; ++r)
+                int   best_d = -1;
+                float best_t = t_cur;
+                for (int d = 0; ok && d < n; ++d)
                 {
-                    tp_launch_expand(ctx, m, x);
-                    tp_launch_reduce(ctx, m, y, plain);
+                    if (std::find(slots.begin(), slots.end(), d) != slots.end()) continue;
+                    std::vector<int> c = slots;
+                    c[(size_t)slot]   = d;
+                    float t           = 0.f;
+                    ok                = time_config(c, &t);
+                    ++tried;
+                    if (ok && t < best_t)
+                    {
+                        best_t = t;
+                        best_d = d;
+                    }
                 }
-                (void)hipEventRecord(e1, s);
-                float t_ms = 0.f;
-                (void)hipEventSynchronize(e1);
-                (void)hipEventElapsedTime(&t_ms, e0, e1);
-                fprintf(stderr, "kept window mapped again, %d products: %.4f ms each\n", reps, t_ms / reps);
+                if (ok && best_d >= 0 && best_t < t_cur * 0.997f)
+                {
+                    if (verbose) fprintf(stderr, "  slot %d: piece #%d for #%d: %.4f -> %.4f ms\n", slot, best_d, slots[(size_t)slot], t_cur, best_t);
+                    slots[(size_t)slot] = best_d;
+                    t_cur               = best_t;
+                    changed             = true;
+                }
             }
+            if (!changed) break;
         }
+        if (!ok)
+        {
+            rc = SPMV_ERR_HIP;
+            break;
+        }
+        if (!time_config(slots, &t_kept))  // (once more: what the handle starts its life with)
+        {
+            rc = SPMV_ERR_HIP;
+            break;
+        }
+        if (verbose)
+        {
+            fprintf(stderr, "two-phase product stream: %d pieces of %zu MB needed, %d to choose from, %d configurations timed; as built %.4f ms, kept", need,
+                    piece >> 20, n, tried, t_first);
+            for (int i = 0; i < need; ++i) fprintf(stderr, " #%d", slots[(size_t)i]);
+            fprintf(stderr, ": %.4f ms\n", t_kept);
+        }
+        std::vector<bool> keep((size_t)n, false);
+        for (int i = 0; i < need; ++i)
+        {
+            m->tp_piece[i]                = cand[(size_t)slots[(size_t)i]];
+            keep[(size_t)slots[(size_t)i]] = true;
+            if (slots[(size_t)i] != i) ++m->tp_pieces_exchanged;  // (pieces exchanged by the search)
+        }
+        for (int d = 0; d < n; ++d)
+            if (!keep[(size_t)d]) (void)hipFree(cand[(size_t)d]);
+        m->tp_place_seen = tried;
+        m->tp_place_gain = t_kept > 0.f ? (int32_t)(1000.0f * t_first / t_kept) : 0;
+        searched         = true;
     } while (0);
-    if (const char* e_v = getenv("SPMV_TP_PLACEMENT_VERBOSE"); e_v && e_v[0] == '1')
-    {
-        fprintf(stderr, "addresses: reservation %p (+%zu MB per window), values %p, columns %p, rows %p, table %p, scratch x %p, y %p\n", blk->va, va_step >> 20,
-                (void*)m->tp_val, (void*)m->tp_col, (void*)m->tp_row, (void*)m->tp_blk, (void*)x, (void*)y);
-        fprintf(stderr, "two-phase product stream: %zu pieces of %zu MB under the stream, %zu more, windows %zu pieces apart; ms per product by window:",
-                need, piece >> 20, extra, stride);
-        for (size_t i = 0; i < ms.size(); ++i) fprintf(stderr, " %.4f%s", ms[i], i == keep && m->tp_xg ? "*" : "");
-        fprintf(stderr, "\n");
-    }
-    if (m->tp_xg)
-    {
-        // the kept window's pieces stay with the handle, every other piece goes back now
-        std::vector<hipMemGenericAllocationHandle_t> kept;
-        for (size_t i = 0; i < blk->handles.size(); ++i)
-        {
-            if (va_step || (i >= keep * stride && i < keep * stride + need))
-                kept.push_back(blk->handles[i]);
-            else
-                (void)hipMemRelease(blk->handles[i]);
-        }
-        blk->handles = kept;
-        blk->sizes.assign(need, piece);
-        blk->map_off = each ? 0 : (size_t)(base - (char*)blk->va);
-        if (each)
-        {
-            (void)hipMemAddressFree(blk->va, blk->size);
-            blk->va   = base;
-            blk->size = need * piece;
-        }
-        m->tp_xg_vm      = blk;
-        m->tp_bytes += (int64_t)(need * piece - bytes);  // the mapping is rounded up to whole pieces: counted
-        m->device_bytes += (int64_t)(need * piece - bytes);
-        m->tp_place_seen = (int32_t)ms.size();
-        m->tp_place_gain = ms[keep] > 0.f ? (int32_t)(1000.0f * (*std::max_element(ms.begin(), ms.end())) / ms[keep]) : 0;
-    }
-    else
-    {
-        // nothing mapped: release whatever was created and go back to one plain allocation
-        (void)mapped_any;
-        for (auto h : blk->handles) (void)hipMemRelease(h);
-        if (blk->va) (void)hipMemAddressFree(blk->va, blk->size);
-        delete blk;
-        (void)hipGetLastError();
-        if (!m->tp_xg && csr_twophase_products_alloc(m, &m->tp_xg, &m->tp_xg_vm) != SPMV_OK && rc == SPMV_OK) rc = SPMV_ERR_ALLOC;
-    }
+    if (!searched)
+        for (size_t i = (size_t)need; i < cand.size(); ++i) (void)hipFree(cand[i]);  // the stream keeps the pieces it was built with
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     if (x) (void)hipFree(x);
@@ -935,53 +739,28 @@ int tp_choose_placement(spmv_mat* m)
 }
 }  // namespace
 
-// experiments ("twophase_products_push" / "_rotate"): several product streams held at once, one of them current
-int csr_twophase_products_push(spmv_mat* m, int mode)
+// "twophase_choose_pieces": run the piece search (again) on a built layout with the handle's current budget
+int csr_twophase_choose_again(spmv_mat* m)
 {
-    SPMV_REQUIRE(m->tp_val && m->tp_padded > 0, "the two-phase layout is not built");
+    SPMV_REQUIRE(m->tp_val && m->tp_padded > 0 && m->tp_npieces > 0, "the two-phase layout is not built");
     SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
-    if (!m->tp_held) m->tp_held = new tp_held_list;
-    const int32_t saved = m->tp_alloc_mode;
-    m->tp_alloc_mode    = mode;
-    double* fresh       = nullptr;
-    void*   fresh_vm    = nullptr;
-    const int rc        = csr_twophase_products_alloc(m, &fresh, &fresh_vm);
-    m->tp_alloc_mode    = saved;
-    if (rc != SPMV_OK) return rc;
-    ((tp_held_list*)m->tp_held)->v.emplace_back(m->tp_xg, m->tp_xg_vm);
-    m->tp_xg    = fresh;
-    m->tp_xg_vm = fresh_vm;
-    return SPMV_OK;
-}
-int csr_twophase_products_rotate(spmv_mat* m)
-{
-    SPMV_REQUIRE(m->tp_held && !((tp_held_list*)m->tp_held)->v.empty(), "no product streams are held");
-    SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
-    auto& v = ((tp_held_list*)m->tp_held)->v;
-    v.emplace_back(m->tp_xg, m->tp_xg_vm);
-    m->tp_xg    = v.front().first;
-    m->tp_xg_vm = v.front().second;
-    v.erase(v.begin());
-    return SPMV_OK;
-}
-
-// experiment ("twophase_place_again"): give the product stream back and run the placement search again
-int csr_twophase_place_again(spmv_mat* m)
-{
-    SPMV_REQUIRE(m->tp_val && m->tp_padded > 0, "the two-phase layout is not built");
-    SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
-    if (m->tp_xg_vm)
+    const int64_t whole = (int64_t)16 << kTpPieceShift;
+    if (m->tp_last_piece_bytes != whole && tp_search_extra(m) > 0)
     {
-        int64_t slack = -(int64_t)sizeof(double) * m->tp_padded;
-        for (size_t n : ((tp_vm_block*)m->tp_xg_vm)->sizes) slack += (int64_t)n;
-        m->tp_bytes -= slack;
-        m->device_bytes -= slack;
+        // the layout was built without a search: its last piece has the stream's exact size; pieces must be interchangeable
+        double* fresh = nullptr;
+        if (hipMalloc(&fresh, (size_t)whole) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            SPMV_FAIL(SPMV_ERR_ALLOC, "twophase_choose_pieces: no memory for a whole last piece");
+        }
+        (void)hipFree(m->tp_piece[m->tp_npieces - 1]);
+        m->tp_piece[m->tp_npieces - 1] = fresh;
+        m->tp_bytes += whole - m->tp_last_piece_bytes;
+        m->device_bytes += whole - m->tp_last_piece_bytes;
+        m->tp_last_piece_bytes = whole;
     }
-    csr_twophase_products_free(m->tp_xg, m->tp_xg_vm);
-    m->tp_xg    = nullptr;
-    m->tp_xg_vm = nullptr;
-    SPMV_TRY(csr_twophase_products_alloc(m, &m->tp_xg, &m->tp_xg_vm));
-    return tp_choose_placement(m);
+    return tp_choose_pieces(m);
 }
 
 int csr_twophase_build(spmv_mat* m)
@@ -1046,16 +825,23 @@ int csr_twophase_build(spmv_mat* m)
         }
         const size_t np     = (size_t)padded;
         const size_t nlines = (np + kTpLine - 1) / kTpLine;
-        if (tp_stream_alloc(m, (void**)&m->tp_val, sizeof(double) * np, 0) != SPMV_OK ||
-            tp_stream_alloc(m, (void**)&m->tp_col, sizeof(unsigned short) * np, 1) != SPMV_OK ||
-            tp_stream_alloc(m, (void**)&m->tp_row, sizeof(unsigned short) * np, 2) != SPMV_OK ||
-            tp_stream_alloc(m, (void**)&m->tp_blk, sizeof(int32_t) * 2 * nlines, 3) != SPMV_OK || hipMalloc(&bpos, sizeof(int32_t) * nlines) != hipSuccess)
+        if (hipMalloc(&m->tp_val, sizeof(double) * np) != hipSuccess || hipMalloc(&m->tp_col, sizeof(unsigned short) * np) != hipSuccess ||
+            hipMalloc(&m->tp_row, sizeof(unsigned short) * np) != hipSuccess ||
+            hipMalloc(&m->tp_blk, sizeof(int32_t) * 2 * nlines) != hipSuccess || hipMalloc(&bpos, sizeof(int32_t) * nlines) != hipSuccess)
         {
             rc = SPMV_ERR_ALLOC;
             break;
         }
         m->tp_padded = padded;
-        if (csr_twophase_products_alloc(m, &m->tp_xg, &m->tp_xg_vm) != SPMV_OK)
+        // the product stream: ceil(pairs / 2^26) pieces of 1 GB (the last one as well: pieces are interchangeable)
+        m->tp_npieces = (int32_t)(((np / 2) + ((size_t)1 << kTpPieceShift) - 1) >> kTpPieceShift);
+        bool got = m->tp_npieces <= kTpMaxPieces;
+        // whole pieces when the search will run (pieces must be interchangeable), else the last one at its exact size
+        const size_t whole = (size_t)16 << kTpPieceShift;
+        const size_t last  = tp_search_extra(m) > 0 ? whole : (np * sizeof(double) - (size_t)(m->tp_npieces - 1) * whole + 255) / 256 * 256;
+        m->tp_last_piece_bytes = (int64_t)last;
+        for (int i = 0; got && i < m->tp_npieces; ++i) got = hipMalloc(&m->tp_piece[i], i + 1 < m->tp_npieces ? whole : last) == hipSuccess;
+        if (!got)
         {
             rc = SPMV_ERR_ALLOC;
             break;
@@ -1089,9 +875,11 @@ int csr_twophase_build(spmv_mat* m)
     m->tp_panels    = P;
     m->tp_pcols     = pcols;
     m->tp_max_rows  = per;
-    m->tp_bytes     = m->tp_padded * 20 + (m->tp_padded + kTpLine - 1) / kTpLine * 8 + (int64_t)(P + 1 + 2 * (ngroups + 1)) * 4;
+    // values 8 + columns 2 + rows 2 bytes per padded entry, the table, the pointers, and the product stream in whole pieces
+    m->tp_bytes     = m->tp_padded * 12 + (m->tp_padded + kTpLine - 1) / kTpLine * 8 + (int64_t)(P + 1 + 2 * (ngroups + 1)) * 4 +
+                      (int64_t)(m->tp_npieces - 1) * ((int64_t)16 << kTpPieceShift) + m->tp_last_piece_bytes;
     m->device_bytes += m->tp_bytes;
-    rc = tp_choose_placement(m);
+    rc = tp_choose_pieces(m);
     if (rc != SPMV_OK) csr_twophase_free(m);
     return rc;
 }
@@ -1104,7 +892,9 @@ int csr_twophase_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, dou
         return SPMV_OK;
     }
     // the kernels dereference exactly these: refuse on the host rather than fault on the GPU
-    if (!A->tp_val || !A->tp_col || !A->tp_row || !A->tp_xg || !A->tp_blk || !A->tp_panel_ptr || !A->tp_group_ptr || !A->tp_gstart || !x || !y ||
+    bool pieces_ok = A->tp_npieces > 0 && A->tp_npieces <= kTpMaxPieces && (int64_t)A->tp_npieces << (kTpPieceShift + 1) >= A->tp_padded;
+    for (int i = 0; pieces_ok && i < A->tp_npieces; ++i) pieces_ok = A->tp_piece[i] != nullptr;
+    if (!A->tp_val || !A->tp_col || !A->tp_row || !pieces_ok || !A->tp_blk || !A->tp_panel_ptr || !A->tp_group_ptr || !A->tp_gstart || !x || !y ||
         A->tp_panels <= 0 || A->tp_pcols <= 0 || A->tp_pcols > kTpPanelCols || A->tp_pcols % 2 != 0 || A->tp_max_rows > kTpGroupRows ||
         A->tp_padded % 2 != 0)
         SPMV_FAIL(SPMV_ERR_INVALID, "two-phase kernel selected but its layout was not built");
@@ -1112,8 +902,9 @@ int csr_twophase_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, dou
     // tp_only = 1 / 2: one phase alone ("twophase_only", accepted by spmv_mat_set_param only under SPMV_EXPERIMENTS=1:
     // tools/tune_twophase.py times the phases; the RESULT IS THEN WRONG)
     const int only = A->tp_only;
-    if (only != 2) tp_launch_expand(ctx, A, x);
-    if (only != 1) tp_launch_reduce(ctx, A, y, ex);
+    const tp_piece_tab tab = tp_table_of(A);
+    if (only != 2) tp_launch_expand(ctx, A, x, tab);
+    if (only != 1) tp_launch_reduce(ctx, A, y, ex, tab);
     SPMV_HIP(hipGetLastError());
     return SPMV_OK;
 }

@@ -92,11 +92,11 @@ def test_random_csr_shapes_through_every_kernel(ctx, orc, pkg, seed):
             A.set_kernel(capi.CSR_PANEL)
             run(A, f"panel layout={layout}->{A.get_param('panel_layout')} unroll={unroll} pipe={pipe} sync={sync} rows={rows} width={width}")
         if nnz + 16 * ((ncol + 6999) // 7000) * 256 < 2**31:
-            for cols, unroll in ((20_000, 6), (7_000, 4)):
+            for cols, rotate in ((20_000, 1), (7_000, 0)):
                 A.set_param("twophase_panel_cols", cols)
-                A.set_param("twophase_unroll", unroll)
+                A.set_param("twophase_rotate", rotate)
                 A.set_kernel(capi.CSR_TWOPHASE)
-                run(A, f"two-phase cols={cols} unroll={unroll}")
+                run(A, f"two-phase cols={cols} rotate={rotate}")
 
 
 @pytest.mark.parametrize("seed", range(24))

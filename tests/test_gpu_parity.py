@@ -419,14 +419,13 @@ def test_csr_twophase_kernel_on_wide_and_ragged_matrices(ctx, orc, pkg):
     ctx.apply(A, dx_odd, dy)
     ctx.sync()
     ol.assert_parity(dy.download(), ref, scale, "twophase, x not 16-byte aligned")
-    # narrower panels (an odd request is rounded down to even: x moves in pairs), both pipeline depths, and every run padding
+    # narrower panels (an odd request is rounded down to even: x moves in pairs) and every run padding
     # (pairs / 64-byte pieces / 128-byte lines: boundaries at any pair of a source line, at half lines, at lines only)
     import os
 
-    for cols, unroll, pad in ((10_000, 3, 8), (7_001, 4, 8), (20_000, 4, 2), (333, 3, 2), (20_000, 3, 16), (4_000, 3, 16)):
+    for cols, unroll, pad in ((10_000, 3, 8), (7_001, 3, 8), (20_000, 3, 2), (333, 3, 2), (20_000, 3, 16), (4_000, 3, 16)):
         os.environ["SPMV_TP_PAD"] = str(pad)
         A.set_param("twophase_panel_cols", cols)
-        A.set_param("twophase_unroll", unroll)
         A.set_kernel(capi.CSR_TWOPHASE)
         os.environ.pop("SPMV_TP_PAD")
         assert A.get_param("twophase_panel_cols") == cols - cols % 2 and A.get_param("twophase_padded") % pad == 0

@@ -13,7 +13,7 @@ from __graft_entry__ import load_package  # noqa: E402
 
 capi = load_package().capi
 os.environ["SPMV_EXPERIMENTS"] = "1"
-os.environ["SPMV_TP_PLACEMENT_TRIES"] = "1"
+os.environ["SPMV_TP_PLACEMENT_BUDGET_MB"] = "0"  # no piece search: the pieces the allocator hands out
 
 
 def main():

@@ -229,7 +229,6 @@ def main():
 
             def setup_tp(A, pcols=pcols, unroll=unroll):
                 A.set_param("twophase_panel_cols", pcols)
-                A.set_param("twophase_unroll", unroll)
                 A.set_kernel(capi.CSR_TWOPHASE)  # rebuilds the layout when the panel width changed
             variants.append((f"two-phase cols={pcols} U={unroll}", setup_tp))
         if a.band and a.band <= 8192:

@@ -5,8 +5,8 @@
     python tools/tune_twophase.py [--ncol 80000000] [--rounds 4] [--builds 1]
 
 Switches of the engine (kernels_csr_twophase.hip), all per handle through spmv_mat_set_param: "twophase_only" 1|2 one phase
-alone (timing only: needs SPMV_EXPERIMENTS=1), "twophase_threads" / "twophase_unroll" the expand instance, "twophase_rotate";
-SPMV_TP_PAD=2|8|16 run padding and SPMV_TP_PLACEMENT_TRIES are read when the layout is built.
+alone (timing only: needs SPMV_EXPERIMENTS=1), "twophase_rotate", "twophase_placement_budget_mb" (the piece search's memory
+budget; 0 = no search); SPMV_TP_PAD=2|8|16 run padding is read when the layout is built.
 """
 import argparse
 import os
@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--builds", type=int, default=1, help="re-build the layout this many times (placement lottery)")
     ap.add_argument("--pads", type=lambda v: [int(t) for t in v.split(",")], default=[8], help="run padding per build, cycled: 2, 8 or 16 entries")
-    ap.add_argument("--tries", type=int, default=12, help="placements of the product stream timed per build (1 = none)")
+    ap.add_argument("--budget-mb", type=int, default=8192, help="memory the piece search may hold beyond the stream (0 = no search)")
     a = ap.parse_args()
     ctx = capi.Context(0)
     A = ctx.gen_csr_uniform(0, a.n, a.ncol, a.k, band=0, seed=1)
@@ -40,26 +40,23 @@ def main():
     for build in range(a.builds):
         pad = a.pads[build % len(a.pads)]
         os.environ["SPMV_TP_PAD"] = str(pad)
-        os.environ["SPMV_TP_PLACEMENT_TRIES"] = str(a.tries)
+        A.set_param("twophase_placement_budget_mb", a.budget_mb)
         for cols in (10_000, 20_000):  # the first forces the re-build of the second: every stream is allocated again
             A.set_param("twophase_panel_cols", cols)
             A.set_kernel(capi.CSR_TWOPHASE)
-        # name, phase alone (0 = both), threads, pairs per lane in flight, rotate
-        variants = [("A 1024 x 3, every workgroup from its panel's start", 1, 1024, 3, 0), ("A 1024 x 3", 1, 1024, 3, 1), ("A 1024 x 4", 1, 1024, 4, 1),
-                    ("A 512 x 6", 1, 512, 6, 1), ("A 512 x 8", 1, 512, 8, 1), ("B", 2, 1024, 3, 1), ("both 1024 x 3", 0, 1024, 3, 1),
-                    ("both 1024 x 4", 0, 1024, 4, 1), ("both 512 x 6", 0, 512, 6, 1)]
+        # name, phase alone (0 = both), rotate
+        variants = [("A, every workgroup from its panel's start", 1, 0), ("A", 1, 1), ("B", 2, 1), ("both", 0, 1)]
         res = {v[0]: [] for v in variants}
         for _ in range(a.rounds):
-            for name, only, threads, unroll, rotate in variants:
+            for name, only, rotate in variants:
                 A.set_param("twophase_only", only)
-                A.set_param("twophase_threads", threads)
-                A.set_param("twophase_unroll", unroll)
                 A.set_param("twophase_rotate", rotate)
                 ctx.apply(A, x, y)
                 res[name].append(ctx.apply_timed(A, x, y, a.reps))
         A.set_param("twophase_only", 0)
         print(f"# build {build}: run padding {pad}, padded entries {A.get_param('twophase_padded')} ({A.get_param('twophase_padded') / A.info.nnz - 1:.2%} padding), "
-              f"placements timed {A.get_param('twophase_placements_timed')}, slowest / kept {A.get_param('twophase_placement_spread') / 1000:.3f}")
+              f"pieces {A.get_param('twophase_pieces')} (timed {A.get_param('twophase_placements_timed')}, exchanged {A.get_param('twophase_pieces_exchanged')}, "
+              f"as built / kept {A.get_param('twophase_placement_spread') / 1000:.3f})")
         for name, ts in res.items():
             print(f"{name:32s} median {statistics.median(ts):.4f} ms   min {min(ts):.4f}", flush=True)
 
