@@ -113,10 +113,12 @@ static void comm_free(spmv_comm* c)
 // (the usual case: rows / n per shard), else a group of n broadcasts, one per slice, so the slices may differ in length
 // (the reference's last shard takes the remainder, src/mat_vec.cpp:245-246).  One host thread drives every
 // communicator, so the calls of all participants sit in ONE group.
-static int rccl_allgather(spmv_comm* c, spmv_vec* const* vecs, const int64_t* offsets)
+// force_broadcasts: take the ragged form whatever the slices (the self-check's second pass: with ONE participant any
+// offsets are "equal", and the group of ncclBroadcast calls would otherwise never run on a one-GPU box).
+static int rccl_allgather(spmv_comm* c, spmv_vec* const* vecs, const int64_t* offsets, bool force_broadcasts = false)
 {
     const int n     = c->n;
-    bool      equal = offsets[0] == 0;
+    bool      equal = offsets[0] == 0 && !force_broadcasts;
     for (int r = 0; r < n; ++r) equal = equal && offsets[r + 1] - offsets[r] == offsets[1] - offsets[0];
     ncclResult_t rc = c->rccl.GroupStart();
     if (equal)
@@ -169,7 +171,7 @@ static bool rccl_self_check(spmv_comm* c, std::string& why)
             ok = hipMemcpyAsync(store[(size_t)i].d, host.data(), sizeof(double) * (size_t)total, hipMemcpyHostToDevice, x->stream) == hipSuccess &&
                  hipStreamSynchronize(x->stream) == hipSuccess;
         }
-        if (ok && rccl_allgather(c, vecs.data(), off.data()) != SPMV_OK)
+        if (ok && rccl_allgather(c, vecs.data(), off.data(), /*force_broadcasts=*/ragged != 0) != SPMV_OK)
         {
             why = spmv_last_error();
             ok  = false;

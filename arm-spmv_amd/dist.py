@@ -13,6 +13,13 @@ the collective logic testable on CPU with gloo, where the tests plug the oracle 
 """
 from __future__ import annotations
 
+import os
+
+# One process per GPU shares device buffers through dmabuf handles on this platform; with the legacy IPC mode RCCL's
+# cross-process registration fails (`hipIpcGetMemHandle: invalid argument`).  Harmless when already set; must be in the
+# environment before the process first touches the GPU, so it is set when this module is imported.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 import torch.distributed as dist
 

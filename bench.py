@@ -485,6 +485,9 @@ def main() -> None:
     ap.add_argument("--keep-csr", action="store_true", help="keep col_ind / values of the CSR copy next to the panel layout")
     ap.add_argument("--no-extra", action="store_true", help="skip the C3 / C4 / band lines after the headline loop")
     ap.add_argument("--no-live-counters", action="store_true", help="do not run the two rocprofv3 --pmc passes; use profiles/pmc_traffic.json")
+    ap.add_argument("--placement-budget-mb", type=int, default=24576,
+                    help="two-phase shards (x several times longer than the shard has rows: N >= 4): device memory the piece search of the product "
+                         "stream may hold while it runs (the engine's own default is 8192; include/spmv_abi.h, 'twophase_placement_budget_mb')")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
@@ -545,6 +548,12 @@ def main() -> None:
         if args.flags:
             A.set_flags(args.flags)
         info = A.info
+        if int(info.kernel) == 5 and args.placement_budget_mb != 8192:
+            # The engine chose its product stream's pieces within its default budget (8 GB beyond the stream) when it built the
+            # layout.  This job has the device to itself, so it grants the search more (transient: freed before the call returns);
+            # one slow rank sets the step of the whole job.  Reported under config.twophase_layout.
+            A.set_param("twophase_placement_budget_mb", args.placement_budget_mb)
+            A.set_param("twophase_choose_pieces", 1)
         ctx.sync()
         setup_s = time.perf_counter() - t_setup  # generation + analysis + layout + trials: one-off, outside the timed region
         # the panel layout holds every entry once more, re-ordered: the product needs nothing else of the CSR copy but
@@ -691,6 +700,11 @@ def main() -> None:
                     "name": name, "format": fmt, "kernel": kernel, "nrow": int(inf.nrow), "ncol": int(inf.ncol), "nnz": nnz2 * parts,
                     "n_gpus": parts, "max_row_nnz": int(inf.max_row_nnz), "kernel_id": int(inf.kernel), "ms": round(ms, 5),
                     "value": round(2.0 * nnz2 * parts / ms / 1e6, 2), "unit": "GFLOP/s", "setup_seconds": round(t_set, 3),
+                    **({"twophase_layout": {"product_stream_pieces": M.get_param("twophase_pieces"),
+                                            "placement_budget_mb": M.get_param("twophase_placement_budget_mb"),
+                                            "configurations_timed": M.get_param("twophase_placements_timed"),
+                                            "pieces_exchanged": M.get_param("twophase_pieces_exchanged"),
+                                            "as_built_over_kept": M.get_param("twophase_placement_spread") / 1000.0}} if int(inf.kernel) == 5 else {}),
                     "roofline": {"bound": "hbm", "achieved": round(b_req / ms / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(b_req / ms / 1e6 / HBM_PEAK_GBS, 4), "bytes_required": b_req, "bytes_required_kind": kind,
                                  "frac_of_format_bytes": round(b_fmt / ms / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": b_fmt,
@@ -728,13 +742,20 @@ def main() -> None:
                     + (f"; rank r holds rows r*{n}..: the band keeps its locality under sharding)" if world > 1 else ")"),
                     "csr", band_shard, tkey=f"csr_n{n}_k{k}_band65536_ncol{ncol}", x_vec=vx, sharded=world > 1)
             if world == 1 and args.band == 0:
-                def c5_shard():
+                def c5_shard(budget_mb=None):
                     M = ctx.gen_csr_uniform(7 * n, 8 * n, 8 * n, k, band=0, seed=args.seed)
+                    if budget_mb and int(M.info.kernel) == 5:
+                        M.set_param("twophase_placement_budget_mb", budget_mb)
+                        M.set_param("twophase_choose_pieces", 1)
                     if int(M.info.kernel) in (4, 5):
                         M.set_param("panel_keep_csr", 0)
                     return M
                 one(f"C5 shard: what the last rank of 8 holds in BASELINE configs[4] (rows {7 * n}-{8 * n} of {8 * n} x {8 * n}, {k} per row; "
-                    "x = 640 MB resident)", "csr", c5_shard, tkey=f"csr_n{n}_k{k}_band0_ncol{8 * n}")
+                    "x = 640 MB resident); the engine's defaults (piece search within 8 GB)", "csr", c5_shard, tkey=f"csr_n{n}_k{k}_band0_ncol{8 * n}")
+                if args.placement_budget_mb != 8192:
+                    one(f"C5 shard, piece search of the product stream within {args.placement_budget_mb} MB (what this bench grants its two-phase "
+                        "shards at N >= 4: --placement-budget-mb)", "csr", lambda: c5_shard(args.placement_budget_mb),
+                        tkey=f"csr_n{n}_k{k}_band0_ncol{8 * n}")
 
         # every rank's own kernel time (the headline takes the slowest): shows whether one rank's placement / layout lags
         per_rank_ms = [round(kernel_ms, 5)]
@@ -746,8 +767,10 @@ def main() -> None:
         twophase = None
         if int(info.kernel) == 5:
             twophase = {"panel_cols": A.get_param("twophase_panel_cols"), "padded_entries": A.get_param("twophase_padded"),
-                        "placements_timed": A.get_param("twophase_placements_timed"),
-                        "slowest_over_kept_placement": A.get_param("twophase_placement_spread") / 1000.0}
+                        "product_stream_pieces": A.get_param("twophase_pieces"), "placement_budget_mb": A.get_param("twophase_placement_budget_mb"),
+                        "configurations_timed": A.get_param("twophase_placements_timed"),
+                        "pieces_exchanged": A.get_param("twophase_pieces_exchanged"),
+                        "as_built_over_kept": A.get_param("twophase_placement_spread") / 1000.0}
         # every rank's kernel choice, set-up time and (two-phase) placement search, so that a rank that lags is visible in
         # rank 0's line: one all-gather of five numbers per rank
         mine = [float(int(info.kernel)), setup_s, float(A.get_param("twophase_placements_timed")) if int(info.kernel) == 5 else 0.0,
@@ -758,8 +781,8 @@ def main() -> None:
             table[rank] = torch.tensor(mine, dtype=torch.float64, device=dev)
             dist.all_reduce(table, op=dist.ReduceOp.SUM)
             per_rank_layout = table.tolist()
-        per_rank_layout = [{"rank": r, "kernel_id": int(v[0]), "setup_seconds": round(v[1], 3), "twophase_placements_timed": int(v[2]),
-                            "twophase_slowest_over_kept_placement": round(v[3], 3), "kernel_ms": round(v[4], 5)}
+        per_rank_layout = [{"rank": r, "kernel_id": int(v[0]), "setup_seconds": round(v[1], 3), "twophase_configurations_timed": int(v[2]),
+                            "twophase_as_built_over_kept": round(v[3], 3), "kernel_ms": round(v[4], 5)}
                            for r, v in enumerate(per_rank_layout)]
         wall_s, kernel_ms, exch_max = max_over_ranks(wall_s, kernel_ms, exch_s or 0.0)
 

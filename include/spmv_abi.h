@@ -214,11 +214,28 @@ int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
  *                    (memory 2x -> 1x the matrix; download, other kernels, re-builds and conversions are then refused)
  *   "panel_trial"    1 / 0 = timing launches when the layout is built, yes / no (-1 = environment, default yes)
  *   "dia_col_bound"  DIA handles: columns >= this are skipped (row shards keep the bound of the whole matrix)
- *   "twophase_panel_cols", "twophase_unroll"   two-phase CSR kernel: columns of x per panel (<= 20000, even) and pairs per lane
- *                    in flight in the expand phase (3, the default, or 4); take effect at the next
- *                    spmv_mat_set_kernel(SPMV_CSR_TWOPHASE) / at the next product
- *   "twophase_realloc"  experiment (tools/probe_twophase_placement.py): move streams of the built two-phase layout to fresh
- *                    allocations; bits 1 products, 2 values, 4 columns, 8 rows
+ *   "twophase_panel_cols"   two-phase CSR kernel: columns of x per panel (<= 20000, even); takes effect at the next
+ *                    spmv_mat_set_kernel(SPMV_CSR_TWOPHASE)
+ *   "twophase_placement_budget_mb", "twophase_choose_pieces"   two-phase CSR kernel, TRANSIENT MEMORY.  The stream of products
+ *                    between the two phases (8 bytes per padded entry: 2.6 GB for 320M entries) lives in pieces of 1 GB,
+ *                    and where those lie in the device's PHYSICAL memory decides a tenth of the product's time (DESIGN.md
+ *                    4.7; nothing can be asked of the allocator).  When the layout is built - by spmv_mat_set_kernel(TWOPHASE),
+ *                    or by the upload / generator calls when AUTO picks this kernel - the engine therefore allocates
+ *                    budget / 1 GB more pieces than the stream needs, times configurations of pieces (3 products each,
+ *                    ~0.3 s in all), keeps the fastest and FREES EVERY OTHER PIECE BEFORE THE CALL RETURNS.  While the call
+ *                    runs it holds: the layout + budget (default 8192 MB, never more than a quarter of the free device
+ *                    memory) + two scratch vectors (8 ncol + 8 nrow bytes).  Afterwards: the layout, its product stream
+ *                    rounded up to whole gigabytes.  "twophase_placement_budget_mb": -1 = default (or the environment's
+ *                    SPMV_TP_PLACEMENT_BUDGET_MB), 0 = no search and no timing launches ("panel_trial" 0 /
+ *                    SPMV_PANEL_TRIAL=0 do the same), otherwise megabytes; it applies to the next build, or at once with
+ *                    "twophase_choose_pieces" (any value): run the search again on the built layout.  Streams below 512 MB
+ *                    are never searched.  The outcome is reported by spmv_mat_get_param (below); a timing launch that fails
+ *                    is an error of the call, not a silent fallback.
+ *   "twophase_rotate"   1 (default): workgroup b of the expand phase starts b / 256 of the way through its panels
+ *   "twophase_only", "twophase_realloc"   experiments, refused unless SPMV_EXPERIMENTS=1 is in the environment: run phase A
+ *                    (1) or B (2) alone - THE PRODUCT IS THEN WRONG - and move streams of the built layout to fresh
+ *                    allocations (bits 1 products, 2 values, 4 columns, 8 rows, 16 table): tools/tune_twophase.py,
+ *                    tools/probe_twophase_moves.py
  *   "symgs_order"    sweep order of spmv_symgs / SPMV_PRECOND_SYMGS: 1 multicolour (default), 0 the matrix's own row order
  *   "panel_trace", "panel_legacy", "panel_two_per_cu"
  *                    diagnostics and experiments kept for the record (tools/trace_panel.py) */
@@ -226,8 +243,9 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value);
 /* What is in effect: "panel_rows", "panel_width", "panel_sort", "panel_groups", "panel_layout", "panel_unroll",
  * "panel_pipe", "panel_sync", "panel_stagger", "panel_pace_ns", "panel_pace_scale", "panel_pace_bumps",
  * "panel_bytes", "panel_keep_csr", "device_bytes", "window_max_span", "window_avg_span", "twophase_panel_cols",
- * "twophase_padded" (entries of the two-phase layout with its padding), "twophase_placements_timed" / "twophase_placement_spread"
- * (candidate allocations of the product stream timed when the layout was built; slowest / kept in 1/1000), "ell_diagonal_slots" (1: the slots of an ELL
+ * "twophase_padded" (entries of the two-phase layout with its padding), "twophase_pieces" (1 GB pieces of its product stream),
+ * "twophase_placement_budget_mb", "twophase_placements_timed" (configurations of pieces timed by the search, 0 = no search ran),
+ * "twophase_placement_spread" (time as built / time kept, in 1/1000), "twophase_pieces_exchanged", "ell_diagonal_slots" (1: the slots of an ELL
  * handle were found to be diagonals and conforming rows read no column index), "symgs_order", "symgs_colours",
  * "symgs_levels_forward", "symgs_levels_backward", "symgs_launches", "symgs_bytes". */
 int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value);
@@ -311,7 +329,12 @@ int spmv_csr_to_ell(spmv_ctx* ctx, const spmv_mat* csr, spmv_mat** out_ell);
  * [col_begin, col_end), REBASED to 0 (it multiplies the caller's own slice of x: ncol = col_end - col_begin);
  * `outside` holds the others with their global columns.  A*x = inside*x[col_begin:col_end] + outside*x, rows and the
  * order inside each row kept.  For the sharded solver step: the inside product needs no exchange and can run while
- * the x all-gather is in flight (no counterpart in the reference). */
+ * the x all-gather is in flight (no counterpart in the reference).
+ * Row bookkeeping: `outside` keeps the shard's row_begin.  `inside` reports row_begin = csr.row_begin - col_begin (see
+ * spmv_mat_get_info): because its columns are rebased, local row i meets its own diagonal at column row_begin + i of
+ * `inside` - the offset the Jacobi diagonal and the Gauss-Seidel sweep of the sharded solver use.  For the usual call
+ * (col_begin = the shard's first row) that is 0: a square block starting at (0, 0).  It is NEGATIVE when col_begin lies
+ * beyond the shard's first row (rows before col_begin have no diagonal inside the block). */
 int spmv_csr_split_columns(spmv_ctx* ctx, const spmv_mat* csr, int32_t col_begin, int32_t col_end,
                            spmv_mat** out_inside, spmv_mat** out_outside);
 

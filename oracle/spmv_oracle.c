@@ -45,8 +45,10 @@ void ORC_NAME(orc_csr_spmv)(int32_t nrow, const int32_t* row_ptr, const int32_t*
     }
 }
 
-/* src/mat_vec.cpp:82-93: the product is formed first (`value = val*x`), then added, so there is
- * nothing to fuse even on aarch64; both flavours are identical and exist only for symmetry. */
+/* src/mat_vec.cpp:82-93: `value = val*x` in one statement, `y[row] += value` in the next.  The plain flavour
+ * (separate multiply and add: x86-64, and any build where the add is an `omp atomic`) is the pinned one; the _fma
+ * flavour fuses the two, which is what g++ -O2 may emit for the serial loop on aarch64 (-ffp-contract=fast works
+ * on the whole expression tree, across the two statements) and what the engine's row-grouped CSC path computes. */
 void ORC_NAME(orc_csc_spmv)(int32_t ncol, const int32_t* col_ptr, const int32_t* row,
                             const double* val, const double* x, double* y)
 {

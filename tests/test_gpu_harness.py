@@ -99,7 +99,11 @@ def test_bench_contract_one_rank_and_two_rank_rehearsal(tmp_path):
     import socket
     import sys
 
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # bench.py sets HSA_ENABLE_IPC_MODE_LEGACY=0 itself (dmabuf IPC: what RCCL's cross-process buffers need on this platform)
+    # before anything touches the GPU: the test takes the variable out of the environment to show that nothing depends on
+    # the caller having exported it
+    env = dict(os.environ)
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--rows", "400000", "--steps", "4", "--warmup", "1",
                         "--cpu-sample-rows", "100000", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -115,6 +119,10 @@ def test_bench_contract_one_rank_and_two_rank_rehearsal(tmp_path):
     kernels = {e["name"]: e["kernel"] for e in line["extra"]}
     assert any("ell_kernel_x2" in v for v in kernels.values()) and any("coo_segscan_kernel" in v for v in kernels.values())
     assert line["cpu_baseline"]["kind"] in ("reference", "port") and line["cpu_baseline"]["value"] > 0
+    # counter traffic as a rate (north_star: "counters reported as achieved HBM GB/s"): live passes or the stamped constants or null
+    rl = line["roofline"]
+    assert "traffic_gbs" in rl and "traffic_source" in rl and (rl["traffic"] is None or abs(rl["traffic_gbs"] - rl["traffic"] / rl["kernel_ms"] / 1e6) < 1.0)
+    assert len(line["config"]["per_rank"]) == 1 and line["config"]["per_rank"][0]["kernel_ms"] > 0 and "y_concatenate_ms" not in line
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -128,6 +136,11 @@ def test_bench_contract_one_rank_and_two_rank_rehearsal(tmp_path):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["ncol"] == 800000 and line["config"]["nnz_total"] == 2 * 400000 * 32
     assert line["value"] > 0 and "with_x_allgather_each_step" in line
+    # the optional gather of the y slices is timed by itself, and every rank's kernel / layout facts reach rank 0's line
+    assert line["y_concatenate_ms"] > 0
+    ranks = line["config"]["per_rank"]
+    assert [r_["rank"] for r_ in ranks] == [0, 1] and all(r_["kernel_ms"] > 0 and r_["kernel_id"] in (1, 2, 4, 5) for r_ in ranks)
+    assert line["config"]["kernel_ms_per_rank"] == [r_["kernel_ms"] for r_ in ranks]
     band = [e for e in line["extra"] if "band of 65536" in e["name"]]  # the band-random variant is reported at every world size
     assert len(band) == 1 and band[0]["n_gpus"] == 2 and band[0]["nnz"] == 2 * 400000 * 32 and 0 < band[0]["roofline"]["frac"] <= 1.0
 
@@ -202,7 +215,8 @@ def test_bench_under_torchrun_with_one_rank_runs_the_rccl_collectives(tmp_path):
     import socket
     import sys
 
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ)
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)  # bench.py sets it itself
     env.pop("SPMV_BENCH_BACKEND", None)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -216,6 +230,7 @@ def test_bench_under_torchrun_with_one_rank_runs_the_rccl_collectives(tmp_path):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["config"]["process_group"].startswith("nccl")
     assert line["with_x_allgather_each_step"]["value"] > 0 and line["with_x_allgather_each_step"]["allgather_ms"] > 0
+    assert line["y_concatenate_ms"] > 0 and len(line["config"]["per_rank"]) == 1
 
 
 def test_allgather_x_over_nccl_world_one():
@@ -251,7 +266,8 @@ dist.barrier()
 dist.destroy_process_group()
 print("nccl world 1 OK")
 """
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ)
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)  # arm-spmv_amd/dist.py sets it when imported
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "nccl world 1 OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 

@@ -1198,6 +1198,20 @@ def test_csr_split_columns_is_exact_and_the_parts_add_up(ctx, orc, pkg):
         ol.assert_parity(y.download(), ref, scale, f"split [{c0},{c1})")
     with pytest.raises(pkg.capi.SpmvError):
         ctx.csr_split_columns(A, 5, n + 1)
+    # a row shard split at a column range that does not start at the shard's first row: `inside` reports
+    # row_begin - col_begin (the column at which local row 0 would meet its diagonal), `outside` the shard's own row_begin
+    b, e = 40_000, 70_000
+    S = ctx.csr_shard(b, e, n, rp.astype(np.int64), cc, cv)
+    for c0, c1, want in ((b, e, 0), (10_000, 90_000, 30_000), (55_000, 99_000, -15_000)):
+        s_in, s_out = ctx.csr_split_columns(S, c0, c1)
+        assert s_in.info.row_begin == want == b - c0 and s_out.info.row_begin == b
+        assert s_in.info.nrow == s_out.info.nrow == e - b and s_in.info.ncol == c1 - c0
+        y = ctx.vector(e - b)
+        y.fill(0.0)
+        ctx.apply(s_in, ctx.vector_from(x[c0:c1]), y)
+        ctx.apply(s_out, ctx.vector_from(x), y)
+        ctx.sync()
+        ol.assert_parity(y.download(), ref[b:e], scale[b:e], f"shard [{b},{e}) split at [{c0},{c1})")
 
 
 def test_handles_give_their_device_memory_back(ctx, pkg):
