@@ -57,6 +57,24 @@ __device__ __forceinline__ void slot_sum2_block(const double* a, const double* b
     __syncthreads();  // s_tot may be reused (block_sum has its own array)
 }
 
+// the same for four accumulators: the first two wavefronts read, one barrier pair
+__device__ __forceinline__ void slot_sum4_block(const double* a, const double* b, const double* c, const double* d, double (&t)[4])
+{
+    static_assert(kDotSlots == 32 && kBlock >= 2 * kWave, "one slot per lane of a 32-lane half, two wavefronts");
+    __shared__ double s_tot4[4];
+    if (threadIdx.x < 2 * kWave)
+    {
+        const int     lane = threadIdx.x & 63, which = (int)(threadIdx.x >> 5);
+        const double* acc  = which == 0 ? a : which == 1 ? b : which == 2 ? c : d;
+        const double  v    = acc[(lane & 31) * kDotStride];
+        const double  tot  = group_sum_swizzle<32>(v);
+        if ((lane & 31) == 0) s_tot4[which] = tot;
+    }
+    __syncthreads();
+    for (int i = 0; i < 4; ++i) t[i] = s_tot4[i];
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(kBlock) void dot_accumulate_kernel(const double* __restrict__ x, const double* __restrict__ y,
                                                                 int64_t n, double* __restrict__ out)
 {
@@ -77,6 +95,8 @@ struct CgScalars
     double rz[4][kDotDoubles];  // Jacobi-preconditioned runs: r_k . z_k with z = D^-1 r (else unused: z = r, r.z = r.r)
     double bb[kDotDoubles];  // b . b
     double status;           // != 0: breakdown (p . A p <= 0: the matrix is not positive definite)
+    double alpha[4];         // two-launch iteration: alpha_k, kept for the recurrence of iteration k + 1
+    double noise_floor;      // two-launch iteration: 1e-28 b.b; at or below it r.r is rounding noise and the updates stop
 };
 
 // r = b - q (q = A x0), p = z = r (PRE: D^-1 r), rr[0] = r.r, rz[0] = r.z, bb = b.b
@@ -335,6 +355,98 @@ __global__ __launch_bounds__(kBlock) void cg_direction_kernel(int64_t n, int k, 
         s->pq[(k + 2) & 3][threadIdx.x * kDotStride] = 0.0;
     }
 }
+// ---- two launches per iteration (round 4) ----------------------------------------------------------------------------------
+// The three-launch iteration needs r.r of the UPDATED residual before it can form beta, hence a kernel boundary between the
+// x / r update and the direction update.  The Chronopoulos-Gear arrangement of the same recurrences moves the product onto
+// the (preconditioned) residual and carries s = A p along, so that everything behind the product is ONE pass:
+//   launch 1   w = A u (u = M^-1 r; u = r without a preconditioner), delta_k = u . w fused into the product's write-back
+//   launch 2   beta = gamma_k / gamma_{k-1};  alpha = gamma_k / (delta_k - beta gamma_k / alpha_{k-1})
+//              p = u + beta p;  s = w + beta s;  x += alpha p;  r -= alpha s;  u = D^-1 r;  gamma_{k+1} += r . u;  rr_{k+1} += r . r
+// with gamma_k = r_k . u_k in rz[k & 3] (unpreconditioned: u = r and gamma = r . r).  Same iterates in exact arithmetic; the
+// same bytes per iteration as the two kernels it replaces (5 reads + 4 writes of a vector against 6 + 3), one launch less:
+// what small systems, which are launch-bound, are made of.  One more work vector (s).
+template <bool PRE, bool WIDE>
+__global__ __launch_bounds__(kBlock) void cg_fused_kernel(int64_t n, int k, const double* __restrict__ w, double* __restrict__ u,
+                                                          double* __restrict__ p, double* __restrict__ sv, double* __restrict__ x,
+                                                          double* __restrict__ r, CgScalars* __restrict__ s, const double* __restrict__ dinv)
+{
+    double (*const G)[kDotDoubles] = PRE ? s->rz : s->rr;  // gamma_k = r_k . u_k lives in rz; without a preconditioner it IS r . r
+    double t[4];
+    slot_sum4_block(G[k & 3], s->pq[k & 3], G[(k + 3) & 3], s->rr[k & 3], t);
+    const double gamma = t[0], delta = t[1], gamma_old = t[2], rr_k = t[3];
+    // the ring slots of iteration k + 2 are cleared whatever happens below (nobody reads or writes them in this launch): an
+    // iteration that passes quietly must still leave r.r = 0 where the host will look for it
+    if (blockIdx.x == 0 && threadIdx.x < kDotSlots)
+    {
+        s->rr[(k + 2) & 3][threadIdx.x * kDotStride] = 0.0;
+        s->rz[(k + 2) & 3][threadIdx.x * kDotStride] = 0.0;
+        s->pq[(k + 2) & 3][threadIdx.x * kDotStride] = 0.0;
+    }
+    // Below |r| = 1e-14 |b| (s->noise_floor = 1e-28 b.b, written by the host once b.b is known) the residual is rounding noise
+    // of the recurrence and this arrangement's alpha - a difference of two nearly equal numbers - is noise too: the iterations
+    // queued behind an exactly solved system pass without touching anything.
+    if (!(rr_k > s->noise_floor)) return;  // uniform over the grid: every thread read the same scalars
+    const double beta  = k > 0 && gamma_old > 0.0 ? gamma / gamma_old : 0.0;
+    const double denom = k > 0 && beta != 0.0 ? delta - beta * gamma / s->alpha[(k + 3) & 3] : delta;
+    if (!(denom > 0.0) || !(gamma > 0.0))
+    {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && gamma > 0.0) s->status = 1.0;  // a residual to speak of and no descent: not SPD
+        return;
+    }
+    const double alpha = gamma / denom;
+    double       rr = 0.0, rz = 0.0;
+    auto one = [&](double wi, double ui, double& pi, double& si, double& xi, double& ri, double di, double& u_out) {
+        pi    = fma(beta, pi, ui);
+        si    = fma(beta, si, wi);
+        xi    = fma(alpha, pi, xi);
+        ri    = fma(-alpha, si, ri);
+        u_out = PRE ? ri * di : ri;
+        rr    = fma(ri, ri, rr);
+        if (PRE) rz = fma(ri, u_out, rz);
+    };
+    if constexpr (WIDE)
+    {
+        const int64_t npairs = n / 2;
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < npairs; i += (int64_t)gridDim.x * kBlock)
+        {
+            const f64x2_t wv = ((const f64x2_t*)w)[i];
+            const f64x2_t uv = PRE ? ((const f64x2_t*)u)[i] : ((const f64x2_t*)r)[i];
+            const f64x2_t dv = PRE ? ((const f64x2_t*)dinv)[i] : f64x2_t{1.0, 1.0};
+            const f64x2_t pv = ((const f64x2_t*)p)[i], sw = ((const f64x2_t*)sv)[i], xv = ((const f64x2_t*)x)[i], rv = ((const f64x2_t*)r)[i];
+            double        pe[2] = {pv[0], pv[1]}, se[2] = {sw[0], sw[1]}, xe[2] = {xv[0], xv[1]}, re[2] = {rv[0], rv[1]}, ue[2];
+            one(wv[0], uv[0], pe[0], se[0], xe[0], re[0], dv[0], ue[0]);
+            one(wv[1], uv[1], pe[1], se[1], xe[1], re[1], dv[1], ue[1]);
+            ((f64x2_t*)p)[i]  = f64x2_t{pe[0], pe[1]};
+            ((f64x2_t*)sv)[i] = f64x2_t{se[0], se[1]};
+            ((f64x2_t*)x)[i]  = f64x2_t{xe[0], xe[1]};
+            ((f64x2_t*)r)[i]  = f64x2_t{re[0], re[1]};
+            if (PRE) ((f64x2_t*)u)[i] = f64x2_t{ue[0], ue[1]};
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+        {
+            const int64_t i = n - 1;
+            double        uo;
+            one(w[i], PRE ? u[i] : r[i], p[i], sv[i], x[i], r[i], PRE ? dinv[i] : 1.0, uo);
+            if (PRE) u[i] = uo;
+        }
+    }
+    else
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        {
+            double uo;
+            one(w[i], PRE ? u[i] : r[i], p[i], sv[i], x[i], r[i], PRE ? dinv[i] : 1.0, uo);
+            if (PRE) u[i] = uo;
+        }
+    const double t_rr = block_sum(rr);
+    __syncthreads();
+    const double t_rz = PRE ? block_sum(rz) : 0.0;
+    if (threadIdx.x == 0)
+    {
+        slot_add(s->rr[(k + 1) & 3], t_rr);
+        if (PRE) slot_add(s->rz[(k + 1) & 3], t_rz);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) s->alpha[k & 3] = alpha;
+}
 }  // namespace
 
 int vec_dot_accumulate(spmv_ctx* ctx, const double* x, const double* y, int64_t n, double* device_out)
@@ -384,9 +496,11 @@ int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int m
     *rel_resid      = 0.0;
     if (n == 0) return SPMV_OK;
     hipStream_t st = ctx->stream;
-    double *    r = nullptr, *p = nullptr, *q = nullptr, *dinv = nullptr, *z = nullptr;
+    double *    r = nullptr, *p = nullptr, *q = nullptr, *dinv = nullptr, *z = nullptr, *sv = nullptr, *u = nullptr;
     CgScalars*  s = nullptr;
     auto        release = [&]() {
+        if (sv) (void)hipFree(sv);
+        if (u) (void)hipFree(u);
         if (z) (void)hipFree(z);
         if (r) (void)hipFree(r);
         if (p) (void)hipFree(p);
@@ -426,6 +540,15 @@ int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int m
     {
         release();
         SPMV_FAIL(SPMV_ERR_ALLOC, "spmv_cg: out of device memory for three work vectors of %lld entries", (long long)n);
+    }
+    // Two launches per iteration (cg_fused_kernel) unless a sweep stands between the product and the updates (symmetric
+    // Gauss-Seidel) or SPMV_CG_THREE_LAUNCHES=1 asks for the textbook arrangement (A/B; read once per solve).
+    const char* e_three = getenv("SPMV_CG_THREE_LAUNCHES");
+    const bool  fused   = !z && !(e_three && e_three[0] == '1');
+    if (fused && (hipMalloc(&sv, sizeof(double) * (size_t)n) != hipSuccess || (dinv && hipMalloc(&u, sizeof(double) * (size_t)n) != hipSuccess)))
+    {
+        release();
+        SPMV_FAIL(SPMV_ERR_ALLOC, "spmv_cg: out of device memory for the work vectors of %lld entries", (long long)n);
     }
     const int  grid  = stream_grid(n);
     const int  grid2 = stream_grid(std::max<int64_t>(1, n / 2));
@@ -480,6 +603,16 @@ int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int m
                 break;
             }
         }
+        if (fused)
+        {
+            // s = A p starts at 0 (beta_0 = 0 multiplies it); the preconditioned residual u_0 = z_0 is what init left in p
+            if (hipMemsetAsync(sv, 0, sizeof(double) * (size_t)n, st) != hipSuccess ||
+                (u && hipMemcpyAsync(u, p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st) != hipSuccess))
+            {
+                rc = SPMV_ERR_HIP;
+                break;
+            }
+        }
         if ((rc = fetch(-1)) != SPMV_OK) break;
         const double bb    = host_sum(h.bb);
         const double limit = rel_tol * rel_tol * bb;  // compare squared norms
@@ -490,9 +623,40 @@ int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int m
             *rel_resid = bb > 0.0 ? sqrt(rr / bb) : 0.0;  // b = 0: x0 solves it if r = 0 (else the caller sees iters = 0)
             break;
         }
+        if (fused)
+        {
+            const double floor_rr = 1e-28 * bb;
+            if (hipMemcpyAsync(&s->noise_floor, &floor_rr, sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+            {
+                rc = SPMV_ERR_HIP;
+                break;
+            }
+        }
         const int every = std::max(1, check_every);
-        // one iteration = three launches on the stream (k enters the kernels only through k & 3)
+        // one iteration = two (fused) or three launches on the stream (k enters the kernels only through k & 3 and k > 0)
         auto iteration = [&](int kk) -> int {
+            if (fused)
+            {
+                const double* in = u ? u : r;  // the product runs on the (preconditioned) residual
+                apply_extra   fx;
+                fx.overwrite = true;
+                fx.dot_w     = in;
+                fx.dot_out   = s->pq[kk & 3];
+                SPMV_TRY(mat_apply_ex(ctx, A, in, q, fx));  // w = A u, delta_k = u . w
+                const int kq = kk == 0 ? 0 : 4 + (kk & 3);  // (k > 0 and k & 3 are all the kernel looks at: graph replay keeps working)
+#define SPMV_CG_FUSED(PRE, WIDE, GRID) \
+    hipLaunchKernelGGL((cg_fused_kernel<PRE, WIDE>), dim3(GRID), dim3(kBlock), 0, st, n, kq, q, u, p, sv, x, r, s, dinv)
+                if (dinv)
+                {
+                    if (wide) SPMV_CG_FUSED(true, true, grid2); else SPMV_CG_FUSED(true, false, grid);
+                }
+                else
+                {
+                    if (wide) SPMV_CG_FUSED(false, true, grid2); else SPMV_CG_FUSED(false, false, grid);
+                }
+#undef SPMV_CG_FUSED
+                return SPMV_OK;
+            }
             apply_extra ex;
             ex.overwrite = true;
             ex.dot_w     = p;
