@@ -679,13 +679,26 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         SPMV_REQUIRE(value >= -1 && value <= (1 << 20), "twophase_placement_budget_mb: -1 (default), 0 (no search) or megabytes");
         m->tp_place_budget_mb = (int32_t)value;
     }
+    else if (!strcmp(name, "twophase_pool_alloc") || !strcmp(name, "twophase_pool_config"))  // experiments (tools/probe_twophase_pairs.py)
+    {
+        const char* e_exp = getenv("SPMV_EXPERIMENTS");
+        SPMV_REQUIRE(e_exp && e_exp[0] == '1', "%s is an experiment: set SPMV_EXPERIMENTS=1", name);
+        SPMV_HIP(hipSetDevice(m->ctx->device));
+        if (!strcmp(name, "twophase_pool_alloc"))
+            SPMV_TRY(csr_twophase_pool_alloc(m, (int)value));
+        else
+            SPMV_TRY(csr_twophase_pool_config(m, value));
+    }
     else if (!strcmp(name, "twophase_choose_pieces"))  // run the piece search of a built two-phase layout (again) with the current budget
     {
         SPMV_HIP(hipSetDevice(m->ctx->device));
         SPMV_TRY(csr_twophase_choose_again(m));
     }
-    else if (!strcmp(name, "twophase_rotate"))  // 1 (default): workgroup b starts b / 256 of the way through each of its panels
-        m->tp_rotate = value ? 1 : 0;
+    else if (!strcmp(name, "twophase_rotate"))  // starting points of the expand phase's workgroups inside their panels: 256 (default), 0 = all at the start
+    {
+        SPMV_REQUIRE(value >= 0 && value <= 256, "twophase_rotate: 0 .. 256 starting points");
+        m->tp_rotate = (int32_t)value;
+    }
     else if (!strcmp(name, "twophase_only"))
     {
         // experiment (tools/tune_twophase.py): run phase A (1) or phase B (2) alone.  THE PRODUCT IS THEN WRONG, so the

@@ -200,6 +200,7 @@ struct spmv_mat
     uint16_t* tp_row       = nullptr;  // [padded] row - group base, (group, panel) order; 0xFFFF = padding
     double*   tp_piece[4] = {};        // the stream between the two phases, (group, panel) order, in pieces of 2^26 pairs (1 GB)
     int32_t   tp_npieces   = 0;
+    void*     tp_pool      = nullptr;  // experiments: a pool of pieces (kernels_csr_twophase.hip: tp_pool)
     int64_t   tp_last_piece_bytes = 0;  // the last piece: a whole one when the piece search ran, else what the stream needs of it
     int32_t*  tp_blk       = nullptr;  // [2 * ceil(padded / 16)] two table words per source line: source pair -> destination pair
     int32_t*  tp_panel_ptr = nullptr;  // [panels + 1]
@@ -209,7 +210,7 @@ struct spmv_mat
     int32_t   tp_pcols_req = 0;  // requested panel width (0 = default)
     int32_t   tp_place_budget_mb = -1;          // memory the piece search may hold beyond the stream (-1: SPMV_TP_PLACEMENT_BUDGET_MB or 8192; 0: no search)
     int32_t   tp_pieces_exchanged = 0;               // pieces of the stream the search exchanged for others
-    int32_t   tp_rotate = 1;                    // expand kernel: workgroup b starts b / 256 of the way through its panels
+    int32_t   tp_rotate = 256;                  // expand kernel: distinct starting points of the workgroups inside their panels (0 / 1: none)
     int32_t   tp_only = 0;                      // experiment (SPMV_EXPERIMENTS=1): 1 / 2 = run phase A / B alone - wrong results
     int32_t   tp_place_seen = 0, tp_place_gain = 0;  // placements of the product stream timed at build; slowest / kept, in 1/1000
     int64_t   tp_padded = 0;
@@ -250,6 +251,8 @@ int  csr_twophase_build(spmv_mat* m);
 void csr_twophase_free(spmv_mat* m);
 bool csr_twophase_worth(const spmv_mat* m);
 int  csr_twophase_choose_again(spmv_mat* m);
+int  csr_twophase_pool_alloc(spmv_mat* m, int extra);
+int  csr_twophase_pool_config(spmv_mat* m, int64_t code);
 
 
 // A sum that thousands of wavefronts add into is kept as kDotSlots partial sums on different 128-byte lines (an

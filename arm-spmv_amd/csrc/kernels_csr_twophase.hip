@@ -224,7 +224,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
             {
                 const int t0  = tb & ~31;
                 const int len = te - t0;
-                return Pan{q, t0, len, tb - t0, rotate ? (int)(((int64_t)len * (int)(blockIdx.x % 256u) / 256) & ~31) : 0};
+                // rotate = number of distinct starting points: 256 (default: every workgroup its own), 0 / 1 none, else workgroup b
+                // takes phase b % rotate (experiments: "twophase_rotate")
+                const int ph = rotate > 1 ? (int)(blockIdx.x % (unsigned)rotate) : 0;
+                return Pan{q, t0, len, tb - t0, rotate > 1 ? (int)(((int64_t)len * ph / rotate) & ~31) : 0};
             }
         }
         return Pan{P, 0, 0, 0, 0};
@@ -304,7 +307,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
                 o.y = vv[k].y * xs[cc[k].y];
                 // the pair's piece from the table in LDS, its place inside the piece in 28 bits
                 char* const ob = tab[dst >> kTpPieceShift];
-                __builtin_nontemporal_store(o, reinterpret_cast<f64x2*>(ob + ((dst & ((1u << kTpPieceShift) - 1u)) << 4)));  // read again only 2.7 GB later: 2-3 %
+                // (nontemporal or plain stores: the same time in fast and slow placements alike, profiles/r04_probe_twophase_classes.txt)
+                __builtin_nontemporal_store(o, reinterpret_cast<f64x2*>(ob + ((dst & ((1u << kTpPieceShift) - 1u)) << 4)));
             }
         }
     };
@@ -432,8 +436,21 @@ __global__ __launch_bounds__(kTpThreads) void tp_reduce_kernel(const int32_t* __
 }
 }  // namespace
 
+struct tp_pool  // experiments: pieces held besides (and including) the stream's
+{
+    std::vector<double*> piece;
+};
+
 void csr_twophase_free(spmv_mat* m)
 {
+    if (m->tp_pool)  // (experiments) the pool owns every piece, the stream's current ones included
+    {
+        auto* pool = (tp_pool*)m->tp_pool;
+        for (double* p : pool->piece) (void)hipFree(p);
+        for (int i = 0; i < kTpMaxPieces; ++i) m->tp_piece[i] = nullptr;
+        delete pool;
+        m->tp_pool = nullptr;
+    }
     for (int i = 0; i < kTpMaxPieces; ++i)
         if (m->tp_piece[i])
         {
@@ -738,6 +755,45 @@ int tp_choose_pieces(spmv_mat* m)
     return rc;
 }
 }  // namespace
+
+// experiments ("twophase_pool_alloc" / "twophase_pool_config", SPMV_EXPERIMENTS=1): a pool of pieces held by the handle and
+// any configuration of them under the stream, chosen from outside (tools/probe_twophase_pairs.py)
+int csr_twophase_pool_alloc(spmv_mat* m, int extra)
+{
+    SPMV_REQUIRE(m->tp_val && m->tp_npieces > 0 && m->tp_last_piece_bytes == ((int64_t)16 << kTpPieceShift), "needs a built layout with whole pieces");
+    SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
+    if (!m->tp_pool)
+    {
+        auto* pool = new tp_pool;
+        for (int i = 0; i < m->tp_npieces; ++i) pool->piece.push_back(m->tp_piece[i]);
+        m->tp_pool = pool;
+    }
+    auto* pool = (tp_pool*)m->tp_pool;
+    for (int i = 0; i < extra; ++i)
+    {
+        double* p = nullptr;
+        if (hipMalloc(&p, (size_t)16 << kTpPieceShift) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            SPMV_FAIL(SPMV_ERR_ALLOC, "twophase_pool_alloc: out of device memory after %d pieces", i);
+        }
+        pool->piece.push_back(p);
+    }
+    return SPMV_OK;
+}
+int csr_twophase_pool_config(spmv_mat* m, int64_t code)  // 6 bits per slot
+{
+    SPMV_REQUIRE(m->tp_pool, "twophase_pool_config: no pool (twophase_pool_alloc first)");
+    auto* pool = (tp_pool*)m->tp_pool;
+    SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
+    for (int i = 0; i < m->tp_npieces; ++i)
+    {
+        const size_t idx = (size_t)((code >> (6 * i)) & 63);
+        SPMV_REQUIRE(idx < pool->piece.size(), "twophase_pool_config: piece %zu of %zu", idx, pool->piece.size());
+        m->tp_piece[i] = pool->piece[idx];
+    }
+    return SPMV_OK;
+}
 
 // "twophase_choose_pieces": run the piece search (again) on a built layout with the handle's current budget
 int csr_twophase_choose_again(spmv_mat* m)

@@ -455,7 +455,7 @@ def live_counters(args) -> dict:
                 if len(last) < 3:
                     return dict(out, error=f"{counter} pass: fewer than 3 dispatches of {name}")
                 per_kernel[name] = sum(float(row["Counter_Value"]) for row in last) / len(last)
-                out["kernel"] = last[-1]["Kernel_Name"].split("(anonymous namespace)::")[-1].split("(")[0]
+                out["kernel"] = last[-1]["Kernel_Name"].split("(anonymous namespace)::", 1)[-1].split("(")[0]
             sums[counter] = sum(per_kernel.values())
     out["traffic"] = int(round((2.0 * sums["FETCH_SIZE"] + sums["WRITE_SIZE"]) * 1024))
     out["fetch_size_kb"], out["write_size_kb"] = round(sums["FETCH_SIZE"], 1), round(sums["WRITE_SIZE"], 1)

@@ -92,7 +92,7 @@ def test_random_csr_shapes_through_every_kernel(ctx, orc, pkg, seed):
             A.set_kernel(capi.CSR_PANEL)
             run(A, f"panel layout={layout}->{A.get_param('panel_layout')} unroll={unroll} pipe={pipe} sync={sync} rows={rows} width={width}")
         if nnz + 16 * ((ncol + 6999) // 7000) * 256 < 2**31:
-            for cols, rotate in ((20_000, 1), (7_000, 0)):
+            for cols, rotate in ((20_000, 256), (7_000, 0), (20_000, 8)):
                 A.set_param("twophase_panel_cols", cols)
                 A.set_param("twophase_rotate", rotate)
                 A.set_kernel(capi.CSR_TWOPHASE)

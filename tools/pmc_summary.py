@@ -13,7 +13,7 @@ rows = collections.OrderedDict()
 for f in glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if sub in r["Kernel_Name"]:
-            key = (int(r["Dispatch_Id"]), r["Kernel_Name"].split("(anonymous namespace)::")[-1].split("(")[0][-48:])
+            key = (int(r["Dispatch_Id"]), r["Kernel_Name"].split("(anonymous namespace)::", 1)[-1].split("(")[0][-48:])
             rows.setdefault(key, {})[r["Counter_Name"]] = float(r["Counter_Value"])
             rows[key]["ms"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
 if "--runs" in sys.argv:

@@ -10,11 +10,11 @@ mkdir -p "$O"
 cd "$R" || exit 1
 timeout -k 10 600 python3 bench.py > "$O/bench_c2_uniform.json" 2> "$O/bench_c2_uniform.err" || exit 1
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 "$R/bench.py" --steps 50 --warmup 5 --no-cpu-baseline > "$O/rocprof_stats.log" 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$O/pmc_fetch.log" 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$O/pmc_write.log" 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --output-format csv -d "$O/pmc_tcc" -- python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$O/pmc_tcc.log" 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_BUSY_sum --output-format csv -d "$O/pmc_req" -- python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$O/pmc_req.log" 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 "$R/bench.py" --steps 50 --warmup 5 --no-cpu-baseline --no-live-counters > "$O/rocprof_stats.log" 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-live-counters > "$O/pmc_fetch.log" 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-live-counters > "$O/pmc_write.log" 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --output-format csv -d "$O/pmc_tcc" -- python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-live-counters > "$O/pmc_tcc.log" 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_BUSY_sum --output-format csv -d "$O/pmc_req" -- python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-live-counters > "$O/pmc_req.log" 2>&1 || exit 1
 cd "$R" || exit 1
 python3 - "$O" <<'PY'
 import csv, glob, re, statistics, sys
@@ -22,7 +22,7 @@ O = sys.argv[1]
 trace = list(csv.DictReader(open(glob.glob(O + "/stats/*/*_kernel_trace.csv")[0])))
 stats = list(csv.DictReader(open(glob.glob(O + "/stats/*/*_kernel_stats.csv")[0])))
 def short(n):
-    return n.split("(anonymous namespace)::")[-1].split("(")[0]
+    return n.split("(anonymous namespace)::", 1)[-1].split("(")[0]
 def is_trial(n):  # csr_panel_kernel<U, LAYOUT, PIPE, TRIAL, TRACE, SYNCT>
     m = re.search(r"csr_panel_kernel<([^>]*)>", n)
     return bool(m) and m.group(1).split(",")[3].strip() == "true"

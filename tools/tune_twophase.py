@@ -45,7 +45,7 @@ def main():
             A.set_param("twophase_panel_cols", cols)
             A.set_kernel(capi.CSR_TWOPHASE)
         # name, phase alone (0 = both), rotate
-        variants = [("A, every workgroup from its panel's start", 1, 0), ("A", 1, 1), ("B", 2, 1), ("both", 0, 1)]
+        variants = [("A, every workgroup from its panel's start", 1, 0), ("A", 1, 256), ("B", 2, 256), ("both", 0, 256)]
         res = {v[0]: [] for v in variants}
         for _ in range(a.rounds):
             for name, only, rotate in variants:
