@@ -561,18 +561,20 @@ void tp_launch_reduce(spmv_ctx* ctx, const spmv_mat* A, double* y, const apply_e
 }
 
 // Where the PRODUCT stream lies in PHYSICAL memory decides a tenth of the product.  With everything else in place, phase A
-// takes 1.14-1.17 ms on the C5 shard when the stream lies in some regions of the device's memory and 1.32-1.34 ms in others
-// (phase B, which reads it back, 0.565 against 0.548: the opposite way, a fifth as much); nothing else matters - not where the
-// values, columns, rows, table, x or y lie, not the virtual address, not how the memory was allocated (plain, one mapped piece,
-// mapped 1 GB pieces), not the translation (the same 2.4e5 UTCL1 misses of 1.5e8 requests either way).  What differs is how
-// readily the MEMORY takes requests: 5.0-5.4M cycles of "read request stalled: out of DRAM credits" in slow regions against
-// 1.7-2.5M in fast ones, 2.0M against 1.2M for the writes (profiles/r04_pmc_twophase_placement.txt,
-// r04_probe_twophase_placement_cause.txt).  A region keeps its mode for as long as it is held; twelve streams held at once
-// showed four fast and eight slow ones; streams cut from mixed regions land in between in proportion (1.70 / 1.78 / 1.835 /
-// 1.89 ms per product with 3 / 2 / 1 / 0 of three 1 GB pieces fast).  The engine cannot see physical addresses, let alone ask
-// for them.  (Round 4 also tried HIP's virtual memory management - one reserved range, windows of physical pieces mapped in
-// turn - and found that on this ROCm (7.2) a virtual address keeps reaching the FIRST piece ever mapped there, after
-// hipMemUnmap, hipMemAddressFree and a new reservation alike: tools/probe_vm_remap.hip.  Nothing here re-maps anything.)
+// takes 1.14-1.17 ms on the C5 shard on some memory and 1.32-1.34 ms on other (phase B, which reads the products back,
+// 0.565 against 0.548: the opposite way, a fifth as much); nothing else matters - not where the values, columns, rows, table,
+// x or y lie, not the virtual address, not how the memory was allocated, not the translation (the same 2.4e5 UTCL1 misses
+// of 1.5e8 requests either way), not nontemporal against plain stores.  Round 4 found the rule
+// (profiles/r04_probe_twophase_classes.txt, r04_probe_twophase_placement_cause.txt, r04_pmc_twophase_placement.txt): the
+// device's memory comes in THREE CLASSES - gigabytes of one class are slow beside each other under the stream and fast
+// beside gigabytes of another; "slow together" is an equivalence relation with exactly three classes (19 / 14 / 27 of 60
+// consecutively allocated gigabytes, in runs of 2 to 17) - and a stream is fast when its pieces come from different classes
+// (1.70 / 1.78 / 1.835 / 1.89 ms per product from three classes down to one).  Three ranks per 12-high HBM3E stack would
+// look like this: the scattered 64-byte writes of phase A lean on one rank's row activations or on three.  A process can
+// neither see nor ask for the class of the memory it is handed.  (Round 4 also tried HIP's virtual memory management - one
+// reserved range, windows of physical pieces mapped in turn - and found that on this ROCm (7.2) a virtual address keeps
+// reaching the FIRST piece ever mapped there, after hipMemUnmap, hipMemAddressFree and a new reservation alike:
+// tools/probe_vm_remap.hip.  Nothing here maps memory.)
 //
 // So the stream is not one allocation but PIECES of 1 GB (kernels: a table of base addresses in LDS), and which pieces it
 // consists of is CHOSEN by measurement: `extra` more pieces than the stream needs are allocated (plain hipMalloc; the budget

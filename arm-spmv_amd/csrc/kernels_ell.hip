@@ -202,6 +202,8 @@ __device__ __forceinline__ void stage_x_windows(double* xs, const int32_t* __res
     __syncthreads();
 }
 
+// (Round 4 double-buffered the value stream and requested its first group before the x stretches go through LDS: the same
+// time on the same box, 0.398 ms on C3 - profiles/r04_tune_ell_c3_double_buffered.txt - so the simpler form stays.)
 template <int UNROLL, bool XWIN>
 __global__ __launch_bounds__(kBlock) void ell_diag_kernel_x2(int nrow, int k, const int32_t* __restrict__ col,
                                                              const double* __restrict__ val, const double* __restrict__ x,
@@ -209,33 +211,23 @@ __global__ __launch_bounds__(kBlock) void ell_diag_kernel_x2(int nrow, int k, co
                                                              const u64* __restrict__ mask, int ncol)
 {
     extern __shared__ double xs[];  // XWIN: the stretches of x this block's conforming entries read (stage_x_windows)
-    const int  r0     = 2 * kBlock * (int)blockIdx.x;
-    const int  i      = r0 + 2 * (int)threadIdx.x;
-    const bool active = i < nrow;  // nrow even: i+1 < nrow too
-    const size_t stride = (size_t)nrow;
-    // The value stream is double-buffered: the group of slots after the one being multiplied is always in flight, and the
-    // first group is requested BEFORE the block's stretches of x go through LDS, so the workgroup (it lives for ~4 us: 256 KB
-    // of values) does not spend its first HBM latency on x alone (round 4: C3 0.391 -> see DESIGN.md 4.3).
-    f64x2 v[2][UNROLL];
-    f64x2 acc{0.0, 0.0};
-    if (active)
-    {
-        acc = *reinterpret_cast<const f64x2*>(y + i);
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-            if (u < k) v[0][u] = load_stream(reinterpret_cast<const f64x2*>(val + (size_t)i + (size_t)u * stride));
-    }
-    if constexpr (XWIN) stage_x_windows(xs, off, k, x, r0, ncol);  // (a barrier: every thread of the block passes here)
-    if (!active) return;
+    const int r0 = 2 * kBlock * (int)blockIdx.x;
+    if constexpr (XWIN) stage_x_windows(xs, off, k, x, r0, ncol);
+    const int i = r0 + 2 * (int)threadIdx.x;
+    if (i >= nrow) return;  // nrow even: i+1 < nrow too
     const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * kBlock + threadIdx.x) >> 6));
     const u64* __restrict__ wm = mask + (size_t)wave * k;  // this wavefront's words: scalar loads
     const u64 bit = 1ull << (threadIdx.x & 63);
     const int32_t* __restrict__ xbase = off + k;
-    size_t at = (size_t)i;
-    auto   group = [&](int s0, const f64x2(&cur)[UNROLL], f64x2(&nxt)[UNROLL]) {
+    f64x2        acc    = *reinterpret_cast<const f64x2*>(y + i);
+    const size_t stride = (size_t)nrow;
+    size_t       at     = (size_t)i;
+    for (int s0 = 0; s0 < k; s0 += UNROLL)
+    {
+        f64x2 v[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
-            if (s0 + UNROLL + u < k) nxt[u] = load_stream(reinterpret_cast<const f64x2*>(val + at + (size_t)(UNROLL + u) * stride));
+            if (s0 + u < k) v[u] = load_stream(reinterpret_cast<const f64x2*>(val + at + (size_t)u * stride));
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
             if (s0 + u < k)
@@ -263,15 +255,10 @@ __global__ __launch_bounds__(kBlock) void ell_diag_kernel_x2(int nrow, int k, co
                     x0            = x[c.x];
                     x1            = x[c.y];
                 }
-                acc.x = fma(cur[u].x, x0, acc.x);
-                acc.y = fma(cur[u].y, x1, acc.y);
+                acc.x = fma(v[u].x, x0, acc.x);
+                acc.y = fma(v[u].y, x1, acc.y);
             }
         at += (size_t)UNROLL * stride;
-    };
-    for (int s0 = 0; s0 < k; s0 += 2 * UNROLL)
-    {
-        group(s0, v[0], v[1]);
-        if (s0 + UNROLL < k) group(s0 + UNROLL, v[1], v[0]);
     }
     *reinterpret_cast<f64x2*>(y + i) = acc;
 }
