@@ -609,7 +609,10 @@ int tp_search_extra(const spmv_mat* m)
     return extra >= 2 ? extra : 0;  // two reference pieces besides the stream's own are the least the scheme needs
 }
 
-int tp_choose_pieces(spmv_mat* m)
+// `early`: pieces the build allocated BEFORE the layout's own arrays (half the budget): together with the ones allocated here,
+// behind them, the pool spans the build's ~5 GB of other allocations as well - the allocator's runs of one class are long
+// (2-17 GB), so the span is what finds a second and a third class.  Consumed (kept or freed) here.
+int tp_choose_pieces(spmv_mat* m, std::vector<double*> early = {})
 {
     spmv_ctx*    ctx   = m->ctx;
     const size_t piece = (size_t)16 << kTpPieceShift;
@@ -618,13 +621,18 @@ int tp_choose_pieces(spmv_mat* m)
     m->tp_place_seen   = 0;
     m->tp_place_gain   = 0;
     m->tp_pieces_exchanged  = 0;
-    if (extra < 2 || need <= 0 || m->tp_last_piece_bytes != (int64_t)piece) return SPMV_OK;  // (pieces must be interchangeable)
+    if (extra < 2 || need <= 0 || m->tp_last_piece_bytes != (int64_t)piece)  // (pieces must be interchangeable)
+    {
+        for (double* p : early) (void)hipFree(p);
+        return SPMV_OK;
+    }
 
     hipStream_t s = ctx->stream;
     double *    x = nullptr, *y = nullptr;
     hipEvent_t  e0 = nullptr, e1 = nullptr;
     int         rc = SPMV_OK;
     std::vector<double*> cand(m->tp_piece, m->tp_piece + need);  // the stream's own pieces are candidates like the others
+    cand.insert(cand.end(), early.begin(), early.end());
     apply_extra plain;
     // ms per product of the configuration `slots` (piece index per slot; slots past `need` repeat the last: never addressed)
     auto time_config = [&](const std::vector<int>& slots, float* out) -> bool {
@@ -658,7 +666,7 @@ int tp_choose_pieces(spmv_mat* m)
             hipMemsetAsync(x, 0, sizeof(double) * (size_t)m->ncol, s) != hipSuccess || hipMemsetAsync(y, 0, sizeof(double) * (size_t)m->nrow, s) != hipSuccess ||
             hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
             break;  // no room for the scratch vectors: the pieces stay as they are
-        for (int i = 0; i < extra; ++i)
+        for (int i = (int)early.size(); i < extra; ++i)
         {
             double* p = nullptr;
             if (hipMalloc(&p, piece) != hipSuccess)
@@ -842,6 +850,25 @@ int csr_twophase_build(spmv_mat* m)
     int32_t *cnt_pg = nullptr, *cnt_gp = nullptr, *start_pg = nullptr, *start_gp = nullptr, *bpos = nullptr;
     int      rc     = SPMV_OK;
     const size_t kbytes = sizeof(int32_t) * (size_t)(keys + 1);
+    // half of the piece search's extra pieces are allocated now, before the layout's arrays (see tp_choose_pieces); the count
+    // comes from the unpadded entry count (the search itself decides with the padded one; a handful of pieces either way)
+    std::vector<double*> early;
+    {
+        const int64_t saved = m->tp_padded;
+        m->tp_padded        = m->nnz;
+        const int extra     = tp_search_extra(m);
+        m->tp_padded        = saved;
+        for (int i = 0; i < extra / 2; ++i)
+        {
+            double* p = nullptr;
+            if (hipMalloc(&p, (size_t)16 << kTpPieceShift) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                break;
+            }
+            early.push_back(p);
+        }
+    }
     do
     {
         if (hipMalloc(&m->tp_gstart, sizeof(int32_t) * gstart.size()) != hipSuccess || hipMalloc(&cnt_pg, kbytes) != hipSuccess ||
@@ -926,6 +953,7 @@ int csr_twophase_build(spmv_mat* m)
     if (rc != SPMV_OK)
     {
         (void)hipStreamSynchronize(s);
+        for (double* p : early) (void)hipFree(p);
         csr_twophase_free(m);
         SPMV_FAIL(rc, "building the two-phase layout (%d groups x %d panels) failed: %s", ngroups, P, hipGetErrorString(hipGetLastError()));
     }
@@ -937,7 +965,7 @@ int csr_twophase_build(spmv_mat* m)
     m->tp_bytes     = m->tp_padded * 12 + (m->tp_padded + kTpLine - 1) / kTpLine * 8 + (int64_t)(P + 1 + 2 * (ngroups + 1)) * 4 +
                       (int64_t)(m->tp_npieces - 1) * ((int64_t)16 << kTpPieceShift) + m->tp_last_piece_bytes;
     m->device_bytes += m->tp_bytes;
-    rc = tp_choose_pieces(m);
+    rc = tp_choose_pieces(m, std::move(early));
     if (rc != SPMV_OK) csr_twophase_free(m);
     return rc;
 }
