@@ -1214,6 +1214,65 @@ def test_csr_split_columns_is_exact_and_the_parts_add_up(ctx, orc, pkg):
         ol.assert_parity(y.download(), ref[b:e], scale[b:e], f"shard [{b},{e}) split at [{c0},{c1})")
 
 
+def test_twophase_piece_search_is_bounded_and_gives_its_memory_back(ctx, orc, pkg, monkeypatch):
+    """The two-phase layout's product stream lives in 1 GB pieces chosen by timing configurations of a pool: the
+    pool is transient - after the build the device holds the handle's own bytes and nothing of the budget - the outcome is
+    on record, a budget of 0 means no timing launches at all, and whichever pieces are kept the product is the same."""
+    import gc
+
+    capi, synth = pkg.capi, pkg.synth
+    for name in ("SPMV_TP_PLACEMENT_BUDGET_MB", "SPMV_PANEL_TRIAL"):  # (the env sweeps of tools/env_sweeps.sh set these: this test is about the defaults)
+        monkeypatch.delenv(name, raising=False)
+    n, ncol, k = 2_500_000, 40_000_000, 32  # 80M entries: a stream of 0.66 GB (one piece), searched because it is >= 512 MB
+    gc.collect()
+    ctx.sync()
+    free0, _ = ctx.mem_info()
+    A = ctx.gen_csr_uniform(0, n, ncol, k, seed=9)
+    ctx.sync()
+    free1, _ = ctx.mem_info()
+    assert A.info.kernel == capi.CSR_TWOPHASE and A.get_param("twophase_pieces") == 1
+    held = A.get_param("device_bytes")
+    # nothing of the 8 GB budget (nor the scratch vectors) is still held: the device's free memory fell by the handle's bytes
+    assert abs((free0 - free1) - held) < 300 << 20, ((free0 - free1) >> 20, held >> 20)
+    assert A.get_param("twophase_placements_timed") >= 2 and A.get_param("twophase_placement_spread") >= 995
+    assert A.get_param("twophase_placement_budget_mb") == -1  # the default: 8192 MB unless the environment says otherwise
+    x, y, yv = ctx.gen_vector(ncol, seed=9), ctx.vector(n), ctx.vector(n)
+    hx = synth.vec_uniform(ncol, seed=9)
+
+    def check(what):
+        y.fill(0.0)
+        ctx.apply(A, x, y)
+        ctx.sync()
+        hy = y.download()
+        for r0 in (0, 1_234_000, n - 1500):
+            rp, cc, cv = synth.csr_uniform(r0, r0 + 1500, ncol, k, seed=9)
+            ref, scale = np.zeros(1500), np.zeros(1500)
+            ol.csr_spmv(orc, rp, cc, cv, hx, ref)
+            ol.csr_abs_row_sums(orc, rp, cc, cv, hx, scale)
+            ol.assert_parity(hy[r0:r0 + 1500], ref, scale, f"{what}: rows {r0}..")
+        return hy
+
+    first = check("pieces as chosen at build")
+    # the search again with a smaller budget, and switched off: same product, the record follows
+    A.set_param("twophase_placement_budget_mb", 3072)
+    A.set_param("twophase_choose_pieces", 1)
+    assert A.get_param("twophase_placements_timed") >= 2
+    again = check("pieces chosen again within 3 GB")
+    A.set_param("twophase_placement_budget_mb", 0)
+    A.set_param("twophase_choose_pieces", 1)
+    assert A.get_param("twophase_placements_timed") == 0
+    off = check("no search")
+    scale_all = np.maximum(np.abs(first), 1e-300)
+    assert np.max(np.abs(first - again) / (scale_all + 32.0)) <= ol.REL_TOL and np.max(np.abs(first - off) / (scale_all + 32.0)) <= ol.REL_TOL
+    ctx.sync()
+    free2, _ = ctx.mem_info()
+    assert abs((free0 - free2) - A.get_param("device_bytes")) < 1500 << 20  # (x, y, yv of this test: 0.36 GB)
+    monkeypatch.delenv("SPMV_EXPERIMENTS", raising=False)
+    with pytest.raises(capi.SpmvError, match="experiment"):
+        A.set_param("twophase_only", 1)  # refused without SPMV_EXPERIMENTS=1: it would make the product wrong
+    del A, x, y, yv
+
+
 def test_handles_give_their_device_memory_back(ctx, pkg):
     """every layout a handle builds (CSR arrays, panel copy, packed words, slice tables, guard words, the regrouped
     copies of COO / ELL handles, solver work vectors) is released with it"""
