@@ -770,7 +770,7 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
     else if (!strcmp(name, "panel_groups"))
         *value = m->pb_ngroups;
     else if (!strcmp(name, "panel_unroll"))
-        *value = m->pb_unroll > 0 ? m->pb_unroll : (m->pb_unroll_tuned > 0 ? m->pb_unroll_tuned : 8);
+        *value = std::min(8, m->pb_unroll > 0 ? m->pb_unroll : (m->pb_unroll_tuned > 0 ? m->pb_unroll_tuned : 8));  // (16 runs 8 since round 4)
     else if (!strcmp(name, "panel_pace_ns"))
         *value = m->pb_pace_ns;
     else if (!strcmp(name, "panel_bytes"))

@@ -994,7 +994,10 @@ static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, doubl
     // two workgroups share a CU when their accumulators fit twice into the 160 KiB LDS
     const int per_cu = (lds <= 80000 && A->pb_two_per_cu) ? 2 : 1;
     const int grid   = std::min(A->pb_ngroups, kNumCu * per_cu);
-    const int unroll = A->pb_unroll > 0 ? A->pb_unroll : (A->pb_unroll_tuned > 0 ? A->pb_unroll_tuned : 8);
+    // chunks of 2, 4 or 8 x 1024 entries.  16 existed through round 3: every instance of it spilled registers to scratch and
+    // ran slower (C2: 1.70 ms against 1.13, the x window of a chunk leaves L2); a request for 16 runs 8.
+    const int unroll_rq = A->pb_unroll > 0 ? A->pb_unroll : (A->pb_unroll_tuned > 0 ? A->pb_unroll_tuned : 8);
+    const int unroll    = unroll_rq >= 16 ? 8 : unroll_rq;
     // optional clock throttle: nanoseconds per chunk -> 10 ns ticks in 22.10 fixed point
     const unsigned long long pace_fp = A->pb_pace_ns > 0 ? (unsigned long long)((double)A->pb_pace_ns * 102.4) : 0ull;
     const int  sync   = (A->pb_sync >= 0 ? A->pb_sync : A->pb_sync_tuned) & 3;
@@ -1009,7 +1012,7 @@ static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, doubl
     const int32_t* arg_col = layout >= 3 ? (const int32_t*)A->pb_pack : A->pb_col;
     const int      pipe_rq = A->pb_pipe >= 0 ? A->pb_pipe : (A->pb_pipe_tuned > 0 ? A->pb_pipe_tuned : 1);
     // gather-first is instantiated for the chunk sizes that are tried; the others take the stream-first order
-    const int pipe = pipe_rq == 2 && !(unroll == 4 || unroll == 8 || (unroll == 16 && layout >= 3)) ? 1 : std::min(pipe_rq, 2);
+    const int pipe = pipe_rq == 2 && !(unroll == 4 || unroll == 8) ? 1 : std::min(pipe_rq, 2);
 #define SPMV_PANEL_LAUNCH(U, LY, PP, TR, TC, SY)                                                                      \
     {                                                                                                                \
         static std::atomic<unsigned long long> granted{0}; /* bit per device */                                      \
@@ -1056,17 +1059,17 @@ static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, doubl
         if (trial) SPMV_PANEL_LAUNCH(U, LY, PP, true, false, -1)     \
         SPMV_PANEL_LAUNCH(U, LY, PP, false, false, -1)               \
     }
-    SPMV_PANEL_CASE(2, 0, 0) SPMV_PANEL_CASE(4, 0, 0) SPMV_PANEL_CASE(8, 0, 0) SPMV_PANEL_CASE(16, 0, 0)
-    SPMV_PANEL_CASE(2, 3, 0) SPMV_PANEL_CASE(4, 3, 0) SPMV_PANEL_CASE(8, 3, 0) SPMV_PANEL_CASE(16, 3, 0)
-    SPMV_PANEL_CASE(2, 0, 1) SPMV_PANEL_CASE(4, 0, 1) SPMV_PANEL_CASE(8, 0, 1) SPMV_PANEL_CASE(16, 0, 1)
-    SPMV_PANEL_CASE(2, 3, 1) SPMV_PANEL_CASE(4, 3, 1) SPMV_PANEL_CASE(8, 3, 1) SPMV_PANEL_CASE(16, 3, 1)
+    SPMV_PANEL_CASE(2, 0, 0) SPMV_PANEL_CASE(4, 0, 0) SPMV_PANEL_CASE(8, 0, 0)
+    SPMV_PANEL_CASE(2, 3, 0) SPMV_PANEL_CASE(4, 3, 0) SPMV_PANEL_CASE(8, 3, 0)
+    SPMV_PANEL_CASE(2, 0, 1) SPMV_PANEL_CASE(4, 0, 1) SPMV_PANEL_CASE(8, 0, 1)
+    SPMV_PANEL_CASE(2, 3, 1) SPMV_PANEL_CASE(4, 3, 1) SPMV_PANEL_CASE(8, 3, 1)
     SPMV_PANEL_CASE(4, 0, 2) SPMV_PANEL_CASE(8, 0, 2)
-    SPMV_PANEL_CASE(4, 3, 2) SPMV_PANEL_CASE(8, 3, 2) SPMV_PANEL_CASE(16, 3, 2)
-    SPMV_PANEL_CASE(2, 4, 0) SPMV_PANEL_CASE(4, 4, 0) SPMV_PANEL_CASE(8, 4, 0) SPMV_PANEL_CASE(16, 4, 0)
-    SPMV_PANEL_CASE(2, 4, 1) SPMV_PANEL_CASE(4, 4, 1) SPMV_PANEL_CASE(8, 4, 1) SPMV_PANEL_CASE(16, 4, 1)
-    SPMV_PANEL_CASE(4, 4, 2) SPMV_PANEL_CASE(8, 4, 2) SPMV_PANEL_CASE(16, 4, 2)
+    SPMV_PANEL_CASE(4, 3, 2) SPMV_PANEL_CASE(8, 3, 2)
+    SPMV_PANEL_CASE(2, 4, 0) SPMV_PANEL_CASE(4, 4, 0) SPMV_PANEL_CASE(8, 4, 0)
+    SPMV_PANEL_CASE(2, 4, 1) SPMV_PANEL_CASE(4, 4, 1) SPMV_PANEL_CASE(8, 4, 1)
+    SPMV_PANEL_CASE(4, 4, 2) SPMV_PANEL_CASE(8, 4, 2)
 #undef SPMV_PANEL_CASE
 #undef SPMV_PANEL_LAUNCH
-    SPMV_FAIL(SPMV_ERR_INVALID, "panel kernel: unroll=%d is not instantiated (2, 4, 8, 16)", unroll);
+    SPMV_FAIL(SPMV_ERR_INVALID, "panel kernel: unroll=%d is not instantiated (2, 4, 8)", unroll);
 }
 }  // namespace spmv

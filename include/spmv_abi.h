@@ -201,7 +201,8 @@ int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
  *   "panel_aos"      entry layout: 4 = 12-byte packed entries, slices of 1024 stored in interleaved pairs and read with 8- and
  *                    16-byte loads (default; falls back to 0 where padding would outweigh it), 3 = the same without the
  *                    pairing (4-/8-byte loads), 0 = three arrays (14 bytes)
- *   "panel_unroll"   chunk = unroll x 1024 entries: 2, 4, 8 or 16 (0 = by trial)
+ *   "panel_unroll"   chunk = unroll x 1024 entries: 2, 4 or 8 (0 = by trial; 16 existed through round 3 - every instance spilled
+ *                    registers - and now runs 8)
  *   "panel_pipe"     order of a chunk's memory instructions: 0 = no pipelining, 1 = next chunk's stream first,
  *                    2 = this chunk's gathers first (-1 = by trial)
  *   "panel_sync"     how the 16 wavefronts of a workgroup are kept in the same chunk: 0 = not at all (local columns),

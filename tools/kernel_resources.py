@@ -94,10 +94,13 @@ def main() -> int:
     ap.add_argument("--all", action="store_true", help="with --check: print every kernel, not only the matching ones")
     args = ap.parse_args()
     patterns: list[str] = []
+    excluded: list[str] = []  # lines starting with "!": kernels no pattern shall claim (third-party code)
     if args.check:
         for line in Path(args.check).read_text().splitlines():
             line = line.split("#", 1)[0].strip()
-            if line:
+            if line.startswith("!"):
+                excluded.append(line[1:].strip())
+            elif line:
                 patterns.append(line)
     rows = []
     for obj in args.objects:
@@ -108,7 +111,7 @@ def main() -> int:
     matched = {p: 0 for p in patterns}
     print(f"{'kernel':<72} {'vgpr':>4} {'agpr':>4} {'sgpr':>4} {'vspill':>6} {'sspill':>6} {'scratch':>7} {'lds':>6}")
     for k in sorted(rows, key=lambda k: (k["object"], k["short"])):
-        hot = [p for p in patterns if fnmatch.fnmatch(k["short"], p)]
+        hot = [] if any(fnmatch.fnmatch(k["short"], e) for e in excluded) else [p for p in patterns if fnmatch.fnmatch(k["short"], p)]
         for p in hot:
             matched[p] += 1
         if patterns and not hot and not args.all:
