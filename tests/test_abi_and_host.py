@@ -84,3 +84,26 @@ def test_synth_generators_are_index_addressable(pkg):
     # known answers pin the generator itself (splitmix64 reference values)
     assert int(s.splitmix64(np.array([0], dtype=np.uint64))[0]) == 0xE220A8397B1DCDAF
     assert int(s.splitmix64(np.array([1], dtype=np.uint64))[0]) == 0x910A2DEC89025CC1
+
+
+def test_no_kernel_of_the_engine_uses_scratch(tmp_path):
+    """`make engine` is gated by tools/kernel_resources.py --check tools/hot_kernels.txt: a kernel of the engine that spills a
+    register or uses scratch memory fails the build (round 3 shipped a spilling expand kernel whose documentation said it
+    did not).  The same check over the objects of the build that was just loaded; a list whose pattern matches no kernel
+    (a renamed kernel) must fail too."""
+    import glob
+    import subprocess
+    import sys
+
+    objs = sorted(glob.glob(str(ROOT / "build" / "obj" / "*.o")))
+    if not objs:
+        pytest.skip("no object files here (the library travelled without its build directory)")
+    tool = str(ROOT / "tools" / "kernel_resources.py")
+    r = subprocess.run([sys.executable, tool, "--check", str(ROOT / "tools" / "hot_kernels.txt")] + objs, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "none uses scratch" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    n = int(r.stdout.strip().splitlines()[-1].split()[2])
+    assert n >= 300  # every kernel the engine defines (rocPRIM's are excluded by name)
+    bad = tmp_path / "patterns.txt"
+    bad.write_text("csr_panel_kernel<*\nno_such_kernel_anywhere*\n")
+    r = subprocess.run([sys.executable, tool, "--check", str(bad)] + objs, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "matched no kernel" in r.stderr
