@@ -40,7 +40,8 @@
 //   tp_row[e'] (uint16: row - group base; 0xFFFF = padding) e' in (group, panel) order
 //   tp_blk[2 * (e / 16) + {0, 1}]  the two table words of every source line
 //   tp_panel_ptr[P + 1], tp_group_ptr[G + 1]     first entry of every panel in e, of every group in e'
-//   tp_xg[padded nnz]         the stream between the phases (scratch owned by the handle), in e' order
+//   tp_piece[i][...]          the stream between the phases (scratch owned by the handle), in e' order, in pieces of 2^26
+//                             pairs (1 GB): pair t lives at tp_piece[t >> 26] + (t & (2^26 - 1)); see tp_choose_pieces()
 #include <algorithm>
 #include <atomic>
 #include <cmath>
