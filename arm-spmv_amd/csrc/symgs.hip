@@ -27,6 +27,7 @@
 // single workgroup that steps through them with barriers — is fixed at set-up.  The cost is the dependency chain: a
 // 7-point Laplacian on 160^3 points has 478 levels each way, i.e. ~0.7k launches of a few microseconds per sweep.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -61,6 +62,13 @@ struct symgs_plan
     int32_t  mode    = 0;      // 0 the matrix's own order, 1 multicolour
     int32_t  colours = 0;
     int64_t  bytes = 0;
+    // proper colourings (no two coupled rows share a colour: every level is a colour) sweep from a copy of the WHOLE rows in
+    // sweep order - rows of a colour contiguous, columns and vectors in the matrix's own numbering - one launch per colour
+    int32_t*             cs_ptr = nullptr;  // [n + 1]
+    int32_t*             cs_col = nullptr;  // [nnz]
+    double*              cs_val = nullptr;  // [nnz]
+    std::vector<int32_t> cs_first;          // [colours + 1] first sweep position of every colour
+    int32_t              cs_lanes = 4;
 };
 
 namespace
@@ -219,6 +227,67 @@ __global__ __launch_bounds__(kBlock) void tri_residual_kernel(int n, const int32
         for (int j = ptr[i] + l; j < ptr[i + 1]; j += LANES) acc = fma(val[j], x[col[j]], acc);
     acc = group_sum<LANES, true>(acc);
     if (i < n && l == 0) t[i] = b[i] - acc;
+}
+
+// ---- the sweep of a proper colouring: one launch per colour, the residual fused into the solve --------------------------------
+// Rows of a colour are not coupled to each other, so x_i = (b_i - sum_{j != i} a_ij x_j) / a_ii for all of them at once IS the
+// Gauss-Seidel update in sweep order (every x_j it reads belongs to another colour: already updated in this half sweep if
+// that colour came earlier, still the old value if it comes later).  The rows are read from a copy in sweep order (cs_*:
+// contiguous per colour), the vectors stay in the matrix's numbering (x gathers by column as the product does, the result goes
+// to x[seq[k]]): one pass over a colour's rows per launch, against a product over one triangle plus a solve over the other in
+// the general scheme.  Round 3 stored the TRIANGLES in sweep order and permuted the vectors on entry and exit: the
+// permutations cost what the contiguous rows saved (profiles/r03_tune_symgs_sweep_order_storage.txt); here nothing is permuted.
+// flag |= 1 if two coupled rows share a colour (any stored entry (i, c), c != i, with colour[i] == colour[c])
+__global__ __launch_bounds__(kBlock) void gs_proper_kernel(int n, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+                                                           const int32_t* __restrict__ colour, int* __restrict__ flag)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int ci  = colour[i];
+    bool      bad = false;
+    for (int j = row_ptr[i]; j < row_ptr[i + 1]; ++j) bad = bad || (col[j] != i && colour[col[j]] == ci);
+    if (bad) atomicOr(flag, 1);
+}
+__global__ __launch_bounds__(kBlock) void gs_row_lengths_kernel(int n, const int32_t* __restrict__ seq, const int32_t* __restrict__ row_ptr,
+                                                                int32_t* __restrict__ len)
+{
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k > n) return;
+    len[k] = k < n ? row_ptr[seq[k] + 1] - row_ptr[seq[k]] : 0;
+}
+__global__ __launch_bounds__(kBlock) void gs_copy_rows_kernel(int n, const int32_t* __restrict__ seq, const int32_t* __restrict__ row_ptr,
+                                                              const int32_t* __restrict__ col, const double* __restrict__ val,
+                                                              const int32_t* __restrict__ cs_ptr, int32_t* __restrict__ cs_col,
+                                                              double* __restrict__ cs_val)
+{
+    const int gid = blockIdx.x * kBlock + threadIdx.x;
+    const int k = gid / 4, l = gid % 4;  // four lanes per row
+    if (k >= n) return;
+    const int i = seq[k], src = row_ptr[i], dst = cs_ptr[k], len = row_ptr[i + 1] - src;
+    for (int j = l; j < len; j += 4)
+    {
+        cs_col[dst + j] = col[src + j];
+        cs_val[dst + j] = val[src + j];
+    }
+}
+template <int LANES>
+__global__ __launch_bounds__(kBlock) void gs_colour_kernel(int first, int rows, const int32_t* __restrict__ seq, const int32_t* __restrict__ ptr,
+                                                           const int32_t* __restrict__ col, const double* __restrict__ val,
+                                                           const double* __restrict__ diag, const double* __restrict__ b, double* x)
+{
+    const int  gid = blockIdx.x * kBlock + threadIdx.x;
+    const int  r = gid / LANES, l = gid % LANES;
+    const bool on = r < rows;
+    const int  k = first + (on ? r : 0), i = seq[k];
+    double     acc = 0.0;
+    if (on)
+        for (int j = ptr[k] + l; j < ptr[k + 1]; j += LANES)
+        {
+            const int c = col[j];
+            if (c != i) acc = fma(val[j], x[c], acc);  // (x[c] is never written by this launch: c belongs to another colour)
+        }
+    acc = group_sum<LANES, true>(acc);
+    if (on && l == 0) x[i] = (b[i] - acc) / diag[i];
 }
 
 template <int LANES>
@@ -421,6 +490,8 @@ void symgs_free(spmv_mat* m)
     if (m->gs->diag) (void)hipFree(m->gs->diag);
     if (m->gs->t) (void)hipFree(m->gs->t);
     if (m->gs->seq) (void)hipFree(m->gs->seq);
+    for (void* q : {(void*)m->gs->cs_ptr, (void*)m->gs->cs_col, (void*)m->gs->cs_val})
+        if (q) (void)hipFree(q);
     m->device_bytes -= m->gs->bytes;
     delete m->gs;
     m->gs = nullptr;
@@ -547,6 +618,50 @@ int symgs_setup(spmv_mat* m)
         }
         if ((rc = analyse_part(ctx, n, g->lo, "lower")) != SPMV_OK) break;
         if ((rc = analyse_part(ctx, n, g->up, "upper")) != SPMV_OK) break;
+        // A proper colouring (every level of either triangle is one colour): the fused sweep's copy of the rows in sweep order.
+        // SPMV_GS_FUSED=0 keeps the general scheme (A/B; read here, at set-up).
+        const char* e_fused = getenv("SPMV_GS_FUSED");
+        int h_improper = 1;
+        if (g->mode == 1 && g->colours > 0 && g->lo.levels == g->colours && g->up.levels == g->colours && !(e_fused && e_fused[0] == '0') &&
+            m->nnz < INT32_MAX)
+        {
+            // (equal counts of levels and colours are necessary, not sufficient: the colouring itself is checked, entry by entry)
+            (void)hipMemsetAsync(flag, 0, sizeof(int), s);
+            hipLaunchKernelGGL(gs_proper_kernel, dim3((unsigned)ceil_div(n, kBlock)), dim3(kBlock), 0, s, n, m->a, m->b, colour, flag);
+            if (hipMemcpyAsync(&h_improper, flag, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+            {
+                rc = SPMV_ERR_HIP;
+                break;
+            }
+        }
+        if (!h_improper)
+        {
+            g->cs_first.assign((size_t)g->colours + 1, 0);
+            int32_t* len = nullptr;
+            if (hipMalloc(&len, sizeof(int32_t) * ((size_t)n + 1)) != hipSuccess || hipMalloc(&g->cs_ptr, sizeof(int32_t) * ((size_t)n + 1)) != hipSuccess ||
+                hipMalloc(&g->cs_col, sizeof(int32_t) * std::max<size_t>(1, (size_t)m->nnz)) != hipSuccess ||
+                hipMalloc(&g->cs_val, sizeof(double) * std::max<size_t>(1, (size_t)m->nnz)) != hipSuccess)
+            {
+                if (len) (void)hipFree(len);
+                rc = SPMV_ERR_ALLOC;
+                break;
+            }
+            hipLaunchKernelGGL(gs_row_lengths_kernel, dim3((unsigned)ceil_div((int64_t)n + 1, kBlock)), dim3(kBlock), 0, s, n, g->seq, m->a, len);
+            rc = exclusive_scan_i32(ctx, len, g->cs_ptr, (int64_t)n + 1);
+            if (rc == SPMV_OK)
+            {
+                hipLaunchKernelGGL(gs_copy_rows_kernel, dim3((unsigned)ceil_div((int64_t)n * 4, kBlock)), dim3(kBlock), 0, s, n, g->seq, m->a, m->b,
+                                   m->v, g->cs_ptr, g->cs_col, g->cs_val);
+                // the forward triangle's levels ARE the colours (ascending row index inside): its level pointers are the colours' first positions
+                if (hipMemcpyAsync(g->cs_first.data(), g->lo.lvl_ptr, sizeof(int32_t) * ((size_t)g->colours + 1), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                    hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess)
+                    rc = SPMV_ERR_HIP;
+            }
+            (void)hipFree(len);
+            if (rc != SPMV_OK) break;
+            if (g->cs_first.front() != 0 || g->cs_first.back() != n) g->cs_first.clear();  // (never: the general scheme then)
+            g->cs_lanes = m->nnz / std::max(1, n) >= 24 ? 16 : (m->nnz / std::max(1, n) >= 3 ? 4 : 1);
+        }
     } while (0);
     (void)hipStreamSynchronize(s);
     for (int32_t* q : {lo_cnt, up_cnt, colour, pos})
@@ -558,7 +673,8 @@ int symgs_setup(spmv_mat* m)
         if (rc == SPMV_ERR_HIP && hipGetLastError() != hipSuccess) set_error("spmv_symgs: set-up failed: %s", hipGetErrorString(hipGetLastError()));
         return rc;
     }
-    g->bytes = (g->lo.nnz + g->up.nnz) * 12 + (int64_t)n * (8 + 8 + 4 + 4 + 8 + 8 + (g->seq ? 4 : 0)) + (int64_t)(g->lo.levels + g->up.levels) * 4;
+    g->bytes = (g->lo.nnz + g->up.nnz) * 12 + (int64_t)n * (8 + 8 + 4 + 4 + 8 + 8 + (g->seq ? 4 : 0)) + (int64_t)(g->lo.levels + g->up.levels) * 4 +
+               (g->cs_ptr ? m->nnz * 12 + ((int64_t)n + 1) * 4 : 0);
     m->device_bytes += g->bytes;
     return SPMV_OK;
 }
@@ -574,6 +690,27 @@ int symgs_sweep(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, bo
     if (!g->lo.ptr || !g->up.ptr || !g->lo.order || !g->up.order || !g->lo.lvl_ptr || !g->up.lvl_ptr || !g->diag || !g->t || !b || !x)
         SPMV_FAIL(SPMV_ERR_INVALID, "spmv_symgs: the plan of this handle is incomplete");
     hipStream_t s = ctx->stream;
+    if (g->cs_ptr && g->seq && !g->cs_first.empty())
+    {
+        // a proper colouring: forward through the colours, backward from the last but one (the last colour's rows would be
+        // recomputed from the very same values)
+        if (zero_guess) SPMV_HIP(hipMemsetAsync(x, 0, sizeof(double) * (size_t)n, s));
+        auto colour = [&](int c) {
+            const int first = g->cs_first[(size_t)c], rows = g->cs_first[(size_t)c + 1] - first;
+            if (rows <= 0) return;
+            const unsigned grid = (unsigned)ceil_div((int64_t)rows * g->cs_lanes, kBlock);
+            if (g->cs_lanes == 1)
+                hipLaunchKernelGGL(gs_colour_kernel<1>, dim3(grid), dim3(kBlock), 0, s, first, rows, g->seq, g->cs_ptr, g->cs_col, g->cs_val, g->diag, b, x);
+            else if (g->cs_lanes == 4)
+                hipLaunchKernelGGL(gs_colour_kernel<4>, dim3(grid), dim3(kBlock), 0, s, first, rows, g->seq, g->cs_ptr, g->cs_col, g->cs_val, g->diag, b, x);
+            else
+                hipLaunchKernelGGL(gs_colour_kernel<16>, dim3(grid), dim3(kBlock), 0, s, first, rows, g->seq, g->cs_ptr, g->cs_col, g->cs_val, g->diag, b, x);
+        };
+        for (int c = 0; c < g->colours; ++c) colour(c);
+        for (int c = g->colours - 2; c >= 0; --c) colour(c);
+        SPMV_HIP(hipGetLastError());
+        return SPMV_OK;
+    }
     if (zero_guess)
         solve(s, g->lo, g->diag, b, x);  // t = b - U 0
     else
@@ -609,8 +746,10 @@ int symgs_info(const spmv_mat* m, const char* what, int64_t* value)
         *value = g ? g->lo.levels : 0;
     else if (!strcmp(what, "symgs_levels_backward"))
         *value = g ? g->up.levels : 0;
-    else if (!strcmp(what, "symgs_launches"))  // per sweep from a non-zero x: two products and the two schedules
-        *value = g ? (int64_t)(2 + g->lo.schedule.size() + g->up.schedule.size()) : 0;
+    else if (!strcmp(what, "symgs_launches"))  // per sweep from a non-zero x: two products and the two schedules; fused: 2 colours - 1
+        *value = g ? (g->cs_ptr && !g->cs_first.empty() ? (int64_t)(2 * g->colours - 1) : (int64_t)(2 + g->lo.schedule.size() + g->up.schedule.size())) : 0;
+    else if (!strcmp(what, "symgs_fused"))  // 1: a proper colouring swept with one launch per colour from the rows in sweep order
+        *value = g && g->cs_ptr && !g->cs_first.empty() ? 1 : 0;
     else if (!strcmp(what, "symgs_bytes"))
         *value = g ? g->bytes : 0;
     else if (!strcmp(what, "symgs_colours"))  // 0: the matrix's own order

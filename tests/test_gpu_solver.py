@@ -295,7 +295,21 @@ def test_symgs_matches_the_sweep_in_the_same_order(ctx, orc, pkg, problem, order
         ctx.sync()
         _symgs_close(x.download(), want, f"{problem} order {order}: {sweeps} sweeps")
     lf, lb = A.get_param("symgs_levels_forward"), A.get_param("symgs_levels_backward")
-    assert 1 <= lf <= n and 1 <= lb <= n and A.get_param("symgs_launches") >= 4
+    fused = A.get_param("symgs_fused")
+    assert 1 <= lf <= n and 1 <= lb <= n and A.get_param("symgs_launches") >= (1 if fused else 4)
+    if order == 1:
+        # a proper colouring (no stored entry couples two rows of one colour) is swept with one launch per colour, forward
+        # through all of them and back from the last but one; anything else takes the general scheme (levels inside colours)
+        proper = not np.any((colour[np.repeat(np.arange(n), np.diff(rp))] == colour[cc]) & (np.repeat(np.arange(n), np.diff(rp)) != cc))
+        assert bool(fused) == (proper and (lf, lb) == (ncol, ncol)), (problem, fused, proper, lf, lb, ncol)
+        if fused:
+            assert A.get_param("symgs_launches") == 2 * ncol - 1
+        if problem in ("tridiagonal_8", "laplacian_3d"):
+            assert fused == 1
+        if problem == "random_pattern":
+            assert fused == 0  # a_ij without a_ji: two coupled rows can share a colour
+    else:
+        assert fused == 0
     if levels and order == 0:
         assert (lf, lb) == levels, (lf, lb, levels)
     if colours and order == 1:
