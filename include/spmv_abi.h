@@ -248,7 +248,8 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value);
  * "twophase_placement_budget_mb", "twophase_placements_timed" (configurations of pieces timed by the search, 0 = no search ran),
  * "twophase_placement_spread" (time as built / time kept, in 1/1000), "twophase_pieces_exchanged", "ell_diagonal_slots" (1: the slots of an ELL
  * handle were found to be diagonals and conforming rows read no column index), "symgs_order", "symgs_colours",
- * "symgs_levels_forward", "symgs_levels_backward", "symgs_launches", "symgs_bytes". */
+ * "symgs_levels_forward", "symgs_levels_backward", "symgs_launches", "symgs_bytes", "symgs_fused" (1: the colouring is proper and
+ * the sweep takes one launch per colour). */
 int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value);
 /* Copy the arrays of a handle back to the host (any pointer may be NULL to skip it).
  *   CSR: a=row_ptr[nrow+1]  b=col_ind[nnz]      v=values[nnz]
