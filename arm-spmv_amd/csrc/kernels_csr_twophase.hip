@@ -810,6 +810,7 @@ int csr_twophase_pool_config(spmv_mat* m, int64_t code)  // 6 bits per slot
 int csr_twophase_choose_again(spmv_mat* m)
 {
     SPMV_REQUIRE(m->tp_val && m->tp_padded > 0 && m->tp_npieces > 0, "the two-phase layout is not built");
+    SPMV_REQUIRE(!m->tp_pool, "twophase_choose_pieces: this handle's pieces belong to an experiment's pool (twophase_pool_alloc)");
     SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
     const int64_t whole = (int64_t)16 << kTpPieceShift;
     if (m->tp_last_piece_bytes != whole && tp_search_extra(m) > 0)
