@@ -485,9 +485,10 @@ def main() -> None:
     ap.add_argument("--keep-csr", action="store_true", help="keep col_ind / values of the CSR copy next to the panel layout")
     ap.add_argument("--no-extra", action="store_true", help="skip the C3 / C4 / band lines after the headline loop")
     ap.add_argument("--no-live-counters", action="store_true", help="do not run the two rocprofv3 --pmc passes; use profiles/pmc_traffic.json")
-    ap.add_argument("--placement-budget-mb", type=int, default=24576,
+    ap.add_argument("--placement-budget-mb", type=int, default=0,
                     help="two-phase shards (x several times longer than the shard has rows: N >= 4): device memory the piece search of the product "
-                         "stream may hold while it runs (the engine's own default is 8192; include/spmv_abi.h, 'twophase_placement_budget_mb')")
+                         "stream may hold while it runs; 0 = 24576 at N > 1 (one slow rank sets the step of the whole job, and the job has the "
+                         "devices to itself) and the engine's own default, 8192, at N = 1 (include/spmv_abi.h, 'twophase_placement_budget_mb')")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
@@ -513,6 +514,8 @@ def main() -> None:
     shard = importlib.import_module("arm_spmv_amd.dist")  # row-range sharding + the x all-gather
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.placement_budget_mb <= 0:
+        args.placement_budget_mb = 24576 if world > 1 else 8192
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
@@ -752,10 +755,9 @@ def main() -> None:
                     return M
                 one(f"C5 shard: what the last rank of 8 holds in BASELINE configs[4] (rows {7 * n}-{8 * n} of {8 * n} x {8 * n}, {k} per row; "
                     "x = 640 MB resident); the engine's defaults (piece search within 8 GB)", "csr", c5_shard, tkey=f"csr_n{n}_k{k}_band0_ncol{8 * n}")
-                if args.placement_budget_mb != 8192:
-                    one(f"C5 shard, piece search of the product stream within {args.placement_budget_mb} MB (what this bench grants its two-phase "
-                        "shards at N >= 4: --placement-budget-mb)", "csr", lambda: c5_shard(args.placement_budget_mb),
-                        tkey=f"csr_n{n}_k{k}_band0_ncol{8 * n}")
+                big = args.placement_budget_mb if args.placement_budget_mb != 8192 else 24576
+                one(f"C5 shard, piece search of the product stream within {big} MB (what this bench grants its two-phase shards at N > 1: "
+                    "--placement-budget-mb)", "csr", lambda: c5_shard(big), tkey=f"csr_n{n}_k{k}_band0_ncol{8 * n}")
 
         # every rank's own kernel time (the headline takes the slowest): shows whether one rank's placement / layout lags
         per_rank_ms = [round(kernel_ms, 5)]
