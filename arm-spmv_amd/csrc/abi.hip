@@ -671,7 +671,7 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
     }
     else if (!strcmp(name, "twophase_panel_cols"))  // takes effect at the next spmv_mat_set_kernel(TWOPHASE)
         m->tp_pcols_req = (int32_t)value;
-    else if (!strcmp(name, "twophase_placement_budget_mb") || !strcmp(name, "placement_budget_mb"))
+    else if (!strcmp(name, "twophase_placement_budget_mb"))
     {
         // memory (MB) the piece search of the two-phase layout may hold beyond the product stream while it runs; 0 = no
         // search; -1 = the default (SPMV_TP_PLACEMENT_BUDGET_MB or 8192).  Takes effect at the next spmv_mat_set_kernel(TWOPHASE)
@@ -799,9 +799,9 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         *value = m->ell_diag ? 1 : 0;
     else if (!strcmp(name, "twophase_panel_cols"))
         *value = m->tp_pcols;
-    else if (!strcmp(name, "twophase_placements_timed") || !strcmp(name, "placement_candidates_timed"))
+    else if (!strcmp(name, "twophase_placements_timed"))
         *value = m->tp_place_seen;
-    else if (!strcmp(name, "twophase_placement_spread") || !strcmp(name, "placement_spread"))  // slowest / kept placement of the product stream, in 1/1000
+    else if (!strcmp(name, "twophase_placement_spread"))  // slowest / kept placement of the product stream, in 1/1000
         *value = m->tp_place_gain;
     else if (!strcmp(name, "twophase_padded"))
         *value = m->tp_padded;
@@ -809,7 +809,7 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         *value = m->tp_npieces;
     else if (!strcmp(name, "twophase_pieces_exchanged"))  // of them: exchanged for other pieces by the search
         *value = m->tp_pieces_exchanged;
-    else if (!strcmp(name, "twophase_placement_budget_mb") || !strcmp(name, "placement_budget_mb"))
+    else if (!strcmp(name, "twophase_placement_budget_mb"))
         *value = m->tp_place_budget_mb;
     else if (!strcmp(name, "window_max_span"))
         *value = m->win_max_span;
