@@ -801,7 +801,7 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         *value = m->tp_pcols;
     else if (!strcmp(name, "twophase_placements_timed"))
         *value = m->tp_place_seen;
-    else if (!strcmp(name, "twophase_placement_spread"))  // slowest / kept placement of the product stream, in 1/1000
+    else if (!strcmp(name, "twophase_placement_spread"))  // time as built / time with the pieces the search kept, in 1/1000
         *value = m->tp_place_gain;
     else if (!strcmp(name, "twophase_padded"))
         *value = m->tp_padded;
