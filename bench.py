@@ -403,6 +403,31 @@ def pmc_child(args) -> None:
     print(json.dumps({"pmc_child": True, "kernel_id": int(A.info.kernel), "panel_layout": layout}), flush=True)
 
 
+PRODUCT_KERNELS = {4: ("csr_panel_kernel",), 5: ("tp_expand_kernel", "tp_reduce_kernel"), 1: ("csr_vector_kernel",), 2: ("csr_ldswin_kernel",),
+                   3: ("csr_scalar_kernel",)}
+
+
+def pmc_mean_of_products(rows: list, kernel_id: int):
+    """From the rows of one counter of a rocprofv3 counter_collection.csv (dicts with Kernel_Name, Dispatch_Id, Counter_Value):
+    per kernel of the product `kernel_id` runs, the mean counter value of its LAST THREE dispatches (the child's three products
+    after the warm-up; the panel kernel's trial launches - `true` as the fourth template argument - are not products), and the
+    short name of the last kernel.  Returns ({kernel: mean}, name) or a string saying what is missing."""
+    per_kernel, shown = {}, None
+    for name in PRODUCT_KERNELS.get(kernel_id, ()):
+        mine = [row for row in rows if name in row["Kernel_Name"]]
+        if name == "csr_panel_kernel":  # template <U, LAYOUT, PIPE, TRIAL, TRACE, SYNC>
+            mine = [row for row in mine if row["Kernel_Name"].split("csr_panel_kernel<")[1].split(">")[0].split(",")[3].strip() == "false"]
+        mine.sort(key=lambda row: int(row["Dispatch_Id"]))
+        last = mine[-3:]
+        if len(last) < 3:
+            return f"fewer than 3 dispatches of {name}"
+        per_kernel[name] = sum(float(row["Counter_Value"]) for row in last) / len(last)
+        shown = last[-1]["Kernel_Name"].split("(anonymous namespace)::", 1)[-1].split("(")[0]
+    if not per_kernel:
+        return f"no product kernel known for kernel id {kernel_id}"
+    return per_kernel, shown
+
+
 def live_counters(args) -> dict:
     """HBM-side traffic of the dominant kernel measured NOW, by this very bench.py: two rocprofv3 --pmc passes (FETCH_SIZE
     and WRITE_SIZE separately: they do not fit one pass, MI355X_MICROARCH.md 'rocprofv3 PMC slots') over `--pmc-child`,
@@ -442,20 +467,10 @@ def live_counters(args) -> dict:
             rows = []
             for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
                 rows += [row for row in csv.DictReader(open(f)) if row["Counter_Name"] == counter]
-            kid = out["child"]["kernel_id"]
-            want = {4: ("csr_panel_kernel",), 5: ("tp_expand_kernel", "tp_reduce_kernel"), 1: ("csr_vector_kernel",), 2: ("csr_ldswin_kernel",),
-                    3: ("csr_scalar_kernel",)}.get(kid, ())
-            per_kernel = {}
-            for name in want:
-                mine = [row for row in rows if name in row["Kernel_Name"]]
-                if name == "csr_panel_kernel":  # product launches only: template <U, LAYOUT, PIPE, TRIAL, TRACE, SYNC>
-                    mine = [row for row in mine if row["Kernel_Name"].split("csr_panel_kernel<")[1].split(">")[0].split(",")[3].strip() == "false"]
-                mine.sort(key=lambda row: int(row["Dispatch_Id"]))
-                last = mine[-3:]  # the three products after the warm-up
-                if len(last) < 3:
-                    return dict(out, error=f"{counter} pass: fewer than 3 dispatches of {name}")
-                per_kernel[name] = sum(float(row["Counter_Value"]) for row in last) / len(last)
-                out["kernel"] = last[-1]["Kernel_Name"].split("(anonymous namespace)::", 1)[-1].split("(")[0]
+            got = pmc_mean_of_products(rows, out["child"]["kernel_id"])
+            if isinstance(got, str):
+                return dict(out, error=f"{counter} pass: {got}")
+            per_kernel, out["kernel"] = got
             sums[counter] = sum(per_kernel.values())
     out["traffic"] = int(round((2.0 * sums["FETCH_SIZE"] + sums["WRITE_SIZE"]) * 1024))
     out["fetch_size_kb"], out["write_size_kb"] = round(sums["FETCH_SIZE"], 1), round(sums["WRITE_SIZE"], 1)

@@ -38,3 +38,25 @@ def test_counters_are_reported_only_for_the_kernel_and_layout_they_were_measured
     for name, e in table.items():
         if isinstance(e, dict) and "match" in e:
             assert e["match"].get("kernel"), name
+
+
+def test_live_counter_rows_are_reduced_to_the_products_of_the_right_kernel():
+    """bench.py's own --pmc passes: of a counter_collection.csv only the last three PRODUCT launches of the kernel that ran count
+    (trial launches of the panel kernel carry `true` as their fourth template argument; set-up kernels are other kernels)"""
+    ns = "spmv::(anonymous namespace)::"
+    sig = "(int const*, int, int const*)"
+    rows = []
+    did = 0
+    for name, val in ([(ns + "gen_csr_uniform_kernel(long)", 9e9)] + [(ns + "csr_panel_kernel<8, 4, 2, true, false, 1>" + sig, 1e9)] * 8 +
+                      [(ns + "csr_panel_kernel<8, 4, 2, false, false, 1>" + sig, v) for v in (7.0, 100.0, 101.0, 102.0)]):
+        did += 1
+        rows.append({"Kernel_Name": name, "Dispatch_Id": str(did), "Counter_Value": str(val), "Counter_Name": "FETCH_SIZE"})
+    per, shown = bench.pmc_mean_of_products(rows, 4)
+    assert per == {"csr_panel_kernel": 101.0} and shown == "csr_panel_kernel<8, 4, 2, false, false, 1>"
+    # the two-phase product is two kernels; their means add up in the caller
+    tp = [{"Kernel_Name": ns + n + "(int, spmv::(anonymous namespace)::tp_piece_tab, int)", "Dispatch_Id": str(i), "Counter_Value": str(v)}
+          for i, (n, v) in enumerate([("tp_expand_kernel<1024, 3, true>", 5.0), ("tp_reduce_kernel", 1.0)] * 4)]
+    per, shown = bench.pmc_mean_of_products(tp, 5)
+    assert per == {"tp_expand_kernel": 5.0, "tp_reduce_kernel": 1.0} and shown == "tp_reduce_kernel"
+    assert "fewer than 3" in bench.pmc_mean_of_products(rows[:10], 4)
+    assert "no product kernel" in bench.pmc_mean_of_products(rows, 99)
