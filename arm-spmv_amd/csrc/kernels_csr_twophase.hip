@@ -306,7 +306,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
                 f64x2          o;
                 o.x = vv[k].x * xs[cc[k].x];
                 o.y = vv[k].y * xs[cc[k].y];
-                // the pair's piece from the table in LDS, its place inside the piece in 28 bits
+                // the pair's piece from the table in LDS, its place inside the piece in 28 bits.  (A scalar base picked with
+                // readfirstlane + ballot where a wavefront writes into one piece - nearly always - and an SGPR-base store were
+                // measured: phase A 1.43 ms against 1.22 with the look-up for every pair; round 4, not kept.)
                 char* const ob = tab[dst >> kTpPieceShift];
                 // (nontemporal or plain stores: the same time in fast and slow placements alike, profiles/r04_probe_twophase_classes.txt)
                 __builtin_nontemporal_store(o, reinterpret_cast<f64x2*>(ob + ((dst & ((1u << kTpPieceShift) - 1u)) << 4)));
