@@ -1214,6 +1214,42 @@ def test_csr_split_columns_is_exact_and_the_parts_add_up(ctx, orc, pkg):
         ol.assert_parity(y.download(), ref[b:e], scale[b:e], f"shard [{b},{e}) split at [{c0},{c1})")
 
 
+def test_twophase_stream_in_four_pieces_agrees_with_the_row_parallel_kernel(ctx, orc, pkg):
+    """The largest product stream the two-phase layout holds takes all four 1 GB pieces of its table (just under 2^29 padded
+    entries): 12.6M rows x 32 over 100M columns.  Every piece boundary lies inside some row group's stretch; the product is
+    compared with the row-parallel kernel over ALL rows (scaled by (|A||x|)_i) and with the oracle on sampled rows."""
+    synth, capi = pkg.synth, pkg.capi
+    n, ncol, k = 12_600_000, 100_000_000, 32
+    free, _ = ctx.mem_info()
+    if free < 60 * 2**30:
+        pytest.skip("needs ~35 GB of device memory")
+    A = ctx.gen_csr_uniform(0, n, ncol, k, seed=11)
+    assert A.info.kernel == capi.CSR_TWOPHASE and A.get_param("twophase_pieces") == 4
+    assert 3 * 2**27 < A.get_param("twophase_padded") < 2**29
+    x = ctx.gen_vector(ncol, seed=11)
+    hx = synth.vec_uniform(ncol, seed=11)
+    y, yv = ctx.vector(n), ctx.vector(n)
+    y.fill(0.0)
+    ctx.apply(A, x, y)
+    ctx.sync()
+    hy = y.download()
+    for r0 in (0, 6_300_000, n - 1000):
+        rp, cc, cv = synth.csr_uniform(r0, r0 + 1000, ncol, k, seed=11)
+        ref, scale = np.zeros(1000), np.zeros(1000)
+        ol.csr_spmv(orc, rp, cc, cv, hx, ref)
+        ol.csr_abs_row_sums(orc, rp, cc, cv, hx, scale)
+        ol.assert_parity(hy[r0:r0 + 1000], ref, scale, f"four pieces: rows {r0}..")
+    scale = _abs_row_scale(ctx, pkg, A, x)
+    A.set_kernel(capi.CSR_VECTOR)
+    yv.fill(0.0)
+    ctx.apply(A, x, yv)
+    ctx.sync()
+    hv = yv.download()
+    err = np.abs(hy - hv) / scale
+    worst = int(np.argmax(err))
+    assert err[worst] <= ol.REL_TOL, f"two-phase (4 pieces) vs row-parallel: row {worst}: {hy[worst]!r} vs {hv[worst]!r}, scaled {err[worst]:.3e}"
+
+
 def test_twophase_piece_search_is_bounded_and_gives_its_memory_back(ctx, orc, pkg, monkeypatch):
     """The two-phase layout's product stream lives in 1 GB pieces chosen by timing configurations of a pool: the
     pool is transient - after the build the device holds the handle's own bytes and nothing of the budget - the outcome is
