@@ -794,14 +794,14 @@ int csr_twophase_pool_alloc(spmv_mat* m, int extra)
     }
     return SPMV_OK;
 }
-int csr_twophase_pool_config(spmv_mat* m, int64_t code)  // 6 bits per slot
+int csr_twophase_pool_config(spmv_mat* m, int64_t code)  // 10 bits per slot
 {
     SPMV_REQUIRE(m->tp_pool, "twophase_pool_config: no pool (twophase_pool_alloc first)");
     auto* pool = (tp_pool*)m->tp_pool;
     SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
     for (int i = 0; i < m->tp_npieces; ++i)
     {
-        const size_t idx = (size_t)((code >> (6 * i)) & 63);
+        const size_t idx = (size_t)((code >> (10 * i)) & 1023);
         SPMV_REQUIRE(idx < pool->piece.size(), "twophase_pool_config: piece %zu of %zu", idx, pool->piece.size());
         m->tp_piece[i] = pool->piece[idx];
     }

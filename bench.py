@@ -502,8 +502,9 @@ def main() -> None:
     ap.add_argument("--no-live-counters", action="store_true", help="do not run the two rocprofv3 --pmc passes; use profiles/pmc_traffic.json")
     ap.add_argument("--placement-budget-mb", type=int, default=0,
                     help="two-phase shards (x several times longer than the shard has rows: N >= 4): device memory the piece search of the product "
-                         "stream may hold while it runs; 0 = 24576 at N > 1 (one slow rank sets the step of the whole job, and the job has the "
-                         "devices to itself) and the engine's own default, 8192, at N = 1 (include/spmv_abi.h, 'twophase_placement_budget_mb')")
+                         "stream may hold while it runs; 0 = 65536 at N > 1 (one slow rank sets the step of the whole job, the job has the devices "
+                         "to itself, and the device's memory comes in one-class chunks of up to ~60 GB: DESIGN 4.7) and the engine's own default, "
+                         "8192, at N = 1 (include/spmv_abi.h, 'twophase_placement_budget_mb')")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
@@ -530,7 +531,7 @@ def main() -> None:
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.placement_budget_mb <= 0:
-        args.placement_budget_mb = 24576 if world > 1 else 8192
+        args.placement_budget_mb = 65536 if world > 1 else 8192
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
@@ -770,7 +771,7 @@ def main() -> None:
                     return M
                 one(f"C5 shard: what the last rank of 8 holds in BASELINE configs[4] (rows {7 * n}-{8 * n} of {8 * n} x {8 * n}, {k} per row; "
                     "x = 640 MB resident); the engine's defaults (piece search within 8 GB)", "csr", c5_shard, tkey=f"csr_n{n}_k{k}_band0_ncol{8 * n}")
-                big = args.placement_budget_mb if args.placement_budget_mb != 8192 else 24576
+                big = args.placement_budget_mb if args.placement_budget_mb != 8192 else 65536
                 one(f"C5 shard, piece search of the product stream within {big} MB (what this bench grants its two-phase shards at N > 1: "
                     "--placement-budget-mb)", "csr", lambda: c5_shard(big), tkey=f"csr_n{n}_k{k}_band0_ncol{8 * n}")
 

@@ -30,7 +30,7 @@ def main():
     A.set_param("twophase_pool_alloc", pool - 2)
 
     def t(a, b):
-        A.set_param("twophase_pool_config", a | (b << 6))
+        A.set_param("twophase_pool_config", a | (b << 10))
         ctx.apply(A, x, y)
         return statistics.median(ctx.apply_timed(A, x, y, 4) for _ in range(2))
 

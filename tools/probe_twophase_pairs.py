@@ -30,7 +30,7 @@ def main():
     print(f"{n} rows x {k}, {ncol} columns: the stream takes {need} piece(s); pool of {pool}", flush=True)
 
     def t(cfg):
-        code = sum(p << (6 * i) for i, p in enumerate(cfg))
+        code = sum(p << (10 * i) for i, p in enumerate(cfg))
         A.set_param("twophase_pool_config", code)
         ctx.apply(A, x, y)
         return statistics.median(ctx.apply_timed(A, x, y, 4) for _ in range(3))

@@ -29,7 +29,7 @@ def main():
     A.set_param("twophase_pool_alloc", pool - 2)
 
     def t(cfg, only=0, reps=6):
-        A.set_param("twophase_pool_config", cfg[0] | (cfg[1] << 6))
+        A.set_param("twophase_pool_config", cfg[0] | (cfg[1] << 10))
         A.set_param("twophase_only", only)
         ctx.apply(A, x, y)
         v = statistics.median(ctx.apply_timed(A, x, y, reps) for _ in range(3))
