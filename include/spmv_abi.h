@@ -233,10 +233,11 @@ int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
  *                    are never searched.  The outcome is reported by spmv_mat_get_param (below); a timing launch that fails
  *                    is an error of the call, not a silent fallback.
  *   "twophase_rotate"   1 (default): workgroup b of the expand phase starts b / 256 of the way through its panels
- *   "twophase_only", "twophase_realloc"   experiments, refused unless SPMV_EXPERIMENTS=1 is in the environment: run phase A
- *                    (1) or B (2) alone - THE PRODUCT IS THEN WRONG - and move streams of the built layout to fresh
- *                    allocations (bits 1 products, 2 values, 4 columns, 8 rows, 16 table): tools/tune_twophase.py,
- *                    tools/probe_twophase_moves.py
+ *   "twophase_only", "twophase_realloc", "twophase_pool_alloc", "twophase_pool_config"   experiments, refused unless
+ *                    SPMV_EXPERIMENTS=1 is in the environment: run phase A (1) or B (2) alone - THE PRODUCT IS THEN WRONG -,
+ *                    move streams of the built layout to fresh allocations (bits 1 products, 2 values, 4 columns, 8 rows,
+ *                    16 table), hold a pool of pieces and put any of them under the product stream (10 bits per slot):
+ *                    tools/tune_twophase.py, tools/probe_twophase_{moves,pairs,classes,rotate}.py
  *   "symgs_order"    sweep order of spmv_symgs / SPMV_PRECOND_SYMGS: 1 multicolour (default), 0 the matrix's own row order
  *   "panel_trace", "panel_legacy", "panel_two_per_cu"
  *                    diagnostics and experiments kept for the record (tools/trace_panel.py) */
