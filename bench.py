@@ -541,6 +541,8 @@ def main() -> None:
     # SPMV_BENCH_BACKEND=gloo rehearses the N>1 control flow with several ranks on ONE GPU (RCCL needs one GPU per
     # rank); the measured configuration is always the default: nccl (= RCCL on ROCm), rank r on GPU r
     backend = os.environ.get("SPMV_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        args.placement_budget_mb = min(args.placement_budget_mb, 8192)  # rehearsal: the ranks share ONE device's memory
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
