@@ -8,7 +8,7 @@
 //   spmv_main <file.mtx> <nshards> [options]          nshards plays the role of main.cpp's nthreads (argv[2])
 //   spmv_main --synthetic uniform|band --n N [--k K] [--band W] [--seed S] <nshards> [options]
 //   spmv_main --synthetic uniform|band --n ROWS_PER_SHARD [--k K] [--band W] [--seed S] --sharded --gpus P [--reps R]
-//             [--check-rows C --check-out FILE]
+//             [--check-rows C --check-out FILE] [--placement-budget-mb M]
 //        the sharded driver at BASELINE sizes (configs[4]: --n 10000000 --k 32 --gpus 8): P row shards of a
 //        (P*n x P*n) matrix, every shard GENERATED ON ITS DEVICE (no host container, so no int32 entry count in the way:
 //        the reference's CSRMatrixMatVectorNuma cannot hold 2.56e9 entries, src/mat_vec.cpp:260-263 rebases per shard for
@@ -42,6 +42,7 @@ struct Options
     unsigned long long seed = 1;
     bool dropin = true, numa = true, verify = false, sharded = false;
     int         gpus = 1, check_rows = 0;
+    long long   placement_budget_mb = -1;  // --sharded: two-phase shards' piece search (-1: the engine's default, 8192)
     std::string check_out;
     bool has(const char* f) const { return ("," + formats + ",").find(std::string(",") + f + ",") != std::string::npos; }
 };
@@ -134,6 +135,13 @@ int run_sharded_synthetic(const Options& o)
         off[(size_t)i + 1] = r1;
         check(spmv_gen_csr_uniform(ctx[(size_t)i], r0, r1, ncol, o.k, band, o.seed, &mat[(size_t)i]), "spmv_gen_csr_uniform(shard)");
         check(spmv_mat_get_info(mat[(size_t)i], &info[(size_t)i]), "spmv_mat_get_info");
+        if (info[(size_t)i].kernel == SPMV_CSR_TWOPHASE && o.placement_budget_mb >= 0)
+        {
+            // a job that has the devices to itself may grant the product stream's piece search more than the engine's 8 GB
+            // (one slow shard sets the step of all of them)
+            check(spmv_mat_set_param(mat[(size_t)i], "twophase_placement_budget_mb", o.placement_budget_mb), "twophase_placement_budget_mb");
+            check(spmv_mat_set_param(mat[(size_t)i], "twophase_choose_pieces", 1), "twophase_choose_pieces");
+        }
         if (info[(size_t)i].kernel == SPMV_CSR_PANEL || info[(size_t)i].kernel == SPMV_CSR_TWOPHASE)
             check(spmv_mat_set_param(mat[(size_t)i], "panel_keep_csr", 0), "panel_keep_csr");  // the product's own layout only: 1x the matrix
         int64_t held = 0;
@@ -256,7 +264,7 @@ int usage()
 {
     printf("Usage: spmv_main <file.mtx> <nshards> [--format coo,csr,csc,ell,dia] [--reps R] [--verify] [--no-dropin] [--no-numa]\n"
            "       spmv_main --synthetic uniform|band --n N [--k K] [--band W] [--seed S] <nshards> [...]\n"
-           "       spmv_main --synthetic uniform|band --n ROWS_PER_SHARD [--k K] [--band W] --sharded --gpus P [--reps R] [--check-rows C --check-out FILE]\n");
+           "       spmv_main --synthetic uniform|band --n ROWS_PER_SHARD [--k K] [--band W] --sharded --gpus P [--reps R] [--check-rows C --check-out FILE] [--placement-budget-mb M]\n");
     return -1;
 }
 }  // namespace
@@ -280,6 +288,7 @@ int main(int argc, char* argv[])
         else if (a == "--sharded") o.sharded = true;
         else if (a == "--gpus") o.gpus = atoi(next());
         else if (a == "--check-rows") o.check_rows = atoi(next());
+        else if (a == "--placement-budget-mb") o.placement_budget_mb = atoll(next());
         else if (a == "--check-out") o.check_out = next();
         else if (a == "--no-dropin") o.dropin = false;
         else if (a == "--no-numa") o.numa = false;
