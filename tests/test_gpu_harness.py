@@ -192,6 +192,24 @@ def test_native_sharded_harness_on_device_generated_shards(tmp_path, pkg, orc, p
     assert _check_sharded_rows(pkg, orc, out, n, parts, k, band, 5) == 3 * 700 * parts
 
 
+def test_native_sharded_harness_with_two_phase_shards_and_a_granted_search_budget(tmp_path, pkg, orc):
+    """twelve shards of 2.5M rows x 30M columns (x twelve times as long as a shard has rows: the two-phase kernel, each stream
+    0.66 GB = one piece, searched): `--placement-budget-mb` grants the piece search of every shard its budget after the
+    build; rows of every shard against the oracle, and the queued variant printed beside the reference-protocol line"""
+    import json
+
+    out = tmp_path / "rows.txt"
+    parts, n, k = 12, 2_500_000, 32
+    r = subprocess.run([str(BIN / "spmv_main"), "--synthetic", "uniform", "--n", str(n), "--k", str(k), "--seed", "5", "--sharded", "--gpus", str(parts),
+                        "--reps", "4", "--placement-budget-mb", "3072", "--check-rows", "400", "--check-out", str(out)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert re.search(r"### CSR NUMA GFLOPS = [0-9.]+", r.stdout) and re.search(r"### CSR NUMA GFLOPS, all repetitions queued and one wait = [0-9.]+", r.stdout)
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["participants"] == parts and line["kernel_of_shard_0"] == 5 and line["queued_one_wait"]["gflops"] > 0
+    assert _check_sharded_rows(pkg, orc, out, n, parts, k, 0, 5) == 3 * 400 * parts
+
+
 def test_native_sharded_harness_at_the_full_shard_shape_of_config_5(tmp_path, pkg, orc):
     """two of the eight shards of BASELINE configs[4] as the native driver builds them is what one GPU's time allows here:
     `--n 10000000 --gpus 2` = shards of 10M rows x 20M columns, 6.4e8 entries in all, no host container anywhere"""
