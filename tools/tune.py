@@ -281,7 +281,7 @@ def main():
         csr = ctx.coo_to_csr(A)
         print(f"same matrix as CSR: auto kernel={csr.info.kernel} lanes={csr.info.lanes_per_row} max_row={csr.info.max_row_nnz}")
         variants = [(f"csr vector L={l}", lambda A, l=l: A.set_kernel(capi.CSR_VECTOR, l)) for l in (16, 64)]
-        for unroll, pace, rows in ((0, -1, 0), (8, 0, 0), (4, 0, 0), (16, 0, 0), (0, -1, n // 512 + 1), (0, -1, n // 1024 + 1), (8, 0, n // 512 + 1)):
+        for unroll, pace, rows in ((0, -1, 0), (8, 0, 0), (4, 0, 0), (0, -1, n // 512 + 1), (0, -1, n // 1024 + 1), (8, 0, n // 512 + 1)):
             def setup(A, unroll=unroll, pace=pace, rows=rows):
                 A.set_param("panel_unroll", unroll)
                 A.set_param("panel_pace_ns", pace)
