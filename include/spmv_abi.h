@@ -247,7 +247,8 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value);
  * "panel_bytes", "panel_keep_csr", "device_bytes", "window_max_span", "window_avg_span", "twophase_panel_cols",
  * "twophase_padded" (entries of the two-phase layout with its padding), "twophase_pieces" (1 GB pieces of its product stream),
  * "twophase_placement_budget_mb", "twophase_placements_timed" (configurations of pieces timed by the search, 0 = no search ran),
- * "twophase_placement_spread" (time as built / time kept, in 1/1000), "twophase_pieces_exchanged", "ell_diagonal_slots" (1: the slots of an ELL
+ * "twophase_placement_spread" (time as built / time kept in 1/1000, both re-timed in turn when the search is over; a
+ * configuration that does not hold up there is dropped for the pieces as built, so never < 1000), "twophase_pieces_exchanged", "ell_diagonal_slots" (1: the slots of an ELL
  * handle were found to be diagonals and conforming rows read no column index), "symgs_order", "symgs_colours",
  * "symgs_levels_forward", "symgs_levels_backward", "symgs_launches", "symgs_bytes", "symgs_fused" (1: the colouring is proper and
  * the sweep takes one launch per colour). */

@@ -1270,7 +1270,7 @@ def test_twophase_piece_search_is_bounded_and_gives_its_memory_back(ctx, orc, pk
     held = A.get_param("device_bytes")
     # nothing of the 8 GB budget (nor the scratch vectors) is still held: the device's free memory fell by the handle's bytes
     assert abs((free0 - free1) - held) < 300 << 20, ((free0 - free1) >> 20, held >> 20)
-    assert A.get_param("twophase_placements_timed") >= 2 and A.get_param("twophase_placement_spread") >= 995
+    assert A.get_param("twophase_placements_timed") >= 2 and A.get_param("twophase_placement_spread") >= 1000  # (the kept configuration held up against the one as built, or the latter stayed)
     assert A.get_param("twophase_placement_budget_mb") == -1  # the default: 8192 MB unless the environment says otherwise
     x, y, yv = ctx.gen_vector(ncol, seed=9), ctx.vector(n), ctx.vector(n)
     hx = synth.vec_uniform(ncol, seed=9)
