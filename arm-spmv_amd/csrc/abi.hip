@@ -89,6 +89,7 @@ void mat_free(spmv_mat* m)
     csr_twophase_free(m);
     symgs_free(m);
     if (m->coo_csr) mat_free(m->coo_csr);
+    coo_free_bins(m);
     delete m;
 }
 
@@ -557,11 +558,20 @@ int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
         SPMV_HIP(hipSetDevice(m->ctx->device));
         m->kernel_forced = kernel != SPMV_CSR_AUTO;
         if (kernel == SPMV_CSR_VECTOR)
+        {
+            // the scan runs over a copy of the entries in column bins when x is beyond an XCD's L2 ("coo_column_bins" = 0 drops it)
             m->kernel = SPMV_CSR_VECTOR;
+            if (!m->cb_bins) SPMV_TRY(coo_build_bins(m, 0, /*only_if_worth=*/true));
+        }
         else
         {
             SPMV_TRY(coo_build_panel(m, /*only_if_worth=*/kernel == SPMV_CSR_AUTO));
             m->kernel = m->coo_csr ? SPMV_CSR_PANEL : SPMV_CSR_VECTOR;
+            if (m->kernel == SPMV_CSR_PANEL)
+            {
+                SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
+                coo_free_bins(m);
+            }
         }
         return SPMV_OK;
     }
@@ -650,6 +660,18 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
             m->v = nullptr;
             m->device_bytes -= m->nnz * 12;
         }
+    }
+    else if (!strcmp(name, "coo_column_bins"))
+    {
+        // COO, segmented scan: bins per XCD of the copy the scan runs over (1..8), 0 = no copy (the scan reads the handle's
+        // own arrays in their order), -1 = as many as keep a slice of x inside an XCD's L2
+        SPMV_REQUIRE(m->format == SPMV_FMT_COO && value >= -1 && value <= 8, "coo_column_bins: a COO handle and -1 .. 8");
+        SPMV_HIP(hipSetDevice(m->ctx->device));
+        SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
+        if (value == 0)
+            coo_free_bins(m);
+        else
+            SPMV_TRY(coo_build_bins(m, value < 0 ? 0 : (int)value, /*only_if_worth=*/false));
     }
     else if (!strcmp(name, "dia_col_bound"))
     {
@@ -761,6 +783,10 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         *value = (m->b && m->v) || m->nnz == 0 ? 1 : 0;
     else if (!strcmp(name, "device_bytes"))
         *value = m->device_bytes;
+    else if (!strcmp(name, "coo_column_bins"))  // bins of the copy the segmented scan runs over (8 x bins per XCD), 0: none
+        *value = m->cb_bins;
+    else if (!strcmp(name, "coo_bins_padded"))
+        *value = m->cb_padded;
     else if (!strcmp(name, "panel_rows"))
         *value = m->pb_built_rows;
     else if (!strcmp(name, "panel_width"))

@@ -226,6 +226,16 @@ struct spmv_mat
     // COO / CSC / ELL: internal row-grouped copy in the panel layout (coo_build_panel, csc_analyse, ell_build_panel); owned
     spmv_mat* coo_csr = nullptr;
 
+    // COO: copy of the entries in column bins, one run of bins per XCD, for the segmented scan (kernels_coo.hip:
+    // coo_build_bins); bins start on workgroup chunks, the padding carries row INT32_MAX
+    int32_t* cb_row = nullptr;
+    int32_t* cb_col = nullptr;
+    double*  cb_val = nullptr;
+    int32_t  cb_bins = 0;             // bins in all (a multiple of 8), 0: no copy
+    int32_t  cb_region[8] = {0};      // first chunk of the XCD's bins
+    int32_t  cb_chunks[8] = {0};      // chunks of the XCD's bins
+    int64_t  cb_padded = 0;           // entries of the copy with its padding
+
     // symmetric Gauss-Seidel (symgs.hip): L / D / U copies, rows by level, launch schedule; built by symgs_setup
     struct spmv::symgs_plan* gs = nullptr;
     int32_t                  gs_order = 1;  // sweep order: 1 multicolour (default), 0 the matrix's own row order
@@ -285,6 +295,8 @@ int ell_build_panel(spmv_mat* m, bool only_if_worth);
 // kernels_coo.hip
 int coo_analyse(spmv_mat* m);
 int coo_build_panel(spmv_mat* m, bool only_if_worth);
+int  coo_build_bins(spmv_mat* m, int bins_per_xcd, bool only_if_worth);  // bins_per_xcd 0: as many as keep a slice of x inside an XCD's L2
+void coo_free_bins(spmv_mat* m);
 int coo_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 // kernels_misc.hip (CSC, DIA, BLAS-1, fill)
 int csc_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);

@@ -22,7 +22,7 @@ namespace spmv
 {
 namespace
 {
-constexpr int kIters      = 8;                     // iterations of 64 entries per wavefront
+constexpr int kIters      = 8;                     // iterations of 64 entries per wavefront (a power of two: coo_bin_place_kernel)
 constexpr int kWaveChunk  = kIters * kWave;        // 512 entries
 constexpr int kBlockChunk = kWaveChunk * (kBlock / kWave);  // 2048 entries per workgroup
 constexpr int kNoRow      = INT32_MAX;             // padding lanes beyond nnz
@@ -35,15 +35,12 @@ __device__ __forceinline__ void add_to_y(double* y, int row, double v, bool atom
         y[row] += v;
 }
 
+// one wavefront's chunk: entries base .. base + kWaveChunk - 1 (those at or beyond nnz are padding)
 template <bool SORTED>
-__global__ __launch_bounds__(kBlock) void coo_segscan_kernel(int64_t nnz, const int32_t* __restrict__ row,
-                                                             const int32_t* __restrict__ col,
-                                                             const double* __restrict__ val,
-                                                             const double* __restrict__ x, double* __restrict__ y)
+__device__ __forceinline__ void segscan_chunk(int64_t base, int64_t nnz, const int32_t* __restrict__ row, const int32_t* __restrict__ col,
+                                              const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y)
 {
-    const int     lane = lane_id();
-    const int64_t base = ((int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * kWaveChunk;
-    if (base >= nnz) return;  // wave-uniform
+    const int lane = lane_id();
 
     // issue every load of the chunk before the first scan
     int    r[kIters];
@@ -113,6 +110,157 @@ __global__ __launch_bounds__(kBlock) void coo_segscan_kernel(int64_t nnz, const 
     if (lane == 0 && carry_row != kNoRow) add_to_y(y, carry_row, carry_val, true);
 }
 
+template <bool SORTED>
+__global__ __launch_bounds__(kBlock) void coo_segscan_kernel(int64_t nnz, const int32_t* __restrict__ row,
+                                                             const int32_t* __restrict__ col,
+                                                             const double* __restrict__ val,
+                                                             const double* __restrict__ x, double* __restrict__ y)
+{
+    const int64_t base = ((int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * kWaveChunk;
+    if (base >= nnz) return;  // wave-uniform
+    segscan_chunk<SORTED>(base, nnz, row, col, val, x, y);
+}
+
+// The scan over the copy in column bins (coo_build_bins).  Workgroups go to the XCDs round-robin (workgroup w runs on
+// XCD w % 8), each XCD has an L2 of its own, and an x beyond 4 MB gathered in entry order misses it with every entry:
+// C4 moved 12.9 GB for the 1.89 GB of its entries (128-byte lines from the fabric, 1.81 ms).  Here XCD c scans only the
+// entries whose columns lie in ITS bins, one bin after the other, so the slice of x it gathers from (<= 2 MB) stays in
+// its L2 (counters: 1.98 GB).  A row is spread over up to `bins` runs now: every run end is an atomic on y.
+//
+// With the gathers served the scan itself was the bound (0.92 ms; 1.16 ms in place with an x of 0.8 MB): six ds_bpermute
+// steps on a double and a flag for every 64 entries.  The copy is the engine's own, so it is laid out for a cheaper
+// scan: inside a wavefront's chunk of 512 entries, entry q of the order sits at (q % 8) * 64 + q / 8 - the loads are the
+// same coalesced ones, and lane l holds the 8 CONSECUTIVE entries 8 l .. 8 l + 7.  A lane reduces its strip serially
+// (runs that begin and end inside it go to y from there), and one 64-lane segmented scan per 512 entries joins the runs
+// that cross lanes: lane l contributes the run open at its end (row rb, sum b); the run open at its start (row ra, sum a,
+// the same run when the strip is a single one) is closed by the lane in which it ends.
+struct coo_bins_tab
+{
+    int32_t region[8];
+    int32_t chunks[8];
+};
+// What bounds it now (tools/probe_coo_bins.py, C4 over 16 bins): with every update of y left out the kernel takes 0.65 ms -
+// 115M gathers of 8 bytes from an L2-resident slice are 115M L2 line operations beside the 15M lines of the streams, the
+// same line-rate bound as the CSR panel product, and entries in row order cannot be sorted by x line.  The
+// updates add 0.10 (8 bins) to 0.23 ms (16): they are device-scope atomics carried out by the memory side, one per run.
+// Tried instead, for row-sorted input with one bin per XCD (a run interior to a chunk is then all of its row in the bin):
+// plain stores to a partial vector per XCD plus a kernel that adds the eight to y - 1.29 + 0.05 ms against 0.75 (the
+// 8-byte stores allocate in the L2 the slice of x lives in; nontemporal ones: 0.97 against 0.88 over 16 bins).  Not kept.
+__global__ __launch_bounds__(kBlock) void coo_segscan_bins_kernel(const coo_bins_tab tab, const int32_t* __restrict__ row,
+                                                                  const int32_t* __restrict__ col, const double* __restrict__ val,
+                                                                  const double* __restrict__ x, double* __restrict__ y)
+{
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    if (slot >= tab.chunks[xcd]) return;
+    const int     lane = lane_id();
+    const int64_t base = ((int64_t)(tab.region[xcd] + slot) * (kBlock / kWave) + (threadIdx.x >> 6)) * kWaveChunk;
+    int           r[kIters];
+    double        p[kIters];
+    {
+        int    c[kIters];
+        double v[kIters];
+#pragma unroll
+        for (int t = 0; t < kIters; ++t)
+        {
+            const int64_t e = base + t * kWave + lane;  // (the copy is padded to whole chunks: no bound to check)
+            r[t]            = load_stream(row + e);
+            c[t]            = load_stream(col + e);
+            v[t]            = load_stream(val + e);
+        }
+#pragma unroll
+        for (int t = 0; t < kIters; ++t) p[t] = v[t] * x[c[t]];  // (padding: 0.0 * x[0], never added to y)
+    }
+    // the lane's strip, serially
+    const int ra     = r[0];
+    int       rb     = r[0];
+    double    a      = 0.0, b = p[0];
+    bool      single = true;
+#pragma unroll
+    for (int t = 1; t < kIters; ++t)
+    {
+        if (r[t] != rb)
+        {
+            if (single)
+            {
+                a      = b;
+                single = false;
+            }
+            else if (rb != kNoRow)
+                unsafeAtomicAdd(y + rb, b);  // begins and ends inside the strip
+            rb = r[t];
+            b  = p[t];
+        }
+        else
+            b += p[t];
+    }
+    // across the lanes
+    const int  prev_rb = bpermute(rb, max(lane - 1, 0));
+    const bool cont    = lane > 0 && ra == prev_rb;   // the run open at my start began before me
+    int        head    = (!single || !cont) ? 1 : 0;  // the run open at my end begins in my strip
+    double     sum     = b;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1)
+    {
+        const int    src = max(lane - d, 0);
+        const double su  = bpermute(sum, src);
+        const int    hu  = bpermute(head, src);
+        if (lane >= d)
+        {
+            if (!head) sum += su;
+            head |= hu;
+        }
+    }
+    const double sum_prev = bpermute(sum, max(lane - 1, 0));
+    const int    next_ra  = bpermute(ra, min(lane + 1, kWave - 1));
+    if (!single && ra != kNoRow) unsafeAtomicAdd(y + ra, a + (cont ? sum_prev : 0.0));           // the run open at my start ends in my strip
+    if ((lane == kWave - 1 || next_ra != rb) && rb != kNoRow) unsafeAtomicAdd(y + rb, sum);  // the run open at my end ends with it
+}
+
+constexpr int kColBuckets = 4096;  // the bins are unions of column buckets of equal width
+__global__ __launch_bounds__(kBlock) void coo_col_histogram_kernel(int64_t nnz, const int32_t* __restrict__ col, int shift, unsigned long long* __restrict__ hist)
+{
+    __shared__ unsigned int h[kColBuckets];
+    for (int i = threadIdx.x; i < kColBuckets; i += kBlock) h[i] = 0;
+    __syncthreads();
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * kBlock) atomicAdd(&h[col[e] >> shift], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < kColBuckets; i += kBlock)
+        if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+}
+__global__ __launch_bounds__(kBlock) void coo_bin_keys_kernel(int64_t nnz, const int32_t* __restrict__ col, int shift, const uint8_t* __restrict__ bin_of_bucket,
+                                                              int32_t* __restrict__ key)
+{
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * kBlock) key[e] = bin_of_bucket[col[e] >> shift];
+}
+__global__ __launch_bounds__(kBlock) void coo_bin_fill_kernel(int64_t padded, int32_t* __restrict__ row, int32_t* __restrict__ col, double* __restrict__ val)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < padded; i += (int64_t)gridDim.x * kBlock)
+    {
+        row[i] = kNoRow;
+        col[i] = 0;
+        val[i] = 0.0;
+    }
+}
+// position i of the order by (bin, entry id) goes to the bin's copy, transposed inside each wavefront's chunk (see coo_segscan_bins_kernel)
+__global__ __launch_bounds__(kBlock) void coo_bin_place_kernel(int64_t nnz, const int32_t* __restrict__ perm, const int32_t* __restrict__ row,
+                                                               const int32_t* __restrict__ col, const double* __restrict__ val, int shift,
+                                                               const uint8_t* __restrict__ bin_of_bucket, const int64_t* __restrict__ bin_src,
+                                                               const int64_t* __restrict__ bin_dst, int32_t* __restrict__ out_row,
+                                                               int32_t* __restrict__ out_col, double* __restrict__ out_val)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * kBlock)
+    {
+        const int32_t e = perm[i];
+        const int32_t c = col[e];
+        const int     b = bin_of_bucket[c >> shift];
+        const int64_t q = i - bin_src[b];  // position in the bin's order; inside a chunk of 512, entry q sits at (q % 8) * 64 + q / 8
+        const int64_t d = bin_dst[b] + (q & ~(int64_t)(kWaveChunk - 1)) + ((q & (kIters - 1)) << 6) + ((q & (kWaveChunk - 1)) >> 3);
+        out_row[d]      = row[e];
+        out_col[d]      = c;
+        out_val[d]      = val[e];
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void coo_sorted_check_kernel(int64_t nnz, const int32_t* __restrict__ row,
                                                                   int32_t* __restrict__ unsorted_flag)
 {
@@ -180,10 +328,159 @@ int coo_build_panel(spmv_mat* m, bool only_if_worth)
     return SPMV_OK;
 }
 
+void coo_free_bins(spmv_mat* m)
+{
+    if (m->cb_row) (void)hipFree(m->cb_row);
+    if (m->cb_col) (void)hipFree(m->cb_col);
+    if (m->cb_val) (void)hipFree(m->cb_val);
+    if (m->cb_bins) m->device_bytes -= m->cb_padded * 16;
+    m->cb_row = m->cb_col = nullptr;
+    m->cb_val = nullptr;
+    m->cb_bins = 0;
+    m->cb_padded = 0;
+}
+
+// The copy in column bins for the segmented scan.  The bins are chosen from a histogram of the columns so that each holds
+// about the same number of ENTRIES (the XCDs finish together whatever the distribution of the columns); bin j belongs to
+// XCD j / bins_per_xcd.  The order inside a bin is the order of the handle's entries (a stable sort by bin), so the runs of
+// row-sorted input stay runs.  Integer work done once per handle; costs 16 bytes per entry of device memory.
+int coo_build_bins(spmv_mat* m, int bins_per_xcd, bool only_if_worth)
+{
+    spmv_ctx* ctx = m->ctx;
+    coo_free_bins(m);
+    // worth it: an x that does not fit an XCD's L2 beside the streams, and enough entries to matter
+    const bool worth = (int64_t)m->ncol * 8 > ((int64_t)3 << 20) && m->nnz >= ((int64_t)2 << 20);
+    if (only_if_worth && !worth) return SPMV_OK;
+    if (m->nnz == 0 || m->ncol <= 0) return SPMV_OK;
+    SPMV_REQUIRE(m->nnz <= (int64_t)INT32_MAX - 64 * kBlockChunk, "the copy in column bins addresses its entries with 32 bits: %lld entries are too many", (long long)m->nnz);
+    if (bins_per_xcd <= 0) bins_per_xcd = (int)std::min<int64_t>(8, std::max<int64_t>(1, ceil_div((int64_t)m->ncol * 8, (int64_t)16 << 20)));
+    SPMV_REQUIRE(bins_per_xcd <= 8, "coo_column_bins: at most 8 bins per XCD, got %d", bins_per_xcd);
+    const int nbins = 8 * bins_per_xcd;
+    int       shift = 0;
+    while (((int64_t)(m->ncol - 1) >> shift) >= kColBuckets) ++shift;
+
+    hipStream_t         s = ctx->stream;
+    unsigned long long* d_hist = nullptr;
+    uint8_t*            d_bin  = nullptr;
+    int64_t*            d_off  = nullptr;  // bin_src[nbins] | bin_dst[nbins]
+    int32_t *           d_key = nullptr, *d_perm = nullptr;
+    int                 rc = SPMV_OK;
+    const unsigned      grid = (unsigned)std::min<int64_t>(kMaxGrid, ceil_div(m->nnz, kBlock));
+    do
+    {
+        if (hipMalloc(&d_hist, sizeof(unsigned long long) * kColBuckets) != hipSuccess || hipMalloc(&d_bin, kColBuckets) != hipSuccess ||
+            hipMalloc(&d_off, sizeof(int64_t) * 2 * (size_t)nbins) != hipSuccess || hipMalloc(&d_key, sizeof(int32_t) * (size_t)m->nnz) != hipSuccess ||
+            hipMalloc(&d_perm, sizeof(int32_t) * (size_t)m->nnz) != hipSuccess)
+        {
+            rc = SPMV_ERR_ALLOC;
+            break;
+        }
+        if (hipMemsetAsync(d_hist, 0, sizeof(unsigned long long) * kColBuckets, s) != hipSuccess)
+        {
+            rc = SPMV_ERR_HIP;
+            break;
+        }
+        hipLaunchKernelGGL(coo_col_histogram_kernel, dim3(grid), dim3(kBlock), 0, s, m->nnz, m->b, shift, d_hist);
+        std::vector<unsigned long long> hist(kColBuckets);
+        if (hipMemcpyAsync(hist.data(), d_hist, sizeof(unsigned long long) * kColBuckets, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess)
+        {
+            rc = SPMV_ERR_HIP;
+            break;
+        }
+        // bin j ends with the bucket at which the running count reaches (j + 1) / nbins of the entries
+        std::vector<uint8_t> bin_of(kColBuckets);
+        std::vector<int64_t> count((size_t)nbins, 0), off(2 * (size_t)nbins, 0);
+        {
+            unsigned long long run = 0;
+            int                j   = 0;
+            for (int b = 0; b < kColBuckets; ++b)
+            {
+                bin_of[(size_t)b] = (uint8_t)j;
+                count[(size_t)j] += (int64_t)hist[(size_t)b];
+                run += hist[(size_t)b];
+                while (j + 1 < nbins && run * (unsigned long long)nbins >= (unsigned long long)m->nnz * (unsigned long long)(j + 1)) ++j;
+            }
+        }
+        int64_t src = 0, dst = 0;
+        for (int j = 0; j < nbins; ++j)
+        {
+            if (j % bins_per_xcd == 0) m->cb_region[j / bins_per_xcd] = (int32_t)(dst / kBlockChunk);
+            off[(size_t)j]         = src;
+            off[(size_t)(nbins + j)] = dst;
+            src += count[(size_t)j];
+            dst += ceil_div(count[(size_t)j], (int64_t)kBlockChunk) * kBlockChunk;
+            if ((j + 1) % bins_per_xcd == 0) m->cb_chunks[j / bins_per_xcd] = (int32_t)(dst / kBlockChunk) - m->cb_region[j / bins_per_xcd];
+        }
+        const int64_t padded = dst;
+        if (hipMemcpyAsync(d_bin, bin_of.data(), kColBuckets, hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(d_off, off.data(), sizeof(int64_t) * 2 * (size_t)nbins, hipMemcpyHostToDevice, s) != hipSuccess)
+        {
+            rc = SPMV_ERR_HIP;
+            break;
+        }
+        hipLaunchKernelGGL(coo_bin_keys_kernel, dim3(grid), dim3(kBlock), 0, s, m->nnz, m->b, shift, d_bin, d_key);
+        int bits = 3;
+        while ((1 << bits) < nbins) ++bits;
+        if (sort_ids_by_key(ctx, d_key, m->nnz, bits, d_perm) != SPMV_OK)
+        {
+            rc = SPMV_ERR_HIP;
+            break;
+        }
+        (void)hipFree(d_key);
+        d_key = nullptr;
+        if (hipMalloc(&m->cb_row, sizeof(int32_t) * (size_t)padded) != hipSuccess || hipMalloc(&m->cb_col, sizeof(int32_t) * (size_t)padded) != hipSuccess ||
+            hipMalloc(&m->cb_val, sizeof(double) * (size_t)padded) != hipSuccess)
+        {
+            rc = SPMV_ERR_ALLOC;
+            break;
+        }
+        hipLaunchKernelGGL(coo_bin_fill_kernel, dim3((unsigned)std::min<int64_t>(kMaxGrid, ceil_div(padded, kBlock))), dim3(kBlock), 0, s, padded, m->cb_row,
+                           m->cb_col, m->cb_val);
+        hipLaunchKernelGGL(coo_bin_place_kernel, dim3(grid), dim3(kBlock), 0, s, m->nnz, d_perm, m->a, m->b, m->v, shift, d_bin, d_off, d_off + nbins,
+                           m->cb_row, m->cb_col, m->cb_val);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        {
+            rc = SPMV_ERR_HIP;
+            break;
+        }
+        m->cb_bins   = nbins;
+        m->cb_padded = padded;
+        m->device_bytes += padded * 16;
+    } while (0);
+    if (d_hist) (void)hipFree(d_hist);
+    if (d_bin) (void)hipFree(d_bin);
+    if (d_off) (void)hipFree(d_off);
+    if (d_key) (void)hipFree(d_key);
+    if (d_perm) (void)hipFree(d_perm);
+    if (rc != SPMV_OK)
+    {
+        coo_free_bins(m);  // (cb_bins is still 0: nothing was accounted yet)
+        if (rc == SPMV_ERR_ALLOC) SPMV_FAIL(rc, "no device memory for the copy of %lld COO entries in column bins", (long long)m->nnz);
+        SPMV_FAIL(rc, "building the copy in column bins failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    return SPMV_OK;
+}
+
 int coo_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
 {
     if (A->nnz == 0) return SPMV_OK;
     if (A->coo_csr && A->kernel == SPMV_CSR_PANEL) return csr_panel_apply(ctx, A->coo_csr, x, y);
+    if (A->cb_bins)
+    {
+        coo_bins_tab tab;
+        int          most = 0;
+        for (int c = 0; c < 8; ++c)
+        {
+            tab.region[c] = A->cb_region[c];
+            tab.chunks[c] = A->cb_chunks[c];
+            most          = std::max(most, A->cb_chunks[c]);
+        }
+        if (most == 0) return SPMV_OK;
+        hipLaunchKernelGGL(coo_segscan_bins_kernel, dim3(8u * (unsigned)most), dim3(kBlock), 0, ctx->stream, tab, A->cb_row, A->cb_col, A->cb_val, x, y);
+        SPMV_HIP(hipGetLastError());
+        return SPMV_OK;
+    }
     const unsigned grid = (unsigned)ceil_div(A->nnz, kBlockChunk);
     if (A->sorted_rows)
         hipLaunchKernelGGL(coo_segscan_kernel<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, A->nnz, A->a, A->b, A->v,

@@ -681,6 +681,9 @@ def main() -> None:
             if fmt == "coo":
                 if kid == 4:
                     return "csr_panel_kernel on the row-grouped copy (12-byte packed entries)", "panel"
+                if M.get_param("coo_column_bins"):
+                    return (f"coo_segscan_bins_kernel (wavefront segmented scan over a copy of the entries in {M.get_param('coo_column_bins')} column "
+                            "bins, one per XCD: each XCD gathers x from a slice that stays in its L2)"), "coo_segscan"
                 return "coo_segscan_kernel (wavefront segmented scan over the entries in file order)", "coo_segscan"
             names = {1: "csr_vector_kernel", 2: "csr_ldswin_kernel", 3: "csr_scalar_kernel", 4: "csr_panel_kernel",
                      5: "tp_expand_kernel + tp_reduce_kernel (two-phase)"}
@@ -744,15 +747,19 @@ def main() -> None:
                 one("C3 with the kernel configs[2] names: coalesced column-major ELL, every column index read (SPMV_FLAG_ELL_READ_COLUMNS)",
                     "ell", c3, tkey="ell_n4000000_k64_columns", flags=8)
 
-                def c4(kernel):
+                def c4(kernel, in_place=False):
                     M = ctx.gen_coo_powerlaw(2_000_000, 2_000_000, 4096, seed=args.seed)
                     if kernel:
                         M.set_kernel(kernel, 0)
+                    if in_place:
+                        M.set_param("coo_column_bins", 0)
                     return M
                 one("C4: COO N=2M, power-law rows up to 4096, row-sorted (BASELINE configs[3]; realised nnz reported) - the kernel the engine picks",
                     "coo", lambda: c4(0), tkey="coo_n2000000_nnz115008628")
-                one("C4 with the kernel configs[3] names: COO segmented scan over the entries as stored (spmv_mat_set_kernel VECTOR)",
-                    "coo", lambda: c4(1), tkey="coo_n2000000_nnz115008628_segscan")
+                one("C4 with the kernel configs[3] names: COO segmented scan (spmv_mat_set_kernel VECTOR), over the entries in column bins per XCD",
+                    "coo", lambda: c4(1), tkey="coo_n2000000_nnz115008628_segscan_bins")
+                one("C4, the segmented scan over the entries as stored (coo_column_bins = 0): every gather of x misses the XCD's L2",
+                    "coo", lambda: c4(1, True), tkey="coo_n2000000_nnz115008628_segscan")
             if args.band == 0:
                 def band_shard():
                     M = ctx.gen_csr_uniform(row_begin, row_end, ncol, k, band=65536, seed=args.seed)

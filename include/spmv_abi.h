@@ -189,7 +189,8 @@ int spmv_mat_validate(const spmv_mat* m);
 /* Force a CSR kernel (and, for VECTOR, lanes_per_row in {1,2,4,...,64}; 0 = keep auto choice).
  * COO, CSC and ELL handles take AUTO (regroup by row and run the panel product when the handle is large and its
  * columns are scattered), VECTOR (the format's own kernel: segmented scan / atomic scatter / one lane per row;
- * for ELL lanes_per_row 1 or 2 picks the one- or two-rows-per-lane variant) or PANEL (regroup now). */
+ * for ELL lanes_per_row 1 or 2 picks the one- or two-rows-per-lane variant; for a large COO handle whose x is beyond an
+ * XCD's L2 the scan runs over a copy of the entries in column bins - "coo_column_bins" below) or PANEL (regroup now). */
 int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row);
 int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
 /* Named parameters.  None is needed in normal use: what is left at its default is chosen when the layout is built, by
@@ -238,6 +239,14 @@ int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
  *                    move streams of the built layout to fresh allocations (bits 1 products, 2 values, 4 columns, 8 rows,
  *                    16 table), hold a pool of pieces and put any of them under the product stream (10 bits per slot):
  *                    tools/tune_twophase.py, tools/probe_twophase_{moves,pairs,classes,rotate}.py
+ *   "coo_column_bins"   COO handles, takes effect at once: the segmented scan (kernel VECTOR) runs over a COPY of the entries in
+ *                    8 x value column bins, the bins of one XCD after the other, so that each XCD gathers x from a slice that
+ *                    stays in its L2 (kernels_coo.hip; C4: 0.76 ms against 1.81).  -1 = as many bins as keep a slice within
+ *                    2 MB (what spmv_mat_set_kernel(VECTOR) does by itself when x is beyond 3 MB and the handle has >= 2M
+ *                    entries), 0 = drop the copy: the scan reads the handle's own arrays in their order, 1..8 = bins per
+ *                    XCD.  Costs 16 bytes per entry of device memory (+ up to 64 x 2048 entries of padding) and, while it is
+ *                    built, 8 bytes per entry more.  Needs fewer than 2^31 - 131072 entries.  A row is spread over up to that
+ *                    many runs, each ending in an atomic on y: results differ from the scan in place by rounding only.
  *   "symgs_order"    sweep order of spmv_symgs / SPMV_PRECOND_SYMGS: 1 multicolour (default), 0 the matrix's own row order
  *   "panel_trace", "panel_legacy", "panel_two_per_cu"
  *                    diagnostics and experiments kept for the record (tools/trace_panel.py) */
@@ -246,6 +255,7 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value);
  * "panel_pipe", "panel_sync", "panel_stagger", "panel_pace_ns", "panel_pace_scale", "panel_pace_bumps",
  * "panel_bytes", "panel_keep_csr", "device_bytes", "window_max_span", "window_avg_span", "twophase_panel_cols",
  * "twophase_padded" (entries of the two-phase layout with its padding), "twophase_pieces" (1 GB pieces of its product stream),
+ * "coo_column_bins" (bins of the copy the COO segmented scan runs over, 0: none), "coo_bins_padded" (its entries with the padding),
  * "twophase_placement_budget_mb", "twophase_placements_timed" (configurations of pieces timed by the search, 0 = no search ran),
  * "twophase_placement_spread" (time as built / time kept in 1/1000, both re-timed in turn when the search is over; a
  * configuration that does not hold up there is dropped for the pieces as built, so never < 1000), "twophase_pieces_exchanged", "ell_diagonal_slots" (1: the slots of an ELL

@@ -203,6 +203,48 @@ def test_coo_ragged_chunk_boundaries(ctx, orc):
         ol.assert_parity(y1, ref, scale, f"coo ragged shuffle={shuffle}")
 
 
+@pytest.mark.parametrize("ncol,skew", [(3000, False), (1, False), (70_000, True), (5_000_000, False)])
+def test_coo_segmented_scan_over_column_bins(ctx, orc, pkg, ncol, skew):
+    """The segmented scan over the copy of the entries in column bins (one run of bins per XCD): 1, 3 and 8 bins
+    per XCD, sorted and shuffled input, columns uniform or with half of the entries in one column (the bins are entry
+    quantiles: some stay empty), against the oracle; dropping the copy gives the bytes back and the scan in place agrees."""
+    capi = pkg.capi
+    rng = np.random.RandomState(ncol % 1000 + 5)
+    nrow = 4000
+    lens = rng.choice([0, 1, 2, 3, 63, 64, 65, 511, 512, 513, 700, 2047, 2049], size=nrow, p=[.3, .2, .1, .1, .05, .05, .05, .03, .03, .03, .03, .02, .01])
+    row = np.repeat(np.arange(nrow, dtype=np.int32), lens)
+    col = rng.randint(0, ncol, size=row.size).astype(np.int32)
+    if skew:
+        col[rng.rand(row.size) < 0.5] = 12345
+    val = rng.uniform(-1, 1, size=row.size)
+    x = rng.uniform(0, 1, size=ncol)
+    rp, cc, cv = ol.coo_to_csr(orc, nrow, row, col, val)
+    ref, scale = np.zeros(nrow), np.zeros(nrow)
+    ol.csr_spmv(orc, rp, cc, cv, x, ref)
+    ol.csr_abs_row_sums(orc, rp, cc, cv, x, scale)
+    for shuffle in (False, True):
+        if shuffle:
+            p = rng.permutation(row.size)
+            row, col, val = row[p], col[p], val[p]
+        A = ctx.coo(nrow, ncol, row, col, val)
+        A.set_kernel(capi.CSR_VECTOR)
+        assert A.get_param("coo_column_bins") == 0  # (too small for the copy to be made unasked)
+        held = A.get_param("device_bytes")
+        for per_xcd in (1, 3, 8):
+            A.set_param("coo_column_bins", per_xcd)
+            assert A.get_param("coo_column_bins") == 8 * per_xcd
+            padded = A.get_param("coo_bins_padded")
+            assert padded % 2048 == 0 and row.size <= padded <= row.size + 8 * per_xcd * 2048
+            assert A.get_param("device_bytes") == held + 16 * padded
+            y1, y3 = _apply_n(ctx, A, x, nrow, 3)
+            ol.assert_parity(y1, ref, scale, f"coo over {8 * per_xcd} column bins, shuffle={shuffle}")
+            ol.assert_parity(y3, 3 * ref, 3 * scale, f"coo over {8 * per_xcd} column bins, three products, shuffle={shuffle}")
+        A.set_param("coo_column_bins", 0)
+        assert A.get_param("coo_column_bins") == 0 and A.get_param("device_bytes") == held
+        y1, _ = _apply_n(ctx, A, x, nrow, 1)
+        ol.assert_parity(y1, ref, scale, f"coo in place after the copy was dropped, shuffle={shuffle}")
+
+
 def test_empty_and_degenerate_inputs(ctx):
     x = np.ones(5)
     for A in (ctx.csr(0, 5, np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0)),
@@ -918,10 +960,15 @@ def test_large_coo_takes_the_panel_path_and_matches_oracle(ctx, orc, pkg):
     yp.fill(0.0)
     ys.fill(0.0)
     ctx.apply(A, x, yp)
-    A.set_kernel(capi.CSR_VECTOR)  # the segmented scan on the same handle
+    A.set_kernel(capi.CSR_VECTOR)  # the segmented scan on the same handle: over the copy in column bins (x = 8 MB, beyond an XCD's L2)
+    assert A.get_param("coo_column_bins") == 8
     ctx.apply(A, x, ys)
+    A.set_param("coo_column_bins", 0)  # and over the handle's own arrays in their order
+    yi = ctx.vector(n)
+    yi.fill(0.0)
+    ctx.apply(A, x, yi)
     ctx.sync()
-    hp, hs = yp.download(), ys.download()
+    hp, hs, hi = yp.download(), ys.download(), yi.download()
     row, col, val = synth.coo_powerlaw(n, n, 4096, seed=4)
     hx = synth.vec_uniform(n, seed=4)
     rp, cc, cv = ol.coo_to_csr(orc, n, row, col, val)
@@ -929,7 +976,8 @@ def test_large_coo_takes_the_panel_path_and_matches_oracle(ctx, orc, pkg):
     ol.csr_spmv(orc, rp, cc, cv, hx, ref)
     ol.csr_abs_row_sums(orc, rp, cc, cv, hx, scale)
     ol.assert_parity(hp, ref, scale, "large coo, panel path")
-    ol.assert_parity(hs, ref, scale, "large coo, segmented scan")
+    ol.assert_parity(hs, ref, scale, "large coo, segmented scan over column bins")
+    ol.assert_parity(hi, ref, scale, "large coo, segmented scan in place")
 
 
 @pytest.mark.parametrize("nrow,k", [(5000, 64), (1001, 20), (257, 1), (4096, 17)])
