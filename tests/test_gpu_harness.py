@@ -118,6 +118,7 @@ def test_bench_contract_one_rank_and_two_rank_rehearsal(tmp_path):
         assert 0 < e["roofline"]["frac"] <= 1.0 and e["roofline"]["bytes_required"] > 0, e
     kernels = {e["name"]: e["kernel"] for e in line["extra"]}
     assert any("ell_kernel_x2" in v for v in kernels.values()) and any("coo_segscan_kernel" in v for v in kernels.values())
+    assert any("coo_segscan_bins_kernel" in v for v in kernels.values())  # the scan over the copy in column bins, one per XCD
     assert line["cpu_baseline"]["kind"] in ("reference", "port") and line["cpu_baseline"]["value"] > 0
     # counter traffic as a rate (north_star: "counters reported as achieved HBM GB/s"): live passes or the stamped constants or null
     rl = line["roofline"]
