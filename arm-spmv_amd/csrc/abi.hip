@@ -561,7 +561,12 @@ int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
         {
             // the scan runs over a copy of the entries in column bins when x is beyond an XCD's L2 ("coo_column_bins" = 0 drops it)
             m->kernel = SPMV_CSR_VECTOR;
-            if (!m->cb_bins) SPMV_TRY(coo_build_bins(m, 0, /*only_if_worth=*/true));
+            if (!m->cb_bins)
+            {
+                const int rc = coo_build_bins(m, 0, /*only_if_worth=*/true);
+                if (rc != SPMV_OK && rc != SPMV_ERR_ALLOC) return rc;  // (no room for the copy: the scan runs over the handle's own arrays)
+                (void)hipGetLastError();
+            }
         }
         else
         {

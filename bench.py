@@ -770,6 +770,14 @@ def main() -> None:
                     + (f"; rank r holds rows r*{n}..: the band keeps its locality under sharding)" if world > 1 else ")"),
                     "csr", band_shard, tkey=f"csr_n{n}_k{k}_band65536_ncol{ncol}", x_vec=vx, sharded=world > 1)
             if world == 1 and args.band == 0:
+                def c2_rows():
+                    M = ctx.gen_csr_uniform(0, n, ncol, k, band=0, seed=args.seed)
+                    M.set_kernel(1, 0)  # SPMV_CSR_VECTOR, lanes per row chosen from the mean row length
+                    return M
+                one("C2 with the kernel configs[1] names: row-parallel CSR, 2^k lanes of a wavefront per row (spmv_mat_set_kernel VECTOR) - "
+                    "every gather of x misses L2 and pulls a 128-byte line over the fabric; the headline is the panel kernel the engine picks",
+                    "csr", c2_rows, x_vec=vx)
+
                 def c5_shard(budget_mb=None):
                     M = ctx.gen_csr_uniform(7 * n, 8 * n, 8 * n, k, band=0, seed=args.seed)
                     if budget_mb and int(M.info.kernel) == 5:
