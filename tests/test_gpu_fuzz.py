@@ -162,6 +162,16 @@ def test_random_coo_in_file_order_with_duplicates(ctx, orc, pkg, seed):
         ctx.apply(A, dx, dy)
         ctx.sync()
         ol.assert_parity(dy.download(), ref, scale, f"coo seed {seed}: {nrow} x {ncol}, {nnz} entries, kernel {kernel}")
+    # the segmented scan over a copy of the entries in column bins (made unasked only for a large handle with a large x)
+    A.set_kernel(capi.CSR_VECTOR)
+    per_xcd = int(rng.integers(1, 9))
+    A.set_param("coo_column_bins", per_xcd)
+    assert A.get_param("coo_column_bins") == (8 * per_xcd if nnz else 0)
+    dy.fill(0.0)
+    ctx.apply(A, dx, dy)
+    ctx.sync()
+    ol.assert_parity(dy.download(), ref, scale, f"coo seed {seed}: {nrow} x {ncol}, {nnz} entries, scan over {8 * per_xcd} column bins")
+    A.set_param("coo_column_bins", 0)
     C = ctx.coo_to_csr(A)
     assert C.info.nnz == nnz
     got = C.download()
