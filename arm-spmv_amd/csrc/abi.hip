@@ -85,6 +85,7 @@ void mat_free(spmv_mat* m)
     if (m->win_span) (void)hipFree(m->win_span);
     if (m->ell_diag) (void)hipFree(m->ell_diag);
     if (m->ell_diag_mask) (void)hipFree(m->ell_diag_mask);
+    ell_free_tiles(m);
     csr_panel_free(m);
     csr_twophase_free(m);
     symgs_free(m);
@@ -666,6 +667,18 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
             m->device_bytes -= m->nnz * 12;
         }
     }
+    else if (!strcmp(name, "ell_tiled_values"))
+    {
+        // ELL whose slots are diagonals: 1 = keep a copy of the values in tiles of 512 rows for the product (never made unasked:
+        // 8 bytes per slot for 1-7 %), 0 = drop it and multiply from the column-major array
+        SPMV_REQUIRE(m->format == SPMV_FMT_ELL && (value == 0 || value == 1), "ell_tiled_values: an ELL handle and 0 or 1");
+        SPMV_HIP(hipSetDevice(m->ctx->device));
+        SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
+        if (value == 0)
+            ell_free_tiles(m);
+        else
+            SPMV_TRY(ell_build_tiles(m, /*only_if_worth=*/false));
+    }
     else if (!strcmp(name, "coo_column_bins"))
     {
         // COO, segmented scan: bins per XCD of the copy the scan runs over (1..8), 0 = no copy (the scan reads the handle's
@@ -788,6 +801,8 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         *value = (m->b && m->v) || m->nnz == 0 ? 1 : 0;
     else if (!strcmp(name, "device_bytes"))
         *value = m->device_bytes;
+    else if (!strcmp(name, "ell_tiled_values"))  // ELL: 1 if the product reads the values from the copy in tiles of 512 rows
+        *value = m->ell_tval ? 1 : 0;
     else if (!strcmp(name, "coo_column_bins"))  // bins of the copy the segmented scan runs over (8 x bins per XCD), 0: none
         *value = m->cb_bins;
     else if (!strcmp(name, "coo_bins_padded"))

@@ -222,6 +222,7 @@ struct spmv_mat
     int32_t* ell_diag      = nullptr;
     void*    ell_diag_mask = nullptr;
     int32_t  ell_diag_lds = 0;  // doubles of LDS the x stretches of a block take (0: none, x from global memory)
+    double*  ell_tval = nullptr;  // the values in tiles of 512 rows, (tile * k + slot) * 512 + row (ell_build_tiles); owned
 
     // COO / CSC / ELL: internal row-grouped copy in the panel layout (coo_build_panel, csc_analyse, ell_build_panel); owned
     spmv_mat* coo_csr = nullptr;
@@ -293,6 +294,8 @@ int ell_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 int ell_analyse(spmv_mat* m);
 int ell_build_panel(spmv_mat* m, bool only_if_worth);
 // kernels_coo.hip
+int  ell_build_tiles(spmv_mat* m, bool only_if_worth);
+void ell_free_tiles(spmv_mat* m);
 int coo_analyse(spmv_mat* m);
 int coo_build_panel(spmv_mat* m, bool only_if_worth);
 int  coo_build_bins(spmv_mat* m, int bins_per_xcd, bool only_if_worth);  // bins_per_xcd 0: as many as keep a slice of x inside an XCD's L2

@@ -204,7 +204,14 @@ __device__ __forceinline__ void stage_x_windows(double* xs, const int32_t* __res
 
 // (Round 4 double-buffered the value stream and requested its first group before the x stretches go through LDS: the same
 // time on the same box, 0.398 ms on C3 - profiles/r04_tune_ell_c3_double_buffered.txt - so the simpler form stays.)
-template <int UNROLL, bool XWIN>
+//
+// TILED (round 4): `val` is the engine's copy of the values in TILES of 512 rows - tile b, slot s, row r at
+// (b * k + s) * 512 + r (ell_build_tiles) - so that what a workgroup reads is one contiguous stretch of 512 * k * 8 bytes
+// instead of k stretches of 4 KB that lie nrow * 8 bytes (C3: 32 MB) apart.  Same loads, same order of the slots, same
+// bits.  C3, A/B in one process: 0.345-0.360 -> 0.331-0.334 ms on a box where the column-major form is fast, 0.4045 ->
+// 0.400 on one where it is slow - what separates the boxes is not the stride.  Opt-in ("ell_tiled_values"): 8 more bytes
+// per slot are a poor price for that.
+template <int UNROLL, bool XWIN, bool TILED>
 __global__ __launch_bounds__(kBlock) void ell_diag_kernel_x2(int nrow, int k, const int32_t* __restrict__ col,
                                                              const double* __restrict__ val, const double* __restrict__ x,
                                                              double* __restrict__ y, const int32_t* __restrict__ off,
@@ -220,8 +227,8 @@ __global__ __launch_bounds__(kBlock) void ell_diag_kernel_x2(int nrow, int k, co
     const u64 bit = 1ull << (threadIdx.x & 63);
     const int32_t* __restrict__ xbase = off + k;
     f64x2        acc    = *reinterpret_cast<const f64x2*>(y + i);
-    const size_t stride = (size_t)nrow;
-    size_t       at     = (size_t)i;
+    const size_t stride = TILED ? (size_t)(2 * kBlock) : (size_t)nrow;
+    size_t       at     = TILED ? (size_t)blockIdx.x * (2 * kBlock) * k + 2 * threadIdx.x : (size_t)i;
     for (int s0 = 0; s0 < k; s0 += UNROLL)
     {
         f64x2 v[UNROLL];
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void ell_diag_kernel_x2(int nrow, int k, co
                 }
                 else
                 {
-                    const i32x2 c = load_stream(reinterpret_cast<const i32x2*>(col + at + (size_t)u * stride));
+                    const i32x2 c = load_stream(reinterpret_cast<const i32x2*>(col + (size_t)i + (size_t)s * nrow));
                     x0            = x[c.x];
                     x1            = x[c.y];
                 }
@@ -462,6 +469,60 @@ static int ell_detect_diagonals(spmv_mat* m)
     return SPMV_OK;
 }
 
+namespace
+{
+constexpr int kEllTileRows = 2 * kBlock;  // the rows of one workgroup of ell_diag_kernel_x2
+__global__ __launch_bounds__(kBlock) void ell_tile_values_kernel(int nrow, int k, const double* __restrict__ val, double* __restrict__ tval)
+{
+    const int64_t slots = (int64_t)nrow * k;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < slots; e += (int64_t)gridDim.x * kBlock)
+    {
+        const int s = (int)(e / nrow), i = (int)(e - (int64_t)s * nrow);
+        tval[((int64_t)(i / kEllTileRows) * k + s) * kEllTileRows + (i % kEllTileRows)] = val[e];
+    }
+}
+}  // namespace
+
+void ell_free_tiles(spmv_mat* m)
+{
+    if (!m->ell_tval) return;
+    (void)hipFree(m->ell_tval);
+    m->ell_tval = nullptr;
+    m->device_bytes -= (int64_t)ceil_div(m->nrow, kEllTileRows) * kEllTileRows * m->k * (int64_t)sizeof(double);
+}
+
+// The values once more, in tiles of 512 rows, for the product over slots that are diagonals (the kernel's TILED form).  Costs
+// 8 bytes per slot of device memory for 1-7 % of C3's time (see the kernel), so it is made only when asked for
+// ("ell_tiled_values" = 1).
+int ell_build_tiles(spmv_mat* m, bool only_if_worth)
+{
+    if (m->ell_tval || !m->ell_diag || m->nrow % 2 != 0) return SPMV_OK;
+    const int64_t slots = (int64_t)m->nrow * m->k;
+    if (only_if_worth && slots < ((int64_t)1 << 20)) return SPMV_OK;  // (a few megabytes: the strides do not matter)
+    spmv_ctx*     ctx    = m->ctx;
+    const int64_t padded = (int64_t)ceil_div(m->nrow, kEllTileRows) * kEllTileRows * m->k;
+    double*       t      = nullptr;
+    if (hipMalloc(&t, sizeof(double) * (size_t)padded) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        if (only_if_worth) return SPMV_OK;
+        SPMV_FAIL(SPMV_ERR_ALLOC, "out of device memory for the tiled copy of the values of an ELL handle (%lld bytes)", (long long)(padded * 8));
+    }
+    hipError_t e = hipMemsetAsync(t, 0, sizeof(double) * (size_t)padded, ctx->stream);
+    hipLaunchKernelGGL(ell_tile_values_kernel, dim3((unsigned)std::min<int64_t>(kMaxGrid, ceil_div(slots, kBlock))), dim3(kBlock), 0, ctx->stream, m->nrow, m->k,
+                       m->v, t);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess)
+    {
+        (void)hipFree(t);
+        SPMV_FAIL(SPMV_ERR_HIP, "tiling the values of an ELL handle failed: %s", hipGetErrorString(e));
+    }
+    m->ell_tval = t;
+    m->device_bytes += padded * (int64_t)sizeof(double);
+    return SPMV_OK;
+}
+
 int ell_analyse(spmv_mat* m)
 {
     m->kernel = SPMV_CSR_VECTOR;  // reported for ELL as "one lane per row"
@@ -482,9 +543,16 @@ int ell_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
         const unsigned grid = (unsigned)ceil_div(A->nrow / 2, kBlock);
         const bool     xwin = A->ell_diag_lds > 0 && A->ell_diag_lds <= 5120;  // the x stretches of 512 rows fit 40 KB of LDS
         const size_t   lds  = xwin ? sizeof(double) * (size_t)A->ell_diag_lds : 0;
-#define SPMV_ELL_DIAG(U, W)                                                                                                                 \
-    hipLaunchKernelGGL((ell_diag_kernel_x2<U, W>), dim3(grid), dim3(kBlock), lds, ctx->stream, A->nrow, A->k, A->b, A->v, x, y, A->ell_diag, \
-                       (const u64*)A->ell_diag_mask, A->ncol)
+#define SPMV_ELL_DIAG(U, W)                                                                                                                         \
+    do                                                                                                                                             \
+    {                                                                                                                                              \
+        if (A->ell_tval)                                                                                                                           \
+            hipLaunchKernelGGL((ell_diag_kernel_x2<U, W, true>), dim3(grid), dim3(kBlock), lds, ctx->stream, A->nrow, A->k, A->b, A->ell_tval, x, y, \
+                               A->ell_diag, (const u64*)A->ell_diag_mask, A->ncol);                                                                \
+        else                                                                                                                                       \
+            hipLaunchKernelGGL((ell_diag_kernel_x2<U, W, false>), dim3(grid), dim3(kBlock), lds, ctx->stream, A->nrow, A->k, A->b, A->v, x, y,       \
+                               A->ell_diag, (const u64*)A->ell_diag_mask, A->ncol);                                                                \
+    } while (0)
         // slots in flight per lane: 4 by default; lanes_per_row 4 / 8 select 8 / 2 (tools/tune.py ell: A/B)
         if (A->lanes_per_row == 4)
         {

@@ -676,7 +676,8 @@ def main() -> None:
                 if kid == 4:
                     return "csr_panel_kernel on the row-grouped copy of the ELL slots", "panel"
                 if M.get_param("ell_diagonal_slots") and not (flags & 8):  # 8 = SPMV_FLAG_ELL_READ_COLUMNS
-                    return "ell_diag_kernel_x2 (slots recognised as diagonals: conforming rows read no column index)", "ell_diagonals"
+                    return ("ell_diag_kernel_x2 (slots recognised as diagonals: conforming rows read no column index"
+                            + ("; values read from the copy in tiles of 512 rows)" if M.get_param("ell_tiled_values") else ")")), "ell_diagonals"
                 return "ell_kernel_x2 (one lane per two rows, column-major slots, every column index read)", "ell_columns"
             if fmt == "coo":
                 if kid == 4:

@@ -239,6 +239,10 @@ int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
  *                    move streams of the built layout to fresh allocations (bits 1 products, 2 values, 4 columns, 8 rows,
  *                    16 table), hold a pool of pieces and put any of them under the product stream (10 bits per slot):
  *                    tools/tune_twophase.py, tools/probe_twophase_{moves,pairs,classes,rotate}.py
+ *   "ell_tiled_values"  ELL handles whose slots were found to be diagonals, takes effect at once: 1 = keep a copy of the values
+ *                    in tiles of 512 rows, (tile * k + slot) * 512 + row, and multiply from it - a workgroup then reads one
+ *                    contiguous stretch instead of k stretches nrow * 8 bytes apart; same bits.  8 bytes per slot of device
+ *                    memory for 1-7 % of the product's time (C3), so never made unasked.  0 = drop it.
  *   "coo_column_bins"   COO handles, takes effect at once: the segmented scan (kernel VECTOR) runs over a COPY of the entries in
  *                    8 x value column bins, the bins of one XCD after the other, so that each XCD gathers x from a slice that
  *                    stays in its L2 (kernels_coo.hip; C4: 0.76 ms against 1.81).  -1 = as many bins as keep a slice within
@@ -255,7 +259,8 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value);
  * "panel_pipe", "panel_sync", "panel_stagger", "panel_pace_ns", "panel_pace_scale", "panel_pace_bumps",
  * "panel_bytes", "panel_keep_csr", "device_bytes", "window_max_span", "window_avg_span", "twophase_panel_cols",
  * "twophase_padded" (entries of the two-phase layout with its padding), "twophase_pieces" (1 GB pieces of its product stream),
- * "coo_column_bins" (bins of the copy the COO segmented scan runs over, 0: none), "coo_bins_padded" (its entries with the padding),
+ * "ell_tiled_values" (1: the ELL product reads its values from the copy in tiles), "coo_column_bins" (bins of the copy the COO
+ * segmented scan runs over, 0: none), "coo_bins_padded" (its entries with the padding),
  * "twophase_placement_budget_mb", "twophase_placements_timed" (configurations of pieces timed by the search, 0 = no search ran),
  * "twophase_placement_spread" (time as built / time kept in 1/1000, both re-timed in turn when the search is over; a
  * configuration that does not hold up there is dropped for the pieces as built, so never < 1000), "twophase_pieces_exchanged", "ell_diagonal_slots" (1: the slots of an ELL

@@ -151,6 +151,20 @@ def test_ell_slots_that_are_diagonals_need_no_column_stream(ctx, orc, pkg, shape
         A.set_flags(flags)
         y1, y50 = _apply_n(ctx, A, x, nrow, NUM_TEST)
         assert np.array_equal(y1, ref), (shape, flags)
+    # the values once more in tiles of 512 rows (what a workgroup reads becomes one contiguous stretch; opt-in): same loads in
+    # the same order, so the same bits - rows that do not conform read their columns from the column-major array as before
+    A.set_flags(0)
+    assert A.get_param("ell_tiled_values") == 0
+    held = A.get_param("device_bytes")
+    A.set_param("ell_tiled_values", 1)
+    if shape == "mostly_irregular":
+        assert A.get_param("ell_tiled_values") == 0 and A.get_param("device_bytes") == held  # (no diagonals: nothing to tile for)
+    else:
+        assert A.get_param("ell_tiled_values") == 1 and A.get_param("device_bytes") == held + 8 * k * 512 * -(-nrow // 512)
+        y1, y50 = _apply_n(ctx, A, x, nrow, NUM_TEST)
+        assert np.array_equal(y1, ref), (shape, "tiled")
+        got = A.download()  # (the handle's own arrays are what they were)
+        assert np.array_equal(got[-1], val) and np.array_equal(got[-2], col)
     # x with NaN where only padding looks (x[0] times 0.0 poisons the padded rows in the reference as well: keep it)
     if shape == "stencil":
         xn = x.copy()
@@ -160,6 +174,10 @@ def test_ell_slots_that_are_diagonals_need_no_column_stream(ctx, orc, pkg, shape
         A.set_flags(0)
         yn, _ = _apply_n(ctx, A, xn, nrow, 1)
         assert np.array_equal(np.isnan(yn), np.isnan(refn)) and np.array_equal(yn[~np.isnan(refn)], refn[~np.isnan(refn)])
+    A.set_param("ell_tiled_values", 0)
+    assert A.get_param("ell_tiled_values") == 0 and A.get_param("device_bytes") == held
+    y1, _ = _apply_n(ctx, A, x, nrow, 1)
+    assert np.array_equal(y1, ref), (shape, "tiles dropped")
 
 
 @pytest.mark.parametrize("make", cases.ALL_CASES, ids=lambda f: f.__name__)

@@ -260,10 +260,14 @@ def main():
         print(f"ELL n={n} k={k} {'uniform columns' if a.band < 0 else 'circulant band'}: auto kernel={A.info.kernel} (4 = panel copy, 1 = one lane per row)")
         x, y = ctx.gen_vector(n, seed=1), ctx.vector(n)
         y.fill(0.0)
-        def x2(A, flags, lanes=2):
+        def x2(A, flags, lanes=2, tiled=0):
             A.set_flags(flags)
             A.set_kernel(capi.CSR_VECTOR, lanes)
-        variants = [("ell x2, slots as diagonals (no index stream)", lambda A: x2(A, 0)), ("the same, 8 slots in flight", lambda A: x2(A, 0, 4)),
+            if A.get_param("ell_tiled_values") != tiled:
+                A.set_param("ell_tiled_values", tiled)
+        print("values in tiles of 512 rows:", A.get_param("ell_tiled_values"))
+        variants = [("ell x2, slots as diagonals (no index stream)", lambda A: x2(A, 0)), ("the same, values in tiles of 512 rows", lambda A: x2(A, 0, 2, 1)),
+                    ("the same, 8 slots in flight", lambda A: x2(A, 0, 4)),
                     ("the same, 2 slots in flight", lambda A: x2(A, 0, 8)), ("ell x2, column indices read", lambda A: x2(A, 8)),
                     ("the same, 8 slots in flight", lambda A: x2(A, 8, 4)), ("ell x1", lambda A: x2(A, 8, 1))]
         sweep(ctx, A, x, y, variants, a.rounds, a.reps, algorithmic_bytes("ell", n, n, n * k, k), n * k)
