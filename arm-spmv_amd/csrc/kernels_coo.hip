@@ -217,12 +217,14 @@ __global__ __launch_bounds__(kBlock) void coo_segscan_bins_kernel(const coo_bins
 }
 
 constexpr int kColBuckets = 4096;  // the bins are unions of column buckets of equal width
+// (a column outside 0 .. ncol-1 is the caller's error and the product's problem, as in the reference; the build stays inside its tables)
+__device__ __forceinline__ int bucket_of(int c, int shift) { return min(max(c >> shift, 0), kColBuckets - 1); }
 __global__ __launch_bounds__(kBlock) void coo_col_histogram_kernel(int64_t nnz, const int32_t* __restrict__ col, int shift, unsigned long long* __restrict__ hist)
 {
     __shared__ unsigned int h[kColBuckets];
     for (int i = threadIdx.x; i < kColBuckets; i += kBlock) h[i] = 0;
     __syncthreads();
-    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * kBlock) atomicAdd(&h[col[e] >> shift], 1u);
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * kBlock) atomicAdd(&h[bucket_of(col[e], shift)], 1u);
     __syncthreads();
     for (int i = threadIdx.x; i < kColBuckets; i += kBlock)
         if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(kBlock) void coo_col_histogram_kernel(int64_t nnz, 
 __global__ __launch_bounds__(kBlock) void coo_bin_keys_kernel(int64_t nnz, const int32_t* __restrict__ col, int shift, const uint8_t* __restrict__ bin_of_bucket,
                                                               int32_t* __restrict__ key)
 {
-    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * kBlock) key[e] = bin_of_bucket[col[e] >> shift];
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * kBlock) key[e] = bin_of_bucket[bucket_of(col[e], shift)];
 }
 __global__ __launch_bounds__(kBlock) void coo_bin_fill_kernel(int64_t padded, int32_t* __restrict__ row, int32_t* __restrict__ col, double* __restrict__ val)
 {
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void coo_bin_place_kernel(int64_t nnz, cons
     {
         const int32_t e = perm[i];
         const int32_t c = col[e];
-        const int     b = bin_of_bucket[c >> shift];
+        const int     b = bin_of_bucket[bucket_of(c, shift)];
         const int64_t q = i - bin_src[b];  // position in the bin's order; inside a chunk of 512, entry q sits at (q % 8) * 64 + q / 8
         const int64_t d = bin_dst[b] + (q & ~(int64_t)(kWaveChunk - 1)) + ((q & (kIters - 1)) << 6) + ((q & (kWaveChunk - 1)) >> 3);
         out_row[d]      = row[e];
