@@ -770,6 +770,8 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
             return SPMV_OK;
         };
         const size_t np = (size_t)m->tp_padded;
+        // (a pool of an experiment owns the pieces: replacing them here would leave the pool holding freed pointers)
+        SPMV_REQUIRE(!((value & 1) && m->tp_pool), "twophase_realloc bit 1: this handle's pieces belong to a pool (twophase_pool_alloc)");
         if (value & 1)  // the product stream's pieces: fresh allocations (its contents need no copy: phase A rewrites all of it)
             for (int i = 0; i < m->tp_npieces; ++i)
             {

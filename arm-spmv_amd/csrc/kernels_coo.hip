@@ -354,6 +354,8 @@ int coo_build_bins(spmv_mat* m, int bins_per_xcd, bool only_if_worth)
     const bool worth = (int64_t)m->ncol * 8 > ((int64_t)3 << 20) && m->nnz >= ((int64_t)2 << 20);
     if (only_if_worth && !worth) return SPMV_OK;
     if (m->nnz == 0 || m->ncol <= 0) return SPMV_OK;
+    // a handle too large for the copy's 32-bit addressing keeps the scan in place when nobody asked for bins by name
+    if (only_if_worth && m->nnz > (int64_t)INT32_MAX - 64 * kBlockChunk) return SPMV_OK;
     SPMV_REQUIRE(m->nnz <= (int64_t)INT32_MAX - 64 * kBlockChunk, "the copy in column bins addresses its entries with 32 bits: %lld entries are too many", (long long)m->nnz);
     if (bins_per_xcd <= 0) bins_per_xcd = (int)std::min<int64_t>(8, std::max<int64_t>(1, ceil_div((int64_t)m->ncol * 8, (int64_t)16 << 20)));
     SPMV_REQUIRE(bins_per_xcd <= 8, "coo_column_bins: at most 8 bins per XCD, got %d", bins_per_xcd);

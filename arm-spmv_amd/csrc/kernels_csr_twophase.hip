@@ -49,6 +49,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "placement_math.hpp"
 #include "wave.hpp"
 
 namespace spmv
@@ -782,7 +783,7 @@ int tp_choose_pieces(spmv_mat* m, std::vector<double*> early = {})
         for (int d = 0; d < n; ++d)
             if (!keep[(size_t)d]) (void)hipFree(cand[(size_t)d]);
         m->tp_place_seen = tried;
-        m->tp_place_gain = t_kept > 0.f ? (int32_t)(1000.0f * t_first / t_kept) : 0;
+        m->tp_place_gain = tp_spread_permille(t_first, t_kept, slots == built);
         searched         = true;
     } while (0);
     if (!searched)

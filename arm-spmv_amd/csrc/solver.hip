@@ -13,6 +13,7 @@
 //
 // Not part of the reference's API: the results are checked against the oracle's product (residual of the solution)
 // in tests/test_gpu_solver.py.
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 
@@ -385,12 +386,28 @@ __global__ __launch_bounds__(kBlock) void cg_fused_kernel(int64_t n, int k, cons
     // Below |r| = 1e-14 |b| (s->noise_floor = 1e-28 b.b, written by the host once b.b is known) the residual is rounding noise
     // of the recurrence and this arrangement's alpha - a difference of two nearly equal numbers - is noise too: the iterations
     // queued behind an exactly solved system pass without touching anything.
-    if (!(rr_k > s->noise_floor)) return;  // uniform over the grid: every thread read the same scalars
-    const double beta  = k > 0 && gamma_old > 0.0 ? gamma / gamma_old : 0.0;
-    const double denom = k > 0 && beta != 0.0 ? delta - beta * gamma / s->alpha[(k + 3) & 3] : delta;
+    // (uniform over the grid: every thread read the same scalars)
+    if (rr_k != rr_k)
+    {
+        if (blockIdx.x == 0 && threadIdx.x == 0) s->status = 2.0;  // r.r is NaN: b, x0 or the matrix hold non-finite numbers
+        return;
+    }
+    if (!(rr_k > s->noise_floor))
+    {
+        // the residual the recurrence ATTAINED travels on with the ring (slot k + 1 was cleared two launches ago and nobody
+        // else writes it in a quiet launch), so the host reports ~1e-14 and not an exact 0 it never reached
+        if (blockIdx.x == 0 && threadIdx.x == 0) s->rr[(k + 1) & 3][0] = rr_k;
+        return;
+    }
+    // k = 0 needs no special case: gamma_old is the 0 the set-up wrote into slot 3 (beta_0 = 0), which is also what lets a
+    // captured graph of four iterations be replayed at k = 4, 8, ... (k enters through k & 3 alone)
+    const double beta  = gamma_old > 0.0 ? gamma / gamma_old : 0.0;
+    const double denom = beta != 0.0 ? delta - beta * gamma / s->alpha[(k + 3) & 3] : delta;
     if (!(denom > 0.0) || !(gamma > 0.0))
     {
-        if (blockIdx.x == 0 && threadIdx.x == 0 && gamma > 0.0) s->status = 1.0;  // a residual to speak of and no descent: not SPD
+        // a residual to speak of and no descent direction: p.Ap <= 0, or r.M^-1 r <= 0 (a Jacobi diagonal with a negative
+        // entry: -I), or one of them NaN - not positive definite, and never a quiet pass
+        if (blockIdx.x == 0 && threadIdx.x == 0) s->status = 1.0;
         return;
     }
     const double alpha = gamma / denom;
@@ -618,6 +635,12 @@ int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int m
         const double limit = rel_tol * rel_tol * bb;  // compare squared norms
         double       rr    = host_sum(h.rr[0]);
         int          k     = 0;
+        if (!std::isfinite(bb) || !std::isfinite(rr))
+        {
+            set_error("spmv_cg: b.b = %g, r0.r0 = %g: b, x0 or the matrix hold non-finite numbers", bb, rr);
+            rc = SPMV_ERR_INVALID;
+            break;
+        }
         if (!(bb > 0.0) || rr <= limit)
         {
             *rel_resid = bb > 0.0 ? sqrt(rr / bb) : 0.0;  // b = 0: x0 solves it if r = 0 (else the caller sees iters = 0)
@@ -643,7 +666,7 @@ int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int m
                 fx.dot_w     = in;
                 fx.dot_out   = s->pq[kk & 3];
                 SPMV_TRY(mat_apply_ex(ctx, A, in, q, fx));  // w = A u, delta_k = u . w
-                const int kq = kk == 0 ? 0 : 4 + (kk & 3);  // (k > 0 and k & 3 are all the kernel looks at: graph replay keeps working)
+                const int kq = kk & 3;  // (k & 3 is all the kernel looks at: a captured graph of four iterations replays at any k % 4 == 0)
 #define SPMV_CG_FUSED(PRE, WIDE, GRID) \
     hipLaunchKernelGGL((cg_fused_kernel<PRE, WIDE>), dim3(GRID), dim3(kBlock), 0, st, n, kq, q, u, p, sv, x, r, s, dinv)
                 if (dinv)
@@ -730,9 +753,15 @@ int cg_solve(spmv_ctx* ctx, const spmv_mat* A, const double* b, double* x, int m
                 rr = host_sum(h.rr[k & 3]);
                 // the status word is only set with r != 0 (an exactly solved system ends the queued iterations quietly, see
                 // the update kernels); it is looked at first because a breakdown leaves the next r.r at its cleared 0
+                if (h.status == 2.0 || !std::isfinite(rr))
+                {
+                    set_error("spmv_cg: the residual is not finite at or before iteration %d (non-finite numbers in b, x0 or the matrix, or overflow)", k);
+                    rc = SPMV_ERR_INVALID;
+                    break;
+                }
                 if (h.status != 0.0)
                 {
-                    set_error("spmv_cg: p.Ap <= 0 at or before iteration %d: the matrix is not positive definite", k);
+                    set_error("spmv_cg: p.Ap <= 0 (or r.M^-1 r <= 0) at or before iteration %d: the matrix is not positive definite", k);
                     rc = SPMV_ERR_INVALID;
                     break;
                 }

@@ -160,6 +160,72 @@ def test_cg_exact_convergence_between_host_checks_is_not_a_breakdown(ctx, pkg):
         np.testing.assert_allclose(x.download(), b_host / diag, rtol=1e-14, atol=0)
 
 
+def test_cg_never_reports_convergence_it_did_not_reach(ctx, pkg, monkeypatch):
+    """Round 4's advisor: the two-launch iteration returned SPMV_OK with rel_resid = 0 and x = x0 (a) for -I under Jacobi
+    (gamma = r.D^-1 r < 0: no status was set unless gamma > 0), (b) for a b with a NaN (the NaN r.r took the quiet
+    noise-floor exit).  Both are errors in either arrangement of the iteration.  (c) Past the noise floor the attained
+    residual is reported, not an exact 0."""
+    n = 1000
+    rp = np.arange(n + 1, dtype=np.int32)
+    cc = np.arange(n, dtype=np.int32)
+    for three in ("0", "1"):
+        monkeypatch.setenv("SPMV_CG_THREE_LAUNCHES", three)
+        A = ctx.csr(n, n, rp, cc, np.full(n, -1.0))  # -I: Jacobi's D^-1 is -I too
+        b, x = ctx.vector_from(np.ones(n)), ctx.vector(n)
+        for jacobi in (False, True):
+            x.fill(0.0)
+            with pytest.raises(pkg.capi.SpmvError, match="not positive definite"):
+                ctx.cg(A, b, x, max_iter=10, rel_tol=1e-8, jacobi=jacobi)
+        # NaN in b: an error, not iters = k with rel_resid = 0
+        nn, rp2, cc2, cv2 = _laplacian_2d(40)
+        L = ctx.csr(nn, nn, rp2, cc2, cv2)
+        bad = np.ones(nn)
+        bad[17] = np.nan
+        for jacobi in (False, True):
+            for check_every in (1, 8):
+                bv, xv = ctx.vector_from(bad), ctx.vector(nn)
+                xv.fill(0.0)
+                with pytest.raises(pkg.capi.SpmvError, match="non-finite|not finite"):
+                    ctx.cg(L, bv, xv, max_iter=40, rel_tol=1e-8, jacobi=jacobi, check_every=check_every)
+        # NaN that enters later (x0 finite, b finite, a NaN matrix value in a row the first product multiplies by 0):
+        cv3 = cv2.copy()
+        cv3[rp2[5]] = np.nan
+        Ln = ctx.csr(nn, nn, rp2, cc2, cv3)
+        bv, xv = ctx.vector_from(np.ones(nn)), ctx.vector(nn)
+        xv.fill(0.0)
+        with pytest.raises(pkg.capi.SpmvError, match="non-finite|not finite|not positive definite"):
+            ctx.cg(Ln, bv, xv, max_iter=40, rel_tol=1e-8, check_every=8)
+    monkeypatch.setenv("SPMV_CG_THREE_LAUNCHES", "0")
+    # (c) a tolerance below what fp64 can reach: iterations run out (or stop at the floor) and the residual reported is the
+    # one attained (> 0 and small), not the cleared slot's 0
+    nn, rp2, cc2, cv2 = _laplacian_2d(64)
+    L = ctx.csr(nn, nn, rp2, cc2, cv2)
+    b_host = np.random.default_rng(8).uniform(-1, 1, nn)
+    bv, xv = ctx.vector_from(b_host), ctx.vector(nn)
+    xv.fill(0.0)
+    iters, relres = ctx.cg(L, bv, xv, max_iter=3000, rel_tol=1e-20, check_every=50)
+    assert iters == 3000 and 0.0 < relres < 1e-12, (iters, relres)
+
+
+def test_cg_graph_replay_takes_the_same_iterations(ctx, pkg, monkeypatch):
+    """SPMV_CG_GRAPH=1 replays four captured iterations per launch.  Round 4's capture baked `k > 0 false` into its first node,
+    so every replay restarted CG (beta = 0): valid iterates, slower convergence.  k now enters through k & 3 alone."""
+    n, rp, cc, cv = _laplacian_2d(128)
+    A = ctx.csr(n, n, rp, cc, cv)
+    b_host = np.random.default_rng(3).uniform(-1, 1, n)
+    counts = {}
+    for graph in ("0", "1"):
+        monkeypatch.setenv("SPMV_CG_GRAPH", graph)
+        for jacobi in (False, True):
+            b, x = ctx.vector_from(b_host), ctx.vector(n)
+            x.fill(0.0)
+            iters, relres = ctx.cg(A, b, x, max_iter=4000, rel_tol=1e-9, check_every=8, jacobi=jacobi)
+            assert relres <= 1e-9
+            counts[(graph, jacobi)] = iters
+    for jacobi in (False, True):
+        assert abs(counts[("1", jacobi)] - counts[("0", jacobi)]) <= 8, counts
+
+
 def test_sharded_cg_with_the_engine_as_local_ops():
     """dist.cg_sharded + dist.HipShardOps on one GPU (world 1; the N > 1 collectives are covered on CPU with gloo in
     tests/test_dist_gloo.py): same answer as the single-device spmv_cg.  In a child process, because torch must
