@@ -104,6 +104,9 @@ SIGNATURES = {
     "spmv_gen_ell_banded": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.POINTER(_vp)]),
     "spmv_gen_dia_banded": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_uint64, C.POINTER(_vp)]),
     "spmv_gen_coo_powerlaw": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.POINTER(_vp)]),
+    "spmv_gen_coo_powerlaw_sorted": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.POINTER(_vp)]),
+    "spmv_mat_partition_rows": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp]),
+    "spmv_csr_extract_rows": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.POINTER(_vp)]),
     "spmv_gen_vec_uniform": (C.c_int, [_vp, _vp, C.c_int64, C.c_uint64]),
 }
 
@@ -301,9 +304,17 @@ class Context:
         _check(self._lib.spmv_gen_dia_banded(self.h, nrow, k, seed, C.byref(h)))
         return Matrix(self, h)
 
-    def gen_coo_powerlaw(self, nrow, ncol, max_len=4096, seed=1) -> "Matrix":
+    def gen_coo_powerlaw(self, nrow, ncol, max_len=4096, seed=1, sorted_by_length=False) -> "Matrix":
+        """row-sorted COO with power-law row lengths; sorted_by_length: the lengths at the distribution's quantiles, longest first"""
         h = _vp()
-        _check(self._lib.spmv_gen_coo_powerlaw(self.h, nrow, ncol, max_len, seed, C.byref(h)))
+        fn = self._lib.spmv_gen_coo_powerlaw_sorted if sorted_by_length else self._lib.spmv_gen_coo_powerlaw
+        _check(fn(self.h, nrow, ncol, max_len, seed, C.byref(h)))
+        return Matrix(self, h)
+
+    def extract_rows(self, csr: "Matrix", row_begin: int, row_end: int) -> "Matrix":
+        """rows [row_begin, row_end) of a device-resident CSR handle (of any context) as a shard on THIS context"""
+        h = _vp()
+        _check(self._lib.spmv_csr_extract_rows(self.h, csr.h, row_begin, row_end, C.byref(h)))
         return Matrix(self, h)
 
     def gen_vector(self, n, index_offset=0, seed=1) -> "Vector":
@@ -488,6 +499,12 @@ class Matrix:
 
     def set_flags(self, flags: int) -> None:
         _check(self.ctx._lib.spmv_mat_set_flags(self.h, flags))
+
+    def partition_rows(self, nparts: int, balance_entries: bool = False) -> np.ndarray:
+        """bounds[nparts + 1] of a row partition of this handle (columns for CSC): equal rows (the reference's split) or by entries"""
+        bounds = np.zeros(nparts + 1, dtype=np.int64)
+        _check(self.ctx._lib.spmv_mat_partition_rows(self.h, nparts, 1 if balance_entries else 0, bounds.ctypes.data))
+        return bounds
 
     def download(self):
         """(a, b, v) host copies; see spmv_mat_download for which array is which per format"""

@@ -1122,16 +1122,62 @@ int spmv_partition_rows_balanced(int64_t nrow, const int64_t* row_ptr64, int32_t
     bounds[0]         = 0;
     for (int32_t p = 1; p < nparts; ++p)
     {
-        // first row whose starting offset reaches p/nparts of the entries
+        // the row boundary whose offset lies NEAREST to p / nparts of the entries (a row is never split; ties go to the later
+        // boundary), kept monotonic
         const int64_t  target = row_ptr64[0] + (int64_t)(((__int128)nnz * p) / nparts);
         const int64_t* it     = std::lower_bound(row_ptr64, row_ptr64 + nrow + 1, target);
         int64_t        r      = it - row_ptr64;
         if (r > nrow) r = nrow;
+        if (r > 0 && target - row_ptr64[r - 1] < row_ptr64[r] - target) --r;
         if (r < bounds[p - 1]) r = bounds[p - 1];
         bounds[p] = r;
     }
     bounds[nparts] = nrow;
     return SPMV_OK;
+}
+
+// bounds of a row partition of a device-resident handle (columns for CSC, which the reference shards by column)
+int spmv_mat_partition_rows(const spmv_mat* m, int32_t nparts, int32_t balance_entries, int64_t* bounds)
+{
+    SPMV_REQUIRE(m && nparts > 0 && bounds, "spmv_mat_partition_rows: bad argument");
+    const int64_t n = m->format == SPMV_FMT_CSC ? m->ncol : m->nrow;
+    // padded formats store the same number of slots for every row: equal rows ARE equal work
+    if (!balance_entries || m->format == SPMV_FMT_ELL || m->format == SPMV_FMT_DIA || n == 0)
+    {
+        for (int32_t p = 0; p < nparts; ++p)
+        {
+            int64_t b = 0, e = 0;
+            SPMV_TRY(spmv_partition_rows(n, nparts, p, &b, &e));
+            bounds[p]     = b;
+            bounds[p + 1] = e;
+        }
+        return SPMV_OK;
+    }
+    std::vector<int64_t> rp64((size_t)n + 1);
+    if (m->format == SPMV_FMT_COO)
+        SPMV_TRY(coo_row_offsets(m, rp64.data()));
+    else
+    {
+        SPMV_REQUIRE(m->a, "spmv_mat_partition_rows: the handle has no offset array");
+        std::vector<int32_t> rp((size_t)n + 1);
+        SPMV_HIP(hipSetDevice(m->ctx->device));
+        SPMV_HIP(hipMemcpyAsync(rp.data(), m->a, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost, m->ctx->stream));
+        SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
+        for (size_t i = 0; i < rp.size(); ++i) rp64[i] = rp[i];
+    }
+    return spmv_partition_rows_balanced(n, rp64.data(), nparts, bounds);
+}
+
+int spmv_csr_extract_rows(spmv_ctx* dst_ctx, const spmv_mat* csr, int64_t row_begin, int64_t row_end, spmv_mat** out)
+{
+    SPMV_REQUIRE(dst_ctx && csr && out, "spmv_csr_extract_rows: null argument");
+    int before = -1;
+    if (hipGetDevice(&before) != hipSuccess) before = -1;
+    spmv_mat* m  = nullptr;
+    int       rc = csr_extract_rows(dst_ctx, csr, row_begin, row_end, &m);
+    if (rc == SPMV_OK) rc = finish(m, out);  // validates and analyses like an uploaded shard (frees on failure)
+    if (before >= 0) (void)hipSetDevice(before);
+    return rc;
 }
 
 // ---- generators -------------------------------------------------------------------------------------------
@@ -1162,7 +1208,14 @@ int spmv_gen_coo_powerlaw(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t max
 {
     SPMV_REQUIRE(ctx && out, "spmv_gen_coo_powerlaw: null argument");
     SPMV_TRY(use_device(ctx));
-    return gen_coo_powerlaw(ctx, nrow, ncol, max_len, seed, out);
+    return gen_coo_powerlaw(ctx, nrow, ncol, max_len, seed, false, out);
+}
+
+int spmv_gen_coo_powerlaw_sorted(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t max_len, uint64_t seed, spmv_mat** out)
+{
+    SPMV_REQUIRE(ctx && out, "spmv_gen_coo_powerlaw_sorted: null argument");
+    SPMV_TRY(use_device(ctx));
+    return gen_coo_powerlaw(ctx, nrow, ncol, max_len, seed, true, out);
 }
 
 int spmv_gen_vec_uniform(spmv_ctx* ctx, spmv_vec* v, int64_t index_offset, uint64_t seed)

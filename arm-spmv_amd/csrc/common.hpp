@@ -326,6 +326,8 @@ int coo_place_by_stable_sort(spmv_ctx* ctx, int64_t nnz, int32_t nrow, const int
                              int32_t* out_col, double* out_val);
 int csr_to_ell(spmv_ctx* ctx, const spmv_mat* csr, spmv_mat** out);
 int csr_split_columns(spmv_ctx* ctx, const spmv_mat* csr, int32_t c0, int32_t c1, spmv_mat** out_in, spmv_mat** out_out);
+int csr_extract_rows(spmv_ctx* dst, const spmv_mat* csr, int64_t r0, int64_t r1, spmv_mat** out);
+int coo_row_offsets(const spmv_mat* coo, int64_t* row_ptr64 /* host, nrow + 1 */);
 int reduce_max_i32(spmv_ctx* ctx, const int32_t* in, int64_t n, int32_t* result);
 // generate.hip
 int gen_csr_uniform(spmv_ctx* ctx, int64_t row_begin, int64_t row_end, int32_t ncol, int32_t k,
@@ -333,7 +335,7 @@ int gen_csr_uniform(spmv_ctx* ctx, int64_t row_begin, int64_t row_end, int32_t n
 int gen_ell_banded(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t k, uint64_t seed,
                    spmv_mat** out);
 int gen_dia_banded(spmv_ctx* ctx, int32_t nrow, int32_t k, uint64_t seed, spmv_mat** out);
-int gen_coo_powerlaw(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t max_len, uint64_t seed,
+int gen_coo_powerlaw(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t max_len, uint64_t seed, bool sorted_by_length,
                      spmv_mat** out);
 int gen_vec_uniform(spmv_ctx* ctx, double* d, int64_t n, int64_t index_offset, uint64_t seed);
 

@@ -8,6 +8,8 @@
 //
 // The packed `diagonal` array the reference also fills (src/matrix.cpp:146-153, "for SymGS") is not
 // consumed by any product; the C++ compat shim builds it on the host when asked.
+#include <vector>
+
 #include "common.hpp"
 #include "wave.hpp"
 
@@ -380,6 +382,80 @@ int csr_split_columns(spmv_ctx* ctx, const spmv_mat* csr, int32_t c0, int32_t c1
     A_in->row_begin  = csr->row_begin - c0;
     *out_in  = A_in;
     *out_out = A_out;
+    return SPMV_OK;
+}
+
+// Rows [r0, r1) of a device-resident CSR handle as a shard of their own on `dst` (any context: the same GPU or a peer) -
+// src/mat_vec.cpp:250-265 on the devices: rebased int32 row_ptr, global columns, the entries copied device to device.
+// Synchronous; ordered behind the work queued on the source's stream.
+int csr_extract_rows(spmv_ctx* dst, const spmv_mat* csr, int64_t r0, int64_t r1, spmv_mat** out)
+{
+    SPMV_REQUIRE(csr->format == SPMV_FMT_CSR && csr->a && (csr->nnz == 0 || (csr->b && csr->v)),
+                 "spmv_csr_extract_rows: input is not a CSR handle with its arrays (panel_keep_csr = 0 released them?)");
+    SPMV_REQUIRE(r0 >= 0 && r0 <= r1 && r1 <= csr->nrow, "spmv_csr_extract_rows: rows [%lld, %lld) outside [0, %d)", (long long)r0, (long long)r1, csr->nrow);
+    spmv_ctx*            sc   = csr->ctx;
+    const int32_t        nrow = (int32_t)(r1 - r0);
+    std::vector<int32_t> rp((size_t)nrow + 1);
+    SPMV_HIP(hipSetDevice(sc->device));
+    SPMV_HIP(hipMemcpyAsync(rp.data(), csr->a + r0, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost, sc->stream));
+    SPMV_HIP(hipStreamSynchronize(sc->stream));
+    const int32_t base = rp[0];
+    const int64_t nnz  = (int64_t)rp[(size_t)nrow] - base;
+    SPMV_REQUIRE(nnz >= 0, "spmv_csr_extract_rows: the handle's row_ptr decreases between rows %lld and %lld", (long long)r0, (long long)r1);
+    for (int32_t& v : rp) v -= base;
+    SPMV_HIP(hipSetDevice(dst->device));
+    spmv_mat* m = nullptr;
+    SPMV_TRY(mat_alloc(dst, SPMV_FMT_CSR, nrow, csr->ncol, nnz, 0, (size_t)nrow + 1, (size_t)nnz, (size_t)nnz, &m));
+    hipError_t e = hipMemcpyAsync(const_cast<int32_t*>(m->a), rp.data(), sizeof(int32_t) * rp.size(), hipMemcpyHostToDevice, dst->stream);
+    if (e == hipSuccess && nnz > 0)
+    {
+        if (sc->device == dst->device)
+        {
+            e = hipMemcpyAsync(const_cast<int32_t*>(m->b), csr->b + base, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToDevice, dst->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(const_cast<double*>(m->v), csr->v + base, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToDevice, dst->stream);
+        }
+        else
+        {
+            e = hipMemcpyPeerAsync(const_cast<int32_t*>(m->b), dst->device, csr->b + base, sc->device, sizeof(int32_t) * (size_t)nnz, dst->stream);
+            if (e == hipSuccess) e = hipMemcpyPeerAsync(const_cast<double*>(m->v), dst->device, csr->v + base, sc->device, sizeof(double) * (size_t)nnz, dst->stream);
+        }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(dst->stream);  // (rp is a host vector about to go out of scope)
+    if (e != hipSuccess)
+    {
+        mat_free(m);
+        SPMV_FAIL(SPMV_ERR_HIP, "spmv_csr_extract_rows: %s", hipGetErrorString(e));
+    }
+    m->row_begin = csr->row_begin + r0;
+    *out         = m;
+    return SPMV_OK;
+}
+
+// row_ptr64[i] = entries of a COO handle in rows < i (a histogram of the row indices + a scan, on the device; the entries
+// may be in any order).  What an entry-balanced row partition of a COO handle is cut from.
+int coo_row_offsets(const spmv_mat* coo, int64_t* row_ptr64)
+{
+    SPMV_REQUIRE(coo->format == SPMV_FMT_COO, "coo_row_offsets: not a COO handle");
+    spmv_ctx*   ctx  = coo->ctx;
+    const int   nrow = coo->nrow;
+    hipStream_t s    = ctx->stream;
+    SPMV_REQUIRE(coo->nnz <= INT32_MAX, "coo_row_offsets: %lld entries do not fit the int32 histogram", (long long)coo->nnz);
+    int32_t* count = nullptr;
+    SPMV_HIP(hipSetDevice(ctx->device));
+    if (hipMalloc(&count, sizeof(int32_t) * ((size_t)nrow + 1)) != hipSuccess) SPMV_FAIL(SPMV_ERR_ALLOC, "coo_row_offsets: out of device memory");
+    std::vector<int32_t> host((size_t)nrow + 1);
+    int                  rc = SPMV_OK;
+    (void)hipMemsetAsync(count, 0, sizeof(int32_t) * ((size_t)nrow + 1), s);
+    if (coo->nnz > 0)
+        hipLaunchKernelGGL(row_histogram_kernel, dim3((unsigned)std::min<int64_t>(kMaxGrid, ceil_div(coo->nnz, kBlock))), dim3(kBlock), 0, s,
+                           coo->nnz, coo->a, count);
+    rc = exclusive_scan_i32(ctx, count, count, (int64_t)nrow + 1);
+    if (rc == SPMV_OK && (hipMemcpyAsync(host.data(), count, sizeof(int32_t) * host.size(), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                          hipStreamSynchronize(s) != hipSuccess))
+        rc = SPMV_ERR_HIP;
+    (void)hipFree(count);
+    if (rc != SPMV_OK) SPMV_FAIL(rc, "coo_row_offsets failed: %s", hipGetErrorString(hipGetLastError()));
+    for (size_t i = 0; i < host.size(); ++i) row_ptr64[i] = host[i];
     return SPMV_OK;
 }
 }  // namespace spmv

@@ -60,7 +60,10 @@ __global__ __launch_bounds__(kBlock) void gen_ell_banded_kernel(int32_t nrow, in
     }
 }
 
-__global__ __launch_bounds__(kBlock) void gen_row_len_kernel(int32_t nrow, int32_t max_len, uint64_t key_len,
+// sorted_by_length: the same distribution taken at its quantiles, u_i = (i + 1) / nrow, instead of drawn: the rows come sorted
+// by length, the longest first - every heavy row at one end of the matrix, the positional skew an equal-rows partition
+// handles worst ("an nnz-balanced split as an option for C4-like skew")
+__global__ __launch_bounds__(kBlock) void gen_row_len_kernel(int32_t nrow, int32_t max_len, uint64_t key_len, int sorted_by_length,
                                                              int32_t* __restrict__ len)
 {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i <= nrow; i += (int64_t)gridDim.x * kBlock)
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(kBlock) void gen_row_len_kernel(int32_t nrow, int32
         int32_t l = 0;
         if (i < nrow)
         {
-            const double u = 1.0 - u64_to_unit(splitmix64(key_len + (uint64_t)i));  // (0,1]
+            const double u = sorted_by_length ? (double)(i + 1) / (double)nrow : 1.0 - u64_to_unit(splitmix64(key_len + (uint64_t)i));  // (0,1]
             const double q = floor(8.0 / u);
             l              = q >= (double)max_len ? max_len : (int32_t)q;
         }
@@ -157,7 +160,7 @@ int gen_ell_banded(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t k, uint64_
     return SPMV_OK;
 }
 
-int gen_coo_powerlaw(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t max_len, uint64_t seed, spmv_mat** out)
+int gen_coo_powerlaw(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t max_len, uint64_t seed, bool sorted_by_length, spmv_mat** out)
 {
     SPMV_REQUIRE(nrow >= 0 && ncol > 0 && max_len > 0, "bad nrow/ncol/max_len");
     int32_t* len     = nullptr;
@@ -173,7 +176,7 @@ int gen_coo_powerlaw(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t max_len,
     do
     {
         hipLaunchKernelGGL(gen_row_len_kernel, dim3(stream_grid(nrow + 1)), dim3(kBlock), 0, ctx->stream, nrow, max_len,
-                           stream_key(seed, kStreamLen), len);
+                           stream_key(seed, kStreamLen), sorted_by_length ? 1 : 0, len);
         if ((rc = exclusive_scan_i32(ctx, len, row_ptr, (int64_t)nrow + 1)) != SPMV_OK) break;
         int32_t nnz = 0;
         if (hipMemcpyAsync(&nnz, row_ptr + nrow, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||

@@ -35,12 +35,24 @@ def all_bounds(nrow: int, world: int) -> list[tuple[int, int]]:
     return [shard_rows(nrow, world, r) for r in range(world)]
 
 
-def allgather_x(x_full: torch.Tensor, x_own: torch.Tensor, nrow: int, group=None) -> None:
+def balanced_bounds(row_ptr64, world: int) -> list[tuple[int, int]]:
+    """[begin, end) per rank with about the same number of STORED ENTRIES each (spmv_partition_rows_balanced) — the option
+    SURVEY.md 8e names for skewed matrices; the reference itself only splits by equal rows (src/mat_vec.cpp:233).  Every rank
+    must compute it from the same offsets (they are small: 8 bytes per row).  Pass the result as `bounds=` below."""
+    b = capi.partition_rows_balanced(row_ptr64, world)
+    return [(int(b[r]), int(b[r + 1])) for r in range(world)]
+
+
+def allgather_x(x_full: torch.Tensor, x_own: torch.Tensor, nrow: int, group=None, bounds=None) -> None:
     """x_full[rows of r] <- rank r's x_own, for every r.  One collective when the slices are equal
-    (all_gather_into_tensor: ring/mesh over xGMI under RCCL), one broadcast per rank otherwise."""
+    (all_gather_into_tensor: ring/mesh over xGMI under RCCL), one broadcast per rank otherwise.
+    bounds: the ranks' row ranges when they are not the equal-rows split (balanced_bounds)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    bounds = all_bounds(nrow, world)
+    equal = bounds is None
+    bounds = all_bounds(nrow, world) if bounds is None else [(int(b), int(e)) for b, e in bounds]
+    if len(bounds) != world or bounds[0][0] != 0 or bounds[-1][1] != nrow or any(bounds[r][1] != bounds[r + 1][0] for r in range(world - 1)):
+        raise ValueError(f"bounds {bounds} do not tile [0, {nrow}) over {world} ranks")
     b, e = bounds[rank]
     if x_own.numel() != e - b:
         raise ValueError(f"rank {rank} owns rows [{b},{e}) but passed a slice of {x_own.numel()} entries")
@@ -49,10 +61,10 @@ def allgather_x(x_full: torch.Tensor, x_own: torch.Tensor, nrow: int, group=None
     if x_full.is_cuda and dist.get_backend(group) == "gloo":
         # rehearsal only (several ranks sharing one GPU, where RCCL refuses to run): stage through the host
         host = torch.empty(nrow, dtype=x_full.dtype)
-        allgather_x(host, x_own.cpu(), nrow, group)
+        allgather_x(host, x_own.cpu(), nrow, group, None if equal else bounds)
         x_full.copy_(host)
         return
-    if nrow % world == 0:
+    if equal and nrow % world == 0:
         dist.all_gather_into_tensor(x_full, x_own.contiguous(), group=group)
         return
     for r, (rb, re) in enumerate(bounds):
@@ -63,10 +75,10 @@ def allgather_x(x_full: torch.Tensor, x_own: torch.Tensor, nrow: int, group=None
             dist.broadcast(part, src=dist.get_global_rank(group, r) if group is not None else r, group=group)
 
 
-def concatenate_y(y_own: torch.Tensor, nrow: int, group=None) -> torch.Tensor:
+def concatenate_y(y_own: torch.Tensor, nrow: int, group=None, bounds=None) -> torch.Tensor:
     """full y on every rank from the row slices (the reference's DIA driver copy-back, generalised)"""
     y_full = torch.empty(nrow, dtype=y_own.dtype, device=y_own.device)
-    allgather_x(y_full, y_own, nrow, group)
+    allgather_x(y_full, y_own, nrow, group, bounds)
     return y_full
 
 

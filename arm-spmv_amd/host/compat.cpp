@@ -655,6 +655,19 @@ namespace
 {
 int    g_numa_reps    = 50;  // NTESTS, src/mat_vec.cpp:201
 double g_last_numa_ms = 0.0;
+// How the sharded drivers cut the rows: 0 = equal rows, the last shard takes the remainder (the reference: src/mat_vec.cpp:151,
+// :233,:245-246 - the default), 1 = by entries (spmv_partition_rows_balanced: every shard about the same number of stored
+// entries; SURVEY.md 8e's option for skewed matrices).  -1 = not set by a call: the environment's SPMV_COMPAT_PARTITION
+// ("nnz" / "entries" / "1" -> by entries, anything else -> rows), read at every driver call.
+int    g_partition    = -1;
+double g_last_slowest_shard_ms = 0.0, g_last_shard_imbalance = 0.0;
+
+bool partition_by_entries()
+{
+    if (g_partition >= 0) return g_partition == 1;
+    const char* e = getenv("SPMV_COMPAT_PARTITION");
+    return e && (!strcmp(e, "nnz") || !strcmp(e, "entries") || !strcmp(e, "1"));
+}
 
 struct Shard
 {
@@ -738,6 +751,28 @@ void run_shards(const char* fmt_name, std::vector<Shard>& shards, const Vector& 
         for (Shard& s : shards) check(spmv_sync(E.ctx(s.device)), "spmv_sync");
         const double qsecs = std::chrono::duration<double>(std::chrono::steady_clock::now() - q0).count();
         printf("### %s NUMA GFLOPS, all repetitions queued and one wait = %.5f\n", fmt_name, flops_per_apply / (qsecs * 1000.0 / g_numa_reps) / 1e6);
+        // How even the partition is: stored entries per shard (max / mean) and every shard's own product time (HIP events, 5
+        // products each, one shard at a time).  With one device per shard the step of the job is its SLOWEST shard; on fewer
+        // devices the shards of a device run one after the other and only the sum shows in the line above.
+        double  slowest = 0.0, sum_ms = 0.0;
+        int64_t most = 0, total = 0;
+        for (size_t i = 0; i < shards.size(); ++i)
+        {
+            spmv_mat_info info;
+            check(spmv_mat_get_info(shards[i].mat, &info), "spmv_mat_get_info(shard)");
+            const int64_t stored = info.format == SPMV_FMT_ELL || info.format == SPMV_FMT_DIA ? (int64_t)info.nrow * info.ell_k : info.nnz;
+            most = std::max(most, stored);
+            total += stored;
+            double ms = 0.0;
+            if (info.nrow > 0)
+                check(spmv_apply_timed(E.ctx(shards[i].device), shards[i].mat, replica_of(shards[i].device), scratch[i], 5, &ms), "spmv_apply_timed(shard)");
+            slowest = std::max(slowest, ms);
+            sum_ms += ms;
+        }
+        g_last_slowest_shard_ms = slowest;
+        g_last_shard_imbalance  = total > 0 ? (double)most * (double)shards.size() / (double)total : 1.0;
+        printf("### %s NUMA shards = %zu, partition by %s: stored entries per shard max / mean = %.3f; slowest shard %.4f ms, all shards one after the other %.4f ms\n",
+               fmt_name, shards.size(), partition_by_entries() ? "entries" : "rows", g_last_shard_imbalance, slowest, sum_ms);
         for (spmv_vec* v : scratch) spmv_vec_destroy(v);
     }
 
@@ -761,14 +796,28 @@ void run_shards(const char* fmt_name, std::vector<Shard>& shards, const Vector& 
     shards.clear();
 }
 
-std::vector<Shard> plan_shards(int64_t nrow, int nthreads)
+// row_ptr64: offsets of the rows (nrow + 1 entries) when the caller has them - the by-entries partition is cut from them;
+// nullptr (formats that store the same number of slots for every row: ELL, DIA) or the default mode: equal rows
+std::vector<Shard> plan_shards(int64_t nrow, int nthreads, const int64_t* row_ptr64 = nullptr)
 {
     Engine&            E = Engine::get();
     std::vector<Shard> shards((size_t)std::max(nthreads, 1));
+    std::vector<int64_t> bounds;
+    if (row_ptr64 && partition_by_entries())
+    {
+        bounds.resize(shards.size() + 1);
+        check(spmv_partition_rows_balanced(nrow, row_ptr64, (int)shards.size(), bounds.data()), "spmv_partition_rows_balanced");
+    }
     for (int i = 0; i < (int)shards.size(); ++i)
     {
         shards[(size_t)i].device = i % E.ngpus();
-        check(spmv_partition_rows(nrow, (int)shards.size(), i, &shards[(size_t)i].row0, &shards[(size_t)i].row1), "spmv_partition_rows");
+        if (!bounds.empty())
+        {
+            shards[(size_t)i].row0 = bounds[(size_t)i];
+            shards[(size_t)i].row1 = bounds[(size_t)i + 1];
+        }
+        else
+            check(spmv_partition_rows(nrow, (int)shards.size(), i, &shards[(size_t)i].row0, &shards[(size_t)i].row1), "spmv_partition_rows");
     }
     return shards;
 }
@@ -776,12 +825,15 @@ std::vector<Shard> plan_shards(int64_t nrow, int nthreads)
 
 void   spmv_compat_set_numa_reps(int reps) { g_numa_reps = reps > 0 ? reps : 1; }
 double spmv_compat_last_numa_ms(void) { return g_last_numa_ms; }
+void   spmv_compat_set_partition(int by_entries) { g_partition = by_entries < 0 ? -1 : (by_entries ? 1 : 0); }
+double spmv_compat_last_slowest_shard_ms(void) { return g_last_slowest_shard_ms; }
+double spmv_compat_last_shard_imbalance(void) { return g_last_shard_imbalance; }
 
 void CSRMatrixMatVectorNuma(const CSRMatrix& A, const Vector& x, Vector& y, int nthreads)
 {
     Engine&              E      = Engine::get();
-    std::vector<Shard>   shards = plan_shards(A.nrow, nthreads);
     std::vector<int64_t> rp64(A.row_ptr, A.row_ptr + A.nrow + 1);
+    std::vector<Shard>   shards = plan_shards(A.nrow, nthreads, rp64.data());
     for (Shard& s : shards)  // rebased row_ptr, global columns (src/mat_vec.cpp:250-265) — done inside the ABI call
         check(spmv_csr_upload_shard(E.ctx(s.device), s.row0, s.row1, A.ncol, rp64.data(), A.col_ind, A.values, &s.mat),
               "spmv_csr_upload_shard");
@@ -793,7 +845,14 @@ void COOMatrixMatVectorNuma(const COOMatrix& A, const Vector& x, Vector& y, int 
     // The reference scans a row-sorted COO for each thread's range (src/mat_vec.cpp:170-183) and is wrong for
     // unsorted input; here every entry goes to the shard that owns its row, in file order.
     Engine&                          E      = Engine::get();
-    std::vector<Shard>               shards = plan_shards(A.nrow, nthreads);
+    std::vector<int64_t>             rp64;
+    if (partition_by_entries())  // entries per row of the file, whatever its order (the reference's scan assumes row-sorted input, :170-183)
+    {
+        rp64.assign((size_t)A.nrow + 1, 0);
+        for (int k = 0; k < A.nnz; ++k) ++rp64[(size_t)A.row_ind[k] + 1];
+        for (int i = 0; i < A.nrow; ++i) rp64[(size_t)i + 1] += rp64[(size_t)i];
+    }
+    std::vector<Shard>               shards = plan_shards(A.nrow, nthreads, rp64.empty() ? nullptr : rp64.data());
     std::vector<std::vector<int>>    rows(shards.size()), cols(shards.size());
     std::vector<std::vector<double>> vals(shards.size());
     // owner of a row = the planned shard whose range holds it (with more shards than rows all but the last are empty,
@@ -861,11 +920,24 @@ void CSCMatrixMatVectorNuma(const CSCMatrix& A, const Vector& x, Vector& y, int 
     };
     std::vector<ColShard> shards((size_t)n);
     std::vector<int>      sub_ptr;
+    std::vector<int64_t>  cbounds;
+    if (partition_by_entries())  // columns cut so that every shard stores about the same number of entries
+    {
+        std::vector<int64_t> cp64(A.col_ptr, A.col_ptr + A.ncol + 1);
+        cbounds.resize((size_t)n + 1);
+        check(spmv_partition_rows_balanced(A.ncol, cp64.data(), n, cbounds.data()), "spmv_partition_rows_balanced(columns)");
+    }
     for (int i = 0; i < n; ++i)
     {
         ColShard& s = shards[(size_t)i];
         s.device    = i % E.ngpus();
-        check(spmv_partition_rows(A.ncol, n, i, &s.c0, &s.c1), "spmv_partition_rows(columns)");  // equal columns, the last takes the rest (:302,315)
+        if (!cbounds.empty())
+        {
+            s.c0 = cbounds[(size_t)i];
+            s.c1 = cbounds[(size_t)i + 1];
+        }
+        else
+            check(spmv_partition_rows(A.ncol, n, i, &s.c0, &s.c1), "spmv_partition_rows(columns)");  // equal columns, the last takes the rest (:302,315)
         const int     base = A.col_ptr[s.c0];
         const int64_t cols = s.c1 - s.c0;
         sub_ptr.resize((size_t)cols + 1);

@@ -7,6 +7,9 @@
 //
 //   spmv_main <file.mtx> <nshards> [options]          nshards plays the role of main.cpp's nthreads (argv[2])
 //   spmv_main --synthetic uniform|band --n N [--k K] [--band W] [--seed S] <nshards> [options]
+//   spmv_main --synthetic powerlaw --n N [--max-len L] [--sorted-by-length] [--seed S] <nshards> [options]
+//        rows of min(L, floor(8 / u)) entries (BASELINE configs[3]'s distribution), drawn (u ~ U(0,1]) or, with
+//        --sorted-by-length, taken at the quantiles: the longest rows first - positional skew for --partition
 //   spmv_main --synthetic uniform|band --n ROWS_PER_SHARD [--k K] [--band W] [--seed S] --sharded --gpus P [--reps R]
 //             [--check-rows C --check-out FILE] [--placement-budget-mb M]
 //        the sharded driver at BASELINE sizes (configs[4]: --n 10000000 --k 32 --gpus 8): P row shards of a
@@ -18,6 +21,10 @@
 // options: --format coo,csr,csc,ell,dia   (default coo,csr,ell)     --reps R (default 50)
 //          --no-dropin   skip the host-vector timing       --no-numa  skip the sharded drivers
 //          --verify      compare every format's y with a serial COO accumulation on the host (main.cpp:45-51; norm-wise 1e-10)
+//          --partition rows|nnz   how the sharded drivers cut the rows: equal rows, the last shard takes the remainder (the
+//                        reference, src/mat_vec.cpp:245-246; default) or by stored entries (spmv_partition_rows_balanced);
+//                        also for --sharded --synthetic powerlaw (one matrix generated on GPU 0, partitioned on the device
+//                        and handed to the participants as row shards: spmv_mat_partition_rows + spmv_csr_extract_rows)
 #include <algorithm>
 #include <chrono>
 #include <climits>
@@ -38,7 +45,8 @@ namespace
 struct Options
 {
     std::string file, synthetic, formats = "coo,csr,ell";
-    int         shards = 1, reps = 50, n = 0, k = 32, band = 0;
+    int         shards = 1, reps = 50, n = 0, k = 32, band = 0, max_len = 4096;
+    bool        sorted_by_length = false, by_entries = false;
     unsigned long long seed = 1;
     bool dropin = true, numa = true, verify = false, sharded = false;
     int         gpus = 1, check_rows = 0;
@@ -111,7 +119,8 @@ int run_sharded_synthetic(const Options& o)
     check(spmv_device_count(&ndev), "spmv_device_count");
     if (ndev < 1) armspmv::die("spmv_device_count: no GPU");
     const int     P    = o.gpus;
-    const int64_t ncol64 = (int64_t)o.n * P;
+    const bool    powerlaw = o.synthetic == "powerlaw";  // ONE matrix of o.n rows cut into P shards (else: P shards of o.n rows each)
+    const int64_t ncol64 = powerlaw ? (int64_t)o.n : (int64_t)o.n * P;
     if (ncol64 > INT32_MAX)
     {
         printf("spmv_main: %lld columns exceed the int32 column indices of the reference's containers\n", (long long)ncol64);
@@ -126,14 +135,35 @@ int run_sharded_synthetic(const Options& o)
     std::vector<spmv_mat_info> info((size_t)P);
     int64_t      nnz_total = 0, bytes_total = 0;
     const double t_build0  = now_s();
+    for (int i = 0; i < P; ++i) check(spmv_ctx_create(i % ndev, &ctx[(size_t)i]), "spmv_ctx_create");
+    // power-law rows: the matrix is generated once on the first participant's GPU, grouped by row there, partitioned from its
+    // row offsets (equal rows, or by entries) and handed to the participants as row shards, device to device
+    spmv_mat*            whole = nullptr;
+    std::vector<int64_t> bounds((size_t)P + 1, 0);
+    if (powerlaw)
+    {
+        spmv_mat* coo = nullptr;
+        check((o.sorted_by_length ? spmv_gen_coo_powerlaw_sorted : spmv_gen_coo_powerlaw)(ctx[0], o.n, ncol, o.max_len, o.seed, &coo), "spmv_gen_coo_powerlaw");
+        check(spmv_coo_to_csr(ctx[0], coo, &whole), "spmv_coo_to_csr");
+        spmv_mat_destroy(coo);
+        check(spmv_mat_partition_rows(whole, P, o.by_entries ? 1 : 0, bounds.data()), "spmv_mat_partition_rows");
+    }
     for (int i = 0; i < P; ++i)
     {
-        check(spmv_ctx_create(i % ndev, &ctx[(size_t)i]), "spmv_ctx_create");
         int64_t r0 = 0, r1 = 0;
-        check(spmv_partition_rows(ncol64, P, i, &r0, &r1), "spmv_partition_rows");
+        if (powerlaw)
+        {
+            r0 = bounds[(size_t)i];
+            r1 = bounds[(size_t)i + 1];
+            check(spmv_csr_extract_rows(ctx[(size_t)i], whole, r0, r1, &mat[(size_t)i]), "spmv_csr_extract_rows(shard)");
+        }
+        else
+        {
+            check(spmv_partition_rows(ncol64, P, i, &r0, &r1), "spmv_partition_rows");
+            check(spmv_gen_csr_uniform(ctx[(size_t)i], r0, r1, ncol, o.k, band, o.seed, &mat[(size_t)i]), "spmv_gen_csr_uniform(shard)");
+        }
         off[(size_t)i]     = r0;
         off[(size_t)i + 1] = r1;
-        check(spmv_gen_csr_uniform(ctx[(size_t)i], r0, r1, ncol, o.k, band, o.seed, &mat[(size_t)i]), "spmv_gen_csr_uniform(shard)");
         check(spmv_mat_get_info(mat[(size_t)i], &info[(size_t)i]), "spmv_mat_get_info");
         if (info[(size_t)i].kernel == SPMV_CSR_TWOPHASE && o.placement_budget_mb >= 0)
         {
@@ -163,13 +193,18 @@ int run_sharded_synthetic(const Options& o)
         check(spmv_vec_create(ctx[(size_t)i], r1 - r0, &ys[(size_t)i]), "spmv_vec_create(y)");
         check(spmv_vec_fill(ys[(size_t)i], 0.0), "spmv_vec_fill(y)");
     }
+    if (whole) spmv_mat_destroy(whole);
     auto sync_all = [&] {
         for (int i = 0; i < P; ++i) check(spmv_sync(ctx[(size_t)i]), "spmv_sync");
     };
     sync_all();
     const double build_s = now_s() - t_build0;
-    printf("### ROW=%lld, COL=%d, NNZ=%lld   (%d shards of %d rows, generated on %d GPU%s)\n", (long long)ncol64, ncol, (long long)nnz_total, P, o.n,
-           std::min(P, ndev), std::min(P, ndev) > 1 ? "s" : "");
+    if (powerlaw)
+        printf("### ROW=%lld, COL=%d, NNZ=%lld   (power-law rows%s, %d shards cut by %s, generated on GPU 0 and handed out device to device)\n",
+               (long long)ncol64, ncol, (long long)nnz_total, o.sorted_by_length ? " sorted by length" : "", P, o.by_entries ? "entries" : "equal rows");
+    else
+        printf("### ROW=%lld, COL=%d, NNZ=%lld   (%d shards of %d rows, generated on %d GPU%s)\n", (long long)ncol64, ncol, (long long)nnz_total, P, o.n,
+               std::min(P, ndev), std::min(P, ndev) > 1 ? "s" : "");
 
     spmv_comm* comm = nullptr;
     check(spmv_comm_create(ctx.data(), P, &comm), "spmv_comm_create");
@@ -240,6 +275,30 @@ int run_sharded_synthetic(const Options& o)
         }
         fclose(f);
     }
+    // every shard's own product time (HIP events, one shard at a time) and its stored entries: with one GPU per participant the
+    // step of the job is its slowest shard, whatever the sum says
+    double  slowest_ms = 0.0, sum_ms = 0.0;
+    int64_t most = 0;
+    std::string per_shard = "[";
+    for (int i = 0; i < P; ++i)
+    {
+        double ms_i = 0.0;
+        if (info[(size_t)i].nrow > 0) check(spmv_apply_timed(ctx[(size_t)i], mat[(size_t)i], xs[(size_t)i], ys[(size_t)i], 5, &ms_i), "spmv_apply_timed(shard)");
+        slowest_ms = std::max(slowest_ms, ms_i);
+        sum_ms += ms_i;
+        most = std::max<int64_t>(most, info[(size_t)i].nnz);
+        char buf[160];
+        snprintf(buf, sizeof buf, "%s{\"rows\": %d, \"entries\": %lld, \"kernel\": %d, \"ms\": %.5f}", i ? ", " : "", info[(size_t)i].nrow, (long long)info[(size_t)i].nnz,
+                 (int)info[(size_t)i].kernel, ms_i);
+        per_shard += buf;
+    }
+    per_shard += "]";
+    const double imbalance = nnz_total > 0 ? (double)most * P / (double)nnz_total : 1.0;
+    printf("### CSR NUMA shards = %d, partition by %s: stored entries per shard max / mean = %.3f; slowest shard %.4f ms, all shards one after the other %.4f ms\n",
+           P, powerlaw && o.by_entries ? "entries" : "rows", imbalance, slowest_ms, sum_ms);
+    printf("{\"sharded_partition\": \"%s\", \"entries_per_shard_max_over_mean\": %.4f, \"slowest_shard_ms\": %.5f, \"sum_of_shards_ms\": %.5f, "
+           "\"gflops_with_one_gpu_per_shard\": %.3f, \"shards\": %s}\n",
+           powerlaw && o.by_entries ? "entries" : "rows", imbalance, slowest_ms, sum_ms, slowest_ms > 0 ? 2.0 * (double)nnz_total / slowest_ms / 1e6 : 0.0, per_shard.c_str());
     const double ms = secs * 1e3 / o.reps;
     printf("{\"harness\": \"spmv_main --sharded\", \"participants\": %d, \"gpus_present\": %d, \"exchange\": \"%s\", \"rows_per_shard\": %d, "
            "\"ncol\": %d, \"nnz_per_row\": %d, \"band\": %d, \"nnz_total\": %lld, \"reps\": %d, \"ms_per_product\": %.5f, \"gflops\": %.3f, "
@@ -264,7 +323,9 @@ int usage()
 {
     printf("Usage: spmv_main <file.mtx> <nshards> [--format coo,csr,csc,ell,dia] [--reps R] [--verify] [--no-dropin] [--no-numa]\n"
            "       spmv_main --synthetic uniform|band --n N [--k K] [--band W] [--seed S] <nshards> [...]\n"
-           "       spmv_main --synthetic uniform|band --n ROWS_PER_SHARD [--k K] [--band W] --sharded --gpus P [--reps R] [--check-rows C --check-out FILE] [--placement-budget-mb M]\n");
+           "       spmv_main --synthetic powerlaw --n N [--max-len L] [--sorted-by-length] <nshards> [--partition rows|nnz] [...]\n"
+           "       spmv_main --synthetic uniform|band --n ROWS_PER_SHARD [--k K] [--band W] --sharded --gpus P [--reps R] [--check-rows C --check-out FILE] [--placement-budget-mb M]\n"
+           "       spmv_main --synthetic powerlaw --n ROWS_IN_ALL [--max-len L] [--sorted-by-length] --sharded --gpus P --partition rows|nnz [...]\n");
     return -1;
 }
 }  // namespace
@@ -286,6 +347,14 @@ int main(int argc, char* argv[])
         else if (a == "--seed") o.seed = strtoull(next(), 0, 10);
         else if (a == "--verify") o.verify = true;
         else if (a == "--sharded") o.sharded = true;
+        else if (a == "--max-len") o.max_len = atoi(next());
+        else if (a == "--sorted-by-length") o.sorted_by_length = true;
+        else if (a == "--partition")
+        {
+            const std::string v = next();
+            if (v != "rows" && v != "nnz" && v != "entries") return usage();
+            o.by_entries = v != "rows";
+        }
         else if (a == "--gpus") o.gpus = atoi(next());
         else if (a == "--check-rows") o.check_rows = atoi(next());
         else if (a == "--placement-budget-mb") o.placement_budget_mb = atoll(next());
@@ -314,10 +383,29 @@ int main(int argc, char* argv[])
     if (o.shards < 1) o.shards = 1;
     if (o.reps < 1) o.reps = 1;
     spmv_compat_set_numa_reps(o.reps);
+    spmv_compat_set_partition(o.by_entries ? 1 : 0);
 
     COOMatrix A;
     if (!o.file.empty())
         COOMatrixRead(o.file.c_str(), A);
+    else if (o.synthetic == "powerlaw")
+    {
+        // power-law rows drawn on the GPU (spmv_gen_coo_powerlaw / _sorted), brought back as the row-sorted COO they are
+        Engine&   E = Engine::get();
+        spmv_mat* g = nullptr;
+        check((o.sorted_by_length ? spmv_gen_coo_powerlaw_sorted : spmv_gen_coo_powerlaw)(E.ctx(0), o.n, o.n, o.max_len, o.seed, &g), "spmv_gen_coo_powerlaw");
+        spmv_mat_info gi;
+        check(spmv_mat_get_info(g, &gi), "spmv_mat_get_info");
+        A.nrow    = o.n;
+        A.ncol    = o.n;
+        A.nnz     = (int)gi.nnz;
+        A.row_ind = new int[(size_t)gi.nnz];
+        A.col_ind = new int[(size_t)gi.nnz];
+        A.values  = new double[(size_t)gi.nnz];
+        check(spmv_mat_download(g, A.row_ind, A.col_ind, A.values), "spmv_mat_download");
+        spmv_mat_destroy(g);
+        printf("### ROW=%d, COL=%d, NNZ=%d\n", A.nrow, A.ncol, A.nnz);
+    }
     else
     {
         // synthetic rows drawn on the GPU (spmv_gen_csr_uniform), brought back as a row-sorted COO

@@ -75,15 +75,20 @@ def ell_banded(nrow: int, ncol: int, k: int, seed: int = 1):
     return col.astype(np.int32), val
 
 
-def powerlaw_lengths(nrow: int, max_len: int = 4096, seed: int = 1) -> np.ndarray:
-    u = 1.0 - to_unit(_draw(stream_key(seed, STREAM_LEN), np.arange(nrow, dtype=np.uint64)))
+def powerlaw_lengths(nrow: int, max_len: int = 4096, seed: int = 1, sorted_by_length: bool = False) -> np.ndarray:
+    """min(max_len, floor(8 / u)); u drawn from U(0,1], or (sorted_by_length) the quantiles u_i = (i + 1) / nrow: the same
+    distribution with the rows sorted by length, the longest first"""
+    if sorted_by_length:
+        u = np.arange(1, nrow + 1, dtype=np.float64) / np.float64(nrow)
+    else:
+        u = 1.0 - to_unit(_draw(stream_key(seed, STREAM_LEN), np.arange(nrow, dtype=np.uint64)))
     q = np.floor(8.0 / u)
     return np.where(q >= max_len, max_len, q).astype(np.int32)
 
 
-def coo_powerlaw(nrow: int, ncol: int, max_len: int = 4096, seed: int = 1):
+def coo_powerlaw(nrow: int, ncol: int, max_len: int = 4096, seed: int = 1, sorted_by_length: bool = False):
     """row-sorted COO with power-law row lengths -> (row, col, val)"""
-    ln = powerlaw_lengths(nrow, max_len, seed).astype(np.int64)
+    ln = powerlaw_lengths(nrow, max_len, seed, sorted_by_length).astype(np.int64)
     row = np.repeat(np.arange(nrow, dtype=np.int64), ln)
     start = np.concatenate(([0], np.cumsum(ln)))[:-1]
     s = np.arange(row.size, dtype=np.int64) - np.repeat(start, ln)

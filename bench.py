@@ -505,6 +505,9 @@ def main() -> None:
                          "stream may hold while it runs; 0 = 65536 at N > 1 (one slow rank sets the step of the whole job, the job has the devices "
                          "to itself, and the device's memory comes in one-class chunks of up to ~60 GB: DESIGN 4.7) and the engine's own default, "
                          "8192, at N = 1 (include/spmv_abi.h, 'twophase_placement_budget_mb')")
+    ap.add_argument("--partition", choices=("rows", "nnz", "both"), default="both",
+                    help="the skewed extra (C4's row lengths sorted by length, the heavy rows at one end): cut into shards by equal rows "
+                         "(the reference's split, src/mat_vec.cpp:245-246), by stored entries (spmv_partition_rows_balanced), or both")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
@@ -792,6 +795,57 @@ def main() -> None:
                 big = args.placement_budget_mb if args.placement_budget_mb != 8192 else 65536
                 one(f"C5 shard, piece search of the product stream within {big} MB (what this bench grants its two-phase shards at N > 1: "
                     "--placement-budget-mb)", "csr", lambda: c5_shard(big), tkey=f"csr_n{n}_k{k}_band0_ncol{8 * n}")
+
+            # the partition of a SKEWED matrix.  C4's row-length distribution taken at its quantiles - the rows
+            # sorted by length, every heavy row at one end - cut into one shard per GPU (8 shards at N = 1, timed one after the
+            # other on the one GPU) by equal rows and by stored entries.  With one GPU per shard the step of the job is its
+            # slowest shard: `value` = 2 nnz / that time.  Generated once per rank on its own GPU, partitioned from the
+            # device-resident handle (spmv_mat_partition_rows) and cut device to device (spmv_csr_extract_rows).
+            def skewed(mode):
+                parts = world if world > 1 else 8
+                t = time.perf_counter()
+                G = ctx.gen_coo_powerlaw(2_000_000, 2_000_000, 4096, seed=args.seed, sorted_by_length=True)
+                W = ctx.coo_to_csr(G)
+                del G
+                bounds = W.partition_rows(parts, mode == "nnz")
+                nnz_all = int(W.info.nnz)
+                mine = list(range(parts)) if world == 1 else [rank]
+                shards = [ctx.extract_rows(W, int(bounds[q]), int(bounds[q + 1])) for q in mine]
+                del W
+                ctx.sync()
+                t_set = time.perf_counter() - t
+                vx2 = ctx.gen_vector(2_000_000, seed=args.seed)
+                table = torch.zeros(parts, 4, dtype=torch.float64, device=dev)
+                for q, S in zip(mine, shards):
+                    inf = S.info
+                    vy2 = ctx.vector(max(int(inf.nrow), 1))
+                    vy2.fill(0.0)
+                    for _ in range(3):
+                        ctx.apply(S, vx2, vy2)
+                    barrier()
+                    ms = ctx.apply_timed(S, vx2, vy2, 20)
+                    table[q] = torch.tensor([float(inf.nrow), float(inf.nnz), float(int(inf.kernel)), ms], dtype=torch.float64, device=dev)
+                    del vy2
+                if grouped:
+                    dist.all_reduce(table, op=dist.ReduceOp.SUM)  # (one row per rank: a one-hot sum)
+                rows_ = table.tolist()
+                slowest = max(r_[3] for r_ in rows_)
+                most = max(r_[1] for r_ in rows_)
+                extra.append({
+                    "name": f"C4's row lengths SORTED BY LENGTH (N = 2M, up to 4096 per row, the heavy rows first), {parts} row shards cut by "
+                            + ("stored entries (spmv_partition_rows_balanced)" if mode == "nnz" else "equal rows (the reference's split, src/mat_vec.cpp:245-246)"),
+                    "format": "csr", "partition": "entries" if mode == "nnz" else "rows", "shards": parts, "nnz": nnz_all,
+                    "measured": ("one shard per rank, all ranks at once" if world > 1 else f"the {parts} shards one after the other on ONE GPU"),
+                    "entries_per_shard_max_over_mean": round(most * parts / nnz_all, 4),
+                    "slowest_shard_ms": round(slowest, 5), "sum_of_shards_ms": round(sum(r_[3] for r_ in rows_), 5),
+                    "value": round(2.0 * nnz_all / slowest / 1e6, 2), "unit": "GFLOP/s with one GPU per shard (the step of the job is its slowest shard)",
+                    "setup_seconds": round(t_set, 3),
+                    "per_shard": [{"rows": int(r_[0]), "entries": int(r_[1]), "kernel_id": int(r_[2]), "ms": round(r_[3], 5)} for r_ in rows_],
+                })
+                del shards, vx2
+
+            for mode in (("rows", "nnz") if args.partition == "both" else (args.partition,)):
+                skewed(mode)
 
         # every rank's own kernel time (the headline takes the slowest): shows whether one rank's placement / layout lags
         per_rank_ms = [round(kernel_ms, 5)]

@@ -213,5 +213,13 @@ void spmv_compat_invalidate(const void* container_values_pointer);
 void spmv_compat_set_numa_reps(int reps);
 // Milliseconds per application measured by the last Numa driver call (device-resident, HIP events).
 double spmv_compat_last_numa_ms(void);
+// How the ...MatVectorNuma drivers cut their shards: 0 = equal rows, the last shard takes the remainder - the reference's split
+// (src/mat_vec.cpp:151,:233,:245-246) and the default; 1 = by stored entries (spmv_partition_rows_balanced; CSC: columns cut
+// by entries; ELL / DIA store the same number of slots for every row and keep equal rows); -1 = back to the environment's
+// SPMV_COMPAT_PARTITION=rows|nnz.  The drivers print `### <FMT> NUMA shards = ...` with the entries per shard (max / mean)
+// and the slowest shard's own product time - the step of a job with one GPU per shard.
+void   spmv_compat_set_partition(int by_entries);
+double spmv_compat_last_slowest_shard_ms(void);
+double spmv_compat_last_shard_imbalance(void);
 
 #endif  // ARM_SPMV_COMPAT_HPP

@@ -361,9 +361,24 @@ int spmv_csr_split_columns(spmv_ctx* ctx, const spmv_mat* csr, int32_t col_begin
 /* Equal rows per part, the last part takes the remainder.  Pure host arithmetic. */
 int spmv_partition_rows(int64_t nrow, int32_t nparts, int32_t part, int64_t* row_begin,
                         int64_t* row_end);
-/* nnz-balanced alternative: bounds[nparts+1], bounds[p] = first row of part p. */
+/* Entry-balanced alternative ("an nnz-balanced split as an option for C4-like skew"): bounds[nparts+1],
+ * bounds[p] = first row of part p; the boundary of part p is the row boundary whose offset lies nearest to p / nparts of the
+ * entries (rows are never split, so a part can exceed its share by at most half its longest boundary row).  The reference
+ * partitions by equal rows only (src/mat_vec.cpp:151,233): that stays the default of every driver; this is the option. */
 int spmv_partition_rows_balanced(int64_t nrow, const int64_t* row_ptr64, int32_t nparts,
                                  int64_t* bounds);
+/* The same for a DEVICE-RESIDENT handle: bounds[nparts+1] over its rows (over its COLUMNS for CSC, which the reference shards
+ * by column, src/mat_vec.cpp:299-337).  balance_entries = 0: equal rows, the last part takes the remainder (the reference's
+ * split); 1: by entries - CSR / CSC from the offset array, COO from a histogram of its row indices taken on the device (any
+ * entry order); ELL and DIA store the same number of slots for every row, so equal rows are equal work and are what they
+ * get either way.  Synchronous; the offsets cross to the host (4 bytes per row), the entries do not. */
+int spmv_mat_partition_rows(const spmv_mat* m, int32_t nparts, int32_t balance_entries, int64_t* bounds);
+/* Rows [row_begin, row_end) of a device-resident CSR handle (local row numbers of that handle) as a shard of their own on
+ * dst_ctx - the same GPU or a peer over xGMI: rebased int32 row_ptr, global column indices (src/mat_vec.cpp:250-265), entries
+ * copied device to device, analysed like an uploaded shard; its row_begin = the source's row_begin + row_begin.  With
+ * spmv_mat_partition_rows this shards a matrix that was generated, converted or uploaded once without a second trip through
+ * the host.  Synchronous.  The source must still hold its CSR arrays (panel_keep_csr = 1). */
+int spmv_csr_extract_rows(spmv_ctx* dst_ctx, const spmv_mat* csr, int64_t row_begin, int64_t row_end, spmv_mat** out);
 
 /* ---- synthetic inputs (counter-based splitmix64) ------------- */
 /* CSR shard with exactly k entries in each of rows [row_begin,row_end) of a (nrow_global x ncol)
@@ -379,6 +394,11 @@ int spmv_gen_ell_banded(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t k, ui
 int spmv_gen_dia_banded(spmv_ctx* ctx, int32_t nrow, int32_t k, uint64_t seed, spmv_mat** out);
 int spmv_gen_coo_powerlaw(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t max_len, uint64_t seed,
                           spmv_mat** out);
+/* The same distribution of row lengths taken at its quantiles (u_i = (i + 1) / nrow) instead of drawn: the rows come SORTED BY
+ * LENGTH, the longest first - every heavy row at one end, the positional skew an equal-rows partition handles worst (the first
+ * of 8 equal-rows shards of N = 2M holds 43 % of the entries).  Columns and values as above. */
+int spmv_gen_coo_powerlaw_sorted(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t max_len, uint64_t seed,
+                                 spmv_mat** out);
 /* v[i] = U(0,1) drawn from (seed, global index index_offset + i). */
 int spmv_gen_vec_uniform(spmv_ctx* ctx, spmv_vec* v, int64_t index_offset, uint64_t seed);
 

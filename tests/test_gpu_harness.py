@@ -73,6 +73,68 @@ def test_sharded_drivers_with_more_shards_than_rows(tmp_path, pkg):
         assert m and float(m.group(1)) <= 1e-10, (name, r.stdout)
 
 
+def test_sharded_drivers_partition_by_rows_or_by_entries(tmp_path, pkg):
+    """SURVEY 8e / 8f-4 through the harness: power-law rows sorted by length (the heavy rows at one end), 8 shards.
+    `--partition rows` is the reference's split (src/mat_vec.cpp:245-246) and the default; `--partition nnz` (or
+    SPMV_COMPAT_PARTITION=nnz for the reference's own main.cpp on the shim) cuts by stored entries.  Every driver verifies
+    under both; the printed balance is lopsided for rows and even for entries.  Then the device-side driver (`--sharded`):
+    one matrix generated on GPU 0, partitioned there and handed out device to device."""
+    import json
+    import os
+
+    def balance(out, fmt):
+        m = re.search(rf"### {fmt} NUMA shards = 8, partition by (\w+): stored entries per shard max / mean = ([0-9.]+); slowest shard ([0-9.]+) ms", out)
+        assert m, out
+        return m.group(1), float(m.group(2)), float(m.group(3))
+
+    base = [str(BIN / "spmv_main"), "--synthetic", "powerlaw", "--n", "60000", "--max-len", "1024", "--sorted-by-length", "8",
+            "--format", "coo,csr,csc,ell", "--verify", "--reps", "3", "--no-dropin"]
+    outs = {}
+    for mode, extra_args, env in (("rows", [], None), ("nnz", ["--partition", "nnz"], None)):
+        r = subprocess.run(base + extra_args, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        for name in ("CSR NUMA", "CSC NUMA", "ELL NUMA", "COO NUMA"):
+            m = re.search(rf"### {name} VERIFY .* = ([0-9.e+-]+) OK", r.stdout)
+            assert m and float(m.group(1)) <= 1e-10, (mode, name, r.stdout)
+        outs[mode] = r.stdout
+    for fmt in ("CSR", "COO"):
+        how_r, imb_r, _ = balance(outs["rows"], fmt)
+        how_n, imb_n, _ = balance(outs["nnz"], fmt)
+        assert how_r == "rows" and how_n == "entries"
+        assert imb_r > 2.5 and imb_n <= 1.05, (fmt, imb_r, imb_n)
+    # ELL stores max_len slots for every row: equal rows are equal work, whatever was asked for
+    assert balance(outs["nnz"], "ELL")[1] <= 1.001
+    # the device-side driver, both partitions, rows checked against the oracle from the seed
+    import oracle_lib as ol
+
+    orc = ol.load_oracle()
+    n, max_len = 300_000, 2048
+    hr, hc, hv = pkg.synth.coo_powerlaw(n, n, max_len, seed=1, sorted_by_length=True)
+    rp = np.concatenate(([0], np.cumsum(np.bincount(hr, minlength=n)))).astype(np.int32)
+    x = pkg.synth.vec_uniform(n, seed=1)
+    ref, scale = np.zeros(n), np.zeros(n)
+    ol.csr_spmv(orc, rp, hc, hv, x, ref)
+    ol.csr_abs_row_sums(orc, rp, hc, hv, x, scale)
+    seen = {}
+    for mode in ("rows", "nnz"):
+        chk = tmp_path / f"rows_{mode}.txt"
+        r = subprocess.run([str(BIN / "spmv_main"), "--synthetic", "powerlaw", "--n", str(n), "--max-len", str(max_len), "--sorted-by-length",
+                            "--sharded", "--gpus", "8", "--partition", mode, "--reps", "3", "--check-rows", "40", "--check-out", str(chk)],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        part = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{") and "sharded_partition" in ln][-1]
+        assert part["sharded_partition"] == ("entries" if mode == "nnz" else "rows") and len(part["shards"]) == 8
+        assert sum(sh["entries"] for sh in part["shards"]) == int(rp[-1]) and sum(sh["rows"] for sh in part["shards"]) == n
+        seen[mode] = part
+        got = np.array([[float(int(a)), float.fromhex(b)] for a, b in (ln.split() for ln in chk.read_text().splitlines())])
+        idx = got[:, 0].astype(np.int64)
+        assert len(idx) >= 8 * 3 * 8
+        ol.assert_parity(got[:, 1], ref[idx], scale[idx], f"spmv_main --sharded powerlaw, partition {mode}")
+    assert seen["rows"]["entries_per_shard_max_over_mean"] > 2.5 and seen["nnz"]["entries_per_shard_max_over_mean"] <= 1.02
+    # with one GPU per shard the job's step is its slowest shard: the even split's slowest shard is the faster one
+    assert seen["nnz"]["slowest_shard_ms"] < seen["rows"]["slowest_shard_ms"]
+
+
 def test_reference_main_cpp_runs_unchanged_on_the_engine(tmp_path, pkg):
     exe = BIN / "ref_main"
     if not exe.exists():
@@ -114,9 +176,15 @@ def test_bench_contract_one_rank_and_two_rank_rehearsal(tmp_path):
     assert line["config"]["process_group"].startswith("none")
     names = " | ".join(e["name"] for e in line["extra"])
     assert "configs[2] names" in names and "configs[3] names" in names and "band of 65536" in names
+    skew = {e["partition"]: e for e in line["extra"] if "partition" in e}  # the skewed matrix cut by equal rows and by entries
+    assert set(skew) == {"rows", "entries"} and all(e["shards"] == 8 and len(e["per_shard"]) == 8 for e in skew.values())
+    assert skew["rows"]["entries_per_shard_max_over_mean"] > 3.0 and skew["entries"]["entries_per_shard_max_over_mean"] <= 1.02
+    assert skew["entries"]["slowest_shard_ms"] < skew["rows"]["slowest_shard_ms"] and skew["entries"]["value"] > skew["rows"]["value"]
     for e in line["extra"]:  # a fraction of the bytes the kernel has to move can never exceed 1
+        if "partition" in e:
+            continue
         assert 0 < e["roofline"]["frac"] <= 1.0 and e["roofline"]["bytes_required"] > 0, e
-    kernels = {e["name"]: e["kernel"] for e in line["extra"]}
+    kernels = {e["name"]: e["kernel"] for e in line["extra"] if "kernel" in e}
     assert any("ell_kernel_x2" in v for v in kernels.values()) and any("coo_segscan_kernel" in v for v in kernels.values())
     assert any("coo_segscan_bins_kernel" in v for v in kernels.values())  # the scan over the copy in column bins, one per XCD
     assert line["cpu_baseline"]["kind"] in ("reference", "port") and line["cpu_baseline"]["value"] > 0
@@ -142,6 +210,9 @@ def test_bench_contract_one_rank_and_two_rank_rehearsal(tmp_path):
     ranks = line["config"]["per_rank"]
     assert [r_["rank"] for r_ in ranks] == [0, 1] and all(r_["kernel_ms"] > 0 and r_["kernel_id"] in (1, 2, 4, 5) for r_ in ranks)
     assert line["config"]["kernel_ms_per_rank"] == [r_["kernel_ms"] for r_ in ranks]
+    skew = {e["partition"]: e for e in line["extra"] if "partition" in e}  # one shard per rank, both partitions, every rank's time on rank 0's line
+    assert set(skew) == {"rows", "entries"} and all(e["shards"] == 2 and all(sh["ms"] > 0 for sh in e["per_shard"]) for e in skew.values())
+    assert skew["rows"]["entries_per_shard_max_over_mean"] > 1.5 and skew["entries"]["entries_per_shard_max_over_mean"] <= 1.02
     band = [e for e in line["extra"] if "band of 65536" in e["name"]]  # the band-random variant is reported at every world size
     assert len(band) == 1 and band[0]["n_gpus"] == 2 and band[0]["nnz"] == 2 * 400000 * 32 and 0 < band[0]["roofline"]["frac"] <= 1.0
 

@@ -753,6 +753,67 @@ def test_row_shards_concatenate_to_unsharded_result(ctx, orc, pkg):
     ol.assert_parity(np.concatenate(pieces), ref, scale, "8 row shards")
 
 
+@pytest.mark.parametrize("fmt", ["csr", "coo"])
+def test_skewed_matrix_sharded_by_rows_and_by_entries(ctx, orc, pkg, fmt):
+    """"an nnz-balanced split as an option for C4-like skew".  Power-law rows SORTED BY LENGTH (every heavy
+    row in the first eighth), 8 shards on one GPU, cut both ways from the device-resident handle (spmv_mat_partition_rows) and
+    handed out device to device (spmv_csr_extract_rows): the concatenated y equals the oracle's under either partition, the
+    equal-rows split is as lopsided as the matrix, the by-entries split is within 2 % of even, and the device generator's sorted
+    variant is the numpy twin's bit for bit."""
+    synth, capi = pkg.synth, pkg.capi
+    n, max_len, parts = 400_000, 4096, 8
+    G = ctx.gen_coo_powerlaw(n, n, max_len, seed=13, sorted_by_length=True)
+    rows, cols, vals = G.download()
+    hr, hc, hv = synth.coo_powerlaw(n, n, max_len, seed=13, sorted_by_length=True)
+    assert np.array_equal(rows, hr) and np.array_equal(cols, hc) and np.array_equal(vals, hv)
+    ln = np.bincount(rows, minlength=n)
+    assert np.all(np.diff(ln) <= 0) and ln[0] == max_len and ln[-1] == 8  # sorted by length, the longest first
+    rp = np.concatenate(([0], np.cumsum(ln))).astype(np.int64)
+    x = synth.vec_uniform(n, seed=13)
+    rp32 = rp.astype(np.int32)
+    ref, scale = np.zeros(n), np.zeros(n)
+    ol.csr_spmv(orc, rp32, cols, vals, x, ref)
+    ol.csr_abs_row_sums(orc, rp32, cols, vals, x, scale)
+    dx = ctx.vector_from(x)
+    if fmt == "coo":
+        # (a COO handle is partitioned from a histogram of its row indices; the shards come from its CSR form)
+        b_rows, b_ent = G.partition_rows(parts, False), G.partition_rows(parts, True)
+        A = ctx.coo_to_csr(G)
+    else:
+        A = ctx.coo_to_csr(G)
+        b_rows, b_ent = A.partition_rows(parts, False), A.partition_rows(parts, True)
+    del G
+    assert list(b_rows) == [capi.partition_rows(n, parts, p)[0] for p in range(parts)] + [n]
+    assert np.array_equal(b_ent, capi.partition_rows_balanced(rp, parts))
+    share_rows = np.diff(rp[b_rows])
+    share_ent = np.diff(rp[b_ent])
+    assert share_rows.max() / share_rows.mean() > 3.0, share_rows            # the first eighth holds most of the matrix
+    assert abs(share_ent / share_ent.mean() - 1.0).max() <= 0.02, share_ent  # within 2 % of even
+    for bounds, what in ((b_rows, "equal rows"), (b_ent, "by entries")):
+        pieces, counts = [], []
+        for p in range(parts):
+            b, e = int(bounds[p]), int(bounds[p + 1])
+            S = ctx.extract_rows(A, b, e)
+            inf = S.info
+            assert inf.row_begin == b and inf.nrow == e - b and inf.nnz == rp[e] - rp[b] and inf.ncol == n
+            srp, scc, svv = S.download()
+            assert np.array_equal(srp, ol.csr_shard_row_ptr(orc, rp32, b, e))
+            assert np.array_equal(scc, cols[rp[b]:rp[e]]) and np.array_equal(svv, vals[rp[b]:rp[e]])
+            dy = ctx.vector(e - b)
+            dy.fill(0.0)
+            ctx.apply(S, dx, dy)
+            ctx.sync()
+            pieces.append(dy.download())
+            counts.append(int(inf.nnz))
+        assert sum(counts) == rp[-1]
+        ol.assert_parity(np.concatenate(pieces), ref, scale, f"8 shards of a length-sorted power-law matrix, {what}")
+    with pytest.raises(capi.SpmvError, match="outside"):
+        ctx.extract_rows(A, 10, n + 1)
+    # padded formats keep equal rows either way (every row stores k slots): asking for balance changes nothing
+    E = ctx.gen_ell_banded(1000, 1000, 8, seed=2)
+    assert np.array_equal(E.partition_rows(3, True), E.partition_rows(3, False))
+
+
 # ---------------------------------------------------------------------------------- full-size properties
 
 def _abs_row_scale(ctx, pkg, A, x):
