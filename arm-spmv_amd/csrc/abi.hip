@@ -571,7 +571,10 @@ int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
         }
         else
         {
-            SPMV_TRY(coo_build_panel(m, /*only_if_worth=*/kernel == SPMV_CSR_AUTO));
+            if (kernel == SPMV_CSR_AUTO)
+                SPMV_TRY(coo_select_kernel(m));  // the scan or the row-grouped copy, timed (select.hip)
+            else
+                SPMV_TRY(coo_build_panel(m, /*only_if_worth=*/false));
             m->kernel = m->coo_csr ? SPMV_CSR_PANEL : SPMV_CSR_VECTOR;
             if (m->kernel == SPMV_CSR_PANEL)
             {
@@ -589,10 +592,15 @@ int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
         SPMV_HIP(hipSetDevice(m->ctx->device));
         m->kernel_forced = kernel != SPMV_CSR_AUTO;
         if (kernel == SPMV_CSR_VECTOR)
-            m->kernel = SPMV_CSR_VECTOR;
+        {
+            m->kernel      = SPMV_CSR_VECTOR;
+            m->ell_variant = 0;  // lanes_per_row (below) picks the variant of the format's own kernel
+        }
+        else if (kernel == SPMV_CSR_AUTO)
+            SPMV_TRY(ell_select_kernel(m));  // the format's own kernels and, where it is a candidate, the row-grouped copy: timed
         else
         {
-            SPMV_TRY(ell_build_panel(m, /*only_if_worth=*/kernel == SPMV_CSR_AUTO));
+            SPMV_TRY(ell_build_panel(m, /*only_if_worth=*/false));
             m->kernel = m->coo_csr ? SPMV_CSR_PANEL : SPMV_CSR_VECTOR;
         }
         return SPMV_OK;
@@ -604,7 +612,11 @@ int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
     if (kernel == SPMV_CSR_AUTO)
     {
         m->kernel_forced = false;
-        if (m->format == SPMV_FMT_CSR && m->b && m->v) csr_choose_kernel(m);
+        if (m->format == SPMV_FMT_CSR && m->b && m->v)
+        {
+            SPMV_HIP(hipSetDevice(m->ctx->device));
+            return csr_select_kernel(m);  // the model and, where it pays, a trial of the candidates (select.hip); builds what it picks
+        }
     }
     else
     {
@@ -863,6 +875,23 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         *value = m->win_max_span;
     else if (!strcmp(name, "window_avg_span"))
         *value = (int64_t)m->win_avg_span;
+    else if (!strcmp(name, "contiguous_permille"))
+        *value = (int64_t)(m->contig_frac * 1000.0 + 0.5);
+    else if (!strcmp(name, "select_candidates"))
+        *value = m->sel_candidates;
+    else if (!strncmp(name, "select_us_", 10))
+    {
+        static const char* const kNames[] = {"", "vector", "ldswin", "scalar", "panel", "twophase", "variant1", "variant2"};
+        int slot = -1;
+        for (int i = 1; i < 8; ++i)
+            if (!strcmp(name + 10, kNames[i])) slot = i;
+        SPMV_REQUIRE(slot > 0, "unknown parameter '%s'", name);
+        *value = (int64_t)(m->sel_us[slot] + 0.5f);
+    }
+    else if (!strcmp(name, "rowgrouped_kernel"))
+        *value = m->coo_csr && (m->format == SPMV_FMT_CSC ? !m->kernel_forced : m->kernel == SPMV_CSR_PANEL) ? m->coo_csr->kernel : 0;
+    else if (!strcmp(name, "ell_variant"))
+        *value = m->ell_variant;
     else
         SPMV_FAIL(SPMV_ERR_INVALID, "unknown parameter '%s'", name);
     return SPMV_OK;

@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 
 #include "spmv_abi.h"
 
@@ -152,6 +153,12 @@ struct spmv_mat
     int32_t  win_max_span = 0;
 
     double   win_avg_span = 0.0;   // mean over row blocks: how local the columns are
+    double   contig_frac  = 0.0;   // CSR: fraction of the entries whose column is the previous entry's + 1 (dense blocks, bands)
+
+    // AUTO selection by measurement (select.hip): candidates timed when the handle was analysed, microseconds per product
+    // by spmv_csr_kernel id (COO / ELL: [1] the format's own kernel, [4] the row-grouped copy); 0 = not timed
+    int32_t  sel_candidates = 0;
+    float    sel_us[8]      = {0};
 
     // CSR panel kernel (kernels_csr_panel.hip): entries re-ordered per row group by column panel / x line
     int32_t*  pb_col         = nullptr;  // [nnz] global column
@@ -222,6 +229,8 @@ struct spmv_mat
     int32_t* ell_diag      = nullptr;
     void*    ell_diag_mask = nullptr;
     int32_t  ell_diag_lds = 0;  // doubles of LDS the x stretches of a block take (0: none, x from global memory)
+    int32_t  ell_variant  = 0;  // which of the format's own kernels AUTO timed fastest: 0 two rows per lane (diagonal slots where found),
+                                // 1 one row per lane, 2 two rows per lane reading every column index
     double*  ell_tval = nullptr;  // the values in tiles of 512 rows, (tile * k + slot) * 512 + row (ell_build_tiles); owned
 
     // COO / CSC / ELL: internal row-grouped copy in the panel layout (coo_build_panel, csc_analyse, ell_build_panel); owned
@@ -250,7 +259,25 @@ int ensure_scratch(spmv_ctx* ctx, size_t bytes);
 
 // kernels_csr.hip
 int csr_analyse(spmv_mat* m);
-void csr_choose_kernel(spmv_mat* m);
+void csr_choose_kernel(spmv_mat* m);  // the model's pick (no launches)
+int  csr_ldswin_capacity();           // columns of x the LDS-window kernel's tile holds
+// select.hip: AUTO by measurement
+bool select_trials_enabled(const spmv_mat* m);
+int  csr_select_kernel(spmv_mat* m);
+// zeroed x (ncol) and y (nrow) for timing launches; freed with the object
+struct select_scratch
+{
+    double *x = nullptr, *y = nullptr;
+    int  alloc(spmv_ctx* ctx, int64_t ncol, int64_t nrow);
+    void release();
+    ~select_scratch() { release(); }
+};
+// ms per product of `launch`: 1 warm-up + 1 product, and 2 x 4 more (the minimum) unless that one was 3x behind best_so_far
+int  select_time(spmv_ctx* ctx, const std::function<int()>& launch, float best_so_far, float* ms);
+void select_note(spmv_mat* m, int slot, float ms);  // records a timed candidate (sel_us[slot], sel_candidates)
+void select_reset(spmv_mat* m);
+constexpr int64_t kSelectMinNnz = (int64_t)64 << 10;  // below: every kernel takes a launch latency, nothing to choose
+constexpr int64_t kSelectMaxNnz = (int64_t)8 << 20;   // CSR above: the model's pick unless a statistic casts doubt on it
 // kernels_csr_panel.hip
 int  csr_panel_build(spmv_mat* m);
 int  panel_choose_pace(spmv_mat* m);
@@ -292,12 +319,15 @@ int csr_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 // kernels_ell.hip
 int ell_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 int ell_analyse(spmv_mat* m);
-int ell_build_panel(spmv_mat* m, bool only_if_worth);
+int ell_build_panel(spmv_mat* m, bool only_if_worth);  // the row-grouped copy with the PANEL kernel forced on it
+int ell_select_kernel(spmv_mat* m);                    // AUTO: the format's own variants and (where a candidate) the row-grouped copy, timed
 // kernels_coo.hip
 int  ell_build_tiles(spmv_mat* m, bool only_if_worth);
 void ell_free_tiles(spmv_mat* m);
 int coo_analyse(spmv_mat* m);
-int coo_build_panel(spmv_mat* m, bool only_if_worth);
+int coo_build_panel(spmv_mat* m, bool only_if_worth);  // the row-grouped copy with the PANEL kernel forced on it
+int coo_select_kernel(spmv_mat* m);                    // AUTO: the segmented scan or the row-grouped copy (which picks its own kernel), timed
+void coo_drop_rowgrouped(spmv_mat* m);
 int  coo_build_bins(spmv_mat* m, int bins_per_xcd, bool only_if_worth);  // bins_per_xcd 0: as many as keep a slice of x inside an XCD's L2
 void coo_free_bins(spmv_mat* m);
 int coo_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
@@ -313,7 +343,7 @@ int vec_axpby(spmv_ctx* ctx, double alpha, const double* x, double beta, const d
 int mat_validate(const spmv_mat* m);
 // convert.hip
 int exclusive_scan_i32(spmv_ctx* ctx, const int32_t* in, int32_t* out, int64_t n);
-int coo_to_csr(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out);
+int coo_to_csr(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out, int32_t force_kernel = 0 /* SPMV_CSR_AUTO: select */);
 // symgs.hip
 int  symgs_setup(spmv_mat* m);
 void symgs_free(spmv_mat* m);

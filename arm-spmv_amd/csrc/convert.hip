@@ -157,7 +157,7 @@ int exclusive_scan_i32(spmv_ctx* ctx, const int32_t* in, int32_t* out, int64_t n
     return SPMV_OK;
 }
 
-int coo_to_csr(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out)
+int coo_to_csr(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out, int32_t force_kernel)
 {
     SPMV_REQUIRE(coo->format == SPMV_FMT_COO, "spmv_coo_to_csr: input is not COO");
     SPMV_REQUIRE(coo->nnz <= INT32_MAX, "spmv_coo_to_csr: %lld entries do not fit int32 row_ptr", (long long)coo->nnz);
@@ -224,6 +224,12 @@ int coo_to_csr(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out)
         SPMV_FAIL(rc, "spmv_coo_to_csr failed (%s)", hipGetErrorString(hipGetLastError()));
     }
     csr->row_begin = coo->row_begin;
+    if (force_kernel != SPMV_CSR_AUTO)
+    {
+        csr->kernel_forced = true;
+        csr->kernel        = force_kernel;
+    }
+    csr->pb_trial = coo->pb_trial;  // ("panel_trial" of the source handle holds for what is built from it)
     if ((rc = csr_analyse(csr)) != SPMV_OK)
     {
         mat_free(csr);

@@ -290,43 +290,112 @@ int coo_analyse(spmv_mat* m)
     SPMV_HIP(hipStreamSynchronize(ctx->stream));
     m->sorted_rows = unsorted ? 0 : 1;
     m->kernel      = SPMV_CSR_VECTOR;  // reported for COO as "segmented scan"
-    if (!m->kernel_forced) SPMV_TRY(coo_build_panel(m, /*only_if_worth=*/true));
+    if (!m->kernel_forced) SPMV_TRY(coo_select_kernel(m));
     return SPMV_OK;
 }
 
-// Large COO with an x beyond L2 is gather-bound in entry order exactly like CSR (C4: 13 % of roofline with the
-// segmented scan).  Such a handle gets the panel layout too: the entries are grouped by row on the device
-// (spmv_coo_to_csr, duplicates and file order inside a row kept) and re-ordered as in kernels_csr_panel.hip; the
-// product then runs csr_panel_kernel (C4: 0.51 ms instead of 1.81).  Only row_ptr and the panel arrays are kept.
-int coo_build_panel(spmv_mat* m, bool only_if_worth)
+void coo_drop_rowgrouped(spmv_mat* m)
 {
-    if (m->coo_csr) return SPMV_OK;
-    const bool worth = m->nnz >= ((int64_t)2 << 20) && m->nrow > 0 && m->nnz / m->nrow >= 2;
-    if (only_if_worth && !worth) return SPMV_OK;
-    if (m->nnz == 0 || m->nnz > (int64_t)INT32_MAX - 65536) return SPMV_OK;
-    spmv_mat* csr = nullptr;
-    SPMV_TRY(coo_to_csr(m->ctx, m, &csr));  // csr_analyse inside picks (and builds) the panel layout when x is large
-    if (csr->kernel != SPMV_CSR_PANEL)
+    if (!m->coo_csr) return;
+    (void)hipStreamSynchronize(m->ctx->stream);
+    m->device_bytes -= m->coo_csr->device_bytes;
+    mat_free(m->coo_csr);
+    m->coo_csr = nullptr;
+    if (m->kernel == SPMV_CSR_PANEL) m->kernel = SPMV_CSR_VECTOR;
+}
+
+namespace
+{
+// adopts a CSR handle as the row-grouped copy; the layouts that do not read col_ind / values give them back
+void adopt_rowgrouped(spmv_mat* m, spmv_mat* csr)
+{
+    if ((csr->kernel == SPMV_CSR_PANEL || csr->kernel == SPMV_CSR_TWOPHASE) && csr->b && csr->v && csr->owned)
     {
-        csr_twophase_free(csr);  // csr_analyse may have chosen (and built) the two-phase layout: not the one that runs here
-        csr->kernel_forced = true;
-        csr->kernel        = SPMV_CSR_PANEL;
-        int rc             = csr_panel_build(csr);
-        if (rc != SPMV_OK)
+        (void)hipFree(const_cast<int32_t*>(csr->b));
+        (void)hipFree(const_cast<double*>(csr->v));
+        csr->device_bytes -= (int64_t)csr->nnz * 12;
+        csr->b = nullptr;
+        csr->v = nullptr;
+    }
+    m->coo_csr = csr;
+    m->kernel  = SPMV_CSR_PANEL;  // reported for COO as "runs from the row-grouped copy" (whichever CSR kernel that copy picked)
+    m->device_bytes += csr->device_bytes;
+}
+int coo_scan_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
+}  // namespace
+
+// AUTO for a COO handle: the segmented scan over the entries as they are, or a copy grouped by row (spmv_coo_to_csr: duplicates
+// and the order inside a row kept) which picks ITS kernel like any CSR handle - row-parallel, LDS window, panel, two-phase
+// (select.hip).  Model: the copy from 1.5M entries on (C4: 0.28 ms against 1.81 for the scan in place).  From 64K entries on
+// both are timed (tools/sweep_structures.py: below 2M entries the copy won 2x on every family but one - an R-MAT graph
+// with a hub row, where the scan won 1.7x; above, the scan won 6-15 % on dense blocks and wide rectangles).
+int coo_select_kernel(spmv_mat* m)
+{
+    spmv_ctx* ctx = m->ctx;
+    select_reset(m);
+    coo_drop_rowgrouped(m);
+    m->kernel = SPMV_CSR_VECTOR;
+    if (m->nnz == 0 || m->nrow <= 0 || m->nnz > (int64_t)INT32_MAX - 65536) return SPMV_OK;
+    const bool model_copy = m->nnz >= ((int64_t)3 << 19);
+    auto       build_copy = [&]() -> int {
+        spmv_mat* csr = nullptr;
+        const int rc  = coo_to_csr(ctx, m, &csr);  // (csr_analyse inside selects the copy's kernel)
+        if (rc == SPMV_OK) adopt_rowgrouped(m, csr);
+        return rc;
+    };
+    if (!select_trials_enabled(m) || m->nnz < kSelectMinNnz) return model_copy ? build_copy() : SPMV_OK;
+    select_scratch sv;
+    if (sv.alloc(ctx, m->ncol, m->nrow) != SPMV_OK) return model_copy ? build_copy() : SPMV_OK;
+    float t_scan = 1e30f, t_copy = 1e30f;
+    int   rc     = SPMV_OK;
+    // the model's pick first: the other one is dropped after a single product when it is 3x behind
+    for (int pass = 0; pass < 2 && rc == SPMV_OK; ++pass)
+    {
+        if ((pass == 0) == model_copy)
         {
-            mat_free(csr);
-            return rc;
+            rc = build_copy();
+            if (rc == SPMV_ERR_ALLOC && !model_copy)
+            {
+                (void)hipGetLastError();
+                rc = SPMV_OK;  // no memory for the copy: the scan runs
+                continue;
+            }
+            if (rc != SPMV_OK) break;
+            rc = select_time(ctx, [&] { return csr_apply(ctx, m->coo_csr, sv.x, sv.y); }, t_scan, &t_copy);
+            if (rc == SPMV_OK) select_note(m, SPMV_CSR_PANEL, t_copy);
+        }
+        else
+        {
+            rc = select_time(ctx, [&] { return coo_scan_apply(ctx, m, sv.x, sv.y); }, t_copy, &t_scan);
+            if (rc == SPMV_OK) select_note(m, SPMV_CSR_VECTOR, t_scan);
         }
     }
-    // the panel kernel reads row_ptr and its own arrays only: drop the CSR copies of col_ind / values
-    (void)hipFree(const_cast<int32_t*>(csr->b));
-    (void)hipFree(const_cast<double*>(csr->v));
-    csr->device_bytes -= (int64_t)csr->nnz * 12;
-    csr->b     = nullptr;
-    csr->v     = nullptr;
-    m->coo_csr = csr;
-    m->kernel  = SPMV_CSR_PANEL;
-    m->device_bytes += csr->device_bytes;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (rc != SPMV_OK) return rc;
+    const bool keep_copy = m->coo_csr && (model_copy ? t_copy <= t_scan * 1.02f : t_copy < t_scan * 0.98f);  // the second one has to win by 2 %
+    if (!keep_copy) coo_drop_rowgrouped(m);
+    m->kernel = m->coo_csr ? SPMV_CSR_PANEL : SPMV_CSR_VECTOR;
+    return SPMV_OK;
+}
+
+// The row-grouped copy with the PANEL kernel forced on it (spmv_mat_set_kernel(coo, SPMV_CSR_PANEL), and the CSC handles'
+// regrouping, kernels_misc.hip).  Large COO with an x beyond L2 is gather-bound in entry order exactly like CSR (C4: 13 % of
+// roofline with the segmented scan in place); the entries are grouped by row on the device (spmv_coo_to_csr, duplicates and
+// file order inside a row kept) and re-ordered as in kernels_csr_panel.hip.  Only row_ptr and the panel arrays are kept.
+int coo_build_panel(spmv_mat* m, bool only_if_worth)
+{
+    if (m->coo_csr && m->coo_csr->kernel == SPMV_CSR_PANEL)
+    {
+        m->kernel = SPMV_CSR_PANEL;
+        return SPMV_OK;
+    }
+    const bool worth = m->nnz >= ((int64_t)3 << 19) && m->nrow > 0;
+    if (only_if_worth && !worth) return SPMV_OK;
+    if (m->nnz == 0 || m->nnz > (int64_t)INT32_MAX - 65536) return SPMV_OK;
+    coo_drop_rowgrouped(m);  // (a copy AUTO made with another kernel)
+    spmv_mat* csr = nullptr;
+    SPMV_TRY(coo_to_csr(m->ctx, m, &csr, SPMV_CSR_PANEL));
+    adopt_rowgrouped(m, csr);
     return SPMV_OK;
 }
 
@@ -469,7 +538,14 @@ int coo_build_bins(spmv_mat* m, int bins_per_xcd, bool only_if_worth)
 int coo_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
 {
     if (A->nnz == 0) return SPMV_OK;
-    if (A->coo_csr && A->kernel == SPMV_CSR_PANEL) return csr_panel_apply(ctx, A->coo_csr, x, y);
+    if (A->coo_csr && A->kernel == SPMV_CSR_PANEL) return csr_apply(ctx, A->coo_csr, x, y);
+    return coo_scan_apply(ctx, A, x, y);
+}
+
+namespace
+{
+int coo_scan_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
+{
     if (A->cb_bins)
     {
         coo_bins_tab tab;
@@ -495,4 +571,5 @@ int coo_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
     SPMV_HIP(hipGetLastError());
     return SPMV_OK;
 }
+}  // namespace
 }  // namespace spmv

@@ -112,9 +112,12 @@ __global__ __launch_bounds__(kBlock) void csr_scalar_kernel(
 constexpr int kWinRows    = 256;       // rows per workgroup (LPR lanes each -> loop over row slabs)
 constexpr int kWinDoubles = 16 * 1024; // 128 KiB x tile; leaves 32 KiB of the CU's 160 KiB unused
 
+// Also counts the entries whose column is the previous entry's + 1 (`contig`; the first entry of a block never counts, an
+// entry that continues the previous ROW's last column does - one in a row's length, immaterial): rows made of contiguous
+// runs read x coalesced under the row-parallel kernel (dense blocks: tools/sweep_structures.py).
 __global__ __launch_bounds__(kBlock) void csr_window_scan_kernel(
     int nrow, int win_rows, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
-    int32_t* __restrict__ win_lo, int32_t* __restrict__ win_span)
+    int32_t* __restrict__ win_lo, int32_t* __restrict__ win_span, unsigned long long* __restrict__ contig)
 {
     const int b     = blockIdx.x;
     const int r0    = b * win_rows;
@@ -122,12 +125,16 @@ __global__ __launch_bounds__(kBlock) void csr_window_scan_kernel(
     const int begin = row_ptr[r0];
     const int end   = row_ptr[r1];
     int       lo = INT32_MAX, hi = -1;
+    unsigned  runs = 0;
     for (int j = begin + threadIdx.x; j < end; j += kBlock)
     {
         const int c = col[j];
         lo          = min(lo, c);
         hi          = max(hi, c);
+        if (j > begin && col[j - 1] + 1 == c) ++runs;
     }
+    for (int off = 32; off > 0; off >>= 1) runs += __shfl_xor(runs, off);
+    if ((threadIdx.x & 63) == 0 && runs) atomicAdd(contig, (unsigned long long)runs);
     __shared__ int s_lo[kBlock / kWave], s_hi[kBlock / kWave];
     for (int off = 32; off > 0; off >>= 1)
     {
@@ -325,27 +332,41 @@ int reduce_max_i32(spmv_ctx* ctx, const int32_t* in, int64_t n, int32_t* result)
     return SPMV_OK;
 }
 
-// AUTO policy (all measured at 32 entries/row, profiles/r01_tune_*):
+// AUTO, the model (no launches; select.hip times candidates on top of it where that pays).  Measured at 32 entries/row in
+// round 1 (profiles/r01_tune_*) and audited on stencils, dense blocks, R-MAT graphs, rectangles and permutations in round 5
+// (tools/sweep_structures.py, profiles/r05_sweep_structures_*.txt):
 //   * enough entries to occupy 256 workgroups of 1024 lanes -> the panel layout.  It beats the row-parallel kernel
 //     without column locality (N = 10M uniform: 1.63 vs 5.9 ms), with it (0.76 vs 1.63 ms in a 4096-wide band,
 //     0.76 vs 2.0 ms at 65536; the column-sorted walk makes neighbouring lanes share x lines), while x still fits
 //     L2 (N = 100k..1.5M: 1.3x..2.8x), and it beats the LDS-window kernel where that applies (N = 4M band 4096
-//     without wrap-around rows: 0.32 vs 0.43 ms);
+//     without wrap-around rows: 0.32 vs 0.43 ms).  "Enough" is 1.5M entries (round 5: 27-point stencil with 1.64M entries
+//     0.0087 vs 0.0116 ms, 200000 x 5000 with 1.6M 0.0088 vs 0.0114; 8-wide blocks with 1.28M 0.0083 vs 0.0066), whatever
+//     the mean row length (a permutation of 8M rows: 0.136 vs 0.171; the two-phase layout 0.092);
+//   * EXCEPT long rows made of contiguous runs (dense blocks of 32 and more: 64 x 64 blocks 0.093 vs 0.116): the
+//     row-parallel kernel reads their x coalesced and adds in registers;
+//   * a few hub rows among short ones (R-MAT: 8436 entries in one row, 16 on average) serialise on the lanes of ONE row
+//     group under the row-parallel kernel (0.177 ms vs 0.016): the panel layout from 64K entries on;
 //   * smaller: stage x in LDS when every row block's column window fits the tile and is re-used, else gather
 //     through L1/L2 with the row-parallel kernel.
 void csr_choose_kernel(spmv_mat* m)
 {
     const double mean       = m->nrow > 0 ? (double)m->nnz / (double)m->nrow : 0.0;
-    const bool   big_enough = m->nnz >= (int64_t)2 << 20 && mean >= 2.0;
+    const bool   big_enough = m->nnz >= (int64_t)3 << 19 && mean >= 0.5;
     const bool   fits       = m->win_max_span > 0 && m->win_max_span <= kWinDoubles;
     const double reuse      = m->win_max_span > 0 ? mean * kWinRows / (double)m->win_max_span : 0.0;
-    if (big_enough)
+    const bool   dense_runs = m->contig_frac >= 0.8 && mean >= 24.0;
+    const bool   hub_rows   = m->nnz >= (int64_t)64 << 10 && m->max_row_nnz >= 1024 && (double)m->max_row_nnz >= 32.0 * std::max(mean, 1.0);
+    if (big_enough && !dense_runs)
         m->kernel = csr_twophase_worth(m) ? SPMV_CSR_TWOPHASE : SPMV_CSR_PANEL;
-    else if (fits && reuse >= 2.0)
+    else if (hub_rows)
+        m->kernel = SPMV_CSR_PANEL;
+    else if (fits && reuse >= 2.0 && !big_enough)
         m->kernel = SPMV_CSR_LDSWIN;
     else
         m->kernel = SPMV_CSR_VECTOR;
 }
+
+int csr_ldswin_capacity() { return kWinDoubles; }
 
 // Row statistics + kernel choice.  Runs once when a CSR handle is created.
 int csr_analyse(spmv_mat* m)
@@ -377,9 +398,15 @@ int csr_analyse(spmv_mat* m)
         SPMV_HIP(hipMalloc(&m->win_lo, sizeof(int32_t) * nblocks));
         SPMV_HIP(hipMalloc(&m->win_span, sizeof(int32_t) * nblocks));
         m->device_bytes += 2 * (int64_t)sizeof(int32_t) * nblocks;
+        unsigned long long* d_contig = (unsigned long long*)((char*)ctx->scratch + 32);  // (scratch holds >= 64 bytes)
+        unsigned long long  h_contig = 0;
+        SPMV_HIP(hipMemsetAsync(d_contig, 0, sizeof(*d_contig), ctx->stream));
         hipLaunchKernelGGL(csr_window_scan_kernel, dim3(nblocks), dim3(kBlock), 0, ctx->stream, m->nrow, kWinRows,
-                           m->a, m->b, m->win_lo, m->win_span);
+                           m->a, m->b, m->win_lo, m->win_span, d_contig);
         SPMV_HIP(hipGetLastError());
+        SPMV_HIP(hipMemcpyAsync(&h_contig, d_contig, sizeof(h_contig), hipMemcpyDeviceToHost, ctx->stream));
+        SPMV_HIP(hipStreamSynchronize(ctx->stream));
+        m->contig_frac = (double)h_contig / (double)m->nnz;
         SPMV_TRY(reduce_max_i32(ctx, m->win_span, nblocks, &m->win_max_span));
         unsigned long long* d_sum = (unsigned long long*)ctx->scratch;
         unsigned long long  total = 0;
@@ -390,7 +417,7 @@ int csr_analyse(spmv_mat* m)
         SPMV_HIP(hipStreamSynchronize(ctx->stream));
         m->win_avg_span = (double)total / nblocks;
     }
-    if (!m->kernel_forced) csr_choose_kernel(m);
+    if (!m->kernel_forced) return csr_select_kernel(m);  // the model, and where it pays a trial of the candidates (select.hip)
     if (m->kernel == SPMV_CSR_PANEL) SPMV_TRY(csr_panel_build(m));
     if (m->kernel == SPMV_CSR_TWOPHASE) SPMV_TRY(csr_twophase_build(m));
     return SPMV_OK;

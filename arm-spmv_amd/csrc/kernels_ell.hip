@@ -326,27 +326,40 @@ __global__ __launch_bounds__(kBlock) void ell_to_csr_kernel(int nrow, int k, con
 }
 }  // namespace
 
-int ell_build_panel(spmv_mat* m, bool only_if_worth)
+namespace
 {
-    if (m->coo_csr) return SPMV_OK;
+// mean number of columns a block of 256 consecutive rows spans (padding ignored); < 0 on failure
+double ell_mean_block_span(spmv_mat* m)
+{
+    spmv_ctx* ctx = m->ctx;
+    if (ensure_scratch(ctx, 64) != SPMV_OK) return -1.0;
+    unsigned long long* d_sum = (unsigned long long*)ctx->scratch;
+    unsigned long long  h_sum = 0;
+    const unsigned      nblk  = (unsigned)ceil_div(m->nrow, kBlock);
+    if (hipMemsetAsync(d_sum, 0, sizeof(unsigned long long), ctx->stream) != hipSuccess) return -1.0;
+    hipLaunchKernelGGL(ell_window_scan_kernel, dim3(nblk), dim3(kBlock), 0, ctx->stream, m->nrow, m->k, m->b, m->v, d_sum);
+    if (hipMemcpyAsync(&h_sum, d_sum, sizeof(h_sum), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return -1.0;
+    return (double)h_sum / nblk;
+}
+
+void ell_drop_rowgrouped(spmv_mat* m)
+{
+    if (!m->coo_csr) return;
+    (void)hipStreamSynchronize(m->ctx->stream);
+    m->device_bytes -= m->coo_csr->device_bytes;
+    mat_free(m->coo_csr);
+    m->coo_csr = nullptr;
+    if (m->kernel == SPMV_CSR_PANEL) m->kernel = SPMV_CSR_VECTOR;
+}
+
+// every slot - padding included, so that the sums and the `0.0 * x[0]` of the reference stay (src/mat_vec.cpp:108-117) -
+// copied row by row into a CSR handle; force_kernel AUTO: the copy picks its kernel like any CSR handle (select.hip)
+int ell_make_rowgrouped(spmv_mat* m, int32_t force_kernel)
+{
     spmv_ctx*     ctx   = m->ctx;
     const int64_t slots = (int64_t)m->nrow * m->k;
-    if (slots == 0 || slots > (int64_t)INT32_MAX - 65536) return SPMV_OK;
-    if (only_if_worth)
-    {
-        if (slots < ((int64_t)2 << 20) || m->k < 2 || (double)m->ncol * 8.0 <= 4.0 * 1048576.0) return SPMV_OK;
-        // how far apart are the columns of 256 consecutive rows, on average?
-        SPMV_TRY(ensure_scratch(ctx, 64));
-        unsigned long long* d_sum = (unsigned long long*)ctx->scratch;
-        unsigned long long  h_sum = 0;
-        const unsigned      nblk  = (unsigned)ceil_div(m->nrow, kBlock);
-        SPMV_HIP(hipMemsetAsync(d_sum, 0, sizeof(unsigned long long), ctx->stream));
-        hipLaunchKernelGGL(ell_window_scan_kernel, dim3(nblk), dim3(kBlock), 0, ctx->stream, m->nrow, m->k, m->b, m->v, d_sum);
-        SPMV_HIP(hipMemcpyAsync(&h_sum, d_sum, sizeof(h_sum), hipMemcpyDeviceToHost, ctx->stream));
-        SPMV_HIP(hipStreamSynchronize(ctx->stream));
-        if ((double)h_sum / nblk <= 131072.0) return SPMV_OK;  // a row block's x window is at most 1 MiB: stays in L2
-    }
-    spmv_mat* csr = nullptr;
+    spmv_mat*     csr   = nullptr;
     SPMV_TRY(mat_alloc(ctx, SPMV_FMT_CSR, m->nrow, m->ncol, slots, 0, (size_t)m->nrow + 1, (size_t)slots, (size_t)slots, &csr));
     hipLaunchKernelGGL(ell_to_csr_kernel, dim3((unsigned)ceil_div((int64_t)m->nrow + 1, kBlock)), dim3(kBlock), 0, ctx->stream,
                        m->nrow, m->k, m->b, m->v, const_cast<int32_t*>(csr->a), const_cast<int32_t*>(csr->b),
@@ -354,11 +367,13 @@ int ell_build_panel(spmv_mat* m, bool only_if_worth)
     int rc = hipGetLastError() == hipSuccess ? SPMV_OK : SPMV_ERR_HIP;
     if (rc == SPMV_OK)
     {
-        csr->max_row_nnz   = m->k;
-        csr->lanes_per_row = 8;
-        csr->kernel_forced = true;
-        csr->kernel        = SPMV_CSR_PANEL;
-        rc                 = csr_panel_build(csr);
+        if (force_kernel != SPMV_CSR_AUTO)
+        {
+            csr->kernel_forced = true;
+            csr->kernel        = force_kernel;
+        }
+        csr->pb_trial = m->pb_trial;
+        rc            = csr_analyse(csr);  // row statistics, kernel (selected or forced), layout
     }
     if (rc != SPMV_OK)
     {
@@ -366,15 +381,122 @@ int ell_build_panel(spmv_mat* m, bool only_if_worth)
         if (rc == SPMV_ERR_HIP) set_error("building the row-grouped copy of an ELL handle failed");
         return rc;
     }
-    // the panel kernel reads row_ptr and its own arrays only
-    (void)hipFree(const_cast<int32_t*>(csr->b));
-    (void)hipFree(const_cast<double*>(csr->v));
-    csr->device_bytes -= slots * 12;
-    csr->b     = nullptr;
-    csr->v     = nullptr;
+    // the panel and two-phase kernels read row_ptr and their own arrays only
+    if ((csr->kernel == SPMV_CSR_PANEL || csr->kernel == SPMV_CSR_TWOPHASE) && csr->b && csr->v)
+    {
+        (void)hipFree(const_cast<int32_t*>(csr->b));
+        (void)hipFree(const_cast<double*>(csr->v));
+        csr->device_bytes -= slots * 12;
+        csr->b = nullptr;
+        csr->v = nullptr;
+    }
     m->coo_csr = csr;
-    m->kernel  = SPMV_CSR_PANEL;
+    m->kernel  = SPMV_CSR_PANEL;  // reported for ELL as "runs from the row-grouped copy"
     m->device_bytes += csr->device_bytes;
+    return SPMV_OK;
+}
+int ell_own_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
+}  // namespace
+
+// the row-grouped copy with the PANEL kernel forced on it (spmv_mat_set_kernel(ell, SPMV_CSR_PANEL)); only_if_worth: the
+// model's gate (no launches): >= 2M slots whose row blocks span more than 1 MiB of an x beyond L2
+int ell_build_panel(spmv_mat* m, bool only_if_worth)
+{
+    if (m->coo_csr && m->coo_csr->kernel == SPMV_CSR_PANEL)
+    {
+        m->kernel = SPMV_CSR_PANEL;
+        return SPMV_OK;
+    }
+    const int64_t slots = (int64_t)m->nrow * m->k;
+    if (slots == 0 || slots > (int64_t)INT32_MAX - 65536) return SPMV_OK;
+    if (only_if_worth)
+    {
+        if (slots < ((int64_t)2 << 20) || m->k < 2 || (double)m->ncol * 8.0 <= 4.0 * 1048576.0) return SPMV_OK;
+        const double span = ell_mean_block_span(m);  // how far apart are the columns of 256 consecutive rows, on average?
+        if (span < 0.0) SPMV_FAIL(SPMV_ERR_HIP, "ELL window scan failed: %s", hipGetErrorString(hipGetLastError()));
+        if (span <= 131072.0) return SPMV_OK;  // a row block's x window is at most 1 MiB: stays in L2
+    }
+    ell_drop_rowgrouped(m);
+    return ell_make_rowgrouped(m, SPMV_CSR_PANEL);
+}
+
+// AUTO for an ELL handle (select.hip; tools/sweep_structures.py).  The format's own kernels: two rows per lane (with the
+// slots' diagonals where they were found: no index stream), one row per lane (more wavefronts: wins below ~200K rows, 2x on a
+// 27-point stencil of 64000 rows), two rows per lane reading every index.  And the row-grouped copy, a candidate where one
+// lane per row cannot work: FEW LONG ROWS (5000 rows x 160 slots: 0.058 ms against 0.008 - a lane walks 160 slots while
+// most of the chip idles) or SCATTERED columns (a row block spanning more than 16 columns per row: 4M x 100K uniform,
+// 0.165 against 0.084; the panel kernel orders the gathers by x line) - not where the slots are diagonals (their x
+// stretches go through LDS) unless the rows are few.  The candidates are timed; without trials the model's gate decides.
+int ell_select_kernel(spmv_mat* m)
+{
+    spmv_ctx* ctx = m->ctx;
+    select_reset(m);
+    ell_drop_rowgrouped(m);
+    m->kernel      = SPMV_CSR_VECTOR;
+    m->ell_variant = 0;
+    const int64_t slots = (int64_t)m->nrow * m->k;
+    if (slots == 0 || m->nrow <= 0) return SPMV_OK;
+    if (!select_trials_enabled(m) || slots < kSelectMinNnz)
+        return m->ell_diag ? SPMV_OK : ell_build_panel(m, /*only_if_worth=*/true);
+    select_scratch sv;
+    if (sv.alloc(ctx, m->ncol, m->nrow) != SPMV_OK) return m->ell_diag ? SPMV_OK : ell_build_panel(m, true);
+    // the format's own variants
+    float best_ms = 1e30f;
+    int   best_v  = 0, rc = SPMV_OK;
+    for (int v = 0; v < 3 && rc == SPMV_OK; ++v)
+    {
+        if (v == 2 && !(m->ell_diag && m->ell_diag_mask)) continue;  // (without diagonal slots variant 0 reads the indices already)
+        m->ell_variant = v;
+        float ms       = 0.f;
+        rc             = select_time(ctx, [&] { return ell_own_apply(ctx, m, sv.x, sv.y); }, best_ms, &ms);
+        if (rc != SPMV_OK) break;
+        select_note(m, v == 0 ? SPMV_CSR_VECTOR : 5 + v, ms);  // slots 1, 6 ("variant1"), 7 ("variant2")
+        if (ms < best_ms * (v ? 0.98f : 1.0f))
+        {
+            best_ms = ms;
+            best_v  = v;
+        }
+    }
+    m->ell_variant = best_v;
+    if (rc != SPMV_OK) return rc;
+    // the row-grouped copy, where it is a candidate
+    bool candidate = m->k >= 2 && slots <= (int64_t)INT32_MAX - 65536;
+    if (candidate)
+    {
+        const bool few_rows = m->nrow <= 65536 && m->k >= 16;
+        if (!few_rows)
+        {
+            if (m->ell_diag)
+                candidate = false;
+            else
+            {
+                const double span = ell_mean_block_span(m);
+                candidate         = span > 16.0 * 256.0;
+            }
+        }
+    }
+    if (candidate)
+    {
+        rc = ell_make_rowgrouped(m, SPMV_CSR_AUTO);
+        if (rc == SPMV_ERR_ALLOC)
+        {
+            (void)hipGetLastError();
+            rc = SPMV_OK;  // no memory for the copy: the format's own kernel runs
+        }
+        else if (rc == SPMV_OK)
+        {
+            float t_copy = 0.f;
+            rc           = select_time(ctx, [&] { return csr_apply(ctx, m->coo_csr, sv.x, sv.y); }, best_ms, &t_copy);
+            if (rc == SPMV_OK)
+            {
+                select_note(m, SPMV_CSR_PANEL, t_copy);
+                if (!(t_copy < best_ms * 0.98f)) ell_drop_rowgrouped(m);
+            }
+        }
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    if (rc != SPMV_OK) return rc;
+    m->kernel = m->coo_csr ? SPMV_CSR_PANEL : SPMV_CSR_VECTOR;
     return SPMV_OK;
 }
 
@@ -527,18 +649,26 @@ int ell_analyse(spmv_mat* m)
 {
     m->kernel = SPMV_CSR_VECTOR;  // reported for ELL as "one lane per row"
     SPMV_TRY(ell_detect_diagonals(m));
-    if (!m->kernel_forced && !m->ell_diag) SPMV_TRY(ell_build_panel(m, /*only_if_worth=*/true));
+    if (!m->kernel_forced) SPMV_TRY(ell_select_kernel(m));
     return SPMV_OK;
 }
 
 int ell_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
 {
     if (A->nrow == 0) return SPMV_OK;
-    if (A->coo_csr && A->kernel == SPMV_CSR_PANEL) return csr_panel_apply(ctx, A->coo_csr, x, y);
+    if (A->coo_csr && A->kernel == SPMV_CSR_PANEL) return csr_apply(ctx, A->coo_csr, x, y);
+    return ell_own_apply(ctx, A, x, y);
+}
+
+namespace
+{
+int ell_own_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
+{
     const bool aligned = (A->nrow % 2 == 0) && (((uintptr_t)A->b % 8) == 0) && (((uintptr_t)A->v % 16) == 0) &&
                          (((uintptr_t)y % 16) == 0);
-    const bool x2 = aligned && !(A->lanes_per_row == 1);  // lanes_per_row==1 forces the one-row kernel
-    if (x2 && A->ell_diag && A->ell_diag_mask && !(A->flags & SPMV_FLAG_ELL_READ_COLUMNS))
+    // lanes_per_row == 1 (spmv_mat_set_kernel) or the variant AUTO timed fastest (ell_variant 1) select the one-row kernel
+    const bool x2 = aligned && !(A->lanes_per_row == 1) && A->ell_variant != 1;
+    if (x2 && A->ell_diag && A->ell_diag_mask && !(A->flags & SPMV_FLAG_ELL_READ_COLUMNS) && A->ell_variant != 2)
     {
         const unsigned grid = (unsigned)ceil_div(A->nrow / 2, kBlock);
         const bool     xwin = A->ell_diag_lds > 0 && A->ell_diag_lds <= 5120;  // the x stretches of 512 rows fit 40 KB of LDS
@@ -587,4 +717,5 @@ int ell_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
     SPMV_HIP(hipGetLastError());
     return SPMV_OK;
 }
+}  // namespace
 }  // namespace spmv

@@ -1,0 +1,170 @@
+// select.hip - AUTO kernel selection by MEASUREMENT ("adaptive format / kernel selection").
+//
+// Rounds 1-4 chose the kernel of a handle from a model (csr_choose_kernel: entry count, mean row length, column windows)
+// whose thresholds were measured on BASELINE's own shapes - exactly 32 entries per row, uniform or band-random columns.
+// Round 5 audited that policy on matrices that look like Matrix Market files (tools/sweep_structures.py: stencils,
+// dense-block diagonals, R-MAT graphs, tall and wide rectangles, permutations; profiles/r05_sweep_structures_*.txt): 29 of 55
+// (matrix, format) rows ran below 0.97 of their best forced kernel, some far below - a hub row of 8436 entries under the
+// row-parallel kernel (0.18 ms against 0.016), an ELL handle of 5000 long rows (0.058 against 0.008), small COO handles
+// (segmented scan 2x slower than the row-grouped copy), contiguous 64-entry rows (panel 0.116 against 0.093).  No set of
+// thresholds covers that range.  What the handle does instead, when it is created (one-off, outside every timed region,
+// like the reference's shard construction, src/mat_vec.cpp:240-268):
+//
+//   1. the model picks as before (improved where the audit showed a plain error: the row-grouped layouts from 1.5M entries
+//      on, not 2M; no lower bound of 2 on the mean row length; skewed rows never go to the row-parallel kernel; long
+//      contiguous rows do);
+//   2. handles between 64K and 8M entries - where the candidates lie within a factor of a few of each other and a product
+//      takes microseconds - TIME the candidates: 1 warm-up + 2 x 4 products each on zeroed scratch vectors (the gather
+//      addresses, not the values, set the time), a candidate that is 3x behind after its first product is dropped at once;
+//      the fastest wins, a later candidate has to win by 2 %.  Larger handles keep the model's pick (a trial of the
+//      row-parallel kernel on C2 would cost 60 ms for a kernel that loses 5x) unless a statistic says the model may be
+//      wrong: long contiguous rows (dense blocks) also time the row-parallel kernel;
+//   3. layouts built for candidates that lost are freed before the call returns.
+// "panel_trial" 0 / SPMV_PANEL_TRIAL=0 (no timing launches at all) leaves step 1 alone.  What was timed is reported:
+// spmv_mat_get_param "select_candidates" and "select_us_<kernel>" (include/spmv_abi.h).
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+#include "common.hpp"
+
+namespace spmv
+{
+bool select_trials_enabled(const spmv_mat* m)
+{
+    if (m->pb_trial == 0) return false;
+    if (m->pb_trial > 0) return true;
+    const char* e = getenv("SPMV_PANEL_TRIAL");  // (read when a handle is built, never on a product's path)
+    return !(e && e[0] == '0');
+}
+
+int select_scratch::alloc(spmv_ctx* ctx, int64_t ncol, int64_t nrow)
+{
+    if (hipMalloc(&x, sizeof(double) * (size_t)std::max<int64_t>(ncol, 1)) != hipSuccess ||
+        hipMalloc(&y, sizeof(double) * (size_t)std::max<int64_t>(nrow, 1)) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        release();
+        return SPMV_ERR_ALLOC;
+    }
+    (void)hipMemsetAsync(x, 0, sizeof(double) * (size_t)std::max<int64_t>(ncol, 1), ctx->stream);
+    (void)hipMemsetAsync(y, 0, sizeof(double) * (size_t)std::max<int64_t>(nrow, 1), ctx->stream);
+    return SPMV_OK;
+}
+void select_scratch::release()
+{
+    if (x) (void)hipFree(x);
+    if (y) (void)hipFree(y);
+    x = y = nullptr;
+}
+
+int select_time(spmv_ctx* ctx, const std::function<int()>& launch, float best_so_far, float* out_ms)
+{
+    auto run = [&](int n, float* ms) -> int {
+        if (hipEventRecord(ctx->ev_begin, ctx->stream) != hipSuccess) return SPMV_ERR_HIP;
+        for (int i = 0; i < n; ++i)
+        {
+            const int rc = launch();
+            if (rc != SPMV_OK) return rc;
+        }
+        if (hipEventRecord(ctx->ev_end, ctx->stream) != hipSuccess || hipEventSynchronize(ctx->ev_end) != hipSuccess ||
+            hipEventElapsedTime(ms, ctx->ev_begin, ctx->ev_end) != hipSuccess)
+        {
+            set_error("kernel selection: a timing launch failed: %s", hipGetErrorString(hipGetLastError()));
+            return SPMV_ERR_HIP;
+        }
+        *ms /= (float)n;
+        return SPMV_OK;
+    };
+    int rc = launch();  // warm-up (first-use set-up of the kernel, LDS grants)
+    if (rc != SPMV_OK) return rc;
+    float first = 0.f;
+    if ((rc = run(1, &first)) != SPMV_OK) return rc;
+    *out_ms = first;
+    if (first > 3.0f * best_so_far) return SPMV_OK;  // hopeless: no more launches for it
+    float a = 0.f, b = 0.f;
+    if ((rc = run(4, &a)) != SPMV_OK || (rc = run(4, &b)) != SPMV_OK) return rc;
+    *out_ms = std::min(a, b);
+    return SPMV_OK;
+}
+
+void select_note(spmv_mat* m, int slot, float ms)
+{
+    if (slot >= 0 && slot < 8) m->sel_us[slot] = ms * 1000.f;
+    ++m->sel_candidates;
+}
+void select_reset(spmv_mat* m)
+{
+    m->sel_candidates = 0;
+    for (float& v : m->sel_us) v = 0.f;
+}
+
+// ---- CSR ----------------------------------------------------------------------------------------------------------
+// Leaves m->kernel chosen and its layout built; layouts of candidates that lost are freed.
+int csr_select_kernel(spmv_mat* m)
+{
+    spmv_ctx* ctx = m->ctx;
+    select_reset(m);
+    csr_choose_kernel(m);  // the model (no launches)
+    const int model = m->kernel;
+    auto build = [&](int kernel) -> int {
+        m->kernel = kernel;
+        if (kernel == SPMV_CSR_PANEL) return csr_panel_build(m);
+        if (kernel == SPMV_CSR_TWOPHASE) return csr_twophase_build(m);
+        return SPMV_OK;
+    };
+    if (m->nrow == 0 || m->nnz == 0 || !m->b || !m->v) return build(model);
+    const double mean = (double)m->nnz / (double)m->nrow;
+    std::vector<int> cand{model};
+    auto             add = [&](int k) {
+        if (std::find(cand.begin(), cand.end(), k) == cand.end()) cand.push_back(k);
+    };
+    if (select_trials_enabled(m) && m->nnz >= kSelectMinNnz)
+    {
+        if (m->nnz < kSelectMaxNnz)
+        {
+            add(SPMV_CSR_PANEL);
+            add(SPMV_CSR_VECTOR);
+            if (m->win_max_span > 0 && m->win_max_span <= csr_ldswin_capacity()) add(SPMV_CSR_LDSWIN);
+            if (mean <= 8.0 && m->max_row_nnz <= 64) add(SPMV_CSR_SCALAR);  // one lane per row: short, even rows only
+        }
+        else if (m->contig_frac >= 0.5 && mean >= 16.0)
+        {
+            add(SPMV_CSR_VECTOR);  // long contiguous rows (dense blocks): the row-parallel kernel reads x coalesced
+            add(SPMV_CSR_PANEL);
+        }
+    }
+    if (cand.size() == 1) return build(model);
+
+    select_scratch sv;
+    if (sv.alloc(ctx, m->ncol, m->nrow) != SPMV_OK) return build(model);  // no room to try: the model's pick
+    int   best = -1, rc = SPMV_OK;
+    float best_ms = 1e30f;
+    for (int k : cand)
+    {
+        if ((rc = build(k)) != SPMV_OK)
+        {
+            if (k == model) return rc;
+            (void)hipGetLastError();
+            rc = SPMV_OK;  // a candidate that cannot be built (no memory for a second layout) is not a candidate
+            continue;
+        }
+        float ms = 0.f;
+        rc       = select_time(ctx, [&] { return csr_apply(ctx, m, sv.x, sv.y); }, best_ms, &ms);
+        if (rc != SPMV_OK) break;
+        select_note(m, k, ms);
+        if (ms < best_ms * (best >= 0 ? 0.98f : 1.0f))
+        {
+            best    = k;
+            best_ms = ms;
+        }
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    if (rc != SPMV_OK) return rc;
+    if (best < 0) best = model;
+    if (best != SPMV_CSR_PANEL) csr_panel_free(m);
+    if (best != SPMV_CSR_TWOPHASE) csr_twophase_free(m);
+    return build(best);  // (a layout that is already in memory with the current parameters is kept as it is)
+}
+
+}  // namespace spmv

@@ -57,9 +57,25 @@ typedef enum spmv_format
     SPMV_FMT_DIA = 4  /* include/matrix.h:117-138, row-major: (row i, diag d) at i*ndiags + d */
 } spmv_format;
 
-/* CSR kernel selection (spmv_mat_set_kernel).  AUTO picks from the statistics gathered when the matrix is created:
- * fewer than 2M entries -> VECTOR (or LDSWIN for narrow bands); larger -> PANEL, or TWOPHASE when the sweeps of x the
- * panel kernel would make (8 XCDs x rounds x 8 * ncol bytes) outweigh the 16 extra bytes per entry of the two phases.
+/* CSR kernel selection (spmv_mat_set_kernel).  AUTO (csrc/select.hip) is decided when the handle is
+ * created - one-off, outside every timed region, like the reference's shard construction (src/mat_vec.cpp:240-268):
+ *   the model   statistics of the matrix: fewer than 1.5M entries -> VECTOR (or LDSWIN for narrow bands; PANEL when a few hub
+ *               rows dwarf the mean: they would serialise on one lane group); larger -> PANEL, or TWOPHASE when the sweeps of x
+ *               the panel kernel would make (8 XCDs x rounds x 8 * ncol bytes) outweigh the 16 extra bytes per entry of the two
+ *               phases, or VECTOR when the rows are long contiguous runs (dense blocks of 32 and more: x is read coalesced);
+ *   the trial   handles of 64K to 8M entries - where a product takes microseconds and the candidates lie within a factor of a
+ *               few - TIME their candidates (PANEL, VECTOR, LDSWIN where the windows fit, SCALAR for short even rows, the
+ *               model's pick): 1 warm-up + 2 x 4 products each on zeroed scratch vectors (8 * (nrow + ncol) bytes, freed
+ *               before the call returns), a candidate 3x behind after its first product is dropped at once, the fastest
+ *               stays, layouts built for the others are freed.  Larger handles keep the model's pick without a launch, unless
+ *               their rows are contiguous runs (then VECTOR and PANEL are timed).  COO and ELL handles time their own
+ *               kernel(s) against a row-grouped CSR copy of themselves - which picks ITS kernel the same way - where that copy
+ *               is a candidate (below).  "panel_trial" 0 / SPMV_PANEL_TRIAL=0: no timing launch anywhere, the model alone.
+ *   what was timed is on record: spmv_mat_get_param "select_candidates", "select_us_vector" / "_ldswin" / "_scalar" / "_panel" /
+ *   "_twophase" (microseconds per product, 0 = not timed; COO / ELL: "_vector" the format's own kernel, "_panel" the copy; ELL
+ *   also "_variant1" one row per lane, "_variant2" two rows per lane reading every index), "rowgrouped_kernel" (the kernel the
+ *   copy of a COO / ELL / CSC handle runs, 0 = no copy in use), "ell_variant", "contiguous_permille".
+ *   Audit on stencils, dense blocks, R-MAT graphs, rectangles, permutations: tools/sweep_structures.py, profiles/r05_sweep_structures_*.
  *
  * Order of the additions (all within the parity tolerance of 1e-10):
  *   SCALAR              the reference's own order (left to right inside a row): bit-identical to its fma flavour;
@@ -187,10 +203,15 @@ int spmv_mat_get_info(const spmv_mat* m, spmv_mat_info* info);
  * SPMV_ERR_INVALID + message if not.  One pass over the index arrays; synchronous. */
 int spmv_mat_validate(const spmv_mat* m);
 /* Force a CSR kernel (and, for VECTOR, lanes_per_row in {1,2,4,...,64}; 0 = keep auto choice).
- * COO, CSC and ELL handles take AUTO (regroup by row and run the panel product when the handle is large and its
- * columns are scattered), VECTOR (the format's own kernel: segmented scan / atomic scatter / one lane per row;
+ * COO, CSC and ELL handles take AUTO, VECTOR (the format's own kernel: segmented scan / atomic scatter / one lane per row;
  * for ELL lanes_per_row 1 or 2 picks the one- or two-rows-per-lane variant; for a large COO handle whose x is beyond an
- * XCD's L2 the scan runs over a copy of the entries in column bins - "coo_column_bins" below) or PANEL (regroup now). */
+ * XCD's L2 the scan runs over a copy of the entries in column bins - "coo_column_bins" below) or PANEL (regroup by row now and
+ * run the panel kernel on that copy).  AUTO for COO: the scan over the entries as they are against a copy grouped by row
+ * (duplicates and the order inside a row kept) that picks its own CSR kernel - timed from 64K entries on, the copy by the
+ * model from 1.5M on.  AUTO for ELL: its own variants timed from 64K slots on; the row-grouped copy (every slot, padding
+ * included: the sums and the reference's 0.0 * x[0] stay) is a candidate where one lane per row cannot work - at most 65536
+ * rows of 16 slots and more, or rows whose blocks of 256 span more than 16 columns per row (scattered) and whose slots are not
+ * diagonals.  AUTO for CSC: regrouped by row from 2M entries on (the model; not timed). */
 int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row);
 int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
 /* Named parameters.  None is needed in normal use: what is left at its default is chosen when the layout is built, by

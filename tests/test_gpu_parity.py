@@ -188,7 +188,14 @@ def test_coo_matches_reference_golden(ctx, orc, pkg, make):
     A = ctx.coo(c["nrow"], c["ncol"], c["row"], c["col"], c["val"])
     sorted_in = bool(np.all(np.diff(c["row"].astype(np.int64)) >= 0))
     assert bool(A.info.sorted_rows) == sorted_in
-    assert A.info.kernel == pkg.capi.CSR_VECTOR  # small: the segmented scan
+    # AUTO: below 64K entries nothing is timed and the segmented scan runs; above, the scan and the row-grouped copy are
+    # timed and the faster one stays (C1 has 160K entries)
+    if len(c["val"]) < 65536:
+        assert A.info.kernel == pkg.capi.CSR_VECTOR and A.get_param("select_candidates") == 0
+    else:
+        assert A.info.kernel in (pkg.capi.CSR_VECTOR, pkg.capi.CSR_PANEL) and A.get_param("select_candidates") == 2
+        y1, _ = _apply_n(ctx, A, c["x"], c["nrow"], 1)
+        ol.assert_parity(y1, g["y1_coo"], scale, f"{c['name']} coo AUTO (kernel {A.info.kernel}, copy runs {A.get_param('rowgrouped_kernel')})")
     for kernel in (pkg.capi.CSR_VECTOR, pkg.capi.CSR_PANEL):  # PANEL: grouped by row on the device, panel layout
         A.set_kernel(kernel)
         assert A.info.kernel == kernel
@@ -507,8 +514,11 @@ def test_csr_twophase_kernel_on_wide_and_ragged_matrices(ctx, orc, pkg):
     ctx.sync()
     assert np.max(np.abs(yw.download() - yv.download())) <= ol.REL_TOL * 16
     del wide
+    # (handles below 8M entries also TIME their candidates: the model's own answer is what SPMV_PANEL_TRIAL=0 leaves)
+    os.environ["SPMV_PANEL_TRIAL"] = "0"
     thin = ctx.gen_csr_uniform(0, 600_000, 40_000_000, 8, seed=3)
-    assert thin.info.kernel == capi.CSR_PANEL
+    os.environ.pop("SPMV_PANEL_TRIAL")
+    assert thin.info.kernel == capi.CSR_PANEL and thin.get_param("select_candidates") == 0
     del thin
     # few entries per row would pass the sweep model, but a band matrix only sweeps its band: the panel kernel stays
     band = ctx.gen_csr_uniform(0, 3_000_000, 3_000_000, 4, band=4096, seed=3)
@@ -517,7 +527,9 @@ def test_csr_twophase_kernel_on_wide_and_ragged_matrices(ctx, orc, pkg):
     sparse = ctx.gen_csr_uniform(0, 3_000_000, 3_000_000, 4, seed=3)  # the same shape with uniform columns takes the two phases
     assert sparse.info.kernel == capi.CSR_TWOPHASE
     del sparse
+    os.environ["SPMV_PANEL_TRIAL"] = "0"
     square = ctx.gen_csr_uniform(0, 600_000, 600_000, 8, seed=3)
+    os.environ.pop("SPMV_PANEL_TRIAL")
     assert square.info.kernel == capi.CSR_PANEL
 
 
@@ -629,7 +641,14 @@ def test_large_coo_handle_keeps_one_layout_only(ctx, pkg):
     rows = np.repeat(np.arange(n, dtype=np.int32), k)
     A = ctx.coo(n, n, rows, col, val)
     nnz = n * k
-    assert A.info.kernel == capi.CSR_PANEL
+    # the handle runs from its row-grouped copy, and that copy keeps ONE layout (since round 5 the copy picks its own kernel:
+    # the two-phase layout here, 12 + 8 bytes per padded entry; before, the panel layout was forced on it) - never both, and
+    # never the copy's col_ind / values beside it
+    assert A.info.kernel == capi.CSR_PANEL and A.get_param("rowgrouped_kernel") in (capi.CSR_PANEL, capi.CSR_TWOPHASE)
+    per_entry = 15 if A.get_param("rowgrouped_kernel") == capi.CSR_PANEL else 24
+    assert A.get_param("device_bytes") <= 16 * nnz + per_entry * nnz + 8 * (n + 1), A.get_param("device_bytes")
+    A.set_kernel(capi.CSR_PANEL)  # forcing the panel layout replaces the copy, it does not add to it
+    assert A.get_param("rowgrouped_kernel") == capi.CSR_PANEL
     assert A.get_param("device_bytes") <= 16 * nnz + 15 * nnz + 8 * (n + 1), A.get_param("device_bytes")
 
 
@@ -707,7 +726,7 @@ def test_csr_ldswin_on_banded_matrix(ctx, orc, pkg):
     A = ctx.csr(n, n, rp, cc, cv)
     # the first and last row blocks wrap around the matrix edge: their window spans all columns, so AUTO must
     # not pick the LDS kernel for this matrix, and forcing it must fail loudly rather than read out of bounds
-    assert A.info.kernel == pkg.capi.CSR_VECTOR
+    assert A.info.kernel != pkg.capi.CSR_LDSWIN and A.get_param("select_us_ldswin") == 0  # (not even timed)
     A.set_kernel(pkg.capi.CSR_LDSWIN)
     with pytest.raises(pkg.capi.SpmvError):
         ctx.apply(A, ctx.vector_from(x), ctx.vector(n))
@@ -716,6 +735,9 @@ def test_csr_ldswin_on_banded_matrix(ctx, orc, pkg):
     rp2 = (rp[lo:hi + 1] - rp[lo]).astype(np.int32)
     cc2, cv2 = cc[rp[lo]:rp[hi]], cv[rp[lo]:rp[hi]]
     B = ctx.csr(hi - lo, n, rp2, cc2, cv2)
+    # 1.66M entries: the LDS-window kernel is a candidate AUTO times (against the panel layout and the row-parallel kernel)
+    assert B.get_param("select_us_ldswin") > 0 and B.get_param("select_candidates") >= 3
+    B.set_kernel(pkg.capi.CSR_LDSWIN)
     assert B.info.kernel == pkg.capi.CSR_LDSWIN
     y1, _ = _apply_n(ctx, B, x, hi - lo, 1)
     ol.assert_parity(y1, ref[lo:hi], scale[lo:hi], "csr ldswin")
@@ -812,6 +834,97 @@ def test_skewed_matrix_sharded_by_rows_and_by_entries(ctx, orc, pkg, fmt):
     # padded formats keep equal rows either way (every row stores k slots): asking for balance changes nothing
     E = ctx.gen_ell_banded(1000, 1000, 8, seed=2)
     assert np.array_equal(E.partition_rows(3, True), E.partition_rows(3, False))
+
+
+def test_auto_times_its_candidates_and_keeps_the_fastest(ctx, orc, pkg, monkeypatch):
+    """AUTO is a measurement where a model cannot know (64K .. 8M entries; tools/sweep_structures.py).
+    What is checked here is the mechanism, not a timing: which candidates were timed, that the kernel kept is the fastest of
+    them by the handle's own record (a later candidate has to win by 2 %), that every candidate computes the same product,
+    that nothing of a losing layout stays allocated, and that SPMV_PANEL_TRIAL=0 leaves the model alone."""
+    capi = pkg.capi
+    names = {1: "vector", 2: "ldswin", 3: "scalar", 4: "panel", 5: "twophase"}
+    rng = np.random.default_rng(17)
+    # (a) a hub row among short ones (R-MAT-like): 40000 rows x 8, one row of 30000 entries: 350K entries
+    n = 40_000
+    lens = np.full(n, 8, np.int64)
+    lens[1234] = 30_000
+    rp = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    cc = rng.integers(0, n, rp[-1]).astype(np.int32)
+    cv = rng.uniform(-1, 1, rp[-1])
+    x = rng.uniform(0, 1, n)
+    ref, scale = np.zeros(n), np.zeros(n)
+    ol.csr_spmv(orc, rp, cc, cv, x, ref)
+    ol.csr_abs_row_sums(orc, rp, cc, cv, x, scale)
+    dx, dy = ctx.vector_from(x), ctx.vector(n)
+
+    def product(M, what):
+        dy.fill(0.0)
+        ctx.apply(M, dx, dy)
+        ctx.sync()
+        ol.assert_parity(dy.download(), ref, scale, what)
+
+    A = ctx.csr(n, n, rp, cc, cv)
+    timed = {k: A.get_param("select_us_" + v) for k, v in names.items() if A.get_param("select_us_" + v) > 0}
+    assert A.get_param("select_candidates") == len(timed) >= 2 and capi.CSR_PANEL in timed and capi.CSR_VECTOR in timed, timed
+    kept = int(A.info.kernel)
+    assert kept in timed and timed[kept] <= 1.03 * min(timed.values()) + 1, (kept, timed)
+    # a lane group of the row-parallel kernel walks the hub row alone: whatever the box, that is not the fastest candidate
+    assert kept != capi.CSR_VECTOR and timed[capi.CSR_VECTOR] > 2 * timed[kept], timed
+    product(A, f"hub row, AUTO kept {names[kept]}")
+    if kept != capi.CSR_PANEL:
+        assert A.get_param("panel_bytes") == 0  # the losing layout went back
+    bytes_auto = A.get_param("device_bytes")
+    for k in (capi.CSR_VECTOR, capi.CSR_SCALAR, capi.CSR_PANEL):
+        A.set_kernel(k)
+        product(A, f"hub row, forced {names[k]}")
+    A.set_kernel(capi.CSR_AUTO)  # selecting again times again and ends in the same state
+    assert A.get_param("select_candidates") >= 2 and A.get_param("device_bytes") <= bytes_auto + (1 << 20)
+    product(A, "hub row, AUTO again")
+    # the model alone (no timing launches): the hub-row rule picks the panel layout
+    monkeypatch.setenv("SPMV_PANEL_TRIAL", "0")
+    B = ctx.csr(n, n, rp, cc, cv)
+    assert B.get_param("select_candidates") == 0 and B.info.kernel == capi.CSR_PANEL
+    product(B, "hub row, model only")
+    monkeypatch.delenv("SPMV_PANEL_TRIAL")
+    # (b) the same matrix as a COO handle: the scan and the row-grouped copy are both timed; the copy picks its own kernel
+    rows = np.repeat(np.arange(n, dtype=np.int32), lens)
+    C = ctx.coo(n, n, rows, cc, cv)
+    assert C.get_param("select_candidates") == 2 and C.get_param("select_us_vector") > 0 and C.get_param("select_us_panel") > 0
+    if C.info.kernel == capi.CSR_PANEL:
+        assert C.get_param("rowgrouped_kernel") in names and C.get_param("select_us_panel") < C.get_param("select_us_vector")
+    else:
+        assert C.get_param("rowgrouped_kernel") == 0 and C.get_param("device_bytes") <= 16 * int(rp[-1]) + 4096  # the copy went back
+    product(C, "hub row, COO AUTO")
+    # (c) few long rows in an ELL handle: 3000 rows x 96 slots over 400K columns - one lane per row leaves the chip idle, the
+    # row-grouped copy is a candidate and (timed) wins by a wide margin on any box
+    nr, K, ncol = 3000, 96, 400_000
+    ec = rng.integers(0, ncol, nr * K).astype(np.int32)
+    ev = rng.uniform(-1, 1, nr * K)
+    xe = rng.uniform(0, 1, ncol)
+    E = ctx.ell(nr, ncol, K, nr * K, ec, ev)
+    assert E.get_param("select_candidates") >= 3 and E.get_param("select_us_panel") > 0
+    assert E.info.kernel == capi.CSR_PANEL and E.get_param("select_us_panel") * 2 < E.get_param("select_us_vector")
+    ye, yv = ctx.vector(nr), ctx.vector(nr)
+    ye.fill(0.0)
+    yv.fill(0.0)
+    dxe = ctx.vector_from(xe)
+    ctx.apply(E, dxe, ye)
+    E.set_kernel(capi.CSR_VECTOR, 1)  # one row per lane: the reference's order, bit-identical to the fma oracle (tested above)
+    ctx.apply(E, dxe, yv)
+    ctx.sync()
+    assert np.max(np.abs(ye.download() - yv.download())) <= ol.REL_TOL * K
+    # (d) handles of 8M entries and more keep the model's pick without a launch (a trial of the row-parallel kernel on C2
+    # would cost 60 ms for a kernel that loses 5x) - unless their rows are long contiguous runs
+    big = ctx.gen_csr_uniform(0, 600_000, 600_000, 16, seed=5)
+    assert big.get_param("select_candidates") == 0 and big.info.kernel == capi.CSR_PANEL and big.get_param("contiguous_permille") < 50
+    del big
+    nb, bs = 150_000, 64  # dense 64 x 64 blocks on the diagonal: 9.6M entries in contiguous runs
+    i = np.arange(nb, dtype=np.int64)
+    brp = (np.arange(nb + 1, dtype=np.int64) * bs).astype(np.int32)
+    bcc = (np.repeat(i // bs * bs, bs) + np.tile(np.arange(bs), nb)).astype(np.int32)
+    D = ctx.csr(nb, nb, brp, bcc, rng.uniform(-1, 1, nb * bs))
+    assert D.get_param("contiguous_permille") > 950 and D.get_param("select_candidates") == 2
+    assert D.get_param("select_us_vector") > 0 and D.get_param("select_us_panel") > 0
 
 
 # ---------------------------------------------------------------------------------- full-size properties
