@@ -675,16 +675,18 @@ def main() -> None:
         def describe(fmt, M, inf, flags):
             """(kernel that runs, which bytes it has to move) of a handle"""
             kid = int(inf.kernel)
+            inner_names = {1: "csr_vector_kernel", 2: "csr_ldswin_kernel", 3: "csr_scalar_kernel", 4: "csr_panel_kernel", 5: "tp_expand_kernel + tp_reduce_kernel (two-phase)"}
+            inner = inner_names.get(M.get_param("rowgrouped_kernel"), "csr_panel_kernel") if fmt in ("ell", "coo") and kid == 4 else None
             if fmt == "ell":
                 if kid == 4:
-                    return "csr_panel_kernel on the row-grouped copy of the ELL slots", "panel"
+                    return f"{inner} on the row-grouped copy of the ELL slots", "panel"
                 if M.get_param("ell_diagonal_slots") and not (flags & 8):  # 8 = SPMV_FLAG_ELL_READ_COLUMNS
                     return ("ell_diag_kernel_x2 (slots recognised as diagonals: conforming rows read no column index"
                             + ("; values read from the copy in tiles of 512 rows)" if M.get_param("ell_tiled_values") else ")")), "ell_diagonals"
                 return "ell_kernel_x2 (one lane per two rows, column-major slots, every column index read)", "ell_columns"
             if fmt == "coo":
                 if kid == 4:
-                    return "csr_panel_kernel on the row-grouped copy (12-byte packed entries)", "panel"
+                    return f"{inner} on the row-grouped copy" + (" (12-byte packed entries)" if inner == "csr_panel_kernel" else ""), "panel"
                 if M.get_param("coo_column_bins"):
                     return (f"coo_segscan_bins_kernel (wavefront segmented scan over a copy of the entries in {M.get_param('coo_column_bins')} column "
                             "bins, one per XCD: each XCD gathers x from a slice that stays in its L2)"), "coo_segscan"

@@ -92,7 +92,12 @@ def test_ell_matches_reference_and_is_bitwise_oracle_fma(ctx, orc, make):
     ol.assert_parity(y50, g["y50_ell"], scale, c["name"] + " ell 50 calls", reps=NUM_TEST)
     ref = np.zeros(c["nrow"])
     ol.ell_spmv(orc, c["nrow"], k, ec, ev, ol.f64(c["x"]), ref, fma=True)
-    assert np.array_equal(y1, ref), "ELL kernel adds in the reference's per-row order: must equal the fma oracle exactly"
+    # (AUTO may run a handle of few long rows from its row-grouped copy - c1: 10000 rows - within the gate above; the format's
+    # own kernels add in the reference's per-row order)
+    for lanes in (1, 2):
+        A.set_kernel(1, lanes)
+        y1, _ = _apply_n(ctx, A, c["x"], c["nrow"], 1)
+        assert np.array_equal(y1, ref), "ELL kernel adds in the reference's per-row order: must equal the fma oracle exactly"
 
 
 def test_ell_odd_row_count_uses_one_row_kernel(ctx, orc):
@@ -918,7 +923,7 @@ def test_auto_times_its_candidates_and_keeps_the_fastest(ctx, orc, pkg, monkeypa
     big = ctx.gen_csr_uniform(0, 600_000, 600_000, 16, seed=5)
     assert big.get_param("select_candidates") == 0 and big.info.kernel == capi.CSR_PANEL and big.get_param("contiguous_permille") < 50
     del big
-    nb, bs = 150_000, 64  # dense 64 x 64 blocks on the diagonal: 9.6M entries in contiguous runs
+    nb, bs = 64 * 2344, 64  # dense 64 x 64 blocks on the diagonal: 9.6M entries in contiguous runs
     i = np.arange(nb, dtype=np.int64)
     brp = (np.arange(nb + 1, dtype=np.int64) * bs).astype(np.int32)
     bcc = (np.repeat(i // bs * bs, bs) + np.tile(np.arange(bs), nb)).astype(np.int32)
