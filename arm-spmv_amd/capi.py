@@ -106,6 +106,8 @@ SIGNATURES = {
     "spmv_gen_coo_powerlaw": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.POINTER(_vp)]),
     "spmv_gen_coo_powerlaw_sorted": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.POINTER(_vp)]),
     "spmv_mat_partition_rows": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp]),
+    "spmv_ctx_xcd_round_robin": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "spmv_apply_host": (C.c_int, [_vp, _vp, _vp, _vp]),
     "spmv_csr_extract_rows": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.POINTER(_vp)]),
     "spmv_gen_vec_uniform": (C.c_int, [_vp, _vp, C.c_int64, C.c_uint64]),
 }
@@ -206,6 +208,21 @@ class Context:
 
     def sync(self):
         _check(self._lib.spmv_sync(self.h))
+
+    def apply_host(self, A: "Matrix", x_host: np.ndarray, y_host: np.ndarray) -> None:
+        """y_host += A * x_host with HOST arrays (float64, contiguous), synchronous: the reference's call shape in one entry point"""
+        if x_host.dtype != np.float64 or y_host.dtype != np.float64 or not x_host.flags.c_contiguous or not y_host.flags.c_contiguous:
+            raise ValueError("apply_host: float64 contiguous arrays")
+        i = A.info
+        if x_host.size != i.ncol or y_host.size != i.nrow:
+            raise ValueError(f"apply_host: x has {x_host.size} entries (ncol {i.ncol}), y {y_host.size} (nrow {i.nrow})")
+        _check(self._lib.spmv_apply_host(self.h, A.h, x_host.ctypes.data, y_host.ctypes.data))
+
+    def xcd_round_robin(self) -> tuple[int, int]:
+        """(1 / 0 / -1, distinct XCD ids seen): the start-up probe of workgroup placement (spmv_ctx_xcd_round_robin)"""
+        rr, seen = C.c_int32(0), C.c_int32(0)
+        _check(self._lib.spmv_ctx_xcd_round_robin(self.h, C.byref(rr), C.byref(seen)))
+        return rr.value, seen.value
 
     # ---- vectors
     def vector(self, n: int) -> "Vector":

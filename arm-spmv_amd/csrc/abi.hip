@@ -167,6 +167,7 @@ int spmv_device_count(int* count)
     return SPMV_OK;
 }
 
+static void xcd_probe(spmv_ctx* ctx);
 static int ctx_create_common(int device, void* borrowed_stream, bool borrow, spmv_ctx** out)
 {
     SPMV_REQUIRE(out, "out is null");
@@ -203,7 +204,62 @@ static int ctx_create_common(int device, void* borrowed_stream, bool borrow, spm
         spmv_ctx_destroy(ctx);
         SPMV_FAIL(SPMV_ERR_HIP, "context setup: %s", hipGetErrorString(e));
     }
+    xcd_probe(ctx);  // one small launch: do workgroups b and b + 8 share an XCD on this device? (see below)
     *out = ctx;
+    return SPMV_OK;
+}
+
+// ---- where do the workgroups of a launch land? --------------------------------------------------------------------------------
+// HIP promises nothing about workgroup -> XCD placement; what is OBSERVED on MI355X is round-robin dealing (workgroup b on XCD
+// (b + c) % 8 for some c that changes from launch to launch).  coo_segscan_bins_kernel (workgroup w scans bin w % 8) and the
+// panel kernel's per-XCD bookkeeping lean on "b and b + 8 share an XCD" for speed.  This probe checks it once per context:
+// 2048 workgroups write the XCC_ID hardware register (bits 3:0 of hwreg 20 on gfx942 / gfx950); the host requires that equal
+// labels b % 8 saw ONE id each and different labels different ids.
+namespace
+{
+__global__ void xcd_probe_kernel(int* __restrict__ out)
+{
+    if (threadIdx.x == 0) out[blockIdx.x] = (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);  // GETREG_IMMED(size - 1, offset, XCC_ID)
+}
+}  // namespace
+
+static void xcd_probe(spmv_ctx* ctx)
+{
+    constexpr int kProbeBlocks = 2048;
+    ctx->xcd_round_robin = -1;
+    if (ensure_scratch(ctx, sizeof(int) * kProbeBlocks) != SPMV_OK) return;
+    int* d = (int*)ctx->scratch;
+    std::vector<int> h(kProbeBlocks, -1);
+    hipLaunchKernelGGL(xcd_probe_kernel, dim3(kProbeBlocks), dim3(64), 0, ctx->stream, d);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(h.data(), d, sizeof(int) * kProbeBlocks, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return;
+    }
+    int  id_of_label[8];
+    bool ok = true;
+    unsigned seen = 0;
+    for (int b = 0; b < kProbeBlocks; ++b)
+    {
+        seen |= 1u << (h[b] & 15);
+        if (b < 8)
+            id_of_label[b] = h[b];
+        else if (h[b] != id_of_label[b & 7])
+            ok = false;
+    }
+    for (int a = 0; a < 8 && ok; ++a)
+        for (int b = a + 1; b < 8; ++b)
+            if (id_of_label[a] == id_of_label[b]) ok = false;
+    ctx->xcds_seen       = __builtin_popcount(seen);
+    ctx->xcd_round_robin = ok ? 1 : 0;
+}
+
+int spmv_ctx_xcd_round_robin(spmv_ctx* ctx, int32_t* round_robin, int32_t* xcds_seen)
+{
+    SPMV_REQUIRE(ctx, "ctx is null");
+    if (round_robin) *round_robin = ctx->xcd_round_robin;
+    if (xcds_seen) *xcds_seen = ctx->xcds_seen;
     return SPMV_OK;
 }
 
@@ -219,6 +275,9 @@ int spmv_ctx_destroy(spmv_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->stage_x) (void)hipFree(ctx->stage_x);
+    if (ctx->stage_y) (void)hipFree(ctx->stage_y);
+    if (ctx->stage_pinned) (void)hipHostFree(ctx->stage_pinned);
     if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
     if (ctx->dev_scalars) (void)hipFree(ctx->dev_scalars);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -980,6 +1039,97 @@ int spmv_apply_timed(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* x, spmv_v
     float ms = 0.f;
     SPMV_HIP(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
     *ms_per_apply = (double)ms / reps;
+    return SPMV_OK;
+}
+
+// ---- the reference's own call shape: host vectors in, host vector out ---------------------------------------------------------
+// CSRMatrixMatVector(A, x, y) and its siblings take HOST vectors on every call (include/mat_vec.h:7-11; main.cpp:56-59 calls
+// them 50 times).  Behind that signature a product costs two hand-overs whatever the kernel does; for small matrices they ARE the
+// cost (C1: kernel 3 us).  Rounds 1-4 paid three synchronous hipMemcpy of pageable memory per call (~17 us each: 67 us per C1
+// product, 4.8 GFLOP/s against the reference's 5.6 on one CPU thread).  Here, for vectors up to 4 MB together: the host copies
+// x and y into a pinned, device-mapped staging buffer (memcpy: 80 KB in 3 us), ONE kernel pulls both into device buffers over
+// the host link, the product runs on those, one kernel pushes y back into the staging buffer, the host polls the stream
+// (hipStreamQuery: no interrupt wake-up) and copies y out.  Three launches on one stream, no hipMemcpy, no atomics on host
+// memory (the products update y in device memory).  Larger vectors take asynchronous copies from / to the caller's memory
+// (the PCIe time dominates there).  The caller's arrays are never registered or mapped: they may be freed or re-allocated
+// between calls without a stale mapping being left behind.
+static int grow(double** p, size_t* have, size_t want)
+{
+    if (*have >= want) return SPMV_OK;
+    if (*p) SPMV_HIP(hipFree(*p));
+    *p    = nullptr;
+    *have = 0;
+    const size_t n = std::max<size_t>(want + want / 4, 4096);
+    if (hipMalloc(p, sizeof(double) * n) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        SPMV_FAIL(SPMV_ERR_ALLOC, "spmv_apply_host: no device memory for a staging vector of %zu entries", n);
+    }
+    *have = n;
+    return SPMV_OK;
+}
+
+int spmv_apply_host(spmv_ctx* ctx, const spmv_mat* A, const double* x_host, double* y_host)
+{
+    SPMV_REQUIRE(ctx && A && (x_host || A->ncol == 0) && (y_host || A->nrow == 0), "spmv_apply_host: null argument");
+    SPMV_REQUIRE(A->ctx == ctx, "spmv_apply_host: the matrix belongs to another context");
+    SPMV_TRY(use_device(ctx));
+    const size_t nx = (size_t)A->ncol, ny = (size_t)A->nrow;
+    if (ny == 0) return SPMV_OK;
+    SPMV_HIP(hipStreamSynchronize(ctx->stream));  // (the staging buffers may still be in use by work queued earlier)
+    SPMV_TRY(grow(&ctx->stage_x, &ctx->stage_x_n, std::max<size_t>(nx, 1)));
+    SPMV_TRY(grow(&ctx->stage_y, &ctx->stage_y_n, ny));
+    spmv_vec vx, vy;
+    vx.ctx = vy.ctx = ctx;
+    vx.n            = (int64_t)nx;
+    vx.d            = ctx->stage_x;
+    vy.n            = (int64_t)ny;
+    vy.d            = ctx->stage_y;
+    constexpr size_t kStagedLimit = ((size_t)4 << 20) / sizeof(double);
+    if (nx + ny <= kStagedLimit)
+    {
+        if (ctx->stage_pinned_n < nx + ny)
+        {
+            if (ctx->stage_pinned) (void)hipHostFree(ctx->stage_pinned);
+            ctx->stage_pinned     = nullptr;
+            ctx->stage_pinned_dev = nullptr;
+            ctx->stage_pinned_n   = 0;
+            const size_t n        = std::max<size_t>(2 * (nx + ny), 32768);
+            void*        dev      = nullptr;
+            if (hipHostMalloc((void**)&ctx->stage_pinned, sizeof(double) * n, hipHostMallocMapped) != hipSuccess ||
+                hipHostGetDevicePointer(&dev, ctx->stage_pinned, 0) != hipSuccess)
+            {
+                if (ctx->stage_pinned) (void)hipHostFree(ctx->stage_pinned);
+                ctx->stage_pinned = nullptr;
+                SPMV_FAIL(SPMV_ERR_ALLOC, "spmv_apply_host: no pinned host memory for %zu staged entries: %s", n, hipGetErrorString(hipGetLastError()));
+            }
+            ctx->stage_pinned_dev = (double*)dev;
+            ctx->stage_pinned_n   = n;
+        }
+        double* hx = ctx->stage_pinned;
+        double* hy = ctx->stage_pinned + nx;
+        if (nx) memcpy(hx, x_host, sizeof(double) * nx);
+        memcpy(hy, y_host, sizeof(double) * ny);
+        SPMV_TRY(vec_copy2(ctx, ctx->stage_x, ctx->stage_pinned_dev, (int64_t)nx, ctx->stage_y, ctx->stage_pinned_dev + nx, (int64_t)ny));
+        SPMV_TRY(apply_checked(ctx, A, &vx, &vy));
+        SPMV_TRY(vec_copy2(ctx, ctx->stage_pinned_dev + nx, ctx->stage_y, (int64_t)ny, nullptr, nullptr, 0));
+        // poll instead of sleeping on an interrupt: the whole call is a few tens of microseconds
+        hipError_t e = hipErrorNotReady;
+        for (int spins = 0; (e = hipStreamQuery(ctx->stream)) == hipErrorNotReady; ++spins)
+            if (spins > 200000)
+            {
+                e = hipStreamSynchronize(ctx->stream);
+                break;
+            }
+        if (e != hipSuccess) SPMV_FAIL(SPMV_ERR_HIP, "spmv_apply_host: %s", hipGetErrorString(e));
+        memcpy(y_host, hy, sizeof(double) * ny);
+        return SPMV_OK;
+    }
+    if (nx) SPMV_HIP(hipMemcpyAsync(ctx->stage_x, x_host, sizeof(double) * nx, hipMemcpyHostToDevice, ctx->stream));
+    SPMV_HIP(hipMemcpyAsync(ctx->stage_y, y_host, sizeof(double) * ny, hipMemcpyHostToDevice, ctx->stream));
+    SPMV_TRY(apply_checked(ctx, A, &vx, &vy));
+    SPMV_HIP(hipMemcpyAsync(y_host, ctx->stage_y, sizeof(double) * ny, hipMemcpyDeviceToHost, ctx->stream));
+    SPMV_HIP(hipStreamSynchronize(ctx->stream));
     return SPMV_OK;
 }
 

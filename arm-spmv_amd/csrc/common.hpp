@@ -103,6 +103,20 @@ struct spmv_ctx
     size_t scratch_bytes = 0;
     double* host_pinned  = nullptr;  // 64 B of pinned host memory for scalar results
     double* dev_scalars  = nullptr;  // one slotted accumulator (kDotDoubles) for scalar results; never re-allocated
+    // Start-up probe (abi.hip: xcd_probe): are the workgroups of a launch dealt round-robin over 8 XCDs, so that workgroups b
+    // and b + 8 share an XCD (and its L2) and b, b + 1, ..., b + 7 sit on 8 different ones?  1 yes / 0 no (a partitioned
+    // device, another dispatch order) / -1 the probe could not run.  Layouts that lean on it for SPEED (the COO scan over one
+    // column bin per XCD) are not built when it is not 1; nothing leans on it for correctness.
+    int32_t xcd_round_robin = -1;
+    int32_t xcds_seen       = 0;
+    // spmv_apply_host (abi.hip): the caller's HOST vectors staged through pinned, device-mapped host memory (small vectors: the
+    // GPU copies them in and out itself, one stream, no hipMemcpy) and device buffers for x and y; grown on demand
+    double* stage_pinned     = nullptr;  // host address
+    double* stage_pinned_dev = nullptr;  // the same memory as the GPU sees it
+    size_t  stage_pinned_n   = 0;        // doubles
+    double* stage_x = nullptr;
+    double* stage_y = nullptr;
+    size_t  stage_x_n = 0, stage_y_n = 0;
 };
 
 namespace spmv
@@ -336,6 +350,7 @@ int csc_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 int csc_analyse(spmv_mat* m);
 int dia_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 int vec_fill(spmv_ctx* ctx, double* d, int64_t n, double a);
+int vec_copy2(spmv_ctx* ctx, double* dst0, const double* src0, int64_t n0, double* dst1, const double* src1, int64_t n1);  // two copies, one launch
 int vec_dot(spmv_ctx* ctx, const double* x, const double* y, int64_t n, double* result);
 int vec_axpby(spmv_ctx* ctx, double alpha, const double* x, double beta, const double* y, double* w,
               int64_t n);

@@ -461,6 +461,21 @@ int coo_build_bins(spmv_mat* m, int bins_per_xcd, bool only_if_worth)
     // worth it: an x that does not fit an XCD's L2 beside the streams, and enough entries to matter
     const bool worth = (int64_t)m->ncol * 8 > ((int64_t)3 << 20) && m->nnz >= ((int64_t)2 << 20);
     if (only_if_worth && !worth) return SPMV_OK;
+    // one bin per XCD is worth its 16 bytes per entry only if workgroups w and w + 8 share an XCD on this device (the start-up
+    // probe of the context: abi.hip xcd_probe).  Where they do not - a partitioned device, another dispatch order - the scan
+    // runs over the handle's own arrays: same results, no copy.
+    if (ctx->xcd_round_robin != 1)
+    {
+        static bool told = false;
+        if (!told)
+        {
+            fprintf(stderr, "libspmv_hip: workgroups are not dealt round-robin over 8 XCDs on device %d (probe: %d, %d XCD ids seen): "
+                            "the COO scan stays on the entries as stored (coo_column_bins = 0)\n", ctx->device, ctx->xcd_round_robin, ctx->xcds_seen);
+            told = true;
+        }
+        if (only_if_worth) return SPMV_OK;
+        SPMV_FAIL(SPMV_ERR_UNSUPPORTED, "coo_column_bins: workgroups w and w + 8 do not share an XCD on this device (spmv_ctx_xcd_round_robin)");
+    }
     if (m->nnz == 0 || m->ncol <= 0) return SPMV_OK;
     // a handle too large for the copy's 32-bit addressing keeps the scan in place when nobody asked for bins by name
     if (only_if_worth && m->nnz > (int64_t)INT32_MAX - 64 * kBlockChunk) return SPMV_OK;

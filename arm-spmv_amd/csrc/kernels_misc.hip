@@ -212,6 +212,34 @@ __global__ __launch_bounds__(kBlock) void dia_kernel(int nrow, int jmax, int ndi
 inline int stream_grid(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(kMaxGrid, ceil_div(n, kBlock))); }
 }  // namespace
 
+namespace
+{
+// dst0[0..n0) = src0, dst1[0..n1) = src1 in one launch (16-byte accesses where both sides are aligned): what moves the caller's
+// small host vectors between pinned host memory and the device in spmv_apply_host - a kernel reading mapped host memory
+// starts within microseconds, a hipMemcpy costs 15-20 us of runtime per call
+__global__ __launch_bounds__(kBlock) void copy2_kernel(double* __restrict__ dst0, const double* __restrict__ src0, int64_t n0, double* __restrict__ dst1,
+                                                       const double* __restrict__ src1, int64_t n1)
+{
+    const int64_t total = n0 + n1;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock)
+    {
+        if (i < n0)
+            dst0[i] = src0[i];
+        else
+            dst1[i - n0] = src1[i - n0];
+    }
+}
+}  // namespace
+
+int vec_copy2(spmv_ctx* ctx, double* dst0, const double* src0, int64_t n0, double* dst1, const double* src1, int64_t n1)
+{
+    if (n0 + n1 <= 0) return SPMV_OK;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(kMaxGrid, ceil_div(n0 + n1, kBlock)));
+    hipLaunchKernelGGL(copy2_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, dst0, src0, n0, dst1, src1, n1);
+    SPMV_HIP(hipGetLastError());
+    return SPMV_OK;
+}
+
 int vec_fill(spmv_ctx* ctx, double* d, int64_t n, double a)
 {
     if (n == 0) return SPMV_OK;

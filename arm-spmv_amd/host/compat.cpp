@@ -95,6 +95,16 @@ spmv_vec* Engine::pooled(int device, int slot, int64_t n)
 
 void Engine::apply_host(int device, const spmv_mat* A, const double* x, int64_t nx, double* y, int64_t ny)
 {
+    spmv_mat_info info;
+    check(spmv_mat_get_info(A, &info), "spmv_mat_get_info");
+    if (info.ncol == nx && info.nrow == ny)
+    {
+        // the engine's own hand-over of host vectors: staged through pinned memory the GPU reads itself when they are small
+        // (three launches, no hipMemcpy), asynchronous copies when they are large (spmv_apply_host, include/spmv_abi.h)
+        check(spmv_apply_host(ctx(device), A, x, y), "spmv_apply_host");
+        return;
+    }
+    // (vectors longer than the matrix needs - the reference never checks, its loops read what they index: src/mat_vec.cpp:46-52)
     spmv_vec* dx = pooled(device, 0, nx);
     spmv_vec* dy = pooled(device, 1, ny);
     check(spmv_vec_upload(dx, 0, nx, x), "spmv_vec_upload(x)");

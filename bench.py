@@ -203,12 +203,25 @@ def cpu_baseline_child(args) -> dict:
     facts = host_limits()  # (before libgomp starts: OMP_PROC_BIND pins the initial thread, and with it sched_getaffinity)
     threads = max(1, min(topo["allowed_physical_cores"], args.cpu_threads if args.cpu_threads > 0 else 1 << 30))
     nrow_total = args.n * max(args.gpus, 1)
-    m = min(args.cpu_sample_rows, args.n)
+    # "the same synthetic matrix as each GPU config".  The OpenMP mode - the value reported - runs on the
+    # WHOLE matrix of the headline (--cpu-sample-rows 0, the default: all args.n rows, 3.84 GB for C2), regenerated bit-exactly
+    # by the numpy twin of the device generator in slabs of 1M rows; the two NUMA-driver modes, which repeat 50 products
+    # inside one call at ~1 GFLOP/s, run on the first --cpu-numa-rows rows of it (said so in their entries).
+    m = args.n if args.cpu_sample_rows <= 0 else min(args.cpu_sample_rows, args.n)
     t0 = time.perf_counter()
-    row_ptr, col, val = synth.csr_uniform(0, m, nrow_total, args.k, band=args.band, seed=args.seed)
+    row_ptr = (np.arange(m + 1, dtype=np.int64) * args.k).astype(np.int32)
+    col, val = np.empty(m * args.k, np.int32), np.empty(m * args.k, np.float64)
+    slab = 1_000_000
+    for r0 in range(0, m, slab):
+        r1 = min(m, r0 + slab)
+        _, c_, v_ = synth.csr_uniform(r0, r1, nrow_total, args.k, band=args.band, seed=args.seed)
+        col[r0 * args.k:r1 * args.k], val[r0 * args.k:r1 * args.k] = c_, v_
+    del c_, v_
     x = synth.vec_uniform(nrow_total, seed=args.seed)
     gen_s = time.perf_counter() - t0
     nnz = int(row_ptr[-1])
+    m_numa = min(args.cpu_numa_rows, m)  # rows of the same matrix the NUMA-driver modes run on
+    nnz_numa = int(row_ptr[m_numa])
     p = ol._p
     orc = ol.load_oracle()
     try:
@@ -267,16 +280,18 @@ def cpu_baseline_child(args) -> dict:
               "thread_sweep": sweep_out}
     modes.append(openmp)
     budget = min(budget, 10.0)
+    numa_sample = (f"rows [0,{m_numa}) of the benchmark matrix ({nnz_numa} entries, full x): this mode repeats 50 products inside one call"
+                   if m_numa < m else "the whole benchmark matrix")
     # ---- the reference's NUMA driver as it is (prints its own line; 50 repetitions inside)
     if ref is not None:
-        y = np.zeros(m)
+        y = np.zeros(m_numa)
         sys.stdout.flush()
         with tempfile.TemporaryFile(mode="w+b") as cap:
             saved = os.dup(1)
             os.dup2(cap.fileno(), 1)
             try:
                 t = time.perf_counter()
-                ref.ref_csr_spmv_numa(m, nrow_total, p(row_ptr), p(col), p(val), p(x), p(y), threads)
+                ref.ref_csr_spmv_numa(m_numa, nrow_total, p(row_ptr), p(col), p(val), p(x), p(y), threads)
                 C.CDLL(None).fflush(None)
                 wall = time.perf_counter() - t
             finally:
@@ -288,16 +303,16 @@ def cpu_baseline_child(args) -> dict:
         for line in text.splitlines():
             if "CSR NUMA GFLOPS" in line:
                 gf = float(line.split("=")[1])
-        modes.append({"mode": "numa_reference", "kind": "reference", "shards": threads, "value": gf, "unit": "GFLOP/s",
+        modes.append({"mode": "numa_reference", "kind": "reference", "shards": threads, "value": gf, "unit": "GFLOP/s", "sample": numa_sample,
                       "note": "the reference's own print-out over its 50 repetitions; it re-creates its pthreads in every one "
                               "(src/mat_vec.cpp:274-281) and builds the shards inside the call", "call_seconds": round(wall, 2)})
     # ---- the same sharding with persistent pinned workers
-    y = np.zeros(m)
+    y = np.zeros(m_numa)
     orc.orc_csr_spmv_sharded.restype = C.c_double
-    reps_p = max(3, min(50, int(budget / max(openmp["ms_per_apply"] * 1e-3, 1e-4))))
-    ms = orc.orc_csr_spmv_sharded(C.c_int32(m), C.c_int32(nrow_total), p(row_ptr), p(col), p(val), p(x), p(y), C.c_int32(threads), C.c_int32(reps_p))
-    modes.append({"mode": "numa_persistent", "kind": "port", "shards": threads, "value": round(2.0 * nnz / (ms * 1e-3) / 1e9, 4) if ms > 0 else None,
-                  "unit": "GFLOP/s", "ms_per_apply": round(ms, 3), "reps": reps_p,
+    reps_p = max(3, min(50, int(budget / max(openmp["ms_per_apply"] * 1e-3 * m_numa / m, 1e-4) / 10)))
+    ms = orc.orc_csr_spmv_sharded(C.c_int32(m_numa), C.c_int32(nrow_total), p(row_ptr), p(col), p(val), p(x), p(y), C.c_int32(threads), C.c_int32(reps_p))
+    modes.append({"mode": "numa_persistent", "kind": "port", "shards": threads, "value": round(2.0 * nnz_numa / (ms * 1e-3) / 1e9, 4) if ms > 0 else None,
+                  "unit": "GFLOP/s", "ms_per_apply": round(ms, 3), "reps": reps_p, "sample": numa_sample,
                   "note": "one pinned persistent worker per shard, private shard + x replica first-touched by its worker"})
     # ---- BASELINE configs[0]: C1 through a Matrix Market file, one thread
     n1, k1 = 10_000, 16
@@ -346,7 +361,8 @@ def cpu_baseline_child(args) -> dict:
         "unit": "GFLOP/s",
         "cores": threads,
         "kind": openmp["kind"],
-        "sample": f"rows [0,{m}) of the benchmark matrix ({nnz} entries, full x of {nrow_total}); headline value = the OpenMP mode, best of a "
+        "sample": (f"the WHOLE benchmark matrix ({m} rows, {nnz} entries, x of {nrow_total}: BASELINE.md section 4's 'same synthetic matrix')" if m == args.n
+                   else f"rows [0,{m}) of the benchmark matrix ({nnz} entries, full x of {nrow_total})") + "; headline value = the OpenMP mode, best of a "
                   f"sweep over team sizes {[e['threads'] for e in sweep_out]} ({openmp['reps']} reps of CSRMatrixMatVector with {threads} threads; "
                   f"{topo['allowed_physical_cores']} physical cores allowed, cgroup CPU quota {facts.get('cgroup_cpu_max')}); arrays first-touched inside "
                   f"the OpenMP team; {gen_s:.1f}s to regenerate the rows on the host",
@@ -366,7 +382,7 @@ def cpu_baseline(args) -> dict:
     env.update({"OMP_PROC_BIND": "spread", "OMP_PLACES": "cores", "OMP_DYNAMIC": "false"})
     env.pop("OMP_NUM_THREADS", None)
     cmd = [sys.executable, str(Path(__file__).resolve()), "--cpu-baseline-child", "--rows", str(args.n), "--per-row", str(args.k),
-           "--band", str(args.band), "--seed", str(args.seed), "--cpu-sample-rows", str(args.cpu_sample_rows),
+           "--band", str(args.band), "--seed", str(args.seed), "--cpu-sample-rows", str(args.cpu_sample_rows), "--cpu-numa-rows", str(args.cpu_numa_rows),
            "--cpu-seconds", str(args.cpu_seconds), "--cpu-threads", str(args.cpu_threads), "--gpus", str(args.gpus)]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
@@ -493,8 +509,11 @@ def main() -> None:
     ap.add_argument("--lanes", type=int, default=0, help="lanes per row for the vector kernel (0 = auto)")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-sample-rows", type=int, default=0,
+                    help="rows of the headline matrix the CPU baseline's OpenMP mode runs on; 0 = all of them (BASELINE.md section 4: the same matrix)")
+    ap.add_argument("--cpu-numa-rows", type=int, default=1_000_000,
+                    help="rows of it the two NUMA-driver modes run on (they repeat 50 products inside one call at ~1 GFLOP/s)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = every physical core this process may use)")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--keep-csr", action="store_true", help="keep col_ind / values of the CSR copy next to the panel layout")

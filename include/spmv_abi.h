@@ -130,6 +130,13 @@ int spmv_ctx_create_on_stream(int device, void* hip_stream, spmv_ctx** out);
 int spmv_ctx_destroy(spmv_ctx* ctx);
 int spmv_sync(spmv_ctx* ctx);
 int spmv_ctx_device(const spmv_ctx* ctx, int* device);
+/* The context's start-up probe of workgroup placement: *round_robin = 1 when the workgroups of a launch are dealt round-robin
+ * over 8 XCDs (b and b + 8 share an XCD and its L2; read from the XCC_ID hardware register by 2048 workgroups when the context
+ * was created), 0 when not (a partitioned device, another dispatch order), -1 when the probe could not run; *xcds_seen = distinct
+ * XCD ids seen.  HIP promises no placement: layouts that lean on it for speed - the COO scan over one column bin per XCD
+ * ("coo_column_bins") - are built only when it is 1 (otherwise the scan runs in place and the library says so once on stderr);
+ * nothing leans on it for correctness.  Either pointer may be NULL. */
+int spmv_ctx_xcd_round_robin(spmv_ctx* ctx, int32_t* round_robin, int32_t* xcds_seen);
 /* free and total device memory in bytes (sizing shards for 288 GB of HBM; checking that handles give memory back) */
 int spmv_ctx_mem_info(spmv_ctx* ctx, int64_t* free_bytes, int64_t* total_bytes);
 
@@ -306,6 +313,15 @@ int spmv_apply(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* x, spmv_vec* y)
  * NUM_TEST loop, main.cpp:56-59).  Returns the mean milliseconds per application.  Synchronous. */
 int spmv_apply_timed(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* x, spmv_vec* y, int32_t reps,
                      double* ms_per_apply);
+
+/* y_host += A * x_host with the caller's HOST vectors, synchronous - the reference's own call shape (include/mat_vec.h:7-11:
+ * every CSRMatrixMatVector(A, x, y) hands over host arrays; main.cpp:56-59 does it 50 times), as ONE entry point so that the
+ * hand-over can be done the cheapest way for its size: vectors of up to 4 MB together go through a pinned, device-mapped
+ * staging buffer of the context that the GPU reads and writes itself (three launches on the context's stream, no hipMemcpy,
+ * the host polls; C1: 67 -> ~30 us per product); larger ones through asynchronous copies.  x_host has ncol entries, y_host
+ * nrow.  The caller's arrays are neither registered nor mapped (they may be freed or moved between calls).  Never part of a
+ * throughput figure: resident vectors (spmv_apply) are what the roofline numbers are measured with. */
+int spmv_apply_host(spmv_ctx* ctx, const spmv_mat* A, const double* x_host, double* y_host);
 
 /* ---- BLAS-1 (include/vec_vec.h:6-7) ---------------------------------------------------------- */
 int spmv_dot(spmv_ctx* ctx, const spmv_vec* x, const spmv_vec* y, double* result); /* synchronous */

@@ -751,6 +751,85 @@ def test_csr_ldswin_on_banded_matrix(ctx, orc, pkg):
     ol.assert_parity(y2, ref[lo:hi], scale[lo:hi], "csr vector on banded")
 
 
+def test_context_probes_where_workgroups_land_and_the_bins_copy_follows_it(ctx, pkg):
+    """HIP promises no workgroup -> XCD placement; the COO scan over one column bin per XCD (and the panel kernel's per-XCD
+    bookkeeping) lean on 'workgroups b and b + 8 share an XCD' for speed.  The context reads XCC_ID from 2048 workgroups when it
+    is created: on an MI355X in its default mode that holds and 8 ids are seen; the copy in column bins is built exactly when the
+    probe says so (a partitioned device would keep the scan in place, with a message, not lose L2 locality silently)."""
+    capi = pkg.capi
+    rr, seen = ctx.xcd_round_robin()
+    assert rr in (0, 1) and 1 <= seen <= 8
+    if rr == 1:
+        assert seen == 8
+    A = ctx.gen_coo_powerlaw(300_000, 600_000, 512, seed=6)  # x = 4.8 MB: beyond an XCD's L2, 2M+ entries
+    assert A.info.nnz >= 2 << 20
+    A.set_kernel(capi.CSR_VECTOR)
+    assert (A.get_param("coo_column_bins") > 0) == (rr == 1)
+
+
+# ---------------------------------------------------------------------------------- host vectors (the reference's call shape)
+@pytest.mark.parametrize("make", cases.ALL_CASES, ids=lambda f: f.__name__)
+def test_apply_host_is_the_resident_product_with_the_hand_over_done_by_the_engine(ctx, orc, pkg, make):
+    """spmv_apply_host: y_host += A x_host in one call (what CSRMatrixMatVector(A, x, y) does 50 times in main.cpp:56-59).  Small
+    vectors travel through pinned memory the GPU reads and writes itself; the product is the very kernel spmv_apply runs, so
+    with a deterministic kernel the result equals the resident product bit for bit - after 1 call and after 50 accumulating
+    ones, with fresh host arrays in every call (nothing of the caller's memory stays registered or mapped)."""
+    capi = pkg.capi
+    c = make()
+    g = golden(c["name"])
+    scale = _scale(orc, c)
+    rp, cc, cv = ol.coo_to_csr(orc, c["nrow"], ol.i32(c["row"]), ol.i32(c["col"]), ol.f64(c["val"]))
+    A = ctx.csr(c["nrow"], c["ncol"], rp, cc, cv)
+    A.set_kernel(capi.CSR_VECTOR)  # a fixed tree per row: the same bits on every call
+    y1_res, y50_res = _apply_n(ctx, A, c["x"], c["nrow"], NUM_TEST)
+    y = np.zeros(c["nrow"])
+    ctx.apply_host(A, np.array(c["x"], dtype=np.float64), y)
+    assert np.array_equal(y, y1_res)
+    ol.assert_parity(y, g["y1_csr"], scale, c["name"] + " apply_host 1 call")
+    for _ in range(NUM_TEST - 1):
+        xs = np.array(c["x"], dtype=np.float64)  # a new host array every call
+        ctx.apply_host(A, xs, y)
+        del xs
+    assert np.array_equal(y, y50_res)
+    ol.assert_parity(y, g["y50_csr"], scale, c["name"] + " apply_host 50 calls", reps=NUM_TEST)
+    # the other formats through the same entry point
+    for M, key in ((ctx.coo(c["nrow"], c["ncol"], c["row"], c["col"], c["val"]), "y1_coo"),):
+        yh = np.zeros(c["nrow"])
+        ctx.apply_host(M, np.array(c["x"], dtype=np.float64), yh)
+        ol.assert_parity(yh, g[key], scale, c["name"] + " apply_host " + key)
+    with pytest.raises(ValueError):
+        ctx.apply_host(A, np.zeros(c["ncol"] + 1), y)
+
+
+def test_apply_host_large_vectors_take_the_copy_path_and_work_queued_before_is_respected(ctx, orc, pkg):
+    """above 4 MB of vectors the hand-over is two asynchronous copies in and one out; a product queued on the context's stream
+    before the call (asynchronous spmv_apply) is finished first, and the staging buffers grow and shrink with the calls"""
+    synth = pkg.synth
+    n, k = 700_000, 6  # x + y = 11 MB
+    rp, cc, cv = synth.csr_uniform(0, n, n, k, seed=33)
+    x = synth.vec_uniform(n, seed=33)
+    ref, scale = np.zeros(n), np.zeros(n)
+    ol.csr_spmv(orc, rp, cc, cv, x, ref)
+    ol.csr_abs_row_sums(orc, rp, cc, cv, x, scale)
+    A = ctx.csr(n, n, rp, cc, cv)
+    dx, dy = ctx.vector_from(x), ctx.vector(n)
+    dy.fill(0.0)
+    ctx.apply(A, dx, dy)  # queued, not waited for
+    y = np.zeros(n)
+    ctx.apply_host(A, x, y)
+    ctx.apply_host(A, x, y)
+    ol.assert_parity(y, 2 * ref, scale, "apply_host, 11 MB of vectors, two calls", reps=2)
+    ctx.sync()
+    ol.assert_parity(dy.download(), ref, scale, "the product queued before")
+    # a small one right after a large one (the staged path with buffers that are larger than it needs)
+    c = cases.tri8()
+    rp8, cc8, cv8 = ol.coo_to_csr(orc, c["nrow"], ol.i32(c["row"]), ol.i32(c["col"]), ol.f64(c["val"]))
+    T = ctx.csr(c["nrow"], c["ncol"], rp8, cc8, cv8)
+    y8 = np.zeros(c["nrow"])
+    ctx.apply_host(T, np.array(c["x"], dtype=np.float64), y8)
+    ol.assert_parity(y8, golden("tri8")["y1_csr"], _scale(orc, c), "apply_host tri8 after a large call")
+
+
 # ---------------------------------------------------------------------------------- sharding on one device
 def test_row_shards_concatenate_to_unsharded_result(ctx, orc, pkg):
     """the NUMA driver's partition (src/mat_vec.cpp:240-268) emulated with 8 shards on one GPU"""
