@@ -708,14 +708,8 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         m->pb_unroll = (int32_t)value;
     else if (!strcmp(name, "panel_aos"))
         m->pb_aos = (int32_t)value;
-    else if (!strcmp(name, "panel_pace_ns"))
-        m->pb_pace_req = (int32_t)value;
     else if (!strcmp(name, "panel_pipe"))
         m->pb_pipe = (int32_t)value;
-    else if (!strcmp(name, "panel_stagger"))
-        m->pb_stagger = (int32_t)value;
-    else if (!strcmp(name, "panel_guard"))
-        m->pb_guard = (int32_t)value;
     else if (!strcmp(name, "panel_two_per_cu"))
         m->pb_two_per_cu = (int32_t)value;
     else if (!strcmp(name, "panel_keep_csr"))
@@ -769,12 +763,8 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
     }
     else if (!strcmp(name, "panel_sync"))
         m->pb_sync = (int32_t)value;
-    else if (!strcmp(name, "panel_legacy"))
-        m->pb_legacy = (int32_t)value;
     else if (!strcmp(name, "panel_trial"))
         m->pb_trial = (int32_t)value;
-    else if (!strcmp(name, "panel_trace"))
-        m->pb_trace = (int32_t)value;
     else if (!strcmp(name, "symgs_order"))  // 1 multicolour, 0 the matrix's own row order; takes effect at the next set-up / sweep
     {
         SPMV_REQUIRE(value == 0 || value == 1, "symgs_order: 0 (row order) or 1 (multicolour), got %lld", (long long)value);
@@ -864,7 +854,6 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
 int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
 {
     SPMV_REQUIRE(m && name && value, "null argument");
-    if (!strncmp(name, "panel_trace@", 12)) return csr_panel_read_trace(m->ctx, atoll(name + 12), value);
     if (!strncmp(name, "symgs_", 6))
     {
         SPMV_REQUIRE(symgs_info(m, name, value) == SPMV_OK, "unknown parameter '%s'", name);
@@ -890,28 +879,12 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         *value = m->pb_ngroups;
     else if (!strcmp(name, "panel_unroll"))
         *value = std::min(8, m->pb_unroll > 0 ? m->pb_unroll : (m->pb_unroll_tuned > 0 ? m->pb_unroll_tuned : 8));  // (16 runs 8 since round 4)
-    else if (!strcmp(name, "panel_pace_ns"))
-        *value = m->pb_pace_ns;
     else if (!strcmp(name, "panel_bytes"))
         *value = m->pb_bytes;
     else if (!strcmp(name, "panel_pipe"))
         *value = m->pb_pipe >= 0 ? m->pb_pipe : (m->pb_pipe_tuned > 0 ? m->pb_pipe_tuned : 1);
-    else if (!strcmp(name, "panel_stagger"))
-        *value = m->pb_stagger;
     else if (!strcmp(name, "panel_sync"))
-        *value = m->pb_sync >= 0 ? m->pb_sync : m->pb_sync_tuned;
-    else if (!strcmp(name, "panel_pace_scale") || !strcmp(name, "panel_pace_bumps"))
-    {
-        // the run-time guard's state: pace stretch in 1/1024 and how often it was stretched (synchronous read)
-        unsigned h[4] = {1024u, 0u, 0u, 0u};
-        if (m->pb_ctl)
-        {
-            SPMV_HIP(hipSetDevice(m->ctx->device));
-            SPMV_HIP(hipMemcpyAsync(h, m->pb_ctl, sizeof(h), hipMemcpyDeviceToHost, m->ctx->stream));
-            SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
-        }
-        *value = !strcmp(name, "panel_pace_scale") ? h[0] : h[3];
-    }
+        *value = (m->pb_sync >= 0 ? m->pb_sync : m->pb_sync_tuned) == 2 ? 3 : (m->pb_sync >= 0 ? m->pb_sync : m->pb_sync_tuned);  // (2, the split barrier, runs 3 since round 5)
     else if (!strcmp(name, "panel_layout"))  // layout in memory: 0 three arrays, 1 records, 3 packed 12-byte entries
         *value = m->pb_pack ? (m->pb_pair ? 4 : 3) : 0;
     else if (!strcmp(name, "ell_diagonal_slots"))  // ELL: 1 if the slots were found to be diagonals (no column stream for conforming rows)
@@ -1047,10 +1020,10 @@ int spmv_apply_timed(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* x, spmv_v
 // them 50 times).  Behind that signature a product costs two hand-overs whatever the kernel does; for small matrices they ARE the
 // cost (C1: kernel 3 us).  Rounds 1-4 paid three synchronous hipMemcpy of pageable memory per call (~17 us each: 67 us per C1
 // product, 4.8 GFLOP/s against the reference's 5.6 on one CPU thread).  Here, for vectors up to 4 MB together: the host copies
-// x and y into a pinned, device-mapped staging buffer (memcpy: 80 KB in 3 us), ONE kernel pulls both into device buffers over
-// the host link, the product runs on those, one kernel pushes y back into the staging buffer, the host polls the stream
-// (hipStreamQuery: no interrupt wake-up) and copies y out.  Three launches on one stream, no hipMemcpy, no atomics on host
-// memory (the products update y in device memory).  Larger vectors take asynchronous copies from / to the caller's memory
+// x and y into a pinned, device-mapped staging buffer (memcpy: 80 KB in 3 us), one kernel pulls x into a device buffer over
+// the host link, the product gathers from there and updates y IN the staging buffer (kernels that add into y with device
+// atomics - the COO scan, the CSC scatter - get y through a device buffer and a third launch instead), the host polls the
+// stream (hipStreamQuery: no interrupt wake-up) and copies y out.  Two launches on one stream, no hipMemcpy.  Larger vectors take asynchronous copies from / to the caller's memory
 // (the PCIe time dominates there).  The caller's arrays are never registered or mapped: they may be freed or re-allocated
 // between calls without a stale mapping being left behind.
 static int grow(double** p, size_t* have, size_t want)
@@ -1110,9 +1083,24 @@ int spmv_apply_host(spmv_ctx* ctx, const spmv_mat* A, const double* x_host, doub
         double* hy = ctx->stage_pinned + nx;
         if (nx) memcpy(hx, x_host, sizeof(double) * nx);
         memcpy(hy, y_host, sizeof(double) * ny);
-        SPMV_TRY(vec_copy2(ctx, ctx->stage_x, ctx->stage_pinned_dev, (int64_t)nx, ctx->stage_y, ctx->stage_pinned_dev + nx, (int64_t)ny));
-        SPMV_TRY(apply_checked(ctx, A, &vx, &vy));
-        SPMV_TRY(vec_copy2(ctx, ctx->stage_pinned_dev + nx, ctx->stage_y, (int64_t)ny, nullptr, nullptr, 0));
+        // Kernels that touch every y_i once with a plain read and a plain store (the row-parallel, LDS-window, scalar, panel and
+        // two-phase CSR kernels, the ELL kernels, and COO / ELL / CSC handles running from their row-grouped CSR copy) update y
+        // IN the staging buffer over the host link: two launches.  The COO scan and the CSC scatter add into y with device
+        // atomics, which host memory may not support: y goes through a device buffer there, three launches.
+        const bool from_copy = A->coo_csr && (A->format == SPMV_FMT_CSC ? !A->kernel_forced : A->kernel == SPMV_CSR_PANEL);
+        const bool y_in_place = A->format == SPMV_FMT_CSR || A->format == SPMV_FMT_ELL || ((A->format == SPMV_FMT_COO || A->format == SPMV_FMT_CSC) && from_copy);
+        if (y_in_place)
+        {
+            vy.d = ctx->stage_pinned_dev + nx;
+            SPMV_TRY(vec_copy2(ctx, ctx->stage_x, ctx->stage_pinned_dev, (int64_t)nx, nullptr, nullptr, 0));
+            SPMV_TRY(apply_checked(ctx, A, &vx, &vy));
+        }
+        else
+        {
+            SPMV_TRY(vec_copy2(ctx, ctx->stage_x, ctx->stage_pinned_dev, (int64_t)nx, ctx->stage_y, ctx->stage_pinned_dev + nx, (int64_t)ny));
+            SPMV_TRY(apply_checked(ctx, A, &vx, &vy));
+            SPMV_TRY(vec_copy2(ctx, ctx->stage_pinned_dev + nx, ctx->stage_y, (int64_t)ny, nullptr, nullptr, 0));
+        }
         // poll instead of sleeping on an interrupt: the whole call is a few tens of microseconds
         hipError_t e = hipErrorNotReady;
         for (int spins = 0; (e = hipStreamQuery(ctx->stream)) == hipErrorNotReady; ++spins)

@@ -192,23 +192,15 @@ struct spmv_mat
     bool      pb_pair        = false;    // layout 4: slices stored in interleaved pairs
     int32_t   pb_slices      = 0;        // layout 3: 1024-entry slices in all (padded entries / 1024)
     int32_t   pb_built_layout = -1;      // pb_aos the layout in memory was built for
-    int32_t   pb_pace_ns     = 0;        // pacing throttle in effect: nanoseconds per chunk on the chip clock (0 = off)
     int32_t   pb_pipe        = -1;      // chunk pipeline: 0 off, 1 stream-first, 2 gather-first, -1 = 1 or 2 by trial
     int32_t   pb_pipe_tuned  = 0;       // the order found by trying (in effect while pb_pipe == -1; 0 = not tried: 1)
-    unsigned* pb_ctl         = nullptr;  // device: {pace scale in 1/1024, worst lag, workgroups done, bumps} (run-time guard)
-    int32_t   pb_guard       = 1;        // stretch the pace at run time when the workgroups fall behind it
-    int32_t   pb_stagger     = 2;        // offsets of a paced schedule: 0 none, 2 XCDs 1/8 of the pace apart
-    int32_t   pb_pace_req    = -1;      // requested pace (-1 = try a few and keep the fastest)
-    int32_t   pb_pace_tuned_ns = 0;      // the pace found by trying (restored when the request goes back to -1)
-    int32_t   pb_pace_tuned_unroll = 0; // what the trial was made for: requested unroll, -1 = unroll chosen too, 0 = not tried
+    int32_t   pb_tuned_key   = 0;        // what the build-time trial was made for (requested unroll / order / sync); 0 = not tried
     int32_t   pb_unroll_tuned = 0;       // chunk size found by trying (in effect while pb_unroll == 0)
     int64_t   pb_max_group_nnz = 0;      // entries of the fullest row group
     int32_t   pb_sync        = -1;       // keep a workgroup's wavefronts together: 0 no, 1 barrier per chunk, 2 priority to late ones,
                                          // 3 barrier between a chunk's loads and its LDS adds; -1 = by trial
     int32_t   pb_sync_tuned  = 0;        // what the trial found (in effect while pb_sync == -1)
     int32_t   pb_trial       = -1;       // timing launches when the layout is built: 1 yes, 0 no, -1 = SPMV_PANEL_TRIAL (default yes)
-    int32_t   pb_legacy      = 0;        // A/B: run the gather-first order through the general kernel (run-time sync switch)
-    int32_t   pb_trace       = 0;        // diagnostic: stamp the phases of every chunk (gather-first pipeline, U = 8)
     int32_t   pb_two_per_cu  = 1;        // allow two workgroups per CU when the accumulators fit twice
     int32_t   pb_ngroups     = 0;
     int32_t   pb_max_rows    = 0;        // rows of the fullest group (sizes the LDS accumulators)
@@ -297,7 +289,6 @@ int  csr_panel_build(spmv_mat* m);
 int  panel_choose_pace(spmv_mat* m);
 void csr_panel_free(spmv_mat* m);
 int  csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
-int  csr_panel_read_trace(spmv_ctx* ctx, int64_t index, int64_t* value);
 // kernels_csr_twophase.hip
 int  csr_twophase_build(spmv_mat* m);
 void csr_twophase_free(spmv_mat* m);

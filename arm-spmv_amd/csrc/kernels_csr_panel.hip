@@ -385,171 +385,109 @@ __global__ void group_nnz_max_kernel(const int32_t* __restrict__ gstart, int ngr
 
 // ---- keeping in step ------------------------------------------------------------------------------------------
 // The x lines one CU pulls into its XCD's L2 serve the other 31 CUs of the XCD only while all of them gather from the
-// same stretch of x.  What keeps them there (tools/trace_panel.py, profiles/r02_trace_*):
-//   * inside a workgroup, a barrier per chunk (SYNC below).  Without it the oldest-first issue arbitration lets
+// same stretch of x.  What keeps them there (round 2's trace build, profiles/r02_trace_*):
+//   * inside a workgroup, a barrier per chunk (SYNCT below).  Without it the oldest-first issue arbitration lets
 //     wavefront 0 start chunk b+1 while wavefront 15 is still issuing chunk b; 2 % of the chunks then take 15 us
 //     instead of 7, the workgroup falls behind its XCD and its gathers start missing L2;
 //   * between workgroups, nothing explicit: who leads the sweep takes the L2 misses and slows down, the others close
-//     up.  (Round 1 throttled every chunk to a clock instead — `pace` below, kept as an option with its run-time
-//     guard; it compensated for the missing barrier and cost 15 %.  A counter gate per XCD and schedules with the
-//     wavefronts or the halves of an XCD apart were measured and dropped: profiles/r01_pmc_gate_variants.txt,
+//     up.  (Round 1 throttled every chunk to a clock instead; it compensated for the missing barrier and cost 15 %.  That
+//     pace, its run-time guard, the per-XCD offsets, a split barrier through an LDS counter and the trace build lived on as
+//     options inside the chunk loop through round 4 and were deleted in round 5 together with the kernel that carried them:
+//     the headline's schedule depended on that dead code being there - see below.  A counter gate per XCD and schedules
+//     with the wavefronts or the halves of an XCD apart were measured and dropped earlier: profiles/r01_pmc_gate_variants.txt,
 //     r01_tune_csr_stagger.txt, r02_tune_csr_c2_ring_paces.txt.)
-struct PanelLds
-{
-    unsigned issued[2];  // split barrier (SYNC 2): lanes that have issued the loads of the even / odd chunks
-};
 
-__device__ __forceinline__ unsigned lds_read(const unsigned* p)
+// ---- the chunk pipeline with its order written down (round 5) ------------------------------------------------------------------
+// Rounds 2-4 ran the panel product through ONE kernel with run-time switches inside its chunk loop (clock pace, pace guard,
+// trace stamps, barrier placement), and its C2 instance owed its schedule to code it never ran: the (run-time dead) pace
+// block split a chunk into basic blocks, and because of that split the compiler (a) copied the next chunk's registers into
+// the current ones AFTER the workgroup barrier instead of before it - so that no wavefront waited for its HBM loads in front
+// of the barrier - and (b) kept the order gathers -> next chunk's stream -> LDS adds.  With the dead block compiled out the
+// chunk became one basic block, the copies (and with them `s_waitcnt vmcnt(0)`) moved in front of the barrier and the loads
+// were interleaved: 1.108 -> 1.25 ms (profiles/r03_tune_csr_c2_no_pace_code.txt).  This kernel depends on no such accident:
+//   * two register sets used in turn (chunk b in A, b + 1 in B, b + 2 in A ...): nothing is copied, so nothing has to have
+//     arrived at the loop's back edge;
+//   * the groups of a chunk's memory instructions - the gathers of x, the next chunk's stream, the LDS adds - are kept apart
+//     by scheduling fences (__builtin_amdgcn_sched_barrier), and nothing of a chunk moves in front of its workgroup barrier;
+//   * ORDER 2 (gather-first): gathers -> next chunk's stream -> adds: vector loads return in order, so the adds wait for the
+//     gathers alone and the HBM latency of the stream runs under them (scattered columns: C2);
+//     ORDER 1 (stream-first): next chunk's stream -> gathers -> adds (local columns: bands; shards whose x is 2-4x their rows);
+//     ORDER 0: no prefetch (kept as the plain reference order);
+//   * SYNCT 1: a workgroup barrier at the top of every chunk, 3: between a chunk's loads and its LDS adds, 0: none - what keeps
+//     the 16 wavefronts of a workgroup in the same chunk and thereby the workgroups of an XCD in step;
+//   * no pace, no guard, no trace, no run-time switch inside the chunk loop.
+// A/B on one box against the round-4 kernel (tools/ab_panel_order.py, profiles/r05_ab_panel_order.txt): C2 1.100 against 1.106 ms,
+// barrier placement 3: 1.114 against 1.146, U = 4: 1.225 against 1.336, the N = 2 shard shape gather-first 1.485 against 1.602.
+// LAYOUT 0: three arrays (value, int32 column, uint16 local row); 3: 12-byte packed entries; 4: the same in paired slices.
+// (The three-array layout - the fallback for groups too sparse to pack - is the one place where the round-4 kernel's accidental
+// schedule stays ahead: C2 forced into it 1.373 against 1.278 ms; with the fences left out 1.39-1.52: profiles/r05_probe_panel_three_array_layout_fences.txt.)
+// TRIAL: the same code under another name, so that build-time trial launches show up apart from products in a kernel trace.
+template <int UNROLL, int LAYOUT, int ORDER, bool TRIAL, int SYNCT>
+__global__ __launch_bounds__(kPanelThreads) void csr_panel_pp_kernel(const int32_t* __restrict__ gstart, int ngroups, const int32_t* __restrict__ row_ptr,
+                                                                     const int32_t* __restrict__ pcol, const uint16_t* __restrict__ prow,
+                                                                     const double* __restrict__ pval, const double* __restrict__ x,
+                                                                     double* __restrict__ y, const int32_t* __restrict__ sbase,
+                                                                     const int32_t* __restrict__ soff, int rowbits, int overwrite,
+                                                                     const double* __restrict__ dot_w, double* __restrict__ dot_out)
 {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ int xcd_id()
-{
-    return __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 7;  // hwreg(HW_REG_XCC_ID, 0, 4)
-}
-
-// Diagnostic build of the gather-first pipeline (panel_trace = 1): lane 0 of wavefronts 0 and 15 of the first 256
-// workgroups stamps 32 chunks of the first round with the chip-wide 100 MHz clock: chunk start, loads issued,
-// gathers back, LDS adds done, next chunk's stream back.  Read through spmv_mat_get_param("panel_trace@<i>").
-constexpr int kTraceWgs = 256, kTraceChunks = 32, kTraceFirst = 16, kTraceStamps = 5;
-__device__ unsigned g_panel_trace[kTraceWgs * 2 * kTraceChunks * kTraceStamps];
-
-// flags: bit 0 = per-XCD offsets of the paced schedule; bits 1-2 = SYNC when it is not a template argument
-//   SYNC 0  nothing (local columns: bands)          SYNC 1  workgroup barrier at the top of every chunk
-//   SYNC 3  the barrier between a chunk's loads and its LDS adds: the early wavefronts wait with their gathers long back
-//   SYNC 2  split barrier through an LDS counter (compile-time only; measured: no better than 3)
-// SYNCT >= 0 fixes the choice at compile time for the C2 instance: a run-time branch between a chunk's loads and its
-// adds costs the compiler's exact wait counts there (1.15 -> 1.33 ms when one was added).
-// TRIAL: same code under another name, so that the launches of the build-time trials show up apart from the products
-// in a kernel trace.
-template <int UNROLL, int LAYOUT, int PIPE = 0, bool TRIAL = false, bool TRACE = false, int SYNCT = -1>
-__global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t* __restrict__ gstart, int ngroups,
-                                                                  const int32_t* __restrict__ row_ptr,
-                                                                  const int32_t* __restrict__ pcol,
-                                                                  const uint16_t* __restrict__ prow,
-                                                                  const double* __restrict__ pval,
-                                                                  const double* __restrict__ x, double* __restrict__ y,
-                                                                  unsigned long long pace_fp, int flags,
-                                                                  const int32_t* __restrict__ sbase,
-                                                                  const int32_t* __restrict__ soff, int rowbits,
-                                                                  int overwrite, const double* __restrict__ dot_w,
-                                                                  double* __restrict__ dot_out, unsigned* __restrict__ ctl)
-{
-    extern __shared__ double acc[];  // G accumulators
-    __shared__ PanelLds      gl;
-    constexpr int STEP   = UNROLL * kPanelThreads;
-    const int     lane   = threadIdx.x & 63;
-    // Run-time guard of the pace (ctl: {scale in 1/1024, worst lag of this launch, workgroups done, bumps}): every
-    // workgroup reports how far behind the schedule it got; the last one to finish stretches the pace by 5 % for the
-    // following launches when that was more than two chunks.  Never shrinks: the next build measures afresh.
-    if (ctl && pace_fp) pace_fp = (pace_fp * __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 10;
-    unsigned lag_max = 0;
-    int round = 0;
-    for (int g = blockIdx.x; g < ngroups; g += gridDim.x, ++round)
+    extern __shared__ double acc[];  // the group's accumulators
+    constexpr int STEP = UNROLL * kPanelThreads;
+    const int     lane = threadIdx.x & 63;
+    for (int g = blockIdx.x; g < ngroups; g += gridDim.x)
     {
         const int r0   = gstart[g];
         const int rows = gstart[g + 1] - r0;
         for (int i = threadIdx.x; i < rows; i += kPanelThreads) acc[i] = 0.0;
-        if (SYNCT == 2 && threadIdx.x == 0) gl.issued[0] = gl.issued[1] = 0u;
         __syncthreads();
-        // LAYOUT 3 keeps its own (padded) entry numbering: whole slices of 1024
+        // the packed layouts keep their own (padded) entry numbering: whole slices of 1024
         const int begin = LAYOUT >= 3 ? soff[g] * kPanelThreads : row_ptr[r0];
         const int end   = LAYOUT >= 3 ? soff[g + 1] * kPanelThreads : row_ptr[r0 + rows];
         const int nfull = (end - begin) / STEP;  // chunks in which every lane has UNROLL valid entries
-        int       e     = begin + threadIdx.x;
+        const int e0    = begin + threadIdx.x;
         const int32_t* __restrict__ sb = LAYOUT >= 3 ? sbase + soff[g] : pcol;  // slice bases of this group (else unused)
-        // optional clock throttle: chunk b does not start before t0 + b * pace on the chip-wide 100 MHz clock
-        const unsigned long long t0 = pace_fp ? __builtin_amdgcn_s_memrealtime() : 0ull;
-        PanelBatch<UNROLL, LAYOUT> cur, nxt;
-        for (int b = 0; b < nfull; ++b)
+        PanelBatch<UNROLL, LAYOUT> A, B;
+        // one chunk: `cur` holds chunk b (its loads requested one chunk ago), chunk b + 1 is requested into `nxt` (the last
+        // chunk re-reads itself: a load behind a branch would make the adds wait for it)
+        auto chunk = [&](PanelBatch<UNROLL, LAYOUT>& cur, PanelBatch<UNROLL, LAYOUT>& nxt, int b) __attribute__((always_inline)) {
+            if constexpr (SYNCT == 1)
+            {
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);  // nothing of this chunk (its unpacking waits for HBM) moves in front of the barrier
+            }
+            const int e_next = e0 + (b + 1 < nfull ? b + 1 : b) * STEP;
+            if constexpr (ORDER == 0) cur.load_raw(pcol, prow, pval, e0 + b * STEP);
+            if constexpr (ORDER == 1)
+            {
+                nxt.load_raw(pcol, prow, pval, e_next);
+                __builtin_amdgcn_sched_barrier(0);  // the next chunk's stream is requested before ...
+            }
+            cur.unpack(sb + b * UNROLL, rowbits);
+            double xv[UNROLL];
+            cur.gather(x, xv);
+            __builtin_amdgcn_sched_barrier(0);  // ... the gathers (stream-first); the gathers before ...
+            if constexpr (ORDER == 2)
+            {
+                nxt.load_raw(pcol, prow, pval, e_next);
+                __builtin_amdgcn_sched_barrier(0);  // ... the next chunk's stream (gather-first); and all loads before the adds
+            }
+            if constexpr (SYNCT == 3)
+            {
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            cur.add(acc, xv);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (ORDER != 0 && nfull > 0) A.load_raw(pcol, prow, pval, e0);
+        int b = 0;
+        for (; b + 1 < nfull; b += 2)
         {
-            const int sync_mode = SYNCT >= 0 ? SYNCT : (flags >> 1) & 3;
-            if (sync_mode == 1) __syncthreads();
-            if constexpr (SYNCT == 2 && PIPE == 2)
-            {
-                // start chunk b when all 16 wavefronts have ISSUED the loads of chunk b-1.  Bounded spin.
-                if (b > 0 && lane == 0)
-                {
-                    const unsigned need  = (unsigned)kPanelThreads * (unsigned)((b - 1) / 2 + 1);
-                    int            spins = 0;
-                    while (lds_read(&gl.issued[(b - 1) & 1]) < need && ++spins < (1 << 18)) __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            if (pace_fp && lane == 0)
-            {
-                const unsigned long long phase = (flags & 1) ? ((unsigned long long)xcd_id() * pace_fp) / kNumXcd : 0ull;
-                if (b > 0 || phase)
-                {
-                    const unsigned long long target = t0 + (((unsigned long long)b * pace_fp + phase) >> 10);
-                    const unsigned long long now    = __builtin_amdgcn_s_memrealtime();
-                    if (now > target) lag_max = max(lag_max, (unsigned)min(now - target, 0xFFFFFFFFull));
-                    int                      spins  = 0;
-                    while (__builtin_amdgcn_s_memrealtime() < target && ++spins < (1 << 16)) __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            if constexpr (PIPE == 2)
-            {
-                // gather-first order: the gathers of chunk b are issued BEFORE the streamed loads of chunk b+1.
-                // Vector loads return in order, so the adds of chunk b wait for the gathers only, and the HBM
-                // latency of the next chunk's stream runs under them instead of in front of the gathers
-                if (b == 0) cur.load_raw(pcol, prow, pval, e);
-                unsigned tr[kTraceStamps];
-                if constexpr (TRACE) tr[0] = (unsigned)__builtin_amdgcn_s_memrealtime();
-                cur.unpack(sb + b * UNROLL, rowbits);
-                double xv[UNROLL];
-                cur.gather(x, xv);
-                // unconditional (the last chunk re-reads itself): behind a branch, the wait-count bookkeeping of the
-                // compiler would make the adds wait for these loads as well
-                nxt.load_raw(pcol, prow, pval, b + 1 < nfull ? e + STEP : e);
-                if constexpr (SYNCT == 2)
-                {
-                    // all 64 lanes (no lane mask, no branch), right behind the loads
-                    (void)__builtin_amdgcn_atomic_inc32(&gl.issued[b & 1], 0xFFFFFFFFu, __ATOMIC_RELAXED, "workgroup");
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr (TRACE)
-                {
-                    tr[1] = (unsigned)__builtin_amdgcn_s_memrealtime();
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * UNROLL) : "memory");  // the gathers are back
-                    tr[2] = (unsigned)__builtin_amdgcn_s_memrealtime();
-                }
-                if (sync_mode == 3) __syncthreads();
-                cur.add(acc, xv);
-                if constexpr (TRACE)
-                {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the LDS adds are done
-                    tr[3] = (unsigned)__builtin_amdgcn_s_memrealtime();
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next chunk's entries are back
-                    tr[4] = (unsigned)__builtin_amdgcn_s_memrealtime();
-                    const int wave = threadIdx.x >> 6;
-                    if (lane == 0 && blockIdx.x < kTraceWgs && round == 0 && (wave == 0 || wave == 15) && b >= kTraceFirst &&
-                        b < kTraceFirst + kTraceChunks)
-                    {
-                        unsigned* o = g_panel_trace + (((size_t)blockIdx.x * 2 + (wave ? 1 : 0)) * kTraceChunks + (b - kTraceFirst)) * kTraceStamps;
-#pragma unroll
-                        for (int i = 0; i < kTraceStamps; ++i) o[i] = tr[i];
-                    }
-                }
-                cur = nxt;
-            }
-            else if constexpr (PIPE == 1)
-            {
-                // the streamed loads of chunk b+1 are issued before the gathers of chunk b: the HBM latency of the
-                // stream and the L1/L2 time of the gathers overlap inside one wavefront instead of adding up
-                if (b == 0) cur.load(pcol, prow, pval, e, sb, rowbits);
-                if (b + 1 < nfull) nxt.load(pcol, prow, pval, e + STEP, sb + (b + 1) * UNROLL, rowbits);
-                cur.apply(x, acc);
-                cur = nxt;
-            }
-            else
-            {
-                cur.load(pcol, prow, pval, e, sb + b * UNROLL, rowbits);
-                cur.apply(x, acc);
-            }
-            e += STEP;
+            chunk(A, B, b);
+            chunk(B, A, b + 1);
         }
-        for (int t = nfull * UNROLL; e < end; e += kPanelThreads, ++t)
-            PanelBatch<1, LAYOUT>::one(pcol, prow, pval, e, x, acc, sb + t, rowbits);
+        if (b < nfull) chunk(A, B, b);
+        int e = e0 + nfull * STEP;
+        for (int t = nfull * UNROLL; e < end; e += kPanelThreads, ++t) PanelBatch<1, LAYOUT>::one(pcol, prow, pval, e, x, acc, sb + t, rowbits);
         __syncthreads();
         // write-back: y += (or =) the group's sums; optionally the solver's dot product w . y_new rides along
         // (spmv_apply_dot: saves the separate pass over w and y)
@@ -567,22 +505,6 @@ __global__ __launch_bounds__(kPanelThreads) void csr_panel_kernel(const int32_t*
         }
         __syncthreads();
     }
-    if (ctl && pace_fp && threadIdx.x == 0)
-    {
-        __hip_atomic_fetch_max(ctl + 1, lag_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        if (__hip_atomic_fetch_add(ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1)
-        {
-            const unsigned worst = __hip_atomic_exchange(ctl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(ctl + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (worst > 2u * (unsigned)(pace_fp >> 10))  // ticks of 10 ns
-            {
-                const unsigned scale = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(ctl, min(scale + scale / 20u, 2048u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(ctl + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
 }
 
 }  // namespace
@@ -596,8 +518,6 @@ void csr_panel_free(spmv_mat* m)
     if (m->pb_sbase) (void)hipFree(m->pb_sbase);
     if (m->pb_soff) (void)hipFree(m->pb_soff);
     if (m->pb_gstart) (void)hipFree(m->pb_gstart);
-    if (m->pb_ctl) (void)hipFree(m->pb_ctl);
-    m->pb_ctl    = nullptr;
     m->pb_gstart = nullptr;
     m->pb_pack   = nullptr;
     m->pb_pair   = false;
@@ -607,7 +527,7 @@ void csr_panel_free(spmv_mat* m)
     m->pb_row = nullptr;
     m->pb_val = nullptr;
     m->pb_built_sort = -1;
-    m->pb_pace_tuned_unroll = 0;
+    m->pb_tuned_key = 0;
     m->pb_unroll_tuned = 0;
     m->device_bytes -= m->pb_bytes;
     m->pb_bytes = 0;
@@ -770,7 +690,6 @@ int csr_panel_build(spmv_mat* m)
     int       max_rows = 0;
     for (int g = 0; g < ngroups; ++g) max_rows = std::max(max_rows, gstart[(size_t)g + 1] - gstart[(size_t)g]);
     SPMV_HIP(hipMalloc(&m->pb_gstart, sizeof(int32_t) * gstart.size()));
-    SPMV_HIP(hipMalloc(&m->pb_ctl, 4 * sizeof(unsigned)));
     SPMV_HIP(hipMemcpyAsync(m->pb_gstart, gstart.data(), sizeof(int32_t) * gstart.size(), hipMemcpyHostToDevice, ctx->stream));
     SPMV_HIP(hipStreamSynchronize(ctx->stream));  // gstart (host) goes out of use only after the copy
     const int P       = (int)ceil_div(m->ncol, W);
@@ -846,55 +765,40 @@ int csr_panel_build(spmv_mat* m)
     return panel_choose_pace(m);
 }
 
-// Pick the pace of the clock throttle by trying it: the best value is "just what the CUs sustain", which
-// depends on the matrix (how many x lines a chunk touches) and on the clock the chip holds.  Candidates are
-// multiples of a model value (1.33 ns per entry and CU, measured on L2-resident problems) plus "no throttle";
-// each is timed on scratch vectors (the gather addresses, not the values, set the time).  Part of the
-// one-off analysis, like the reference's shard construction before its timed loop.
 static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, bool trial, const apply_extra& ex);
 
-static void panel_guard_reset(spmv_mat* m)
-{
-    const unsigned init[4] = {1024u, 0u, 0u, 0u};
-    if (m->pb_ctl)
-    {
-        (void)hipMemcpyAsync(m->pb_ctl, init, sizeof(init), hipMemcpyHostToDevice, m->ctx->stream);
-        (void)hipStreamSynchronize(m->ctx->stream);  // `init` is on the stack
-    }
-}
-
+// Chooses, by timing a few launches on scratch vectors (the gather addresses, not the values, set the time), the chunk
+// size, the order of a chunk's loads and how the 16 wavefronts of a workgroup are kept together.  Part of the one-off
+// analysis, like the reference's shard construction before its timed loop (src/mat_vec.cpp:240-268).
+//   scattered columns (C2, C4): U = 8, gather-first, a workgroup barrier at the top of every chunk.  With the barrier the
+//     workgroups of an XCD fall into step by themselves (whoever leads the sweep of x takes the L2 misses and slows down);
+//     without it wavefront 0 starts the next chunk while wavefront 15 is still issuing this one and starves it (round 2's
+//     trace), which is what the clock pace of round 1 was really compensating;
+//   local columns (bands): U = 4, gather-first, the barrier between a chunk's loads and its adds (round 5: 0.615 ms on the
+//     65536 band against 0.630-0.647 for every candidate of the round-4 list);
+//   shards whose x is 2-4x their rows: U = 8, stream-first, barrier at the top.
+// The list is what tools/sweep_panel_configs.py ranks first on those shapes (profiles/r05_sweep_panel_configs_*.txt).
+// (The function keeps its name from round 1, when what it chose was the pace of a clock throttle.)
 int panel_choose_pace(spmv_mat* m)
 {
-    // Chooses, by timing a few launches on scratch vectors (the gather addresses, not the values, set the time), the
-    // chunk size, the order of a chunk's loads and how the 16 wavefronts of a workgroup are kept together:
-    //   scattered columns (C2): U = 8, gather-first, a workgroup barrier per chunk, NO clock throttle.  With the barrier
-    //     the workgroups of an XCD fall into step by themselves (whoever leads the sweep of x takes the L2 misses and
-    //     slows down); without it wavefront 0 starts the next chunk while wavefront 15 is still issuing this one and
-    //     starves it (tools/trace_panel.py), which is what the clock pace of round 1 was really compensating;
-    //   local columns (bands): U = 4, stream-first, no barrier.
-    // A requested pace (panel_pace_ns >= 0) is applied to every candidate; there is no pace search any more.
     spmv_ctx* ctx = m->ctx;
-    panel_guard_reset(m);
-    const int key = 1000 + std::max(m->pb_unroll, 0) * 10 + (m->pb_pipe + 1) + (m->pb_stagger & 3) * 100000 + ((m->pb_sync + 1) & 7) * 1000000;
-    m->pb_pace_ns = m->pb_pace_req >= 0 ? m->pb_pace_req : 0;
-    if (m->pb_pace_tuned_unroll == key) return SPMV_OK;  // already tried for this layout and these requests
-    m->pb_pace_tuned_unroll = 0;
-    m->pb_unroll_tuned      = 0;
-    m->pb_pipe_tuned        = 0;
-    m->pb_sync_tuned        = 0;
-    m->pb_pace_tuned_ns     = 0;
+    const int key = 1000 + std::max(m->pb_unroll, 0) * 10 + (m->pb_pipe + 1) + ((m->pb_sync + 1) & 7) * 1000000;
+    if (m->pb_tuned_key == key) return SPMV_OK;  // already tried for this layout and these requests
+    m->pb_tuned_key    = 0;
+    m->pb_unroll_tuned = 0;
+    m->pb_pipe_tuned   = 0;
+    m->pb_sync_tuned   = 0;
     if (m->pb_unroll > 0 && m->pb_pipe >= 0 && m->pb_sync >= 0) return SPMV_OK;  // nothing left to choose
     const bool worth = (double)m->ncol * 8.0 > 4.0 * 1048576.0 && m->pb_max_group_nnz >= 8LL * 8 * kPanelThreads;
     if (!worth) return SPMV_OK;  // x fits L2 or the groups are a few chunks long: nothing to keep in step
     // SPMV_PANEL_TRIAL=0 (or panel_trial = 0): no timing launches at all; take what wins on scattered columns and costs
-    // 2 % on local ones (U = 8, gather-first, barrier between loads and adds)
-    const char* env_trial = getenv("SPMV_PANEL_TRIAL");
-    if (m->pb_trial == 0 || (m->pb_trial < 0 && env_trial && atoi(env_trial) == 0))
+    // a few per cent on local ones (U = 8, gather-first, barrier at the top of the chunk)
+    if (!select_trials_enabled(m))
     {
-        m->pb_unroll_tuned      = m->pb_unroll <= 0 ? 8 : 0;
-        m->pb_pipe_tuned        = m->pb_pack ? 2 : 1;
-        m->pb_sync_tuned        = m->pb_pack ? 3 : 1;
-        m->pb_pace_tuned_unroll = key;
+        m->pb_unroll_tuned = m->pb_unroll <= 0 ? 8 : 0;
+        m->pb_pipe_tuned   = m->pb_pack ? 2 : 1;
+        m->pb_sync_tuned   = 1;
+        m->pb_tuned_key    = key;
         return SPMV_OK;
     }
     double *x = nullptr, *y = nullptr;
@@ -923,12 +827,10 @@ int panel_choose_pace(spmv_mat* m)
     {
         int unroll, pipe, sync;
     };
-    // (stream-first with a barrier is what the shard shapes with x 2-4x the rows take: at N = 2, 10M x 20M, {8, stream-first,
-    // barrier} 1.46 ms, {4, ...} 1.51, the best gather-first candidate 1.62: profiles/r03_tune_csr_shard_shapes_n2_n4.txt)
-    const Try packed_tries[] = {{8, 2, 3}, {8, 2, 1}, {4, 2, 1}, {4, 1, 1}, {8, 1, 1}, {4, 1, 0}, {8, 1, 0}};
-    const Try plain_tries[]  = {{8, 1, 1}, {8, 1, 0}, {4, 1, 0}, {2, 1, 0}};
+    const Try packed_tries[] = {{8, 2, 1}, {8, 2, 3}, {4, 2, 3}, {8, 1, 1}, {8, 1, 3}, {4, 2, 1}, {4, 1, 0}, {8, 1, 0}};
+    const Try plain_tries[]  = {{8, 1, 1}, {4, 1, 1}, {4, 1, 3}, {8, 2, 1}, {8, 1, 0}, {4, 1, 0}, {2, 1, 0}};
     const Try* tries  = m->pb_pack ? packed_tries : plain_tries;
-    const int  ntries = m->pb_pack ? 7 : 4;
+    const int  ntries = m->pb_pack ? 8 : 7;
     Try    best{m->pb_unroll > 0 ? m->pb_unroll : 8, m->pb_pipe >= 0 ? m->pb_pipe : 1, m->pb_sync >= 0 ? m->pb_sync : 0};
     double best_ms = 1e30;
     int    tried   = 0;
@@ -959,22 +861,11 @@ int panel_choose_pace(spmv_mat* m)
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(x);
     (void)hipFree(y);
-    m->pb_unroll_tuned      = rc == SPMV_OK && m->pb_unroll <= 0 ? best.unroll : 0;
-    m->pb_pipe_tuned        = rc == SPMV_OK ? best.pipe : 0;
-    m->pb_sync_tuned        = rc == SPMV_OK ? best.sync : 0;
-    m->pb_pace_tuned_unroll = rc == SPMV_OK ? key : 0;
+    m->pb_unroll_tuned = rc == SPMV_OK && m->pb_unroll <= 0 ? best.unroll : 0;
+    m->pb_pipe_tuned   = rc == SPMV_OK ? best.pipe : 0;
+    m->pb_sync_tuned   = rc == SPMV_OK ? best.sync : 0;
+    m->pb_tuned_key    = rc == SPMV_OK ? key : 0;
     return rc;
-}
-
-int csr_panel_read_trace(spmv_ctx* ctx, int64_t index, int64_t* value)
-{
-    constexpr int64_t n = (int64_t)kTraceWgs * 2 * kTraceChunks * kTraceStamps;
-    if (index < 0 || index >= n) SPMV_FAIL(SPMV_ERR_INVALID, "panel_trace@%lld: the trace holds %lld stamps", (long long)index, (long long)n);
-    unsigned v = 0;
-    SPMV_HIP(hipStreamSynchronize(ctx->stream));
-    SPMV_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_panel_trace), sizeof(v), (size_t)index * sizeof(unsigned)));
-    *value = v;
-    return SPMV_OK;
 }
 
 int csr_panel_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
@@ -997,79 +888,46 @@ static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, doubl
     // chunks of 2, 4 or 8 x 1024 entries.  16 existed through round 3: every instance of it spilled registers to scratch and
     // ran slower (C2: 1.70 ms against 1.13, the x window of a chunk leaves L2); a request for 16 runs 8.
     const int unroll_rq = A->pb_unroll > 0 ? A->pb_unroll : (A->pb_unroll_tuned > 0 ? A->pb_unroll_tuned : 8);
-    const int unroll    = unroll_rq >= 16 ? 8 : unroll_rq;
-    // optional clock throttle: nanoseconds per chunk -> 10 ns ticks in 22.10 fixed point
-    const unsigned long long pace_fp = A->pb_pace_ns > 0 ? (unsigned long long)((double)A->pb_pace_ns * 102.4) : 0ull;
-    const int  sync   = (A->pb_sync >= 0 ? A->pb_sync : A->pb_sync_tuned) & 3;
-    const int  flags  = ((A->pb_stagger & 3) == 2 ? 1 : 0) | (sync << 1);
-    const int  layout = A->pb_pack ? (A->pb_pair ? 4 : 3) : 0;
+    const int unroll    = unroll_rq >= 16 ? 8 : (unroll_rq >= 8 ? 8 : (unroll_rq >= 4 ? 4 : 2));
+    const int sync_rq   = (A->pb_sync >= 0 ? A->pb_sync : A->pb_sync_tuned) & 3;
+    const int sync      = sync_rq == 2 ? 3 : sync_rq;  // (2 was the split barrier through an LDS counter: measured no better than 3, deleted in round 5)
+    const int layout    = A->pb_pack ? (A->pb_pair ? 4 : 3) : 0;
     // the kernel dereferences exactly these arrays: refuse on the host rather than fault on the GPU
     const bool have = layout >= 3 ? (A->pb_pack && A->pb_sbase && A->pb_soff && A->pb_val && A->pb_rowbits > 0 && A->pb_rowbits < 32)
                                   : (A->pb_col && A->pb_row && A->pb_val);
     if (!A->pb_gstart || !x || !y || !have)
         SPMV_FAIL(SPMV_ERR_INVALID, "panel kernel: layout %d is selected but its arrays are not there", layout);
-    unsigned*      ctl     = (trial || !A->pb_guard) ? nullptr : A->pb_ctl;  // the trials must not train the guard
     const int32_t* arg_col = layout >= 3 ? (const int32_t*)A->pb_pack : A->pb_col;
     const int      pipe_rq = A->pb_pipe >= 0 ? A->pb_pipe : (A->pb_pipe_tuned > 0 ? A->pb_pipe_tuned : 1);
-    // gather-first is instantiated for the chunk sizes that are tried; the others take the stream-first order
-    const int pipe = pipe_rq == 2 && !(unroll == 4 || unroll == 8) ? 1 : std::min(pipe_rq, 2);
-#define SPMV_PANEL_LAUNCH(U, LY, PP, TR, TC, SY)                                                                      \
-    {                                                                                                                \
-        static std::atomic<unsigned long long> granted{0}; /* bit per device */                                      \
-        if (!((granted.load(std::memory_order_relaxed) >> ctx->device) & 1ull))                                      \
-        {                                                                                                            \
-            SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_kernel<U, LY, PP, TR, TC, SY>,                       \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160008));                       \
-            granted.fetch_or(1ull << ctx->device, std::memory_order_relaxed);                                        \
-        }                                                                                                            \
-        hipLaunchKernelGGL((csr_panel_kernel<U, LY, PP, TR, TC, SY>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream, \
-                           A->pb_gstart, A->pb_ngroups, A->a, arg_col, A->pb_row, A->pb_val, x, y, pace_fp, flags, A->pb_sbase,  \
-                           A->pb_soff, A->pb_rowbits, ex.overwrite ? 1 : 0, ex.dot_w, ex.dot_out, ctl);              \
-        SPMV_HIP(hipGetLastError());                                                                                 \
-        return SPMV_OK;                                                                                              \
+    const int      pipe    = std::max(0, std::min(pipe_rq, 2));
+#define SPMV_PANEL_PP(U, LY, OR, TR, SY)                                                                                               \
+    {                                                                                                                                  \
+        static std::atomic<unsigned long long> granted{0}; /* bit per device */                                                        \
+        if (!((granted.load(std::memory_order_relaxed) >> ctx->device) & 1ull))                                                        \
+        {                                                                                                                              \
+            SPMV_HIP(hipFuncSetAttribute((const void*)csr_panel_pp_kernel<U, LY, OR, TR, SY>, hipFuncAttributeMaxDynamicSharedMemorySize, 160008)); \
+            granted.fetch_or(1ull << ctx->device, std::memory_order_relaxed);                                                          \
+        }                                                                                                                              \
+        hipLaunchKernelGGL((csr_panel_pp_kernel<U, LY, OR, TR, SY>), dim3(grid), dim3(kPanelThreads), lds, ctx->stream, A->pb_gstart,  \
+                           A->pb_ngroups, A->a, arg_col, A->pb_row, A->pb_val, x, y, A->pb_sbase, A->pb_soff, A->pb_rowbits,           \
+                           ex.overwrite ? 1 : 0, ex.dot_w, ex.dot_out);                                                                \
+        SPMV_HIP(hipGetLastError());                                                                                                   \
+        return SPMV_OK;                                                                                                                \
     }
-    // the C2 instance (packed, U = 8, gather-first): the wavefront sync is a compile-time choice; panel_legacy = 1
-    // routes it through the run-time switch for A/B, panel_trace = 1 through the diagnostic build
-    if (layout == 3 && unroll == 8 && pipe == 2 && !A->pb_legacy)
-    {
-        if (A->pb_trace && !trial) SPMV_PANEL_LAUNCH(8, 3, 2, false, true, -1)
-#define SPMV_PANEL_CT(SY)                                          \
-    if (sync == SY)                                                \
-    {                                                              \
-        if (trial) SPMV_PANEL_LAUNCH(8, 3, 2, true, false, SY)     \
-        SPMV_PANEL_LAUNCH(8, 3, 2, false, false, SY)               \
+#define SPMV_PANEL_PP_SY(U, LY, OR)                                                                        \
+    if (unroll == U && layout == LY && pipe == OR)                                                         \
+    {                                                                                                      \
+        if (sync == 0) { if (trial) SPMV_PANEL_PP(U, LY, OR, true, 0) SPMV_PANEL_PP(U, LY, OR, false, 0) } \
+        if (sync == 1) { if (trial) SPMV_PANEL_PP(U, LY, OR, true, 1) SPMV_PANEL_PP(U, LY, OR, false, 1) } \
+        if (sync == 3) { if (trial) SPMV_PANEL_PP(U, LY, OR, true, 3) SPMV_PANEL_PP(U, LY, OR, false, 3) } \
     }
-        SPMV_PANEL_CT(0) SPMV_PANEL_CT(1) SPMV_PANEL_CT(2) SPMV_PANEL_CT(3)
-#undef SPMV_PANEL_CT
-    }
-    if (layout == 4 && unroll == 8 && pipe == 2)
-    {
-#define SPMV_PANEL_CT(SY)                                          \
-    if (sync == SY)                                                \
-    {                                                              \
-        if (trial) SPMV_PANEL_LAUNCH(8, 4, 2, true, false, SY)     \
-        SPMV_PANEL_LAUNCH(8, 4, 2, false, false, SY)               \
-    }
-        SPMV_PANEL_CT(0) SPMV_PANEL_CT(1) SPMV_PANEL_CT(3)
-#undef SPMV_PANEL_CT
-    }
-#define SPMV_PANEL_CASE(U, LY, PP)                                   \
-    if (unroll == U && layout == LY && pipe == PP)                   \
-    {                                                                \
-        if (trial) SPMV_PANEL_LAUNCH(U, LY, PP, true, false, -1)     \
-        SPMV_PANEL_LAUNCH(U, LY, PP, false, false, -1)               \
-    }
-    SPMV_PANEL_CASE(2, 0, 0) SPMV_PANEL_CASE(4, 0, 0) SPMV_PANEL_CASE(8, 0, 0)
-    SPMV_PANEL_CASE(2, 3, 0) SPMV_PANEL_CASE(4, 3, 0) SPMV_PANEL_CASE(8, 3, 0)
-    SPMV_PANEL_CASE(2, 0, 1) SPMV_PANEL_CASE(4, 0, 1) SPMV_PANEL_CASE(8, 0, 1)
-    SPMV_PANEL_CASE(2, 3, 1) SPMV_PANEL_CASE(4, 3, 1) SPMV_PANEL_CASE(8, 3, 1)
-    SPMV_PANEL_CASE(4, 0, 2) SPMV_PANEL_CASE(8, 0, 2)
-    SPMV_PANEL_CASE(4, 3, 2) SPMV_PANEL_CASE(8, 3, 2)
-    SPMV_PANEL_CASE(2, 4, 0) SPMV_PANEL_CASE(4, 4, 0) SPMV_PANEL_CASE(8, 4, 0)
-    SPMV_PANEL_CASE(2, 4, 1) SPMV_PANEL_CASE(4, 4, 1) SPMV_PANEL_CASE(8, 4, 1)
-    SPMV_PANEL_CASE(4, 4, 2) SPMV_PANEL_CASE(8, 4, 2)
-#undef SPMV_PANEL_CASE
-#undef SPMV_PANEL_LAUNCH
-    SPMV_FAIL(SPMV_ERR_INVALID, "panel kernel: unroll=%d is not instantiated (2, 4, 8)", unroll);
+#define SPMV_PANEL_PP_OR(U, LY) SPMV_PANEL_PP_SY(U, LY, 0) SPMV_PANEL_PP_SY(U, LY, 1) SPMV_PANEL_PP_SY(U, LY, 2)
+    SPMV_PANEL_PP_OR(8, 4) SPMV_PANEL_PP_OR(4, 4) SPMV_PANEL_PP_OR(2, 4)
+    SPMV_PANEL_PP_OR(8, 3) SPMV_PANEL_PP_OR(4, 3) SPMV_PANEL_PP_OR(2, 3)
+    SPMV_PANEL_PP_OR(8, 0) SPMV_PANEL_PP_OR(4, 0) SPMV_PANEL_PP_OR(2, 0)
+#undef SPMV_PANEL_PP_OR
+#undef SPMV_PANEL_PP_SY
+#undef SPMV_PANEL_PP
+    SPMV_FAIL(SPMV_ERR_INVALID, "panel kernel: unroll=%d layout=%d order=%d sync=%d is not instantiated", unroll, layout, pipe, sync);
 }
 }  // namespace spmv

@@ -431,12 +431,17 @@ def pmc_mean_of_products(rows: list, kernel_id: int):
     per_kernel, shown = {}, None
     for name in PRODUCT_KERNELS.get(kernel_id, ()):
         mine = [row for row in rows if name in row["Kernel_Name"]]
-        if name == "csr_panel_kernel":  # template <U, LAYOUT, PIPE, TRIAL, TRACE, SYNC>
-            mine = [row for row in mine if row["Kernel_Name"].split("csr_panel_kernel<")[1].split(">")[0].split(",")[3].strip() == "false"]
+        if name == "csr_panel_kernel":
+            # template <U, LAYOUT, PIPE, TRIAL, TRACE, SYNC>, or the gather-first order written down (round 5):
+            # csr_panel_pp_kernel<U, LAYOUT, ORDER, TRIAL, SYNC> - the fourth argument says "a build-time trial launch" in both
+            mine = [row for row in rows if "csr_panel_kernel<" in row["Kernel_Name"] or "csr_panel_pp_kernel<" in row["Kernel_Name"]]
+            mine = [row for row in mine if row["Kernel_Name"].split("_kernel<")[1].split(">")[0].split(",")[3].strip() == "false"]
         mine.sort(key=lambda row: int(row["Dispatch_Id"]))
         last = mine[-3:]
         if len(last) < 3:
             return f"fewer than 3 dispatches of {name}"
+        if any(row["Kernel_Name"] != last[-1]["Kernel_Name"] for row in last):
+            return f"the last three product dispatches of {name} are not one kernel"
         per_kernel[name] = sum(float(row["Counter_Value"]) for row in last) / len(last)
         shown = last[-1]["Kernel_Name"].split("(anonymous namespace)::", 1)[-1].split("(")[0]
     if not per_kernel:
@@ -683,7 +688,7 @@ def main() -> None:
             (y_concat_ms,) = max_over_ranks(1e3 * (time.perf_counter() - t1) / 10)
             del y_full
 
-        panel_names = ("rows", "width", "groups", "layout", "unroll", "pipe", "sync", "stagger", "pace_ns", "bytes")
+        panel_names = ("rows", "width", "groups", "layout", "unroll", "pipe", "sync", "bytes")
 
         def panel_of(M):
             try:
@@ -801,7 +806,7 @@ def main() -> None:
                     return M
                 one("C2 with the kernel configs[1] names: row-parallel CSR, 2^k lanes of a wavefront per row (spmv_mat_set_kernel VECTOR) - "
                     "every gather of x misses L2 and pulls a 128-byte line over the fabric; the headline is the panel kernel the engine picks",
-                    "csr", c2_rows, x_vec=vx)
+                    "csr", c2_rows, tkey=f"csr_n{n}_k{k}_band0_ncol{ncol}_vector", x_vec=vx)
 
                 def c5_shard(budget_mb=None):
                     M = ctx.gen_csr_uniform(7 * n, 8 * n, 8 * n, k, band=0, seed=args.seed)

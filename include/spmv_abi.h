@@ -234,12 +234,13 @@ int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
  *                    registers - and now runs 8)
  *   "panel_pipe"     order of a chunk's memory instructions: 0 = no pipelining, 1 = next chunk's stream first,
  *                    2 = this chunk's gathers first (-1 = by trial)
- *   "panel_sync"     how the 16 wavefronts of a workgroup are kept in the same chunk: 0 = not at all (local columns),
- *                    1 = workgroup barrier per chunk, 3 = barrier between a chunk's loads and its LDS adds, 2 = split
- *                    barrier through an LDS counter (-1 = by trial; DESIGN.md 4.2: this is what keeps the workgroups of
- *                    an XCD in step on scattered columns, and what made the clock pace below unnecessary)
- *   "panel_pace_ns"  clock throttle, nanoseconds per chunk (-1 / 0 = off: the default since round 2; > 0 = on);
- *   "panel_guard", "panel_stagger"   run-time guard and per-XCD offsets of that throttle (only with a pace)
+ *   "panel_sync"     how the 16 wavefronts of a workgroup are kept in the same chunk: 0 = not at all, 1 = workgroup barrier at
+ *                    the top of every chunk, 3 = barrier between a chunk's loads and its LDS adds (-1 = by trial; DESIGN.md 4.2:
+ *                    this is what keeps the workgroups of an XCD in step on scattered columns).  (2, a split barrier through an LDS
+ *                    counter, was measured no better than 3 and runs 3 since round 5.)
+ *                    Round 1's clock throttle and what hung on it - "panel_pace_ns", "panel_guard", "panel_stagger", the trace build
+ *                    "panel_trace", the A/B switch "panel_legacy" - were deleted in round 5 with the kernel that carried them
+ *                    inside its chunk loop (the headline's schedule had come to depend on that dead code: DESIGN.md 4.2).
  *   "panel_keep_csr" 0 = release col_ind / values of a CSR handle whose product runs from the panel or two-phase layout
  *                    (memory 2x -> 1x the matrix; download, other kernels, re-builds and conversions are then refused)
  *   "panel_trial"    1 / 0 = timing launches when the layout is built, yes / no (-1 = environment, default yes)
@@ -280,11 +281,10 @@ int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
  *                    built, 8 bytes per entry more.  Needs fewer than 2^31 - 131072 entries.  A row is spread over up to that
  *                    many runs, each ending in an atomic on y: results differ from the scan in place by rounding only.
  *   "symgs_order"    sweep order of spmv_symgs / SPMV_PRECOND_SYMGS: 1 multicolour (default), 0 the matrix's own row order
- *   "panel_trace", "panel_legacy", "panel_two_per_cu"
- *                    diagnostics and experiments kept for the record (tools/trace_panel.py) */
+ *   "panel_two_per_cu"   0 = never two workgroups per CU (default 1: two when their accumulators fit the LDS twice) */
 int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value);
 /* What is in effect: "panel_rows", "panel_width", "panel_sort", "panel_groups", "panel_layout", "panel_unroll",
- * "panel_pipe", "panel_sync", "panel_stagger", "panel_pace_ns", "panel_pace_scale", "panel_pace_bumps",
+ * "panel_pipe", "panel_sync",
  * "panel_bytes", "panel_keep_csr", "device_bytes", "window_max_span", "window_avg_span", "twophase_panel_cols",
  * "twophase_padded" (entries of the two-phase layout with its padding), "twophase_pieces" (1 GB pieces of its product stream),
  * "ell_tiled_values" (1: the ELL product reads its values from the copy in tiles), "coo_column_bins" (bins of the copy the COO
@@ -317,8 +317,8 @@ int spmv_apply_timed(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* x, spmv_v
 /* y_host += A * x_host with the caller's HOST vectors, synchronous - the reference's own call shape (include/mat_vec.h:7-11:
  * every CSRMatrixMatVector(A, x, y) hands over host arrays; main.cpp:56-59 does it 50 times), as ONE entry point so that the
  * hand-over can be done the cheapest way for its size: vectors of up to 4 MB together go through a pinned, device-mapped
- * staging buffer of the context that the GPU reads and writes itself (three launches on the context's stream, no hipMemcpy,
- * the host polls; C1: 67 -> ~30 us per product); larger ones through asynchronous copies.  x_host has ncol entries, y_host
+ * staging buffer of the context that the GPU reads and writes itself (two launches on the context's stream - three for the
+ * kernels that add into y with atomics -, no hipMemcpy, the host polls; C1: 67 -> ~35 us per product); larger ones through asynchronous copies.  x_host has ncol entries, y_host
  * nrow.  The caller's arrays are neither registered nor mapped (they may be freed or moved between calls).  Never part of a
  * throughput figure: resident vectors (spmv_apply) are what the roofline numbers are measured with. */
 int spmv_apply_host(spmv_ctx* ctx, const spmv_mat* A, const double* x_host, double* y_host);

@@ -104,7 +104,7 @@ def test_no_kernel_of_the_engine_uses_scratch(tmp_path):
     n = int(r.stdout.strip().splitlines()[-1].split()[2])
     assert n >= 300  # every kernel the engine defines (rocPRIM's are excluded by name)
     bad = tmp_path / "patterns.txt"
-    bad.write_text("csr_panel_kernel<*\nno_such_kernel_anywhere*\n")
+    bad.write_text("csr_panel_pp_kernel<*\nno_such_kernel_anywhere*\n")
     r = subprocess.run([sys.executable, tool, "--check", str(bad)] + objs, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "matched no kernel" in r.stderr
 

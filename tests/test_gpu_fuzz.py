@@ -87,7 +87,7 @@ def test_random_csr_shapes_through_every_kernel(ctx, orc, pkg, seed):
         combos.append((4, 8, 2, 1, 0, 0))  # the C2 instance
         for layout, unroll, pipe, sync, rows, width in combos:
             for k, v in (("panel_aos", layout), ("panel_unroll", unroll), ("panel_pipe", pipe), ("panel_sync", sync), ("panel_rows", rows),
-                         ("panel_width", width), ("panel_pace_ns", 0)):
+                         ("panel_width", width)):
                 A.set_param(k, v)
             A.set_kernel(capi.CSR_PANEL)
             run(A, f"panel layout={layout}->{A.get_param('panel_layout')} unroll={unroll} pipe={pipe} sync={sync} rows={rows} width={width}")

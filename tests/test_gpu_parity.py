@@ -1164,8 +1164,7 @@ def test_csr_panel_kernel_matches_reference_golden(ctx, orc, pkg, make):
         A.set_param("panel_unroll", unroll)
         A.set_param("panel_sync", sync)
         A.set_param("panel_pipe", pipe)
-        A.set_param("panel_pace_ns", pace)
-        A.set_kernel(pkg.capi.CSR_PANEL)
+        A.set_kernel(pkg.capi.CSR_PANEL)  # (`pace`, the last number of a case, was round 1's clock throttle: deleted in round 5)
         y1, y50 = _apply_n(ctx, A, c["x"], c["nrow"], NUM_TEST)
         what = f"{c['name']} panel rows={rows} width={width} sort={srt} layout={aos} unroll={unroll} sync={sync} pipe={pipe} pace={pace}"
         ol.assert_parity(y1, g["y1_csr"], scale, what + " 1 call")
@@ -1411,11 +1410,12 @@ def test_packed_layout_pads_do_not_leak_non_finite_x(ctx, orc, pkg):
         ol.assert_parity(got, ref, scale, f"packed layout {layout}, inf at every slice base")
 
 
-def test_panel_pace_guard_stretches_a_pace_the_chip_cannot_hold(ctx, pkg):
-    """run-time guard of the clock throttle: with a pace far below what the CUs sustain the workgroups fall behind, the
-    last one to finish stretches the pace for the next launches; the products stay correct throughout"""
+def test_panel_product_every_order_and_barrier_placement_at_size(ctx, pkg):
+    """the chunk pipeline with its order written down (round 5: two register sets in turn, scheduling fences, no pace / guard /
+    trace code): every chunk size x order x barrier placement x layout on a matrix with many groups, chunks and ragged tails,
+    against the row-parallel kernel; the parameters the removed machinery had are refused by name"""
     capi = pkg.capi
-    n, k = 4_000_000, 32
+    n, k = 1_000_000, 24
     A = ctx.gen_csr_uniform(0, n, n, k, seed=21)
     x = ctx.gen_vector(n, seed=22)
     yv, yp = ctx.vector(n), ctx.vector(n)
@@ -1424,24 +1424,24 @@ def test_panel_pace_guard_stretches_a_pace_the_chip_cannot_hold(ctx, pkg):
     ctx.apply(A, x, yv)
     ctx.sync()
     ref = yv.download()
-    A.set_param("panel_unroll", 8)
-    A.set_param("panel_pipe", 2)
-    A.set_param("panel_pace_ns", 2000)  # a quarter of what a chunk of 8192 entries takes
-    A.set_kernel(capi.CSR_PANEL)
-    assert A.get_param("panel_pace_scale") == 1024 and A.get_param("panel_pace_bumps") == 0
-    for _ in range(6):
-        yp.fill(0.0)
-        ctx.apply(A, x, yp)
-        ctx.sync()
-        assert np.max(np.abs(yp.download() - ref)) <= ol.REL_TOL * k
-    assert A.get_param("panel_pace_bumps") >= 3 and A.get_param("panel_pace_scale") > 1024
-    A.set_param("panel_guard", 0)
-    A.set_kernel(capi.CSR_PANEL)  # re-selecting resets the guard
-    assert A.get_param("panel_pace_scale") == 1024
-    yp.fill(0.0)
-    ctx.apply(A, x, yp)
-    ctx.sync()
-    assert A.get_param("panel_pace_bumps") == 0 and np.max(np.abs(yp.download() - ref)) <= ol.REL_TOL * k
+    for layout in (4, 3, 0):
+        A.set_param("panel_aos", layout)
+        for unroll in (2, 4, 8, 16):
+            for order in (0, 1, 2):
+                for sync in (0, 1, 2, 3):
+                    A.set_param("panel_unroll", unroll)
+                    A.set_param("panel_pipe", order)
+                    A.set_param("panel_sync", sync)
+                    A.set_kernel(capi.CSR_PANEL)
+                    assert A.get_param("panel_layout") == layout and A.get_param("panel_unroll") == min(unroll, 8)
+                    assert A.get_param("panel_sync") == (3 if sync == 2 else sync)  # the split barrier of rounds 2-4 runs 3
+                    yp.fill(0.0)
+                    ctx.apply(A, x, yp)
+                    ctx.sync()
+                    assert np.max(np.abs(yp.download() - ref)) <= ol.REL_TOL * k, (layout, unroll, order, sync)
+    for gone in ("panel_pace_ns", "panel_guard", "panel_stagger", "panel_trace", "panel_legacy"):
+        with pytest.raises(capi.SpmvError, match="unknown parameter"):
+            A.set_param(gone, 0)
 
 
 def test_large_ell_with_scattered_columns_runs_the_panel_product(ctx, pkg):

@@ -18,7 +18,7 @@ def main():
     A = ctx.gen_csr_uniform(0, n, n, k, band=0, seed=1)
     x, y = ctx.gen_vector(n, seed=1), ctx.vector(n)
     y.fill(0.0)
-    for k_, v in (("panel_aos", 3), ("panel_unroll", 8), ("panel_pace_ns", 0), ("panel_pipe", 2), ("panel_sync", 3), ("panel_trial", 0)):
+    for k_, v in (("panel_aos", 3), ("panel_unroll", 8), ("panel_pipe", 2), ("panel_sync", 3), ("panel_trial", 0)):
         A.set_param(k_, v)
     for build in range(int(sys.argv[1]) if len(sys.argv) > 1 else 8):
         for rows in (19_000, 0):  # the first forces the re-build of the second (0 = the default: 19532)

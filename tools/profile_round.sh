@@ -24,7 +24,7 @@ stats = list(csv.DictReader(open(glob.glob(O + "/stats/*/*_kernel_stats.csv")[0]
 def short(n):
     return n.split("(anonymous namespace)::", 1)[-1].split("(")[0]
 def is_trial(n):  # csr_panel_kernel<U, LAYOUT, PIPE, TRIAL, TRACE, SYNCT>
-    m = re.search(r"csr_panel_kernel<([^>]*)>", n)
+    m = re.search(r"csr_panel(?:_pp)?_kernel<([^>]*)>", n)
     return bool(m) and m.group(1).split(",")[3].strip() == "true"
 rows = sorted(trace, key=lambda r: int(r["Start_Timestamp"]))
 # runs of consecutive dispatches of one kernel: bench.py launches every workload's product 5 + 50 times back to back
@@ -39,7 +39,7 @@ if cur:
 with open(O + "/timed_region.txt", "w") as out:
     for run in runs:
         name = run[0]["Kernel_Name"]
-        if len(run) < 50 or is_trial(name) or not any(k in name for k in ("csr_panel_kernel", "ell_kernel", "ell_diag_kernel", "coo_segscan_kernel", "coo_segscan_bins_kernel")):
+        if len(run) < 50 or is_trial(name) or not any(k in name for k in ("csr_panel_kernel", "csr_panel_pp_kernel", "ell_kernel", "ell_diag_kernel", "coo_segscan_kernel", "coo_segscan_bins_kernel")):
             continue
         d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in run]
         tail = d[-50:]

@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--full", action="store_true", help="every lanes x flags combination")
-    ap.add_argument("--panel", default="", help="panel variants 'unroll,pace_ns,pipe,layout,sync[,rows[,legacy]];...' (0 / -1 = by trial)")
+    ap.add_argument("--panel", default="", help="panel variants 'unroll,pipe,layout,sync[,rows];...' (0 / -1 = by trial)")
     ap.add_argument("--twophase", default="20000,6;20000,4;10000,6;10000,4", help="two-phase variants 'panel_cols,unroll;...'")
     ap.add_argument("--no-panel", action="store_true", help="csr: leave the panel variants out")
     a = ap.parse_args()
@@ -211,17 +211,16 @@ def main():
             variants = []
             combos = [tuple(int(t) for t in item.split(",")) for item in a.panel.split(";")]
         else:
-            combos = [(8, 0, 2, 4, 3), (8, 0, 2, 4, 1), (8, 0, 2, 3, 1), (4, 0, 2, 4, 1), (4, 0, 1, 4, 0), (8, 0, 1, 4, 0), (0, -1, -1, 4, -1)]
-        for combo in combos:  # --panel fields: unroll,pace_ns,pipe,layout,sync[,rows[,legacy]]  (0 / -1 = by trial)
-            combo = combo + (0, -1, -1, 4, -1, 0, 0)[len(combo):]
-            unroll, pace, pipe, aos, sync, rows, legacy = combo[:7]
+            combos = [(8, 2, 4, 1), (8, 2, 4, 3), (4, 2, 4, 3), (8, 1, 4, 1), (8, 1, 4, 3), (4, 2, 4, 1), (4, 1, 4, 0), (8, 1, 4, 0), (0, -1, 4, -1)]
+        for combo in combos:  # --panel fields: unroll,pipe,layout,sync[,rows]  (0 / -1 = by trial)
+            combo = combo + (0, -1, 4, -1, 0)[len(combo):]
+            unroll, pipe, aos, sync, rows = combo[:5]
 
-            def setup(A, unroll=unroll, pace=pace, pipe=pipe, aos=aos, sync=sync, rows=rows, legacy=legacy):
-                for k, v in (("panel_aos", aos), ("panel_rows", rows), ("panel_unroll", unroll), ("panel_pace_ns", pace),
-                             ("panel_pipe", pipe), ("panel_sync", sync), ("panel_legacy", legacy)):
+            def setup(A, unroll=unroll, pipe=pipe, aos=aos, sync=sync, rows=rows):
+                for k, v in (("panel_aos", aos), ("panel_rows", rows), ("panel_unroll", unroll), ("panel_pipe", pipe), ("panel_sync", sync)):
                     A.set_param(k, v)
                 A.set_kernel(capi.CSR_PANEL)  # rebuilds the layout when the parameters changed
-            variants.append((f"panel U={unroll} pace={pace}ns pipe={pipe} layout={aos} sync={sync} rows={rows} legacy={legacy}", setup))
+            variants.append((f"panel U={unroll} pipe={pipe} layout={aos} sync={sync} rows={rows}", setup))
         if a.no_panel:
             variants = []
         for item in [t for t in a.twophase.split(";") if t]:
@@ -235,22 +234,11 @@ def main():
             for lanes in (4, 8, 16):
                 variants.append((f"ldswin L={lanes}", lambda A, lanes=lanes: A.set_kernel(capi.CSR_LDSWIN, lanes)))
         sweep(ctx, A, x, y, variants, a.rounds, a.reps, algorithmic_bytes("csr", n, ncol, n * k), n * k)
-        for name, v in (("panel_aos", 4), ("panel_rows", 0), ("panel_unroll", 0), ("panel_pace_ns", -1), ("panel_pipe", -1), ("panel_stagger", 2),
-                        ("panel_sync", -1), ("panel_legacy", 0)):
+        for name, v in (("panel_aos", 4), ("panel_rows", 0), ("panel_unroll", 0), ("panel_pipe", -1), ("panel_sync", -1)):
             A.set_param(name, v)
         A.set_kernel(capi.CSR_PANEL)
-        chosen = {k: A.get_param("panel_" + k) for k in ("rows", "groups", "layout", "unroll", "pipe", "sync", "stagger", "pace_ns", "bytes")}
+        chosen = {k: A.get_param("panel_" + k) for k in ("rows", "groups", "layout", "unroll", "pipe", "sync", "bytes")}
         print("chosen by trial:", chosen)
-        if chosen["pace_ns"] > 0:
-            # the run-time guard: start from a pace the chip cannot hold and watch it stretch back
-            A.set_param("panel_unroll", chosen["unroll"])
-            A.set_param("panel_pipe", chosen["pipe"])
-            A.set_param("panel_pace_ns", int(chosen["pace_ns"] * 0.8))
-            A.set_kernel(capi.CSR_PANEL)
-            for i in range(8):
-                ms = ctx.apply_timed(A, x, y, 3)
-                print(f"guard: pace {int(chosen['pace_ns'] * 0.8)} ns x {A.get_param('panel_pace_scale') / 1024:.3f} "
-                      f"(bumps {A.get_param('panel_pace_bumps')}): {ms:.4f} ms per product over 3 launches")
     elif a.what == "ell":
         n, k = a.n or 4_000_000, a.k or 64
         if a.band < 0:  # uniform-random columns: ELL made from the CSR generator
@@ -285,15 +273,14 @@ def main():
         csr = ctx.coo_to_csr(A)
         print(f"same matrix as CSR: auto kernel={csr.info.kernel} lanes={csr.info.lanes_per_row} max_row={csr.info.max_row_nnz}")
         variants = [(f"csr vector L={l}", lambda A, l=l: A.set_kernel(capi.CSR_VECTOR, l)) for l in (16, 64)]
-        for unroll, pace, rows in ((0, -1, 0), (8, 0, 0), (4, 0, 0), (0, -1, n // 512 + 1), (0, -1, n // 1024 + 1), (8, 0, n // 512 + 1)):
-            def setup(A, unroll=unroll, pace=pace, rows=rows):
+        for unroll, rows in ((0, 0), (8, 0), (4, 0), (0, n // 512 + 1), (0, n // 1024 + 1), (8, n // 512 + 1)):
+            def setup(A, unroll=unroll, rows=rows):
                 A.set_param("panel_unroll", unroll)
-                A.set_param("panel_pace_ns", pace)
                 A.set_param("panel_rows", rows)
                 A.set_kernel(capi.CSR_PANEL)
-            variants.append((f"csr panel U={unroll} pace={pace} rows={rows}", setup))
+            variants.append((f"csr panel U={unroll} rows={rows}", setup))
         sweep(ctx, csr, x, y, variants, a.rounds, a.reps, algorithmic_bytes("csr", n, n, nnz), nnz)
-        print("panel layout:", {k: csr.get_param("panel_" + k) for k in ("rows", "groups", "pace_ns", "unroll", "pipe", "layout")})
+        print("panel layout:", {k: csr.get_param("panel_" + k) for k in ("rows", "groups", "unroll", "pipe", "sync", "layout")})
 
 
 if __name__ == "__main__":
