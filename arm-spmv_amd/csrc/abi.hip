@@ -725,8 +725,12 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
                          "panel_keep_csr = 0 needs an owned CSR handle whose panel or two-phase layout is built");
             SPMV_HIP(hipSetDevice(m->ctx->device));
             SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
-            (void)hipFree(const_cast<int32_t*>(m->b));
-            (void)hipFree(const_cast<double*>(m->v));
+            // a two-phase handle first offers the gigabytes it is about to release to its product stream's piece search
+            // (kernels_csr_twophase.hip: memory of another moment of the allocator's history, at no transient cost)
+            bool keep_b = false, keep_v = false;
+            if (m->kernel == SPMV_CSR_TWOPHASE) SPMV_TRY(csr_twophase_offer_csr_copy(m, &keep_b, &keep_v));
+            if (!keep_b) (void)hipFree(const_cast<int32_t*>(m->b));
+            if (!keep_v) (void)hipFree(const_cast<double*>(m->v));
             m->b = nullptr;
             m->v = nullptr;
             m->device_bytes -= m->nnz * 12;
@@ -763,6 +767,8 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
     }
     else if (!strcmp(name, "panel_sync"))
         m->pb_sync = (int32_t)value;
+    else if (!strcmp(name, "twophase_offer_csr_copy"))
+        m->tp_offer_csr = value < 0 || value > 2 ? 1 : (int32_t)value;  // (2: tests - a carved piece is taken whatever the timings say)
     else if (!strcmp(name, "panel_trial"))
         m->pb_trial = (int32_t)value;
     else if (!strcmp(name, "symgs_order"))  // 1 multicolour, 0 the matrix's own row order; takes effect at the next set-up / sweep
@@ -891,6 +897,11 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         *value = m->ell_diag ? 1 : 0;
     else if (!strcmp(name, "twophase_panel_cols"))
         *value = m->tp_pcols;
+    else if (!strcmp(name, "twophase_pieces_carved"))  // pieces of the product stream that lie inside the released CSR copy's allocations
+    {
+        *value = 0;
+        for (int i = 0; i < m->tp_npieces; ++i) *value += m->tp_piece_carved[i] ? 1 : 0;
+    }
     else if (!strcmp(name, "twophase_placements_timed"))
         *value = m->tp_place_seen;
     else if (!strcmp(name, "twophase_placement_spread"))  // time as built / time with the pieces the search kept, in 1/1000

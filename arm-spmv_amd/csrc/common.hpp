@@ -212,6 +212,10 @@ struct spmv_mat
     uint16_t* tp_col       = nullptr;  // [padded] column - panel base, same order
     uint16_t* tp_row       = nullptr;  // [padded] row - group base, (group, panel) order; 0xFFFF = padding
     double*   tp_piece[4] = {};        // the stream between the two phases, (group, panel) order, in pieces of 2^26 pairs (1 GB)
+    bool      tp_piece_carved[4] = {}; // the piece lies inside tp_parent[] (an allocation taken over from the released CSR copy), not its own
+    void*     tp_parent[2] = {};       // allocations of the CSR copy (values, column indices) the product stream took over at panel_keep_csr = 0
+    int32_t   tp_carve_taken = 0;      // bit k: the last search took allocation k of those on offer
+    int32_t   tp_offer_csr = 1;        // panel_keep_csr = 0 offers the CSR copy's gigabytes to the piece search first (0: A/B, just release them)
     int32_t   tp_npieces   = 0;
     void*     tp_pool      = nullptr;  // experiments: a pool of pieces (kernels_csr_twophase.hip: tp_pool)
     int64_t   tp_last_piece_bytes = 0;  // the last piece: a whole one when the piece search ran, else what the stream needs of it
@@ -294,6 +298,7 @@ int  csr_twophase_build(spmv_mat* m);
 void csr_twophase_free(spmv_mat* m);
 bool csr_twophase_worth(const spmv_mat* m);
 int  csr_twophase_choose_again(spmv_mat* m);
+int  csr_twophase_offer_csr_copy(spmv_mat* m, bool* keep_b, bool* keep_v);
 int  csr_twophase_pool_alloc(spmv_mat* m, int extra);
 int  csr_twophase_pool_config(spmv_mat* m, int64_t code);
 

@@ -456,10 +456,16 @@ void csr_twophase_free(spmv_mat* m)
         m->tp_pool = nullptr;
     }
     for (int i = 0; i < kTpMaxPieces; ++i)
-        if (m->tp_piece[i])
+    {
+        if (m->tp_piece[i] && !m->tp_piece_carved[i]) (void)hipFree(m->tp_piece[i]);  // (a carved piece lies inside a parent, below)
+        m->tp_piece[i]        = nullptr;
+        m->tp_piece_carved[i] = false;
+    }
+    for (void*& parent : m->tp_parent)
+        if (parent)
         {
-            (void)hipFree(m->tp_piece[i]);
-            m->tp_piece[i] = nullptr;
+            (void)hipFree(parent);
+            parent = nullptr;
         }
     m->tp_npieces = 0;
     for (void** p : {(void**)&m->tp_val, (void**)&m->tp_col, (void**)&m->tp_row, (void**)&m->tp_blk, (void**)&m->tp_panel_ptr,
@@ -616,7 +622,17 @@ int tp_search_extra(const spmv_mat* m)
 // `early`: pieces the build allocated BEFORE the layout's own arrays (half the budget): together with the ones allocated here,
 // behind them, the pool spans the build's ~5 GB of other allocations as well - the allocator's runs of one class are long
 // (2-17 GB), so the span is what finds a second and a third class.  Consumed (kept or freed) here.
-int tp_choose_pieces(spmv_mat* m, std::vector<double*> early = {})
+// `carve`: allocations the handle is ABOUT TO RELEASE (the CSR copy's values and column indices, at panel_keep_csr = 0): whole
+// gigabytes inside them are candidates too - memory of another moment of the allocator's history at no transient cost at
+// all.  A parent that ends up under the stream is kept by the layout instead of being released (tp_parent) and the pieces
+// it replaced are freed; the others go back to the caller untouched (their contents are garbage afterwards: the search
+// writes products into them, which is why they are only offered when they are about to be released).
+struct tp_carve
+{
+    void*  base;
+    size_t bytes;
+};
+int tp_choose_pieces(spmv_mat* m, std::vector<double*> early = {}, std::vector<tp_carve> carve = {}, bool fresh = true)
 {
     spmv_ctx*    ctx   = m->ctx;
     const size_t piece = (size_t)16 << kTpPieceShift;
@@ -625,11 +641,16 @@ int tp_choose_pieces(spmv_mat* m, std::vector<double*> early = {})
     m->tp_place_seen   = 0;
     m->tp_place_gain   = 0;
     m->tp_pieces_exchanged  = 0;
+    m->tp_carve_taken  = 0;
     if (extra < 2 || need <= 0 || m->tp_last_piece_bytes != (int64_t)piece)  // (pieces must be interchangeable)
     {
         for (double* p : early) (void)hipFree(p);
         return SPMV_OK;
     }
+    // carved candidates: whole pieces inside the allocations on offer; parent_of[i] = index into `carve`, -1 = an allocation of its own
+    std::vector<int> parent_of((size_t)need, -1);
+    for (int i = 0; i < need; ++i)
+        if (m->tp_piece_carved[i]) parent_of[(size_t)i] = -2;  // carved earlier: lies in a parent the layout already keeps
 
     hipStream_t s = ctx->stream;
     double *    x = nullptr, *y = nullptr;
@@ -637,6 +658,13 @@ int tp_choose_pieces(spmv_mat* m, std::vector<double*> early = {})
     int         rc = SPMV_OK;
     std::vector<double*> cand(m->tp_piece, m->tp_piece + need);  // the stream's own pieces are candidates like the others
     cand.insert(cand.end(), early.begin(), early.end());
+    parent_of.resize(cand.size(), -1);
+    for (size_t k = 0; k < carve.size(); ++k)
+        for (size_t off = 0; off + piece <= carve[k].bytes; off += piece)
+        {
+            cand.push_back((double*)((char*)carve[k].base + off));
+            parent_of.push_back((int)k);
+        }
     apply_extra plain;
     // ms per product of the configuration `slots` (piece index per slot; slots past `need` repeat the last: never addressed)
     auto time_config = [&](const std::vector<int>& slots, float* out) -> bool {
@@ -670,7 +698,7 @@ int tp_choose_pieces(spmv_mat* m, std::vector<double*> early = {})
             hipMemsetAsync(x, 0, sizeof(double) * (size_t)m->ncol, s) != hipSuccess || hipMemsetAsync(y, 0, sizeof(double) * (size_t)m->nrow, s) != hipSuccess ||
             hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
             break;  // no room for the scratch vectors: the pieces stay as they are
-        for (int i = (int)early.size(); i < extra; ++i)
+        for (int i = (int)early.size(); fresh && i < extra; ++i)
         {
             double* p = nullptr;
             if (hipMalloc(&p, piece) != hipSuccess)
@@ -679,9 +707,23 @@ int tp_choose_pieces(spmv_mat* m, std::vector<double*> early = {})
                 break;
             }
             cand.push_back(p);
+            parent_of.push_back(-1);
         }
         const int n = (int)cand.size();
-        if (n < need + 2) break;
+        if (n < need + (carve.empty() ? 2 : 1)) break;
+        // A large pool is SAMPLED: the classes of physical memory come in runs of gigabytes to tens of gigabytes, so
+        // every k-th piece of a 64 GB pool reaches as far as all of them; the descent then times ~16 pieces per slot instead of
+        // 64 (bench.py's grant at N > 1: 390 configurations and 4.8 s of set-up per rank in round 4, ~100 and ~1 s now).
+        // The stream's own pieces and the carved ones always take part.
+        std::vector<bool> in_play((size_t)n, true);
+        {
+            int pool = 0;
+            for (int d = need; d < n; ++d) pool += parent_of[(size_t)d] == -1 ? 1 : 0;
+            const int stride = pool > 24 ? (pool + 15) / 16 : 1;
+            int       seen   = 0;
+            for (int d = need; d < n; ++d)
+                if (parent_of[(size_t)d] == -1 && (seen++ % stride) != 0) in_play[(size_t)d] = false;
+        }
         tp_grant_lds(ctx);
         // the configuration the layout was built with
         std::vector<int> slots((size_t)need);
@@ -707,7 +749,7 @@ int tp_choose_pieces(spmv_mat* m, std::vector<double*> early = {})
                 float best_t = t_cur;
                 for (int d = 0; ok && d < n; ++d)
                 {
-                    if (std::find(slots.begin(), slots.end(), d) != slots.end()) continue;
+                    if (!in_play[(size_t)d] || std::find(slots.begin(), slots.end(), d) != slots.end()) continue;
                     std::vector<int> c = slots;
                     c[(size_t)slot]   = d;
                     float t           = 0.f;
@@ -740,7 +782,19 @@ int tp_choose_pieces(spmv_mat* m, std::vector<double*> early = {})
         std::vector<int> built((size_t)need);
         for (int i = 0; i < need; ++i) built[(size_t)i] = i;
         t_kept = t_first;
-        if (slots != built)
+        // tests ("twophase_offer_csr_copy" 2): a carved piece goes under slot 0 whatever the timings say, so that the kernels,
+        // the accounting and the release of a stream that lies partly inside the old CSR copy are exercised on every box
+        bool forced = false;
+        if (m->tp_offer_csr == 2 && !carve.empty())
+            for (int d = need; d < n && !forced; ++d)
+                if (parent_of[(size_t)d] >= 0 && std::find(slots.begin(), slots.end(), d) == slots.end())
+                {
+                    bool has = false;
+                    for (int sidx : slots) has = has || parent_of[(size_t)sidx] >= 0;
+                    if (!has) slots[0] = d;
+                    forced = true;
+                }
+        if (slots != built && !forced)
         {
             float t_b = 1e30f, t_k = 1e30f;
             for (int rep = 0; ok && rep < 3; ++rep)
@@ -776,18 +830,48 @@ int tp_choose_pieces(spmv_mat* m, std::vector<double*> early = {})
         std::vector<bool> keep((size_t)n, false);
         for (int i = 0; i < need; ++i)
         {
-            m->tp_piece[i]                = cand[(size_t)slots[(size_t)i]];
-            keep[(size_t)slots[(size_t)i]] = true;
-            if (slots[(size_t)i] != i) ++m->tp_pieces_exchanged;  // (pieces exchanged by the search)
+            const int d                    = slots[(size_t)i];
+            m->tp_piece[i]                 = cand[(size_t)d];
+            m->tp_piece_carved[i]          = parent_of[(size_t)d] != -1;
+            keep[(size_t)d]                = true;
+            if (d != i) ++m->tp_pieces_exchanged;  // (pieces exchanged by the search)
+            if (parent_of[(size_t)d] >= 0)
+            {
+                // the allocation this piece lies in stays with the layout (freed with it); once per parent
+                tp_carve& c = carve[(size_t)parent_of[(size_t)d]];
+                if (c.base)
+                {
+                    for (void*& slot : m->tp_parent)
+                        if (!slot)
+                        {
+                            slot = c.base;
+                            m->tp_bytes += (int64_t)c.bytes;
+                            m->device_bytes += (int64_t)c.bytes;
+                            c.base = nullptr;  // (taken: the caller must not free it)
+                            break;
+                        }
+                }
+            }
         }
         for (int d = 0; d < n; ++d)
-            if (!keep[(size_t)d]) (void)hipFree(cand[(size_t)d]);
+            if (!keep[(size_t)d] && parent_of[(size_t)d] == -1)
+            {
+                (void)hipFree(cand[(size_t)d]);
+                if (d < need)  // one of the stream's own allocations made way for a carved piece
+                {
+                    m->tp_bytes -= (int64_t)piece;
+                    m->device_bytes -= (int64_t)piece;
+                }
+            }
+        m->tp_carve_taken = 0;
+        for (const tp_carve& c : carve) m->tp_carve_taken |= c.base ? 0 : 1 << (int)(&c - carve.data());
         m->tp_place_seen = tried;
         m->tp_place_gain = tp_spread_permille(t_first, t_kept, slots == built);
         searched         = true;
     } while (0);
     if (!searched)
-        for (size_t i = (size_t)need; i < cand.size(); ++i) (void)hipFree(cand[i]);  // the stream keeps the pieces it was built with
+        for (size_t i = (size_t)need; i < cand.size(); ++i)
+            if (parent_of[i] == -1) (void)hipFree(cand[i]);  // the stream keeps the pieces it was built with
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     if (x) (void)hipFree(x);
@@ -802,6 +886,7 @@ int tp_choose_pieces(spmv_mat* m, std::vector<double*> early = {})
 int csr_twophase_pool_alloc(spmv_mat* m, int extra)
 {
     SPMV_REQUIRE(m->tp_val && m->tp_npieces > 0 && m->tp_last_piece_bytes == ((int64_t)16 << kTpPieceShift), "needs a built layout with whole pieces");
+    for (int i = 0; i < m->tp_npieces; ++i) SPMV_REQUIRE(!m->tp_piece_carved[i], "twophase_pool_alloc: a piece of this stream lies inside the released CSR copy");
     SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
     if (!m->tp_pool)
     {
@@ -859,6 +944,28 @@ int csr_twophase_choose_again(spmv_mat* m)
         m->tp_last_piece_bytes = whole;
     }
     return tp_choose_pieces(m);
+}
+
+// panel_keep_csr = 0 on a two-phase handle: before col_ind / values of the CSR copy are released, whole gigabytes inside them
+// stand as candidates for the product stream beside the pieces it has (no fresh allocation: zero transient footprint).  Returns
+// in *keep_b / *keep_v whether the layout took the allocation over (then the caller must not free it).
+int csr_twophase_offer_csr_copy(spmv_mat* m, bool* keep_b, bool* keep_v)
+{
+    *keep_b = *keep_v = false;
+    if (!m->tp_val || m->tp_npieces <= 0 || m->tp_pool || !m->b || !m->v || !m->owned || !m->tp_offer_csr) return SPMV_OK;
+    if (m->tp_parent[0] || m->tp_parent[1]) return SPMV_OK;  // (once)
+    SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
+    std::vector<tp_carve> carve{{(void*)m->v, sizeof(double) * (size_t)m->nnz}, {(void*)m->b, sizeof(int32_t) * (size_t)m->nnz}};
+    const int seen0 = m->tp_place_seen, gain0 = m->tp_place_gain, exch0 = m->tp_pieces_exchanged;
+    const int rc    = tp_choose_pieces(m, {}, carve, /*fresh=*/false);
+    if (rc != SPMV_OK) return rc;
+    *keep_v = (m->tp_carve_taken & 1) != 0;
+    *keep_b = (m->tp_carve_taken & 2) != 0;
+    // the record keeps both searches: configurations add up, the spread multiplies, exchanges add up
+    m->tp_place_seen += seen0;
+    m->tp_place_gain = gain0 > 0 && m->tp_place_gain > 0 ? (int32_t)((int64_t)gain0 * m->tp_place_gain / 1000) : std::max(gain0, m->tp_place_gain);
+    m->tp_pieces_exchanged += exch0;
+    return SPMV_OK;
 }
 
 int csr_twophase_build(spmv_mat* m)

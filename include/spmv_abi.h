@@ -262,6 +262,12 @@ int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
  *                    "twophase_choose_pieces" (any value): run the search again on the built layout.  Streams below 512 MB
  *                    are never searched.  The outcome is reported by spmv_mat_get_param (below); a timing launch that fails
  *                    is an error of the call, not a silent fallback.
+ *                    Round 5: (a) a pool of more than 24 extra pieces is SAMPLED (every k-th piece, ~16 per slot): the classes of
+ *                    physical memory come in runs of gigabytes to tens of gigabytes, so a 64 GB pool reaches as far with a
+ *                    quarter of the timing launches; (b) "panel_keep_csr" 0 on a two-phase handle first offers the whole
+ *                    gigabytes inside the col_ind / values arrays it is about to release to the search (no allocation, ~0.1 s):
+ *                    an array that ends up under the stream stays with the layout, the pieces it replaced are freed
+ *                    ("twophase_pieces_carved"; "twophase_offer_csr_copy" 0 switches the offer off).
  *   "twophase_rotate"   1 (default): workgroup b of the expand phase starts b / 256 of the way through its panels
  *   "twophase_only", "twophase_realloc", "twophase_pool_alloc", "twophase_pool_config"   experiments, refused unless
  *                    SPMV_EXPERIMENTS=1 is in the environment: run phase A (1) or B (2) alone - THE PRODUCT IS THEN WRONG -,
@@ -287,6 +293,7 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value);
  * "panel_pipe", "panel_sync",
  * "panel_bytes", "panel_keep_csr", "device_bytes", "window_max_span", "window_avg_span", "twophase_panel_cols",
  * "twophase_padded" (entries of the two-phase layout with its padding), "twophase_pieces" (1 GB pieces of its product stream),
+ * "twophase_pieces_carved" (how many of them lie inside allocations taken over from the released CSR copy),
  * "ell_tiled_values" (1: the ELL product reads its values from the copy in tiles), "coo_column_bins" (bins of the copy the COO
  * segmented scan runs over, 0: none), "coo_bins_padded" (its entries with the padding),
  * "twophase_placement_budget_mb", "twophase_placements_timed" (configurations of pieces timed by the search, 0 = no search ran),

@@ -1633,6 +1633,59 @@ def test_twophase_piece_search_is_bounded_and_gives_its_memory_back(ctx, orc, pk
     del A, x, y, yv
 
 
+@pytest.mark.parametrize("offer", [0, 1, 2], ids=["released", "offered", "carved piece forced under the stream"])
+def test_twophase_stream_may_move_into_the_csr_copy_it_releases(ctx, orc, pkg, monkeypatch, offer):
+    """panel_keep_csr = 0 on a two-phase handle (round 5): the whole gigabytes inside col_ind / values are candidates for the
+    product stream before they are released - memory from another moment of the allocator's history at no transient cost.
+    Whatever the search decides (0: not offered; 1: offered, the timings decide; 2: a carved piece forced under slot 0), the
+    product is the oracle's, the handle's byte count equals what the device actually lost, and everything comes back with it."""
+    import gc
+
+    capi, synth = pkg.capi, pkg.synth
+    for name in ("SPMV_TP_PLACEMENT_BUDGET_MB", "SPMV_PANEL_TRIAL"):
+        monkeypatch.delenv(name, raising=False)
+    n, ncol, k = 4_500_000, 40_000_000, 32  # 144M entries: values 1.15 GB (one whole gigabyte to carve), a stream of two pieces
+    gc.collect()
+    ctx.sync()
+    free0, _ = ctx.mem_info()
+    A = ctx.gen_csr_uniform(0, n, ncol, k, seed=19)
+    assert A.info.kernel == capi.CSR_TWOPHASE and A.get_param("twophase_pieces") == 2 and A.get_param("twophase_pieces_carved") == 0
+    timed_at_build = A.get_param("twophase_placements_timed")
+    A.set_param("twophase_offer_csr_copy", offer)
+    A.set_param("panel_keep_csr", 0)
+    ctx.sync()
+    carved = A.get_param("twophase_pieces_carved")
+    assert carved == 0 if offer == 0 else (carved >= 1 if offer == 2 else carved in (0, 1))
+    if offer:
+        assert A.get_param("twophase_placements_timed") > timed_at_build and A.get_param("twophase_placement_spread") >= 1000
+    free1, _ = ctx.mem_info()
+    held = A.get_param("device_bytes")
+    assert abs((free0 - free1) - held) < 300 << 20, ((free0 - free1) >> 20, held >> 20, carved)
+    # a carved piece keeps its whole parent (values: 1.15 GB for 1 GB of stream) and gives one fresh gigabyte back
+    matrix = 12 * n * k
+    assert held <= 1.0 * matrix + 2.2e9 + (0.2e9 if carved else 0) + 8 * n * 2, (held, matrix)
+    x, y = ctx.gen_vector(ncol, seed=19), ctx.vector(n)
+    hx = synth.vec_uniform(ncol, seed=19)
+    for rep in range(2):
+        y.fill(0.0)
+        ctx.apply(A, x, y)
+        ctx.sync()
+        hy = y.download()
+        for r0 in (0, 2_222_000, n - 1500):
+            rp, cc, cv = synth.csr_uniform(r0, r0 + 1500, ncol, k, seed=19)
+            ref, scale = np.zeros(1500), np.zeros(1500)
+            ol.csr_spmv(orc, rp, cc, cv, hx, ref)
+            ol.csr_abs_row_sums(orc, rp, cc, cv, hx, scale)
+            ol.assert_parity(hy[r0:r0 + 1500], ref, scale, f"offer {offer}, carved {carved}, product {rep}: rows {r0}..")
+    with pytest.raises(capi.SpmvError):
+        A.download()  # the CSR arrays are gone either way (released, or under the stream)
+    del A, x, y
+    gc.collect()
+    ctx.sync()
+    free2, _ = ctx.mem_info()
+    assert abs(free0 - free2) < 300 << 20, ((free0 - free2) >> 20,)
+
+
 def test_handles_give_their_device_memory_back(ctx, pkg):
     """every layout a handle builds (CSR arrays, panel copy, packed words, slice tables, guard words, the regrouped
     copies of COO / ELL handles, solver work vectors) is released with it"""
