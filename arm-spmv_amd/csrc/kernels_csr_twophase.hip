@@ -755,6 +755,9 @@ int tp_choose_pieces(spmv_mat* m, std::vector<double*> early = {}, std::vector<t
                     float t           = 0.f;
                     ok                = time_config(c, &t);
                     ++tried;
+                    // a carved piece keeps its whole parent allocated (2.56 GB of values for one gigabyte of stream on the C5
+                    // shard): it has to be worth 2 % of the product, not the 0.3 % a fresh gigabyte has to be
+                    if (parent_of[(size_t)d] >= 0) t *= 1.02f;
                     if (ok && t < best_t)
                     {
                         best_t = t;
@@ -853,16 +856,21 @@ int tp_choose_pieces(spmv_mat* m, std::vector<double*> early = {}, std::vector<t
                 }
             }
         }
+        // allocations of their own under the stream: before (the first `need` candidates that are no carved pieces) and after
+        int own_before = 0, own_after = 0;
+        for (int d = 0; d < need; ++d) own_before += parent_of[(size_t)d] == -1 ? 1 : 0;
         for (int d = 0; d < n; ++d)
-            if (!keep[(size_t)d] && parent_of[(size_t)d] == -1)
-            {
+        {
+            if (parent_of[(size_t)d] != -1) continue;
+            if (keep[(size_t)d])
+                ++own_after;
+            else
                 (void)hipFree(cand[(size_t)d]);
-                if (d < need)  // one of the stream's own allocations made way for a carved piece
-                {
-                    m->tp_bytes -= (int64_t)piece;
-                    m->device_bytes -= (int64_t)piece;
-                }
-            }
+        }
+        // (an own piece exchanged for a fresh one changes nothing; one that made way for a carved piece is a gigabyte less -
+        // the parent's bytes were added above)
+        m->tp_bytes -= (int64_t)(own_before - own_after) * (int64_t)piece;
+        m->device_bytes -= (int64_t)(own_before - own_after) * (int64_t)piece;
         m->tp_carve_taken = 0;
         for (const tp_carve& c : carve) m->tp_carve_taken |= c.base ? 0 : 1 << (int)(&c - carve.data());
         m->tp_place_seen = tried;

@@ -527,8 +527,9 @@ def main() -> None:
     ap.add_argument("--placement-budget-mb", type=int, default=0,
                     help="two-phase shards (x several times longer than the shard has rows: N >= 4): device memory the piece search of the product "
                          "stream may hold while it runs; 0 = 65536 at N > 1 (one slow rank sets the step of the whole job, the job has the devices "
-                         "to itself, and the device's memory comes in one-class chunks of up to ~60 GB: DESIGN 4.7) and the engine's own default, "
-                         "8192, at N = 1 (include/spmv_abi.h, 'twophase_placement_budget_mb')")
+                         "to itself, and the device's memory comes in one-class chunks of up to ~60 GB: DESIGN 4.7; since round 5 the pool is "
+                         "sampled, ~1-2 s of set-up per rank instead of 4.8) and the engine's own default, 8192, at N = 1 (include/spmv_abi.h, "
+                         "'twophase_placement_budget_mb')")
     ap.add_argument("--partition", choices=("rows", "nnz", "both"), default="both",
                     help="the skewed extra (C4's row lengths sorted by length, the heavy rows at one end): cut into shards by equal rows "
                          "(the reference's split, src/mat_vec.cpp:245-246), by stored entries (spmv_partition_rows_balanced), or both")
