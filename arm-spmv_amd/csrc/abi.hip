@@ -205,6 +205,17 @@ static int ctx_create_common(int device, void* borrowed_stream, bool borrow, spm
         SPMV_FAIL(SPMV_ERR_HIP, "context setup: %s", hipGetErrorString(e));
     }
     xcd_probe(ctx);  // one small launch: do workgroups b and b + 8 share an XCD on this device? (see below)
+    {
+        int large = 0;
+        if (hipDeviceGetAttribute(&large, hipDeviceAttributeIsLargeBar, device) == hipSuccess && large)
+        {
+            unsigned* reg = nullptr;
+            if (hipDeviceGetAttribute((int*)&reg, hipDeviceAttributeHdpMemFlushCntl, device) == hipSuccess) ctx->hdp_flush = reg;
+            const char* off = getenv("SPMV_HOST_STORES");  // SPMV_HOST_STORES=0: never store into device memory from the CPU (A/B; read once per context)
+            ctx->large_bar  = !(off && off[0] == '0');
+        }
+        (void)hipGetLastError();
+    }
     *out = ctx;
     return SPMV_OK;
 }
@@ -1031,10 +1042,12 @@ int spmv_apply_timed(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* x, spmv_v
 // them 50 times).  Behind that signature a product costs two hand-overs whatever the kernel does; for small matrices they ARE the
 // cost (C1: kernel 3 us).  Rounds 1-4 paid three synchronous hipMemcpy of pageable memory per call (~17 us each: 67 us per C1
 // product, 4.8 GFLOP/s against the reference's 5.6 on one CPU thread).  Here, for vectors up to 4 MB together: the host copies
-// x and y into a pinned, device-mapped staging buffer (memcpy: 80 KB in 3 us), one kernel pulls x into a device buffer over
-// the host link, the product gathers from there and updates y IN the staging buffer (kernels that add into y with device
-// atomics - the COO scan, the CSC scatter - get y through a device buffer and a third launch instead), the host polls the
-// stream (hipStreamQuery: no interrupt wake-up) and copies y out.  Two launches on one stream, no hipMemcpy.  Larger vectors take asynchronous copies from / to the caller's memory
+// y into a pinned, device-mapped staging buffer (memcpy: 80 KB in 3 us) and stores x straight into a device buffer where the
+// platform lets the CPU do that (large BAR: 80 KB in 2 us; elsewhere x goes through the staging buffer and one kernel pulls it
+// over the host link), the product gathers x from device memory and updates y IN the staging buffer (kernels that add into y
+// with device atomics - the COO scan, the CSC scatter - get y through a device buffer and two more launches instead), the
+// host polls the stream (hipStreamQuery: no interrupt wake-up) and copies y out.  ONE launch, no hipMemcpy: what is left of a
+// C1 product is the 12-17 us a kernel launch takes from doorbell to completion signal on this platform.  Larger vectors take asynchronous copies from / to the caller's memory
 // (the PCIe time dominates there).  The caller's arrays are never registered or mapped: they may be freed or re-allocated
 // between calls without a stale mapping being left behind.
 static int grow(double** p, size_t* have, size_t want)
@@ -1092,7 +1105,7 @@ int spmv_apply_host(spmv_ctx* ctx, const spmv_mat* A, const double* x_host, doub
         }
         double* hx = ctx->stage_pinned;
         double* hy = ctx->stage_pinned + nx;
-        if (nx) memcpy(hx, x_host, sizeof(double) * nx);
+        if (nx && !ctx->large_bar) memcpy(hx, x_host, sizeof(double) * nx);
         memcpy(hy, y_host, sizeof(double) * ny);
         // Kernels that touch every y_i once with a plain read and a plain store (the row-parallel, LDS-window, scalar, panel and
         // two-phase CSR kernels, the ELL kernels, and COO / ELL / CSC handles running from their row-grouped CSR copy) update y
@@ -1100,15 +1113,26 @@ int spmv_apply_host(spmv_ctx* ctx, const spmv_mat* A, const double* x_host, doub
         // atomics, which host memory may not support: y goes through a device buffer there, three launches.
         const bool from_copy = A->coo_csr && (A->format == SPMV_FMT_CSC ? !A->kernel_forced : A->kernel == SPMV_CSR_PANEL);
         const bool y_in_place = A->format == SPMV_FMT_CSR || A->format == SPMV_FMT_ELL || ((A->format == SPMV_FMT_COO || A->format == SPMV_FMT_CSC) && from_copy);
+        // x: where the CPU can store into device memory (large BAR) it writes x into the device buffer itself - 80 KB in 2 us,
+        // no launch (tools/probe_host_write_vram.hip: the next kernel sees the stores, also right after a kernel that read the
+        // previous contents; the HDP flush register is written behind them as the platform prescribes for such stores).
+        // Elsewhere one kernel pulls x out of the staging buffer over the host link.
+        const bool direct = ctx->large_bar != 0;
+        if (direct && nx)
+        {
+            memcpy(ctx->stage_x, x_host, sizeof(double) * nx);
+            __sync_synchronize();
+            if (ctx->hdp_flush) *ctx->hdp_flush = 1u;
+        }
         if (y_in_place)
         {
             vy.d = ctx->stage_pinned_dev + nx;
-            SPMV_TRY(vec_copy2(ctx, ctx->stage_x, ctx->stage_pinned_dev, (int64_t)nx, nullptr, nullptr, 0));
+            if (!direct) SPMV_TRY(vec_copy2(ctx, ctx->stage_x, ctx->stage_pinned_dev, (int64_t)nx, nullptr, nullptr, 0));
             SPMV_TRY(apply_checked(ctx, A, &vx, &vy));
         }
         else
         {
-            SPMV_TRY(vec_copy2(ctx, ctx->stage_x, ctx->stage_pinned_dev, (int64_t)nx, ctx->stage_y, ctx->stage_pinned_dev + nx, (int64_t)ny));
+            SPMV_TRY(vec_copy2(ctx, ctx->stage_x, ctx->stage_pinned_dev, direct ? 0 : (int64_t)nx, ctx->stage_y, ctx->stage_pinned_dev + nx, (int64_t)ny));
             SPMV_TRY(apply_checked(ctx, A, &vx, &vy));
             SPMV_TRY(vec_copy2(ctx, ctx->stage_pinned_dev + nx, ctx->stage_y, (int64_t)ny, nullptr, nullptr, 0));
         }

@@ -117,6 +117,11 @@ struct spmv_ctx
     double* stage_x = nullptr;
     double* stage_y = nullptr;
     size_t  stage_x_n = 0, stage_y_n = 0;
+    // can the CPU store straight into device memory (large BAR: hipDeviceAttributeIsLargeBar)?  Then spmv_apply_host writes a
+    // small x into its device buffer itself (80 KB in 2 us) instead of launching a kernel that pulls it over the host link;
+    // hdp_flush: the HDP flush register (hipDeviceAttributeHdpMemFlushCntl), written after such stores
+    int32_t            large_bar = 0;
+    volatile unsigned* hdp_flush = nullptr;
 };
 
 namespace spmv

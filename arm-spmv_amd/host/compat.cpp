@@ -141,7 +141,7 @@ void drop(T*& p)
 }
 
 // Fingerprint of a host container for the device-copy cache (engine.hpp): dimensions, array addresses and up to
-// 2048 evenly spaced elements of every array (first and last included).  Cheap enough for every call (a few
+// 2048 (small arrays: 256) evenly spaced elements of every array (first and last included).  Cheap enough for every call (a few
 // thousand reads next to the PCIe copies of x and y); catches a re-pointed or re-allocated container and edits that
 // touch a sampled element.  An in-place edit that dodges every sample needs spmv_compat_invalidate().
 inline uint64_t fp_mix(uint64_t h, uint64_t v)
@@ -155,7 +155,9 @@ uint64_t fp_array(uint64_t h, const T* p, size_t n)
     h = fp_mix(h, (uint64_t)(uintptr_t)p);
     h = fp_mix(h, (uint64_t)n);
     if (!p || n == 0) return h;
-    const size_t samples = std::min<size_t>(n, 2048);
+    // (2048 samples of arrays with a million elements and more; 256 of smaller ones, where the hand-over of x and y is tens of
+    // microseconds and three times 2048 scattered reads would be a fifth of the call)
+    const size_t samples = std::min<size_t>(n, n >= ((size_t)1 << 20) ? 2048 : 256);
     for (size_t k = 0; k < samples; ++k)
     {
         const size_t i = samples > 1 ? (size_t)(((unsigned __int128)k * (n - 1)) / (samples - 1)) : 0;

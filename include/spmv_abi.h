@@ -324,8 +324,9 @@ int spmv_apply_timed(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* x, spmv_v
 /* y_host += A * x_host with the caller's HOST vectors, synchronous - the reference's own call shape (include/mat_vec.h:7-11:
  * every CSRMatrixMatVector(A, x, y) hands over host arrays; main.cpp:56-59 does it 50 times), as ONE entry point so that the
  * hand-over can be done the cheapest way for its size: vectors of up to 4 MB together go through a pinned, device-mapped
- * staging buffer of the context that the GPU reads and writes itself (two launches on the context's stream - three for the
- * kernels that add into y with atomics -, no hipMemcpy, the host polls; C1: 67 -> ~35 us per product); larger ones through asynchronous copies.  x_host has ncol entries, y_host
+ * staging buffer of the context that the GPU reads and writes itself, x by CPU stores straight into device memory where the
+ * platform has a large BAR (one launch on the context's stream - three for the kernels that add into y with atomics -, no
+ * hipMemcpy, the host polls; SPMV_HOST_STORES=0: x through the staging buffer and a second launch); larger ones through asynchronous copies.  x_host has ncol entries, y_host
  * nrow.  The caller's arrays are neither registered nor mapped (they may be freed or moved between calls).  Never part of a
  * throughput figure: resident vectors (spmv_apply) are what the roofline numbers are measured with. */
 int spmv_apply_host(spmv_ctx* ctx, const spmv_mat* A, const double* x_host, double* y_host);
