@@ -419,7 +419,7 @@ def pmc_child(args) -> None:
     print(json.dumps({"pmc_child": True, "kernel_id": int(A.info.kernel), "panel_layout": layout}), flush=True)
 
 
-PRODUCT_KERNELS = {4: ("csr_panel_kernel",), 5: ("tp_expand_kernel", "tp_reduce_kernel"), 1: ("csr_vector_kernel",), 2: ("csr_ldswin_kernel",),
+PRODUCT_KERNELS = {4: ("csr_panel_pp_kernel",), 5: ("tp_expand_kernel", "tp_reduce_kernel"), 1: ("csr_vector_kernel",), 2: ("csr_ldswin_kernel",),
                    3: ("csr_scalar_kernel",)}
 
 
@@ -431,9 +431,9 @@ def pmc_mean_of_products(rows: list, kernel_id: int):
     per_kernel, shown = {}, None
     for name in PRODUCT_KERNELS.get(kernel_id, ()):
         mine = [row for row in rows if name in row["Kernel_Name"]]
-        if name == "csr_panel_kernel":
-            # template <U, LAYOUT, PIPE, TRIAL, TRACE, SYNC>, or the gather-first order written down (round 5):
-            # csr_panel_pp_kernel<U, LAYOUT, ORDER, TRIAL, SYNC> - the fourth argument says "a build-time trial launch" in both
+        if name == "csr_panel_pp_kernel":
+            # csr_panel_pp_kernel<U, LAYOUT, ORDER, TRIAL, SYNC> (rounds 2-4: csr_panel_kernel<U, LAYOUT, PIPE, TRIAL, TRACE, SYNC>):
+            # the fourth argument says "a build-time trial launch" in both
             mine = [row for row in rows if "csr_panel_kernel<" in row["Kernel_Name"] or "csr_panel_pp_kernel<" in row["Kernel_Name"]]
             mine = [row for row in mine if row["Kernel_Name"].split("_kernel<")[1].split(">")[0].split(",")[3].strip() == "false"]
         mine.sort(key=lambda row: int(row["Dispatch_Id"]))
@@ -700,8 +700,8 @@ def main() -> None:
         def describe(fmt, M, inf, flags):
             """(kernel that runs, which bytes it has to move) of a handle"""
             kid = int(inf.kernel)
-            inner_names = {1: "csr_vector_kernel", 2: "csr_ldswin_kernel", 3: "csr_scalar_kernel", 4: "csr_panel_kernel", 5: "tp_expand_kernel + tp_reduce_kernel (two-phase)"}
-            inner = inner_names.get(M.get_param("rowgrouped_kernel"), "csr_panel_kernel") if fmt in ("ell", "coo") and kid == 4 else None
+            inner_names = {1: "csr_vector_kernel", 2: "csr_ldswin_kernel", 3: "csr_scalar_kernel", 4: "csr_panel_pp_kernel", 5: "tp_expand_kernel + tp_reduce_kernel (two-phase)"}
+            inner = inner_names.get(M.get_param("rowgrouped_kernel"), "csr_panel_pp_kernel") if fmt in ("ell", "coo") and kid == 4 else None
             if fmt == "ell":
                 if kid == 4:
                     return f"{inner} on the row-grouped copy of the ELL slots", "panel"
@@ -711,12 +711,12 @@ def main() -> None:
                 return "ell_kernel_x2 (one lane per two rows, column-major slots, every column index read)", "ell_columns"
             if fmt == "coo":
                 if kid == 4:
-                    return f"{inner} on the row-grouped copy" + (" (12-byte packed entries)" if inner == "csr_panel_kernel" else ""), "panel"
+                    return f"{inner} on the row-grouped copy" + (" (12-byte packed entries)" if inner == "csr_panel_pp_kernel" else ""), "panel"
                 if M.get_param("coo_column_bins"):
                     return (f"coo_segscan_bins_kernel (wavefront segmented scan over a copy of the entries in {M.get_param('coo_column_bins')} column "
                             "bins, one per XCD: each XCD gathers x from a slice that stays in its L2)"), "coo_segscan"
                 return "coo_segscan_kernel (wavefront segmented scan over the entries in file order)", "coo_segscan"
-            names = {1: "csr_vector_kernel", 2: "csr_ldswin_kernel", 3: "csr_scalar_kernel", 4: "csr_panel_kernel",
+            names = {1: "csr_vector_kernel", 2: "csr_ldswin_kernel", 3: "csr_scalar_kernel", 4: "csr_panel_pp_kernel",
                      5: "tp_expand_kernel + tp_reduce_kernel (two-phase)"}
             return names.get(kid, str(kid)), "csr"
 
@@ -909,7 +909,7 @@ def main() -> None:
         gflops = 2.0 * nnz_total * args.steps / wall_s / 1e9
         bytes_launch = algorithmic_bytes("csr", n, ncol, nnz_rank)
         achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9
-        kernel_names = {1: "csr_vector_kernel", 2: "csr_ldswin_kernel", 3: "csr_scalar_kernel", 4: "csr_panel_kernel",
+        kernel_names = {1: "csr_vector_kernel", 2: "csr_ldswin_kernel", 3: "csr_scalar_kernel", 4: "csr_panel_pp_kernel",
                         5: "tp_expand_kernel + tp_reduce_kernel (two-phase)"}
         kernel_name = kernel_names.get(int(info.kernel), str(info.kernel))
         panel = panel_of(A) if int(info.kernel) == 4 else None

@@ -26,14 +26,14 @@ def test_counters_are_reported_only_for_the_kernel_and_layout_they_were_measured
     table = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
     key = "csr_n10000000_k32_band0_ncol10000000"
     layout = dict(table[key]["match"]["panel_layout"])
-    got = bench.measured_counters(key, "csr_panel_kernel", layout)
+    got = bench.measured_counters(key, "csr_panel_pp_kernel", layout)
     assert got["traffic"] == table[key]["hbm_bytes_per_launch"] and got["l2_line_ops"] == table[key]["tcp_tcc_read_req"] + table[key]["tcc_miss"]
     assert 270e6 < got["l2_line_ops"] < 280e6
     other = dict(layout, unroll=4)
-    stale = bench.measured_counters(key, "csr_panel_kernel", other)
+    stale = bench.measured_counters(key, "csr_panel_pp_kernel", other)
     assert stale["traffic"] is None and stale["l2_line_ops"] is None and "stale" in stale["measured_on"]
     assert bench.measured_counters(key, "tp_expand_kernel + tp_reduce_kernel (two-phase)", None)["traffic"] is None
-    assert bench.measured_counters("no_such_workload", "csr_panel_kernel", layout) == {"traffic": None, "l2_line_ops": None, "measured_on": None}
+    assert bench.measured_counters("no_such_workload", "csr_panel_pp_kernel", layout) == {"traffic": None, "l2_line_ops": None, "measured_on": None}
     # every entry of the table that carries a stamp names a kernel
     for name, e in table.items():
         if isinstance(e, dict) and "match" in e:
@@ -47,12 +47,15 @@ def test_live_counter_rows_are_reduced_to_the_products_of_the_right_kernel():
     sig = "(int const*, int, int const*)"
     rows = []
     did = 0
-    for name, val in ([(ns + "gen_csr_uniform_kernel(long)", 9e9)] + [(ns + "csr_panel_kernel<8, 4, 2, true, false, 1>" + sig, 1e9)] * 8 +
-                      [(ns + "csr_panel_kernel<8, 4, 2, false, false, 1>" + sig, v) for v in (7.0, 100.0, 101.0, 102.0)]):
+    for name, val in ([(ns + "gen_csr_uniform_kernel(long)", 9e9)] + [(ns + "csr_panel_pp_kernel<8, 4, 2, true, 1>" + sig, 1e9)] * 8 +
+                      [(ns + "csr_panel_pp_kernel<8, 4, 2, false, 1>" + sig, v) for v in (7.0, 100.0, 101.0, 102.0)]):
         did += 1
         rows.append({"Kernel_Name": name, "Dispatch_Id": str(did), "Counter_Value": str(val), "Counter_Name": "FETCH_SIZE"})
     per, shown = bench.pmc_mean_of_products(rows, 4)
-    assert per == {"csr_panel_kernel": 101.0} and shown == "csr_panel_kernel<8, 4, 2, false, false, 1>"
+    assert per == {"csr_panel_pp_kernel": 101.0} and shown == "csr_panel_pp_kernel<8, 4, 2, false, 1>"
+    # three product launches that are not one kernel (a handle re-selected between them) are not a measurement
+    mixed = rows + [{"Kernel_Name": ns + "csr_panel_pp_kernel<4, 4, 2, false, 3>" + sig, "Dispatch_Id": str(did + 1), "Counter_Value": "5", "Counter_Name": "FETCH_SIZE"}]
+    assert "not one kernel" in bench.pmc_mean_of_products(mixed, 4)
     # the two-phase product is two kernels; their means add up in the caller
     tp = [{"Kernel_Name": ns + n + "(int, spmv::(anonymous namespace)::tp_piece_tab, int)", "Dispatch_Id": str(i), "Counter_Value": str(v)}
           for i, (n, v) in enumerate([("tp_expand_kernel<1024, 3, true>", 5.0), ("tp_reduce_kernel", 1.0)] * 4)]
