@@ -32,6 +32,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "arm_spmv_compat.hpp"
@@ -84,6 +85,12 @@ void resident(const char* name, double nnz, int nrow, const Vector& x, int reps,
     check(spmv_vec_fill(dy, 0.0), "spmv_vec_fill");
     double ms = 0.0;
     check(spmv_apply(E.ctx(0), m, dx, dy), "spmv_apply");  // warm-up
+    check(spmv_vec_fill(dy, 0.0), "spmv_vec_fill");
+    // 20 ms of quiet first: products launched within a millisecond of device memory being allocated or freed (the handle
+    // and the vectors were just made) ran up to 2x slower on this platform, whichever kernel they were
+    check(spmv_sync(E.ctx(0)), "spmv_sync");
+    std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    check(spmv_apply(E.ctx(0), m, dx, dy), "spmv_apply");
     check(spmv_vec_fill(dy, 0.0), "spmv_vec_fill");
     check(spmv_apply_timed(E.ctx(0), m, dx, dy, reps, &ms), "spmv_apply_timed");
     spmv_mat_info info;
