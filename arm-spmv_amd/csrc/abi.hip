@@ -654,6 +654,24 @@ int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
         }
         return SPMV_OK;
     }
+    if (m->format == SPMV_FMT_CSC)
+    {
+        // CSC: AUTO = the scatter or the row-grouped copy, timed; VECTOR = the scatter over the columns; PANEL = regroup now, panel layout
+        SPMV_REQUIRE(kernel == SPMV_CSR_AUTO || kernel == SPMV_CSR_VECTOR || kernel == SPMV_CSR_PANEL,
+                     "CSC handles take kernel AUTO (0), VECTOR (1: scatter over the columns) or PANEL (4), got %d", kernel);
+        SPMV_HIP(hipSetDevice(m->ctx->device));
+        m->kernel_forced = kernel != SPMV_CSR_AUTO;
+        if (kernel == SPMV_CSR_VECTOR)
+            m->kernel = SPMV_CSR_VECTOR;
+        else if (kernel == SPMV_CSR_AUTO)
+            SPMV_TRY(csc_select_kernel(m));
+        else
+        {
+            SPMV_TRY(csc_build_rowgrouped(m, SPMV_CSR_PANEL));
+            m->kernel = m->coo_csr ? SPMV_CSR_PANEL : SPMV_CSR_VECTOR;
+        }
+        return SPMV_OK;
+    }
     if (m->format == SPMV_FMT_ELL)
     {
         // ELL: AUTO = panel layout when the columns are scattered, VECTOR = one lane per row, PANEL = build it now
@@ -943,7 +961,7 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         *value = (int64_t)(m->sel_us[slot] + 0.5f);
     }
     else if (!strcmp(name, "rowgrouped_kernel"))
-        *value = m->coo_csr && (m->format == SPMV_FMT_CSC ? !m->kernel_forced : m->kernel == SPMV_CSR_PANEL) ? m->coo_csr->kernel : 0;
+        *value = m->coo_csr && m->kernel == SPMV_CSR_PANEL ? m->coo_csr->kernel : 0;
     else if (!strcmp(name, "ell_variant"))
         *value = m->ell_variant;
     else
@@ -1111,7 +1129,7 @@ int spmv_apply_host(spmv_ctx* ctx, const spmv_mat* A, const double* x_host, doub
         // two-phase CSR kernels, the ELL kernels, and COO / ELL / CSC handles running from their row-grouped CSR copy) update y
         // IN the staging buffer over the host link: two launches.  The COO scan and the CSC scatter add into y with device
         // atomics, which host memory may not support: y goes through a device buffer there, three launches.
-        const bool from_copy = A->coo_csr && (A->format == SPMV_FMT_CSC ? !A->kernel_forced : A->kernel == SPMV_CSR_PANEL);
+        const bool from_copy = A->coo_csr && A->kernel == SPMV_CSR_PANEL;
         const bool y_in_place = A->format == SPMV_FMT_CSR || A->format == SPMV_FMT_ELL || ((A->format == SPMV_FMT_COO || A->format == SPMV_FMT_CSC) && from_copy);
         // x: where the CPU can store into device memory (large BAR) it writes x into the device buffer itself - 80 KB in 2 us,
         // no launch (tools/probe_host_write_vram.hip: the next kernel sees the stores, also right after a kernel that read the

@@ -349,6 +349,9 @@ int coo_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 // kernels_misc.hip (CSC, DIA, BLAS-1, fill)
 int csc_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 int csc_analyse(spmv_mat* m);
+int csc_select_kernel(spmv_mat* m);                       // AUTO: the scatter or the row-grouped copy (which picks its own kernel), timed
+int csc_build_rowgrouped(spmv_mat* m, int32_t force_kernel);
+void csc_drop_rowgrouped(spmv_mat* m);
 int dia_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 int vec_fill(spmv_ctx* ctx, double* d, int64_t n, double a);
 int vec_copy2(spmv_ctx* ctx, double* dst0, const double* src0, int64_t n0, double* dst1, const double* src1, int64_t n1);  // two copies, one launch

@@ -321,14 +321,48 @@ __global__ __launch_bounds__(kBlock) void csc_expand_cols_kernel(int ncol, const
     for (int j = col_ptr[c] + threadIdx.x % LPC; j < end; j += LPC) col_of_entry[j] = c;
 }
 
-int csc_analyse(spmv_mat* m)
+namespace
 {
-    const bool worth = m->nnz >= ((int64_t)2 << 20) && m->nrow > 0 && m->nnz / m->nrow >= 2 &&
-                       m->nnz <= (int64_t)INT32_MAX - 65536 && launch_fits(m->ncol, 8);
-    if (!worth || m->coo_csr) return SPMV_OK;
-    spmv_ctx* ctx = m->ctx;
+int csc_scatter_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
+{
+    constexpr int LPC = 8;
+    if (!launch_fits(A->ncol, LPC)) SPMV_FAIL(SPMV_ERR_UNSUPPORTED, "CSC product: %d columns are more than one launch holds", A->ncol);
+    hipLaunchKernelGGL(csc_kernel<LPC>, dim3((unsigned)ceil_div(A->ncol, kBlock / LPC)), dim3(kBlock), 0, ctx->stream,
+                       A->ncol, A->a, A->b, A->v, x, y);
+    SPMV_HIP(hipGetLastError());
+    return SPMV_OK;
+}
+}  // namespace
+
+void csc_drop_rowgrouped(spmv_mat* m)
+{
+    if (!m->coo_csr) return;
+    (void)hipStreamSynchronize(m->ctx->stream);
+    m->device_bytes -= m->coo_csr->device_bytes;
+    mat_free(m->coo_csr);
+    m->coo_csr = nullptr;
+    if (m->kernel == SPMV_CSR_PANEL) m->kernel = SPMV_CSR_VECTOR;
+}
+
+// The entries of a CSC handle grouped by row on the device (column expansion + spmv_coo_to_csr through a borrowed COO view of
+// the same arrays: duplicates and the column-major order inside a row kept) as an internal CSR handle; force_kernel AUTO: that
+// copy picks its kernel like any CSR handle (select.hip), PANEL: the panel layout (spmv_mat_set_kernel(csc, SPMV_CSR_PANEL)).
+int csc_build_rowgrouped(spmv_mat* m, int32_t force_kernel)
+{
+    if (m->coo_csr && (force_kernel == SPMV_CSR_AUTO || m->coo_csr->kernel == force_kernel))
+    {
+        m->kernel = SPMV_CSR_PANEL;
+        return SPMV_OK;
+    }
+    if (m->nnz == 0 || m->nnz > (int64_t)INT32_MAX - 65536 || !launch_fits(m->ncol, 8)) return SPMV_OK;
+    csc_drop_rowgrouped(m);
+    spmv_ctx* ctx  = m->ctx;
     int32_t*  cols = nullptr;
-    SPMV_HIP(hipMalloc(&cols, sizeof(int32_t) * (size_t)m->nnz));
+    if (hipMalloc(&cols, sizeof(int32_t) * (size_t)m->nnz) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        SPMV_FAIL(SPMV_ERR_ALLOC, "no device memory for the column indices of %lld CSC entries", (long long)m->nnz);
+    }
     constexpr int LPC = 8;
     hipLaunchKernelGGL(csc_expand_cols_kernel<LPC>, dim3((unsigned)ceil_div(m->ncol, kBlock / LPC)), dim3(kBlock), 0,
                        ctx->stream, m->ncol, m->a, cols);
@@ -343,28 +377,82 @@ int csc_analyse(spmv_mat* m)
     view.b      = cols;
     view.v      = m->v;
     view.owned  = false;
-    view.kernel_forced = true;  // no panel build for the temporary view itself
-    int rc = coo_analyse(&view);  // sortedness of the row indices
-    if (rc == SPMV_OK) rc = coo_build_panel(&view, /*only_if_worth=*/false);
+    view.pb_trial      = m->pb_trial;
+    view.kernel_forced = true;  // nothing is selected or built for the temporary view itself
+    int       rc  = coo_analyse(&view);  // sortedness of the row indices
+    spmv_mat* csr = nullptr;
+    if (rc == SPMV_OK) rc = coo_to_csr(ctx, &view, &csr, force_kernel);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(cols);
     if (rc != SPMV_OK) return rc;
-    m->coo_csr = view.coo_csr;  // adopt; `view` itself owns nothing else
-    m->device_bytes += m->coo_csr->device_bytes;
-    view.coo_csr = nullptr;
+    // the panel and two-phase layouts read row_ptr and their own arrays only
+    if ((csr->kernel == SPMV_CSR_PANEL || csr->kernel == SPMV_CSR_TWOPHASE) && csr->b && csr->v)
+    {
+        (void)hipFree(const_cast<int32_t*>(csr->b));
+        (void)hipFree(const_cast<double*>(csr->v));
+        csr->device_bytes -= (int64_t)csr->nnz * 12;
+        csr->b = nullptr;
+        csr->v = nullptr;
+    }
+    m->coo_csr = csr;
+    m->kernel  = SPMV_CSR_PANEL;  // reported for CSC as "runs from the row-grouped copy"
+    m->device_bytes += csr->device_bytes;
     return SPMV_OK;
+}
+
+// AUTO for a CSC handle (round 5, select.hip): the scatter over the columns (one fp64 atomic on y per entry) or the copy grouped
+// by row.  Model: the copy from 1.5M entries on; from 64K entries on both are timed.
+int csc_select_kernel(spmv_mat* m)
+{
+    spmv_ctx* ctx = m->ctx;
+    select_reset(m);
+    csc_drop_rowgrouped(m);
+    m->kernel = SPMV_CSR_VECTOR;
+    if (m->nnz == 0 || m->nrow <= 0 || m->ncol <= 0) return SPMV_OK;
+    const bool model_copy = m->nnz >= ((int64_t)3 << 19);
+    if (!select_trials_enabled(m) || m->nnz < kSelectMinNnz) return model_copy ? csc_build_rowgrouped(m, SPMV_CSR_AUTO) : SPMV_OK;
+    select_scratch sv;
+    if (sv.alloc(ctx, m->ncol, m->nrow) != SPMV_OK) return model_copy ? csc_build_rowgrouped(m, SPMV_CSR_AUTO) : SPMV_OK;
+    float t_own = 1e30f, t_copy = 1e30f;
+    int   rc    = csc_build_rowgrouped(m, SPMV_CSR_AUTO);
+    if (rc == SPMV_ERR_ALLOC)
+    {
+        (void)hipGetLastError();
+        return SPMV_OK;  // no memory for the copy: the scatter runs
+    }
+    if (rc != SPMV_OK) return rc;
+    if (!m->coo_csr) return SPMV_OK;
+    for (int pass = 0; pass < 2 && rc == SPMV_OK; ++pass)  // twice round, the minimum per candidate (select.hip: transients)
+    {
+        float t = 0.f;
+        if ((rc = select_time(ctx, [&] { return csr_apply(ctx, m->coo_csr, sv.x, sv.y); }, t_own, &t)) != SPMV_OK) break;
+        t_copy = std::min(t_copy, t);
+        if (pass == 1 && t_own > 8.0f * t_copy) break;
+        if ((rc = select_time(ctx, [&] { return csc_scatter_apply(ctx, m, sv.x, sv.y); }, t_copy, &t)) != SPMV_OK) break;
+        t_own = std::min(t_own, t);
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    if (rc != SPMV_OK) return rc;
+    select_note(m, SPMV_CSR_PANEL, t_copy);
+    select_note(m, SPMV_CSR_VECTOR, t_own);
+    const bool keep_copy = model_copy ? t_copy <= t_own * 1.02f : t_copy < t_own * 0.98f;
+    if (!keep_copy) csc_drop_rowgrouped(m);
+    m->kernel = m->coo_csr ? SPMV_CSR_PANEL : SPMV_CSR_VECTOR;
+    return SPMV_OK;
+}
+
+int csc_analyse(spmv_mat* m)
+{
+    m->kernel = SPMV_CSR_VECTOR;  // reported for CSC as "scatter over the columns"
+    if (m->kernel_forced) return SPMV_OK;
+    return csc_select_kernel(m);
 }
 
 int csc_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
 {
     if (A->ncol == 0 || A->nnz == 0) return SPMV_OK;
-    if (A->coo_csr && !A->kernel_forced) return csr_panel_apply(ctx, A->coo_csr, x, y);
-    constexpr int LPC = 8;
-    if (!launch_fits(A->ncol, LPC)) SPMV_FAIL(SPMV_ERR_UNSUPPORTED, "CSC product: %d columns are more than one launch holds", A->ncol);
-    hipLaunchKernelGGL(csc_kernel<LPC>, dim3((unsigned)ceil_div(A->ncol, kBlock / LPC)), dim3(kBlock), 0, ctx->stream,
-                       A->ncol, A->a, A->b, A->v, x, y);
-    SPMV_HIP(hipGetLastError());
-    return SPMV_OK;
+    if (A->coo_csr && A->kernel == SPMV_CSR_PANEL) return csr_apply(ctx, A->coo_csr, x, y);
+    return csc_scatter_apply(ctx, A, x, y);
 }
 
 int dia_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)

@@ -490,9 +490,9 @@ int mat_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
 int mat_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, const apply_extra& ex)
 {
     // COO / ELL / CSC handles that run from their row-grouped copy: that copy is a CSR handle with a kernel of its own
-    if ((A->format == SPMV_FMT_COO || A->format == SPMV_FMT_ELL) && A->coo_csr && A->kernel == SPMV_CSR_PANEL && A->nnz > 0 && A->nrow > 0)
+    if ((A->format == SPMV_FMT_COO || A->format == SPMV_FMT_ELL || A->format == SPMV_FMT_CSC) && A->coo_csr && A->kernel == SPMV_CSR_PANEL && A->nnz > 0 &&
+        A->nrow > 0 && A->ncol > 0)
         return mat_apply_ex(ctx, A->coo_csr, x, y, ex);
-    if (A->format == SPMV_FMT_CSC && A->coo_csr && !A->kernel_forced && A->nnz > 0 && A->ncol > 0) return mat_apply_ex(ctx, A->coo_csr, x, y, ex);
     // the panel kernel does all of it in its write-back
     if (A->format == SPMV_FMT_CSR && A->kernel == SPMV_CSR_PANEL && A->nrow > 0 && A->nnz > 0) return csr_panel_apply_ex(ctx, A, x, y, ex);
     if (A->format == SPMV_FMT_CSR && A->kernel == SPMV_CSR_TWOPHASE) return csr_twophase_apply_ex(ctx, A, x, y, ex);

@@ -218,7 +218,8 @@ int spmv_mat_validate(const spmv_mat* m);
  * model from 1.5M on.  AUTO for ELL: its own variants timed from 64K slots on; the row-grouped copy (every slot, padding
  * included: the sums and the reference's 0.0 * x[0] stay) is a candidate where one lane per row cannot work - at most 65536
  * rows of 16 slots and more, or rows whose blocks of 256 span more than 16 columns per row (scattered) and whose slots are not
- * diagonals.  AUTO for CSC: regrouped by row from 2M entries on (the model; not timed). */
+ * diagonals.  AUTO for CSC: the scatter over the columns (one atomic on y per entry) against the copy grouped by row, timed
+ * from 64K entries on, the copy by the model from 1.5M on. */
 int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row);
 int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
 /* Named parameters.  None is needed in normal use: what is left at its default is chosen when the layout is built, by

@@ -1292,12 +1292,30 @@ def test_large_csc_is_regrouped_by_row_and_matches_oracle(ctx, orc, pkg):
     ol.csc_spmv(orc, cp, cr, cw, x, ref)
     ol.csr_abs_row_sums(orc, rp, col, val, x, scale)
     A = ctx.csc(n, n, cp, cr, cw)
-    assert A.info.device_bytes > 12 * n * k + 12 * n * k - 1  # CSC arrays + the panel copy (12- or 14-byte entries)
-    for forced in (False, True):
-        if forced:
-            A.set_kernel(capi.CSR_VECTOR)
+    # 4.8M entries: AUTO times the scatter against the copy grouped by row (round 5; rounds 1-4: the model alone, the panel
+    # layout forced on the copy); the copy wins on any box (one atomic on y per entry against a row-grouped product)
+    assert A.info.kernel == capi.CSR_PANEL and A.get_param("rowgrouped_kernel") in (1, 2, 3, 4, 5)
+    assert A.info.device_bytes > 12 * n * k + 12 * n * k - 1  # CSC arrays + the copy (12-byte entries, or CSR's own 12)
+    for kernel, what in ((None, "AUTO"), (capi.CSR_VECTOR, "scatter forced"), (capi.CSR_PANEL, "panel layout forced on the copy"), (capi.CSR_AUTO, "AUTO again")):
+        if kernel is not None:
+            A.set_kernel(kernel)
+        if kernel == capi.CSR_PANEL:
+            assert A.get_param("rowgrouped_kernel") == capi.CSR_PANEL
+        if kernel == capi.CSR_VECTOR:
+            assert A.info.kernel == capi.CSR_VECTOR and A.get_param("rowgrouped_kernel") == 0
         y1, _ = _apply_n(ctx, A, x, n, 1)
-        ol.assert_parity(y1, ref, scale, f"large csc forced_scatter={forced}")
+        ol.assert_parity(y1, ref, scale, f"large csc, {what}")
+    # a small one (the golden cases are below the 64K entries where anything is timed): 100K entries, both paths
+    n2, k2 = 12_500, 8
+    rp2, col2, val2 = synth.csr_uniform(0, n2, n2, k2, seed=32)
+    cp2, cr2, cw2 = ol.coo_to_csc(orc, n2, np.repeat(np.arange(n2, dtype=np.int32), k2), col2, val2)
+    x2 = synth.vec_uniform(n2, seed=32)
+    ref2, scale2 = np.zeros(n2), np.zeros(n2)
+    ol.csc_spmv(orc, cp2, cr2, cw2, x2, ref2)
+    ol.csr_abs_row_sums(orc, rp2, col2, val2, x2, scale2)
+    S = ctx.csc(n2, n2, cp2, cr2, cw2)
+    y1, _ = _apply_n(ctx, S, x2, n2, 1)
+    ol.assert_parity(y1, ref2, scale2, f"small csc AUTO (kernel {S.info.kernel}, copy runs {S.get_param('rowgrouped_kernel')})")
 
 
 def test_malformed_matrices_are_refused_before_any_kernel_indexes_with_them(ctx, pkg):

@@ -216,6 +216,23 @@ def run_case(ctx, name, build, out):
     rows.append(("coo", f"copy:{NAMES.get(inner, inner)}" if inner else ("segscan over bins" if A.get_param("coo_column_bins") else "segscan"), res, trial_record(A)))
     del A
 
+    # ---- CSC handle (what CSCMatrix(COO) of the reference holds)
+    order = np.lexsort((r, c))
+    cp = np.concatenate(([0], np.cumsum(np.bincount(c, minlength=ncol)))).astype(np.int32)
+    A = ctx.csc(nrow, ncol, cp, r[order], v[order])
+    del order
+    check(ctx, A, x, y, ref, scale, f"{name} csc auto")
+    res = {"auto": timed(ctx, A, x, y, reps)}
+    for kern, label in ((1, "scatter"), (4, "panel")):
+        ms = try_kernel(ctx, A, kern, 0, x, y, ref, scale, reps, f"{name} csc {label}")
+        if ms is not None:
+            res[label] = ms
+    A.set_kernel(0)
+    res["auto"] = min(res["auto"], timed(ctx, A, x, y, reps))
+    inner = A.get_param("rowgrouped_kernel")
+    rows.append(("csc", f"copy:{NAMES.get(inner, inner)}" if inner else "scatter", res, trial_record(A)))
+    del A
+
     # ---- ELL handle, where the padding stays within 4x the entries and 1.5e9 slots
     K = int(ln.max())
     if K > 0 and nrow * K <= max(4 * nnz, 1) and nrow * K <= 400_000_000:
@@ -248,7 +265,7 @@ def run_case(ctx, name, build, out):
         ratio = best / res["auto"]
         # AUTO running the very kernel that is also the best forced one differs from it by timing noise only
         same = (best_name == picked or (picked == "diag-slots" and best_name == "lane/2rows") or (picked == "copy:panel" and best_name == "panel")
-                or (picked.startswith("segscan") and best_name == "segscan"))
+                or (picked.startswith("segscan") and best_name == "segscan") or (picked == "scatter" and best_name == "scatter"))
         close = res["auto"] - best <= 0.0005  # half a microsecond: below what two timings of one kernel differ by at launch-latency scale
         verdict = "OK" if ratio >= 0.97 else ("OK (the same kernel: timing noise)" if same and ratio >= 0.93 else
                                               ("OK (within 0.5 us: launch-latency scale)" if close else "<-- BELOW 0.97"))
