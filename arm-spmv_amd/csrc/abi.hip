@@ -1059,7 +1059,7 @@ int spmv_apply_timed(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* x, spmv_v
 // CSRMatrixMatVector(A, x, y) and its siblings take HOST vectors on every call (include/mat_vec.h:7-11; main.cpp:56-59 calls
 // them 50 times).  Behind that signature a product costs two hand-overs whatever the kernel does; for small matrices they ARE the
 // cost (C1: kernel 3 us).  Rounds 1-4 paid three synchronous hipMemcpy of pageable memory per call (~17 us each: 67 us per C1
-// product, 4.8 GFLOP/s against the reference's 5.6 on one CPU thread).  Here, for vectors up to 4 MB together: the host copies
+// product, 4.8 GFLOP/s against the reference's 5.6 on one CPU thread).  Here, for vectors up to 1 MB together (tools/probe_apply_host_sizes.py: beyond ~1.5 MB the copies' fixed cost is paid back by their higher rate): the host copies
 // y into a pinned, device-mapped staging buffer (memcpy: 80 KB in 3 us) and stores x straight into a device buffer where the
 // platform lets the CPU do that (large BAR: 80 KB in 2 us; elsewhere x goes through the staging buffer and one kernel pulls it
 // over the host link), the product gathers x from device memory and updates y IN the staging buffer (kernels that add into y
@@ -1100,7 +1100,12 @@ int spmv_apply_host(spmv_ctx* ctx, const spmv_mat* A, const double* x_host, doub
     vx.d            = ctx->stage_x;
     vy.n            = (int64_t)ny;
     vy.d            = ctx->stage_y;
-    constexpr size_t kStagedLimit = ((size_t)4 << 20) / sizeof(double);
+    // (SPMV_HOST_STAGED_MB: the limit in megabytes, for tools/probe_apply_host_sizes.py; read per call, this is not a product's path
+    // that anything is measured on)
+    static const size_t kStagedLimit = [] {
+        const char* e = getenv("SPMV_HOST_STAGED_MB");
+        return ((size_t)(e && atoi(e) > 0 ? atoi(e) : 1) << 20) / sizeof(double);
+    }();
     if (nx + ny <= kStagedLimit)
     {
         if (ctx->stage_pinned_n < nx + ny)

@@ -140,6 +140,7 @@ int csr_select_kernel(spmv_mat* m)
         {
             add(SPMV_CSR_VECTOR);  // long contiguous rows (dense blocks): the row-parallel kernel reads x coalesced
             add(SPMV_CSR_PANEL);
+            if (m->win_max_span > 0 && m->win_max_span <= csr_ldswin_capacity()) add(SPMV_CSR_LDSWIN);  // (64 x 64 blocks: 0.092 against 0.094 / 0.113)
         }
     }
     if (cand.size() == 1) return build(model);

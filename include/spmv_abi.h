@@ -113,7 +113,9 @@ typedef struct spmv_mat_info
     int64_t nnz;      /* stored nonzeros (ELL: true nnz given at creation, not nrow*k) */
     int64_t row_begin; /* first global row of this shard (0 for an unsharded matrix) */
     int32_t max_row_nnz;
-    int32_t kernel;   /* spmv_csr_kernel actually selected (CSR only) */
+    int32_t kernel;   /* CSR: the spmv_csr_kernel in effect.  COO / ELL / CSC: 1 = the format's own kernel (segmented scan / lanes
+                         over rows / scatter over columns), 4 = the product runs from the handle's row-grouped CSR copy, whichever
+                         kernel that copy runs (spmv_mat_get_param "rowgrouped_kernel") */
     int32_t lanes_per_row; /* CSR vector kernel: lanes cooperating on one row */
     int32_t sorted_rows;   /* COO: 1 if row indices are non-decreasing */
     int64_t device_bytes;  /* bytes of device memory owned by the handle */
@@ -259,7 +261,10 @@ int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
  *                    memory) + two scratch vectors (8 ncol + 8 nrow bytes).  Afterwards: the layout, its product stream
  *                    rounded up to whole gigabytes.  "twophase_placement_budget_mb": -1 = default (or the environment's
  *                    SPMV_TP_PLACEMENT_BUDGET_MB), 0 = no search and no timing launches ("panel_trial" 0 /
- *                    SPMV_PANEL_TRIAL=0 do the same), otherwise megabytes; it applies to the next build, or at once with
+ *                    SPMV_PANEL_TRIAL=0 do the same), otherwise megabytes.  PRECEDENCE: a value >= 0 set on the handle wins
+ *                    over the environment variable, which is consulted only while the handle's value is -1 (and only when a
+ *                    layout is built or the search is run again, never on a product's path); "panel_trial" 0 /
+ *                    SPMV_PANEL_TRIAL=0 override both (no search); it applies to the next build, or at once with
  *                    "twophase_choose_pieces" (any value): run the search again on the built layout.  Streams below 512 MB
  *                    are never searched.  The outcome is reported by spmv_mat_get_param (below); a timing launch that fails
  *                    is an error of the call, not a silent fallback.
@@ -324,7 +329,7 @@ int spmv_apply_timed(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* x, spmv_v
 
 /* y_host += A * x_host with the caller's HOST vectors, synchronous - the reference's own call shape (include/mat_vec.h:7-11:
  * every CSRMatrixMatVector(A, x, y) hands over host arrays; main.cpp:56-59 does it 50 times), as ONE entry point so that the
- * hand-over can be done the cheapest way for its size: vectors of up to 4 MB together go through a pinned, device-mapped
+ * hand-over can be done the cheapest way for its size: vectors of up to 1 MB together go through a pinned, device-mapped
  * staging buffer of the context that the GPU reads and writes itself, x by CPU stores straight into device memory where the
  * platform has a large BAR (one launch on the context's stream - three for the kernels that add into y with atomics -, no
  * hipMemcpy, the host polls; SPMV_HOST_STORES=0: x through the staging buffer and a second launch); larger ones through asynchronous copies.  x_host has ncol entries, y_host

@@ -66,6 +66,38 @@ def test_partition_rows_host_arithmetic(pkg, orc):
     assert share.sum() == rp[-1] and share.max() <= rp[-1] / 4 + 4096
 
 
+def test_balanced_partition_takes_the_nearest_row_boundary(pkg):
+    """spmv_partition_rows_balanced: boundary p = the row boundary whose offset lies nearest to p / nparts of the entries (ties go
+    to the later one), monotone, rows never split - against a plain numpy restatement on random and adversarial offsets"""
+    capi = pkg.capi
+    rng = np.random.default_rng(77)
+    cases_ = []
+    for _ in range(40):
+        nrow = int(rng.integers(1, 400))
+        kind = rng.integers(0, 4)
+        lens = (rng.integers(0, 50, nrow) if kind == 0 else np.where(rng.random(nrow) < 0.05, rng.integers(1000, 5000, nrow), rng.integers(0, 3, nrow))
+                if kind == 1 else np.zeros(nrow, np.int64) if kind == 2 else np.sort(rng.integers(0, 200, nrow))[::-1])
+        cases_.append(np.concatenate(([0], np.cumsum(lens))).astype(np.int64))
+    cases_.append(np.array([0, 0, 0, 10, 10, 10], np.int64))  # every entry in one row
+    cases_.append(np.array([5, 7, 9, 11], np.int64))          # offsets that do not start at 0 (a slice of a larger array)
+    for rp in cases_:
+        nrow = len(rp) - 1
+        for parts in (1, 2, 3, 8, 13):
+            got = capi.partition_rows_balanced(rp, parts)
+            want = [0]
+            nnz = int(rp[-1] - rp[0])
+            for p in range(1, parts):
+                target = int(rp[0]) + (nnz * p) // parts
+                r = int(np.searchsorted(rp, target, side="left"))
+                r = min(r, nrow)
+                if r > 0 and target - int(rp[r - 1]) < int(rp[r]) - target:
+                    r -= 1
+                want.append(max(r, want[-1]))
+            want.append(nrow)
+            assert list(got) == want, (rp[:12], parts, list(got), want)
+            assert got[0] == 0 and got[-1] == nrow and np.all(np.diff(got) >= 0)
+
+
 def test_synth_generators_are_index_addressable(pkg):
     s = pkg.synth
     rp, c, v = s.csr_uniform(0, 1000, 5000, 8, seed=3)
@@ -81,6 +113,11 @@ def test_synth_generators_are_index_addressable(pkg):
     assert ln.min() >= 8 and ln.max() == 4096 and 40 < ln.mean() < 80
     r, cc, vv = s.coo_powerlaw(2000, 3000, 4096, seed=1)
     assert np.all(np.diff(r) >= 0) and len(r) == s.powerlaw_lengths(2000, 4096, 1).sum()
+    # the same distribution at its quantiles: rows sorted by length, the longest first (positional skew for the partition tests)
+    ls = s.powerlaw_lengths(200_000, 4096, seed=1, sorted_by_length=True)
+    assert np.all(np.diff(ls) <= 0) and ls[0] == 4096 and ls[-1] == 8 and abs(ls.mean() - ln.mean()) < 2.0
+    rs, cs, vs = s.coo_powerlaw(2000, 3000, 4096, seed=1, sorted_by_length=True)
+    assert np.all(np.diff(rs) >= 0) and len(rs) == s.powerlaw_lengths(2000, 4096, 1, True).sum() and cs.max() < 3000
     # known answers pin the generator itself (splitmix64 reference values)
     assert int(s.splitmix64(np.array([0], dtype=np.uint64))[0]) == 0xE220A8397B1DCDAF
     assert int(s.splitmix64(np.array([1], dtype=np.uint64))[0]) == 0x910A2DEC89025CC1
