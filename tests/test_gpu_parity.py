@@ -1014,7 +1014,7 @@ def test_auto_times_its_candidates_and_keeps_the_fastest(ctx, orc, pkg, monkeypa
     brp = (np.arange(nb + 1, dtype=np.int64) * bs).astype(np.int32)
     bcc = (np.repeat(i // bs * bs, bs) + np.tile(np.arange(bs), nb)).astype(np.int32)
     D = ctx.csr(nb, nb, brp, bcc, rng.uniform(-1, 1, nb * bs))
-    assert D.get_param("contiguous_permille") > 950 and D.get_param("select_candidates") == 2
+    assert D.get_param("contiguous_permille") > 950 and D.get_param("select_candidates") in (2, 3)  # row-parallel, panel, LDS window (its windows fit)
     assert D.get_param("select_us_vector") > 0 and D.get_param("select_us_panel") > 0
 
 
