@@ -88,6 +88,7 @@ void mat_free(spmv_mat* m)
     ell_free_tiles(m);
     csr_panel_free(m);
     csr_twophase_free(m);
+    csr_segscan_free(m);
     symgs_free(m);
     if (m->coo_csr) mat_free(m->coo_csr);
     coo_free_bins(m);
@@ -616,7 +617,7 @@ int spmv_mat_get_info(const spmv_mat* m, spmv_mat_info* info)
 int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
 {
     SPMV_REQUIRE(m, "null matrix");
-    SPMV_REQUIRE(kernel >= SPMV_CSR_AUTO && kernel <= SPMV_CSR_TWOPHASE, "unknown kernel id %d", kernel);
+    SPMV_REQUIRE(kernel >= SPMV_CSR_AUTO && kernel <= SPMV_CSR_SEGSCAN, "unknown kernel id %d", kernel);
     SPMV_REQUIRE(lanes_per_row == 0 || (lanes_per_row >= 1 && lanes_per_row <= 64 &&
                                         (lanes_per_row & (lanes_per_row - 1)) == 0),
                  "lanes_per_row must be 0 or a power of two in 1..64, got %d", lanes_per_row);
@@ -711,6 +712,7 @@ int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
         m->kernel        = kernel;
         m->kernel_forced = true;
     }
+    if (m->kernel != SPMV_CSR_SEGSCAN) csr_segscan_free(m);
     if (m->format == SPMV_FMT_CSR && m->kernel == SPMV_CSR_PANEL)
     {
         SPMV_HIP(hipSetDevice(m->ctx->device));
@@ -720,6 +722,12 @@ int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
     {
         SPMV_HIP(hipSetDevice(m->ctx->device));
         SPMV_TRY(csr_twophase_build(m));
+    }
+    if (m->kernel == SPMV_CSR_SEGSCAN)
+    {
+        SPMV_REQUIRE(m->format == SPMV_FMT_CSR, "kernel SEGSCAN (6) is a CSR kernel (a COO handle's VECTOR is the same scan)");
+        SPMV_HIP(hipSetDevice(m->ctx->device));
+        SPMV_TRY(csr_segscan_build(m));
     }
     return SPMV_OK;
 }
@@ -957,6 +965,7 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         int slot = -1;
         for (int i = 1; i < 8; ++i)
             if (!strcmp(name + 10, kNames[i])) slot = i;
+        if (!strcmp(name + 10, "segscan")) slot = SPMV_CSR_SEGSCAN;  // (CSR handles; the slot is an ELL handle's "variant1")
         SPMV_REQUIRE(slot > 0, "unknown parameter '%s'", name);
         *value = (int64_t)(m->sel_us[slot] + 0.5f);
     }

@@ -238,6 +238,10 @@ struct spmv_mat
     int64_t   tp_padded = 0;
     int64_t   tp_bytes   = 0;
 
+    // CSR segmented-scan kernel (kernels_coo.hip: csr_segscan_build): the row of every entry
+    int32_t* seg_row = nullptr;  // [nnz]
+    bool     sel_no_segscan = false;  // the handle is the row-grouped copy of a COO handle: that handle's own kernel IS this scan
+
     // ELL whose slots are diagonals (kernels_ell.hip: ell_detect_diagonals): slot s holds column i + off[s] in the row
     // pairs whose bit is set; the product reads no column index there.  ell_diag = off[K] | xbase[K] | clusters
     // (kernels_ell.hip: stage_x_windows); mask[wavefront * K + s] = 64 row pairs
@@ -346,6 +350,9 @@ void coo_drop_rowgrouped(spmv_mat* m);
 int  coo_build_bins(spmv_mat* m, int bins_per_xcd, bool only_if_worth);  // bins_per_xcd 0: as many as keep a slice of x inside an XCD's L2
 void coo_free_bins(spmv_mat* m);
 int coo_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
+int  csr_segscan_build(spmv_mat* m);  // SPMV_CSR_SEGSCAN: the row index per entry the scan runs over
+void csr_segscan_free(spmv_mat* m);
+int  csr_segscan_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 // kernels_misc.hip (CSC, DIA, BLAS-1, fill)
 int csc_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 int csc_analyse(spmv_mat* m);
@@ -362,6 +369,7 @@ int vec_axpby(spmv_ctx* ctx, double alpha, const double* x, double beta, const d
 int mat_validate(const spmv_mat* m);
 // convert.hip
 int exclusive_scan_i32(spmv_ctx* ctx, const int32_t* in, int32_t* out, int64_t n);
+constexpr int32_t kCsrAutoNoSegscan = -1;  // coo_to_csr's force_kernel: AUTO among the kernels a COO handle does not have itself
 int coo_to_csr(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out, int32_t force_kernel = 0 /* SPMV_CSR_AUTO: select */);
 // symgs.hip
 int  symgs_setup(spmv_mat* m);

@@ -224,7 +224,9 @@ int coo_to_csr(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out, int32_t force
         SPMV_FAIL(rc, "spmv_coo_to_csr failed (%s)", hipGetErrorString(hipGetLastError()));
     }
     csr->row_begin = coo->row_begin;
-    if (force_kernel != SPMV_CSR_AUTO)
+    if (force_kernel == kCsrAutoNoSegscan)
+        csr->sel_no_segscan = true;  // (the COO handle that asks has that scan itself, over its own arrays)
+    else if (force_kernel != SPMV_CSR_AUTO)
     {
         csr->kernel_forced = true;
         csr->kernel        = force_kernel;

@@ -341,7 +341,7 @@ int coo_select_kernel(spmv_mat* m)
     const bool model_copy = m->nnz >= ((int64_t)3 << 19);
     auto       build_copy = [&]() -> int {
         spmv_mat* csr = nullptr;
-        const int rc  = coo_to_csr(ctx, m, &csr);  // (csr_analyse inside selects the copy's kernel)
+        const int rc  = coo_to_csr(ctx, m, &csr, kCsrAutoNoSegscan);  // (csr_analyse inside selects the copy's kernel)
         if (rc == SPMV_OK) adopt_rowgrouped(m, csr);
         return rc;
     };
@@ -596,6 +596,73 @@ int coo_build_bins(spmv_mat* m, int bins_per_xcd, bool only_if_worth)
         if (rc == SPMV_ERR_ALLOC) SPMV_FAIL(rc, "no device memory for the copy of %lld COO entries in column bins", (long long)m->nnz);
         SPMV_FAIL(rc, "building the copy in column bins failed: %s", hipGetErrorString(hipGetLastError()));
     }
+    return SPMV_OK;
+}
+
+// ---- the same scan over a CSR handle (SPMV_CSR_SEGSCAN) --------------------------------------------------------------
+// Every other CSR kernel gives a row to one lane, one group of lanes or (panel layout: its row group) one workgroup; a row
+// that holds a large share of the entries - the dense row of an arrow matrix, a constraint row, a hub - then runs on one
+// CU while 255 wait (tools/sweep_structures.py "odd": 1M entries in a row, 1.26 ms under the panel kernel, 74 ms
+// row-parallel).  The scan cuts the ENTRIES into equal pieces whatever their rows; what it needs is the row of every
+// entry, 4 bytes each, written once here.  Rows without entries are never touched (y += 0).
+namespace
+{
+__global__ __launch_bounds__(kBlock) void csr_expand_rows_kernel(int nrow, int64_t nnz, const int32_t* __restrict__ row_ptr, int32_t* __restrict__ row)
+{
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * kBlock)
+    {
+        // the last r with row_ptr[r] <= e (row_ptr[0] = 0 and row_ptr[nrow] = nnz are checked when the handle is made)
+        int lo = 0, hi = nrow;
+        while (hi - lo > 1)
+        {
+            const int mid = lo + (hi - lo) / 2;
+            if ((int64_t)row_ptr[mid] <= e)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        row[e] = lo;
+    }
+}
+}  // namespace
+
+int csr_segscan_build(spmv_mat* m)
+{
+    if (m->seg_row || m->nnz == 0 || m->nrow == 0) return SPMV_OK;
+    SPMV_REQUIRE(m->format == SPMV_FMT_CSR && m->a && m->b && m->v, "the segmented scan runs over a CSR handle's own arrays");
+    spmv_ctx* ctx = m->ctx;
+    if (hipMalloc(&m->seg_row, sizeof(int32_t) * (size_t)m->nnz) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        m->seg_row = nullptr;
+        SPMV_FAIL(SPMV_ERR_ALLOC, "no device memory for the row index of %lld entries (segmented scan)", (long long)m->nnz);
+    }
+    hipLaunchKernelGGL(csr_expand_rows_kernel, dim3((unsigned)std::min<int64_t>(kMaxGrid * 4, ceil_div(m->nnz, kBlock))), dim3(kBlock), 0, ctx->stream,
+                       (int)m->nrow, m->nnz, m->a, m->seg_row);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+    {
+        csr_segscan_free(m);
+        SPMV_FAIL(SPMV_ERR_HIP, "writing the row index per entry failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    m->device_bytes += (int64_t)sizeof(int32_t) * m->nnz;
+    return SPMV_OK;
+}
+
+void csr_segscan_free(spmv_mat* m)
+{
+    if (!m->seg_row) return;
+    (void)hipFree(m->seg_row);
+    m->seg_row = nullptr;
+    m->device_bytes -= (int64_t)sizeof(int32_t) * m->nnz;
+}
+
+int csr_segscan_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
+{
+    if (A->nnz == 0) return SPMV_OK;
+    if (!A->seg_row || !A->b || !A->v) SPMV_FAIL(SPMV_ERR_INVALID, "segmented scan selected but its row index was never built");
+    hipLaunchKernelGGL(coo_segscan_kernel<true>, dim3((unsigned)ceil_div(A->nnz, kBlockChunk)), dim3(kBlock), 0, ctx->stream, A->nnz, A->seg_row, A->b,
+                       A->v, x, y);
+    SPMV_HIP(hipGetLastError());
     return SPMV_OK;
 }
 

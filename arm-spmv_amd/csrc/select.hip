@@ -116,6 +116,7 @@ int csr_select_kernel(spmv_mat* m)
         m->kernel = kernel;
         if (kernel == SPMV_CSR_PANEL) return csr_panel_build(m);
         if (kernel == SPMV_CSR_TWOPHASE) return csr_twophase_build(m);
+        if (kernel == SPMV_CSR_SEGSCAN) return csr_segscan_build(m);
         return SPMV_OK;
     };
     if (m->nrow == 0 || m->nnz == 0 || !m->b || !m->v) return build(model);
@@ -124,8 +125,16 @@ int csr_select_kernel(spmv_mat* m)
     auto             add = [&](int k) {
         if (std::find(cand.begin(), cand.end(), k) == cand.end()) cand.push_back(k);
     };
+    // a row with 1/128 of the entries and more: under every row-wise kernel that row is one workgroup's work at best
+    // (the panel kernel: 1.25 us per 1024 entries of it) - the scan over the entries in equal pieces is a candidate
+    const bool long_row = !m->sel_no_segscan && m->max_row_nnz >= 4096 && (int64_t)m->max_row_nnz * 128 >= m->nnz;
     if (select_trials_enabled(m) && m->nnz >= kSelectMinNnz)
     {
+        if (long_row)
+        {
+            add(SPMV_CSR_SEGSCAN);
+            add(SPMV_CSR_PANEL);  // (also beyond 8M entries, where the model is otherwise taken at its word)
+        }
         if (m->nnz < kSelectMaxNnz)
         {
             add(SPMV_CSR_PANEL);
@@ -188,6 +197,7 @@ int csr_select_kernel(spmv_mat* m)
     if (best < 0) best = model;
     if (best != SPMV_CSR_PANEL) csr_panel_free(m);
     if (best != SPMV_CSR_TWOPHASE) csr_twophase_free(m);
+    if (best != SPMV_CSR_SEGSCAN) csr_segscan_free(m);
     return build(best);  // (a layout that is already in memory with the current parameters is kept as it is)
 }
 

@@ -83,7 +83,9 @@ typedef enum spmv_format
  *   PANEL, TWOPHASE     products are added into per-row accumulators in LDS with ds_add_f64 in ARRIVAL order: two calls
  *                       on the same data may differ in the last bits (the reference's CSR loop is deterministic per row,
  *                       src/mat_vec.cpp:57-65; its COO and CSC loops are not: `omp atomic`, :36-39, :88-91).  Callers that
- *                       need run-to-run identical bits select VECTOR (spmv_mat_set_kernel(A, SPMV_CSR_VECTOR, 0)). */
+ *                       need run-to-run identical bits select VECTOR (spmv_mat_set_kernel(A, SPMV_CSR_VECTOR, 0));
+ *   SEGSCAN             a fixed tree inside a wavefront's 512 entries; rows that cross into another wavefront's entries are joined by
+ *                       atomic adds on y in arrival order (like the COO scan). */
 typedef enum spmv_csr_kernel
 {
     SPMV_CSR_AUTO     = 0,
@@ -91,7 +93,12 @@ typedef enum spmv_csr_kernel
     SPMV_CSR_LDSWIN   = 2, /* row blocks whose x window is staged in LDS (banded matrices) */
     SPMV_CSR_SCALAR   = 3, /* one lane per row, strictly left-to-right (bitwise = oracle _fma) */
     SPMV_CSR_PANEL    = 4, /* row groups x column panels: x gathered from L2, y accumulated in LDS */
-    SPMV_CSR_TWOPHASE = 5  /* x-stationary expand + y-stationary reduce (x far larger than the rows held: C5 shards) */
+    SPMV_CSR_TWOPHASE = 5, /* x-stationary expand + y-stationary reduce (x far larger than the rows held: C5 shards) */
+    SPMV_CSR_SEGSCAN  = 6  /* the entries in row order, 512 per wavefront whatever row they belong to, joined by a segmented scan
+                              (the COO kernel over a row index per entry, 4 bytes per entry on top of the CSR arrays): a matrix whose
+                              longest rows hold a large share of the entries - arrow shapes, a few dense rows - where every other CSR
+                              kernel leaves that row to ONE wavefront or workgroup (1M entries in one row: 1.26 ms there, 0.045 here).
+                              CSR handles only; AUTO times it where the longest row exceeds 1/128 of the entries */
 } spmv_csr_kernel;
 
 /* Tuning bits for spmv_mat_set_flags (speed only; results stay within the parity tolerance). */

@@ -403,7 +403,7 @@ def test_random_large_csr_shapes(ctx, orc, pkg, seed):
     A = ctx.csr(nrow, ncol, rp, cc, cv)
     dx, dy = ctx.vector_from(x), ctx.vector(nrow)
     runs = [("auto", lambda: None), ("vector", lambda: A.set_kernel(capi.CSR_VECTOR)), ("panel", lambda: A.set_kernel(capi.CSR_PANEL)),
-            ("two-phase", lambda: A.set_kernel(capi.CSR_TWOPHASE))]
+            ("two-phase", lambda: A.set_kernel(capi.CSR_TWOPHASE)), ("scan", lambda: A.set_kernel(capi.CSR_SEGSCAN))]
     for name, setup in runs:
         setup()
         dy.fill(0.0)
@@ -441,7 +441,7 @@ def test_random_spd_systems_through_cg_and_the_fused_dot(ctx, orc, pkg, seed):
     ol.csr_spmv(orc, rp, cc, vv, xh, ref)
     ol.csr_abs_row_sums(orc, rp, cc, vv, xh, scale)
     x, w, y = ctx.vector_from(xh), ctx.vector_from(wh), ctx.vector(n)
-    for kernel in (capi.CSR_AUTO, capi.CSR_VECTOR, capi.CSR_SCALAR, capi.CSR_PANEL, capi.CSR_TWOPHASE):
+    for kernel in (capi.CSR_AUTO, capi.CSR_VECTOR, capi.CSR_SCALAR, capi.CSR_PANEL, capi.CSR_TWOPHASE, capi.CSR_SEGSCAN):
         if kernel == capi.CSR_TWOPHASE and len(vv) < 1000:
             continue
         A.set_kernel(kernel)

@@ -50,7 +50,7 @@ def test_csr_matches_reference_golden(ctx, orc, pkg, make):
     capi = pkg.capi
     for kernel, lanes in ((capi.CSR_AUTO, 0), (capi.CSR_VECTOR, 1), (capi.CSR_VECTOR, 2), (capi.CSR_VECTOR, 4),
                           (capi.CSR_VECTOR, 8), (capi.CSR_VECTOR, 16), (capi.CSR_VECTOR, 32), (capi.CSR_VECTOR, 64),
-                          (capi.CSR_SCALAR, 0), (capi.CSR_TWOPHASE, 0)):
+                          (capi.CSR_SCALAR, 0), (capi.CSR_TWOPHASE, 0), (capi.CSR_SEGSCAN, 0)):
         for flags in (0, capi.FLAG_DPP_REDUCE, capi.FLAG_XCD_REMAP):
             if kernel != capi.CSR_VECTOR and flags:
                 continue
@@ -933,7 +933,7 @@ def test_auto_times_its_candidates_and_keeps_the_fastest(ctx, orc, pkg, monkeypa
     that nothing of a losing layout stays allocated, and that SPMV_PANEL_TRIAL=0 leaves the model alone."""
     capi = pkg.capi
     monkeypatch.delenv("SPMV_PANEL_TRIAL", raising=False)  # (this test is about the trials; tools/env_sweeps.sh also runs the suite without them)
-    names = {1: "vector", 2: "ldswin", 3: "scalar", 4: "panel", 5: "twophase"}
+    names = {1: "vector", 2: "ldswin", 3: "scalar", 4: "panel", 5: "twophase", 6: "segscan"}
     rng = np.random.default_rng(17)
     # (a) a hub row among short ones (R-MAT-like): 40000 rows x 8, one row of 30000 entries: 350K entries
     n = 40_000
@@ -965,7 +965,7 @@ def test_auto_times_its_candidates_and_keeps_the_fastest(ctx, orc, pkg, monkeypa
     if kept != capi.CSR_PANEL:
         assert A.get_param("panel_bytes") == 0  # the losing layout went back
     bytes_auto = A.get_param("device_bytes")
-    for k in (capi.CSR_VECTOR, capi.CSR_SCALAR, capi.CSR_PANEL):
+    for k in (capi.CSR_VECTOR, capi.CSR_SCALAR, capi.CSR_PANEL, capi.CSR_SEGSCAN):
         A.set_kernel(k)
         product(A, f"hub row, forced {names[k]}")
     A.set_kernel(capi.CSR_AUTO)  # selecting again times again and ends in the same state
@@ -1016,6 +1016,97 @@ def test_auto_times_its_candidates_and_keeps_the_fastest(ctx, orc, pkg, monkeypa
     D = ctx.csr(nb, nb, brp, bcc, rng.uniform(-1, 1, nb * bs))
     assert D.get_param("contiguous_permille") > 950 and D.get_param("select_candidates") in (2, 3)  # row-parallel, panel, LDS window (its windows fit)
     assert D.get_param("select_us_vector") > 0 and D.get_param("select_us_panel") > 0
+
+
+def test_rows_that_hold_most_of_the_entries_go_through_the_scan(ctx, orc, pkg, monkeypatch):
+    """Round 5 (tools/sweep_structures.py "odd"): an arrow matrix - dense first row, dense first column, a diagonal - under
+    every row-wise CSR kernel leaves its long row to one wavefront or one workgroup (1M entries: 1.26 ms under the panel
+    kernel, 74 ms row-parallel).  SPMV_CSR_SEGSCAN cuts the ENTRIES into equal pieces (the COO scan over a row index per
+    entry); AUTO times it where the longest row holds 1/128 of the entries and the model picks it from 1/64 and 65536 on."""
+    capi = pkg.capi
+    monkeypatch.delenv("SPMV_PANEL_TRIAL", raising=False)
+    rng = np.random.default_rng(23)
+    n = 120_000
+    # rows 1000..2999 are EMPTY (the scan never touches them: y += 0), row 0 is dense, every other row has (i, 0) and (i, i)
+    lens = np.full(n, 2, np.int64)
+    lens[0] = n
+    lens[1000:3000] = 0
+    rp = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    cc = np.empty(rp[-1], np.int32)
+    cc[:n] = np.arange(n)
+    body = np.flatnonzero(lens[1:] > 0) + 1
+    cc[n::2] = 0
+    cc[n + 1::2] = body
+    cv = rng.uniform(-1, 1, rp[-1])
+    x = rng.uniform(0, 1, n)
+    y0 = rng.uniform(-1, 1, n)
+    ref, scale = y0.copy(), np.zeros(n)
+    ol.csr_spmv(orc, rp, cc, cv, x, ref)  # y += A x on top of y0
+    ol.csr_abs_row_sums(orc, rp, cc, cv, x, scale)
+    scale = scale + np.abs(y0)
+    dx = ctx.vector_from(x)
+
+    def product(M, what):
+        dy = ctx.vector_from(y0)
+        ctx.apply(M, dx, dy)
+        ctx.sync()
+        got = dy.download()
+        ol.assert_parity(got, ref, scale, what)
+        assert np.array_equal(got[1000:3000], y0[1000:3000]), what  # rows without entries: untouched, bit for bit
+
+    A = ctx.csr(n, n, rp, cc, cv)
+    base = 4 * (n + 1) + 12 * int(rp[-1])
+    assert A.info.max_row_nnz == n and A.info.kernel == capi.CSR_SEGSCAN, A.info.kernel
+    assert A.get_param("select_us_segscan") > 0 and A.get_param("select_us_panel") > 3 * A.get_param("select_us_segscan")
+    assert A.get_param("panel_bytes") == 0 and base + 4 * int(rp[-1]) <= A.info.device_bytes <= base + 4 * int(rp[-1]) + (1 << 20)
+    product(A, "arrow, AUTO (segmented scan)")
+    for k in (capi.CSR_PANEL, capi.CSR_VECTOR, capi.CSR_SCALAR):
+        A.set_kernel(k)
+        assert A.info.kernel == k
+        product(A, f"arrow, forced kernel {k}")
+    A.set_kernel(capi.CSR_VECTOR)
+    assert A.info.device_bytes <= base + (1 << 20) + A.get_param("panel_bytes")  # the row index went back with the kernel
+    A.set_kernel(capi.CSR_SEGSCAN)
+    assert A.info.kernel == capi.CSR_SEGSCAN
+    product(A, "arrow, scan forced")
+    # the solver's fused extras (y = A x, w . y) on a kernel that has no write-back of its own: CG on an SPD arrow
+    m = 70_000
+    l2 = np.full(m, 2, np.int64)
+    l2[0] = m
+    rp2 = np.concatenate(([0], np.cumsum(l2))).astype(np.int32)
+    c2 = np.empty(rp2[-1], np.int32)
+    c2[:m] = np.arange(m)
+    c2[m::2] = 0
+    c2[m + 1::2] = np.arange(1, m)
+    v2 = np.empty(rp2[-1])
+    v2[:m] = 1e-3
+    v2[0] = 4.0
+    v2[m::2] = 1e-3
+    v2[m + 1::2] = 2.0 + rng.uniform(0, 1, m - 1)
+    S = ctx.csr(m, m, rp2, c2, v2)
+    assert S.info.kernel == capi.CSR_SEGSCAN
+    xs = rng.uniform(-1, 1, m)
+    bs = np.zeros(m)
+    ol.csr_spmv(orc, rp2, c2, v2, xs, bs)
+    sol = ctx.vector(m)
+    iters, relres = ctx.cg(S, ctx.vector_from(bs), sol, max_iter=200, rel_tol=1e-12, check_every=4)
+    assert relres <= 1e-12 and np.max(np.abs(sol.download() - xs)) < 1e-9, (iters, relres)
+    # a CSC handle of the arrow: its row-grouped copy may pick the scan; a COO handle's copy never does (the handle has it itself)
+    rows = np.repeat(np.arange(n, dtype=np.int32), lens)
+    cp, cr, cw = ol.coo_to_csc(orc, n, rows, cc, cv)
+    C = ctx.csc(n, n, cp, cr, cw)
+    assert C.info.kernel == capi.CSR_PANEL and C.get_param("rowgrouped_kernel") == capi.CSR_SEGSCAN
+    product(C, "arrow as CSC, AUTO")
+    O = ctx.coo(n, n, rows, cc, cv)
+    assert O.get_param("rowgrouped_kernel") != capi.CSR_SEGSCAN
+    product(O, "arrow as COO, AUTO")
+    with pytest.raises(capi.SpmvError, match="COO handles take"):
+        O.set_kernel(capi.CSR_SEGSCAN)
+    # the model alone
+    monkeypatch.setenv("SPMV_PANEL_TRIAL", "0")
+    B = ctx.csr(n, n, rp, cc, cv)
+    assert B.get_param("select_candidates") == 0 and B.info.kernel == capi.CSR_SEGSCAN
+    product(B, "arrow, model only")
 
 
 # ---------------------------------------------------------------------------------- full-size properties
@@ -1294,7 +1385,7 @@ def test_large_csc_is_regrouped_by_row_and_matches_oracle(ctx, orc, pkg):
     A = ctx.csc(n, n, cp, cr, cw)
     # 4.8M entries: AUTO times the scatter against the copy grouped by row (round 5; rounds 1-4: the model alone, the panel
     # layout forced on the copy); the copy wins on any box (one atomic on y per entry against a row-grouped product)
-    assert A.info.kernel == capi.CSR_PANEL and A.get_param("rowgrouped_kernel") in (1, 2, 3, 4, 5)
+    assert A.info.kernel == capi.CSR_PANEL and A.get_param("rowgrouped_kernel") in (1, 2, 3, 4, 5, 6)
     assert A.info.device_bytes > 12 * n * k + 12 * n * k - 1  # CSC arrays + the copy (12-byte entries, or CSR's own 12)
     for kernel, what in ((None, "AUTO"), (capi.CSR_VECTOR, "scatter forced"), (capi.CSR_PANEL, "panel layout forced on the copy"), (capi.CSR_AUTO, "AUTO again")):
         if kernel is not None:

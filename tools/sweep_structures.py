@@ -25,7 +25,7 @@ sys.path.insert(0, str(ROOT))
 from __graft_entry__ import load_package  # noqa: E402
 
 capi = load_package().capi
-NAMES = {0: "auto", 1: "vector", 2: "ldswin", 3: "scalar", 4: "panel", 5: "twophase"}
+NAMES = {0: "auto", 1: "vector", 2: "ldswin", 3: "scalar", 4: "panel", 5: "twophase", 6: "segscan"}
 
 
 # ---------------------------------------------------------------------------------------------- generators (host, numpy)
@@ -97,6 +97,42 @@ def rectangle(nrow, ncol, k, seed=5):
     return _finish(nrow, ncol, r, c, 6)
 
 
+def arrow(n):
+    """diagonal + a dense first row + a dense first column: one hub row and one hub column of n entries each"""
+    i = np.arange(n, dtype=np.int64)
+    r = np.concatenate((i, np.zeros(n - 1, np.int64), i[1:]))
+    c = np.concatenate((i, i[1:], np.zeros(n - 1, np.int64)))
+    return _finish(n, n, r, c, 9)
+
+
+def few_dense_rows(n, k, dense, seed=10):
+    """k uniform entries per row, and `dense` rows that hold an entry in every column"""
+    rng = np.random.default_rng(seed)
+    r = np.repeat(np.arange(n, dtype=np.int64), k)
+    c = rng.integers(0, n, r.size)
+    rows = rng.choice(n, dense, replace=False)
+    r = np.concatenate((r, np.repeat(rows, n)))
+    c = np.concatenate((c, np.tile(np.arange(n, dtype=np.int64), dense)))
+    return _finish(n, n, r, c, 11)
+
+
+def banded_contiguous(n, half):
+    """2 * half + 1 contiguous entries around the diagonal (clipped at the edges): a band stored entry by entry"""
+    i = np.repeat(np.arange(n, dtype=np.int64), 2 * half + 1)
+    c = i + np.tile(np.arange(-half, half + 1, dtype=np.int64), n)
+    ok = (c >= 0) & (c < n)
+    return _finish(n, n, i[ok], c[ok], 12)
+
+
+def mostly_empty(n, frac, k, seed=13):
+    """a fraction of the rows hold k uniform entries, the others none"""
+    rng = np.random.default_rng(seed)
+    rows = np.sort(rng.choice(n, int(n * frac), replace=False)).astype(np.int64)
+    r = np.repeat(rows, k)
+    c = rng.integers(0, n, r.size)
+    return _finish(n, n, r, c, 14)
+
+
 def permutation(n, seed=7):
     p = np.random.default_rng(seed).permutation(n)
     return _finish(n, n, np.arange(n, dtype=np.int64), p, 8)
@@ -121,6 +157,16 @@ CASES = {
     "tall_small": ("rect", lambda: rectangle(200_000, 5_000, 8)),
     "wide_100k_x_4M": ("rect", lambda: rectangle(100_000, 4_000_000, 160)),
     "wide_small": ("rect", lambda: rectangle(5_000, 200_000, 160)),
+    "arrow_1M": ("odd", lambda: arrow(1_000_000)),
+    "arrow_small": ("odd", lambda: arrow(60_000)),
+    "dense_rows_200k": ("odd", lambda: few_dense_rows(200_000, 16, 4)),
+    "dense_row_in_32M": ("odd", lambda: few_dense_rows(1_000_000, 32, 1)),
+    "dense_rows_in_16M": ("odd", lambda: few_dense_rows(500_000, 32, 8)),
+    "tridiagonal_8M": ("odd", lambda: banded_contiguous(8_000_000, 1)),
+    "band33_2M": ("odd", lambda: banded_contiguous(2_000_000, 16)),
+    "band33_small": ("odd", lambda: banded_contiguous(30_000, 16)),
+    "one_column_1M": ("odd", lambda: rectangle(1_000_000, 1, 1)),
+    "mostly_empty_4M": ("odd", lambda: mostly_empty(4_000_000, 0.05, 64)),
     "permutation_8M": ("rows", lambda: permutation(8_000_000)),
     "permutation_small": ("rows", lambda: permutation(300_000)),
 }
@@ -190,7 +236,7 @@ def run_case(ctx, name, build, out):
     auto_k = int(A.info.kernel)
     check(ctx, A, x, y, ref, scale, f"{name} csr auto")
     res = {"auto": timed(ctx, A, x, y, reps)}
-    for kern in (1, 2, 3, 4, 5):
+    for kern in (1, 2, 3, 4, 5, 6):
         if kern == 5 and nnz < 2_000_000:
             continue
         ms = try_kernel(ctx, A, kern, 0, x, y, ref, scale, reps, f"{name} csr {NAMES[kern]}")
@@ -198,7 +244,7 @@ def run_case(ctx, name, build, out):
             res[NAMES[kern]] = ms
     A.set_kernel(0)
     res["auto"] = min(res["auto"], timed(ctx, A, x, y, reps))
-    rows.append(("csr", NAMES[int(A.info.kernel)], res, trial_record(A)))
+    rows.append(("csr", NAMES[int(A.info.kernel)], res, trial_record(A).replace("variant1", "segscan")))
     del A
 
     # ---- COO handle (row-sorted, as .mtx files converted by the reference arrive)
