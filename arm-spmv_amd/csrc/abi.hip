@@ -89,6 +89,7 @@ void mat_free(spmv_mat* m)
     csr_panel_free(m);
     csr_twophase_free(m);
     csr_segscan_free(m);
+    csr_split_free(m);
     symgs_free(m);
     if (m->coo_csr) mat_free(m->coo_csr);
     coo_free_bins(m);
@@ -617,7 +618,7 @@ int spmv_mat_get_info(const spmv_mat* m, spmv_mat_info* info)
 int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
 {
     SPMV_REQUIRE(m, "null matrix");
-    SPMV_REQUIRE(kernel >= SPMV_CSR_AUTO && kernel <= SPMV_CSR_SEGSCAN, "unknown kernel id %d", kernel);
+    SPMV_REQUIRE(kernel >= SPMV_CSR_AUTO && kernel <= SPMV_CSR_SPLIT, "unknown kernel id %d", kernel);
     SPMV_REQUIRE(lanes_per_row == 0 || (lanes_per_row >= 1 && lanes_per_row <= 64 &&
                                         (lanes_per_row & (lanes_per_row - 1)) == 0),
                  "lanes_per_row must be 0 or a power of two in 1..64, got %d", lanes_per_row);
@@ -713,6 +714,7 @@ int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
         m->kernel_forced = true;
     }
     if (m->kernel != SPMV_CSR_SEGSCAN) csr_segscan_free(m);
+    if (m->format == SPMV_FMT_CSR && m->kernel != SPMV_CSR_SPLIT) csr_split_free(m);
     if (m->format == SPMV_FMT_CSR && m->kernel == SPMV_CSR_PANEL)
     {
         SPMV_HIP(hipSetDevice(m->ctx->device));
@@ -728,6 +730,12 @@ int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
         SPMV_REQUIRE(m->format == SPMV_FMT_CSR, "kernel SEGSCAN (6) is a CSR kernel (a COO handle's VECTOR is the same scan)");
         SPMV_HIP(hipSetDevice(m->ctx->device));
         SPMV_TRY(csr_segscan_build(m));
+    }
+    if (m->kernel == SPMV_CSR_SPLIT)
+    {
+        SPMV_REQUIRE(m->format == SPMV_FMT_CSR, "kernel SPLIT (7) is a CSR kernel");
+        SPMV_HIP(hipSetDevice(m->ctx->device));
+        SPMV_TRY(csr_split_build(m));
     }
     return SPMV_OK;
 }
@@ -749,6 +757,12 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         m->pb_pipe = (int32_t)value;
     else if (!strcmp(name, "panel_two_per_cu"))
         m->pb_two_per_cu = (int32_t)value;
+    else if (!strcmp(name, "split_row_threshold"))
+    {
+        // rows of this many entries and more are "long" under kernel SPLIT (0: the default); takes effect at the next spmv_mat_set_kernel
+        SPMV_REQUIRE(value >= 0 && value <= INT32_MAX, "split_row_threshold must be 0 (default) or a row length, got %lld", (long long)value);
+        m->split_threshold = (int32_t)value;
+    }
     else if (!strcmp(name, "panel_keep_csr"))
     {
         // 0: release col_ind / values of a CSR handle whose product runs from the panel layout (which holds the same
@@ -965,7 +979,8 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         int slot = -1;
         for (int i = 1; i < 8; ++i)
             if (!strcmp(name + 10, kNames[i])) slot = i;
-        if (!strcmp(name + 10, "segscan")) slot = SPMV_CSR_SEGSCAN;  // (CSR handles; the slot is an ELL handle's "variant1")
+        if (!strcmp(name + 10, "segscan")) slot = SPMV_CSR_SEGSCAN;  // (CSR handles; the slots are an ELL handle's "variant1" / "variant2")
+        if (!strcmp(name + 10, "split")) slot = SPMV_CSR_SPLIT;
         SPMV_REQUIRE(slot > 0, "unknown parameter '%s'", name);
         *value = (int64_t)(m->sel_us[slot] + 0.5f);
     }
@@ -973,6 +988,14 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         *value = m->coo_csr && m->kernel == SPMV_CSR_PANEL ? m->coo_csr->kernel : 0;
     else if (!strcmp(name, "ell_variant"))
         *value = m->ell_variant;
+    else if (!strcmp(name, "split_row_threshold"))
+        *value = m->format == SPMV_FMT_CSR ? csr_split_threshold(m) : 0;
+    else if (!strcmp(name, "split_long_rows"))
+        *value = m->split_long_rows;
+    else if (!strcmp(name, "split_long_entries"))
+        *value = m->split_long_nnz;
+    else if (!strcmp(name, "split_inner_kernel"))
+        *value = m->format == SPMV_FMT_CSR && m->kernel == SPMV_CSR_SPLIT && m->coo_csr ? m->coo_csr->kernel : 0;
     else
         SPMV_FAIL(SPMV_ERR_INVALID, "unknown parameter '%s'", name);
     return SPMV_OK;

@@ -242,6 +242,15 @@ struct spmv_mat
     int32_t* seg_row = nullptr;  // [nnz]
     bool     sel_no_segscan = false;  // the handle is the row-grouped copy of a COO handle: that handle's own kernel IS this scan
 
+    // CSR long-row split (kernels_csr_split.hip): the long rows in chunks over the handle's own arrays, the others in `coo_csr`
+    int32_t* split_chunks = nullptr;      // [3 * nchunks] row | first entry | end, per chunk of a long row
+    int32_t  split_nchunks = 0;
+    int32_t  split_threshold = 0;         // rows of this many entries and more are long (0: max(4096, longest / 16))
+    int32_t  split_built_threshold = 0;   // what the split in memory was built with
+    int32_t  split_long_rows = 0;
+    int64_t  split_long_nnz = 0;
+    bool     sel_no_split = false;        // the handle is the short-row part of a split
+
     // ELL whose slots are diagonals (kernels_ell.hip: ell_detect_diagonals): slot s holds column i + off[s] in the row
     // pairs whose bit is set; the product reads no column index there.  ell_diag = off[K] | xbase[K] | clusters
     // (kernels_ell.hip: stage_x_windows); mask[wavefront * K + s] = 64 row pairs
@@ -252,7 +261,8 @@ struct spmv_mat
                                 // 1 one row per lane, 2 two rows per lane reading every column index
     double*  ell_tval = nullptr;  // the values in tiles of 512 rows, (tile * k + slot) * 512 + row (ell_build_tiles); owned
 
-    // COO / CSC / ELL: internal row-grouped copy in the panel layout (coo_build_panel, csc_analyse, ell_build_panel); owned
+    // COO / CSC / ELL: internal row-grouped copy in the panel layout (coo_build_panel, csc_analyse, ell_build_panel); owned.
+    // CSR with kernel SPLIT: the copy without the long rows
     spmv_mat* coo_csr = nullptr;
 
     // COO: copy of the entries in column bins, one run of bins per XCD, for the segmented scan (kernels_coo.hip:
@@ -353,6 +363,12 @@ int coo_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 int  csr_segscan_build(spmv_mat* m);  // SPMV_CSR_SEGSCAN: the row index per entry the scan runs over
 void csr_segscan_free(spmv_mat* m);
 int  csr_segscan_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
+// kernels_csr_split.hip
+int  csr_split_build(spmv_mat* m);
+void csr_split_free(spmv_mat* m);
+int  csr_split_threshold(const spmv_mat* m);
+int  csr_split_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
+int  csr_split_long_rows_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 // kernels_misc.hip (CSC, DIA, BLAS-1, fill)
 int csc_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 int csc_analyse(spmv_mat* m);

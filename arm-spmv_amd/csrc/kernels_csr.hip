@@ -356,11 +356,11 @@ void csr_choose_kernel(spmv_mat* m)
     const double reuse      = m->win_max_span > 0 ? mean * kWinRows / (double)m->win_max_span : 0.0;
     const bool   dense_runs = m->contig_frac >= 0.8 && mean >= 24.0;
     const bool   hub_rows   = m->nnz >= (int64_t)64 << 10 && m->max_row_nnz >= 1024 && (double)m->max_row_nnz >= 32.0 * std::max(mean, 1.0);
-    // one row with 1/64 of the entries and more than a workgroup gets through in the time of a product (arrow shapes, dense
-    // constraint rows: 4 rows of 200000 among 200000 of 16, panel 0.256 ms, scan 0.049)
-    const bool   long_row   = !m->sel_no_segscan && m->max_row_nnz >= 65536 && (int64_t)m->max_row_nnz * 64 >= m->nnz;
+    // one row with 1/64 of the entries, and more of them than a workgroup gets through in the time of a product (arrow shapes,
+    // dense constraint rows: 4 rows of 200000 among 200000 of 16, panel 0.256 ms, segmented scan 0.049, long rows split off 0.027)
+    const bool   long_row   = !m->sel_no_split && m->max_row_nnz >= 65536 && (int64_t)m->max_row_nnz * 64 >= m->nnz;
     if (long_row)
-        m->kernel = SPMV_CSR_SEGSCAN;
+        m->kernel = SPMV_CSR_SPLIT;
     else if (big_enough && !dense_runs)
         m->kernel = csr_twophase_worth(m) ? SPMV_CSR_TWOPHASE : SPMV_CSR_PANEL;
     else if (hub_rows)
@@ -426,6 +426,7 @@ int csr_analyse(spmv_mat* m)
     if (m->kernel == SPMV_CSR_PANEL) SPMV_TRY(csr_panel_build(m));
     if (m->kernel == SPMV_CSR_TWOPHASE) SPMV_TRY(csr_twophase_build(m));
     if (m->kernel == SPMV_CSR_SEGSCAN) SPMV_TRY(csr_segscan_build(m));
+    if (m->kernel == SPMV_CSR_SPLIT) SPMV_TRY(csr_split_build(m));
     return SPMV_OK;
 }
 
@@ -465,6 +466,7 @@ int csr_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
         case SPMV_CSR_PANEL: return csr_panel_apply(ctx, A, x, y);
         case SPMV_CSR_TWOPHASE: return csr_twophase_apply_ex(ctx, A, x, y, apply_extra{});
         case SPMV_CSR_SEGSCAN: return csr_segscan_apply(ctx, A, x, y);
+        case SPMV_CSR_SPLIT: return csr_split_apply(ctx, A, x, y);
         case SPMV_CSR_VECTOR:
         case SPMV_CSR_AUTO:
         default:

@@ -117,6 +117,7 @@ int csr_select_kernel(spmv_mat* m)
         if (kernel == SPMV_CSR_PANEL) return csr_panel_build(m);
         if (kernel == SPMV_CSR_TWOPHASE) return csr_twophase_build(m);
         if (kernel == SPMV_CSR_SEGSCAN) return csr_segscan_build(m);
+        if (kernel == SPMV_CSR_SPLIT) return csr_split_build(m);
         return SPMV_OK;
     };
     if (m->nrow == 0 || m->nnz == 0 || !m->b || !m->v) return build(model);
@@ -128,6 +129,11 @@ int csr_select_kernel(spmv_mat* m)
     // a row with 1/128 of the entries and more: under every row-wise kernel that row is one workgroup's work at best
     // (the panel kernel: 1.25 us per 1024 entries of it) - the scan over the entries in equal pieces is a candidate
     const bool long_row = !m->sel_no_segscan && m->max_row_nnz >= 4096 && (int64_t)m->max_row_nnz * 128 >= m->nnz;
+    // a few rows far longer than the others (hubs of a graph, dense constraint rows): those rows in chunks, the rest through
+    // a copy with a kernel of its own (kernels_csr_split.hip).  R-MAT scale 20, longest row 69348 of 16.8M entries (1/242):
+    // panel 0.094 ms, split 0.076; an arrow of 60000 rows: scan 0.0092, split 0.0056
+    const bool hub_rows = !m->sel_no_split && m->max_row_nnz >= 4096 && (double)m->max_row_nnz >= 32.0 * std::max(mean, 1.0) &&
+                          (m->nnz < kSelectMaxNnz || (int64_t)m->max_row_nnz * 512 >= m->nnz);
     if (select_trials_enabled(m) && m->nnz >= kSelectMinNnz)
     {
         if (long_row)
@@ -135,6 +141,7 @@ int csr_select_kernel(spmv_mat* m)
             add(SPMV_CSR_SEGSCAN);
             add(SPMV_CSR_PANEL);  // (also beyond 8M entries, where the model is otherwise taken at its word)
         }
+        if (hub_rows) add(SPMV_CSR_SPLIT);
         if (m->nnz < kSelectMaxNnz)
         {
             add(SPMV_CSR_PANEL);
@@ -198,6 +205,7 @@ int csr_select_kernel(spmv_mat* m)
     if (best != SPMV_CSR_PANEL) csr_panel_free(m);
     if (best != SPMV_CSR_TWOPHASE) csr_twophase_free(m);
     if (best != SPMV_CSR_SEGSCAN) csr_segscan_free(m);
+    if (best != SPMV_CSR_SPLIT) csr_split_free(m);
     return build(best);  // (a layout that is already in memory with the current parameters is kept as it is)
 }
 

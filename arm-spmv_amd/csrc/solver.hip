@@ -496,6 +496,16 @@ int mat_apply_ex(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, c
     // the panel kernel does all of it in its write-back
     if (A->format == SPMV_FMT_CSR && A->kernel == SPMV_CSR_PANEL && A->nrow > 0 && A->nnz > 0) return csr_panel_apply_ex(ctx, A, x, y, ex);
     if (A->format == SPMV_FMT_CSR && A->kernel == SPMV_CSR_TWOPHASE) return csr_twophase_apply_ex(ctx, A, x, y, ex);
+    if (A->format == SPMV_FMT_CSR && A->kernel == SPMV_CSR_SPLIT && A->coo_csr)
+    {
+        // the short rows with the overwrite fused into their kernel, the long rows added on top, the dot product over the finished y
+        apply_extra first;
+        first.overwrite = ex.overwrite;
+        SPMV_TRY(mat_apply_ex(ctx, A->coo_csr, x, y, first));
+        SPMV_TRY(csr_split_long_rows_apply(ctx, A, x, y));
+        if (ex.dot_w) SPMV_TRY(vec_dot_accumulate(ctx, ex.dot_w, y, A->nrow, ex.dot_out));
+        return SPMV_OK;
+    }
     int rc = SPMV_OK;
     if (A->format == SPMV_FMT_CSR && csr_vector_apply_ex(ctx, A, x, y, ex, &rc)) return rc;  // row-parallel kernel: fused too
     if (ex.overwrite) SPMV_TRY(vec_fill(ctx, y, A->nrow, 0.0));

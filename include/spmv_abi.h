@@ -85,7 +85,9 @@ typedef enum spmv_format
  *                       src/mat_vec.cpp:57-65; its COO and CSC loops are not: `omp atomic`, :36-39, :88-91).  Callers that
  *                       need run-to-run identical bits select VECTOR (spmv_mat_set_kernel(A, SPMV_CSR_VECTOR, 0));
  *   SEGSCAN             a fixed tree inside a wavefront's 512 entries; rows that cross into another wavefront's entries are joined by
- *                       atomic adds on y in arrival order (like the COO scan). */
+ *                       atomic adds on y in arrival order (like the COO scan);
+ *   SPLIT               the long rows: a fixed tree per chunk of 4096 entries, chunks joined by atomic adds in arrival order; the
+ *                       other rows: as the inner kernel. */
 typedef enum spmv_csr_kernel
 {
     SPMV_CSR_AUTO     = 0,
@@ -94,11 +96,17 @@ typedef enum spmv_csr_kernel
     SPMV_CSR_SCALAR   = 3, /* one lane per row, strictly left-to-right (bitwise = oracle _fma) */
     SPMV_CSR_PANEL    = 4, /* row groups x column panels: x gathered from L2, y accumulated in LDS */
     SPMV_CSR_TWOPHASE = 5, /* x-stationary expand + y-stationary reduce (x far larger than the rows held: C5 shards) */
-    SPMV_CSR_SEGSCAN  = 6  /* the entries in row order, 512 per wavefront whatever row they belong to, joined by a segmented scan
+    SPMV_CSR_SEGSCAN  = 6, /* the entries in row order, 512 per wavefront whatever row they belong to, joined by a segmented scan
                               (the COO kernel over a row index per entry, 4 bytes per entry on top of the CSR arrays): a matrix whose
                               longest rows hold a large share of the entries - arrow shapes, a few dense rows - where every other CSR
                               kernel leaves that row to ONE wavefront or workgroup (1M entries in one row: 1.26 ms there, 0.045 here).
                               CSR handles only; AUTO times it where the longest row exceeds 1/128 of the entries */
+    SPMV_CSR_SPLIT    = 7  /* the rows of "split_row_threshold" entries and more (default: a sixteenth of the longest row, at least
+                              4096) stay in the handle's own arrays and run in chunks of 4096 entries, one workgroup and one atomic
+                              add on y each; every other row goes into a copy without them, which picks its own kernel (reported
+                              as "split_inner_kernel"; the panel layout as a rule).  For LARGE handles with a few dense rows, where
+                              SEGSCAN makes every entry pay for them (1M rows x 32 + one dense row: panel 1.26 ms, scan 0.47,
+                              split 0.15).  CSR handles only; AUTO times it beside SEGSCAN from 1M entries on */
 } spmv_csr_kernel;
 
 /* Tuning bits for spmv_mat_set_flags (speed only; results stay within the parity tolerance). */

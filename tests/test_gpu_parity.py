@@ -933,7 +933,7 @@ def test_auto_times_its_candidates_and_keeps_the_fastest(ctx, orc, pkg, monkeypa
     that nothing of a losing layout stays allocated, and that SPMV_PANEL_TRIAL=0 leaves the model alone."""
     capi = pkg.capi
     monkeypatch.delenv("SPMV_PANEL_TRIAL", raising=False)  # (this test is about the trials; tools/env_sweeps.sh also runs the suite without them)
-    names = {1: "vector", 2: "ldswin", 3: "scalar", 4: "panel", 5: "twophase", 6: "segscan"}
+    names = {1: "vector", 2: "ldswin", 3: "scalar", 4: "panel", 5: "twophase", 6: "segscan", 7: "split"}
     rng = np.random.default_rng(17)
     # (a) a hub row among short ones (R-MAT-like): 40000 rows x 8, one row of 30000 entries: 350K entries
     n = 40_000
@@ -965,11 +965,14 @@ def test_auto_times_its_candidates_and_keeps_the_fastest(ctx, orc, pkg, monkeypa
     if kept != capi.CSR_PANEL:
         assert A.get_param("panel_bytes") == 0  # the losing layout went back
     bytes_auto = A.get_param("device_bytes")
-    for k in (capi.CSR_VECTOR, capi.CSR_SCALAR, capi.CSR_PANEL, capi.CSR_SEGSCAN):
+    for k in (capi.CSR_VECTOR, capi.CSR_SCALAR, capi.CSR_PANEL, capi.CSR_SEGSCAN, capi.CSR_SPLIT):
         A.set_kernel(k)
         product(A, f"hub row, forced {names[k]}")
     A.set_kernel(capi.CSR_AUTO)  # selecting again times again and ends in the same state
-    assert A.get_param("select_candidates") >= 2 and A.get_param("device_bytes") <= bytes_auto + (1 << 20)
+    assert A.get_param("select_candidates") >= 2
+    if int(A.info.kernel) == kept:  # (two candidates within microseconds of each other may swap places between two trials)
+        assert A.get_param("device_bytes") <= bytes_auto + (1 << 20)
+    assert A.get_param("device_bytes") <= 4 * (n + 1) + 12 * int(rp[-1]) + 16 * int(rp[-1]) + (1 << 20)  # the arrays + ONE layout
     product(A, "hub row, AUTO again")
     # the model alone (no timing launches): the hub-row rule picks the panel layout
     monkeypatch.setenv("SPMV_PANEL_TRIAL", "0")
@@ -1056,10 +1059,16 @@ def test_rows_that_hold_most_of_the_entries_go_through_the_scan(ctx, orc, pkg, m
 
     A = ctx.csr(n, n, rp, cc, cv)
     base = 4 * (n + 1) + 12 * int(rp[-1])
-    assert A.info.max_row_nnz == n and A.info.kernel == capi.CSR_SEGSCAN, A.info.kernel
-    assert A.get_param("select_us_segscan") > 0 and A.get_param("select_us_panel") > 3 * A.get_param("select_us_segscan")
-    assert A.get_param("panel_bytes") == 0 and base + 4 * int(rp[-1]) <= A.info.device_bytes <= base + 4 * int(rp[-1]) + (1 << 20)
-    product(A, "arrow, AUTO (segmented scan)")
+    assert A.info.max_row_nnz == n and A.info.kernel in (capi.CSR_SEGSCAN, capi.CSR_SPLIT), A.info.kernel
+    t_scan, t_split, t_panel = (A.get_param("select_us_" + k) for k in ("segscan", "split", "panel"))
+    assert t_scan > 0 and t_split > 0 and t_panel > 3 * max(t_scan, t_split), (t_scan, t_split, t_panel)
+    assert (A.info.kernel == capi.CSR_SPLIT) == (t_split < 0.98 * t_scan) or abs(t_split - t_scan) <= 1, (t_scan, t_split)
+    assert A.get_param("panel_bytes") == 0
+    if A.info.kernel == capi.CSR_SEGSCAN:  # the row index per entry, and nothing of the candidates that lost
+        assert base + 4 * int(rp[-1]) <= A.info.device_bytes <= base + 4 * int(rp[-1]) + (1 << 20)
+    else:
+        assert A.info.device_bytes < base + 16 * (int(rp[-1]) - n) + (2 << 20)
+    product(A, "arrow, AUTO")
     for k in (capi.CSR_PANEL, capi.CSR_VECTOR, capi.CSR_SCALAR):
         A.set_kernel(k)
         assert A.info.kernel == k
@@ -1069,6 +1078,21 @@ def test_rows_that_hold_most_of_the_entries_go_through_the_scan(ctx, orc, pkg, m
     A.set_kernel(capi.CSR_SEGSCAN)
     assert A.info.kernel == capi.CSR_SEGSCAN
     product(A, "arrow, scan forced")
+    # kernel SPLIT: the dense row in chunks of 4096 entries over the handle's own arrays, the other rows through a copy
+    A.set_kernel(capi.CSR_SPLIT)
+    assert A.info.kernel == capi.CSR_SPLIT and A.get_param("split_row_threshold") == n // 16
+    assert A.get_param("split_long_rows") == 1 and A.get_param("split_long_entries") == n and A.get_param("split_inner_kernel") in (1, 2, 3, 4, 5)
+    # the row index of the scan went back; the copy holds the short rows only (the panel layout forced above stays until AUTO or a re-build)
+    assert A.info.device_bytes < base + A.get_param("panel_bytes") + 16 * (int(rp[-1]) - n) + (2 << 20)
+    product(A, "arrow, long-row split")
+    for T in (2, 1, 1 << 30):  # every row with entries is "long" (the copy is empty); the same; none is (no chunk at all)
+        A.set_param("split_row_threshold", T)
+        A.set_kernel(capi.CSR_SPLIT)
+        assert A.get_param("split_long_rows") == (n - 2000 if T <= 2 else 0)
+        product(A, f"arrow, split at {T}")
+    A.set_param("split_row_threshold", 0)
+    A.set_kernel(capi.CSR_VECTOR)
+    assert A.info.device_bytes <= base + (1 << 20) + A.get_param("panel_bytes")
     # the solver's fused extras (y = A x, w . y) on a kernel that has no write-back of its own: CG on an SPD arrow
     m = 70_000
     l2 = np.full(m, 2, np.int64)
@@ -1084,18 +1108,21 @@ def test_rows_that_hold_most_of_the_entries_go_through_the_scan(ctx, orc, pkg, m
     v2[m::2] = 1e-3
     v2[m + 1::2] = 2.0 + rng.uniform(0, 1, m - 1)
     S = ctx.csr(m, m, rp2, c2, v2)
-    assert S.info.kernel == capi.CSR_SEGSCAN
+    assert S.info.kernel in (capi.CSR_SEGSCAN, capi.CSR_SPLIT)
     xs = rng.uniform(-1, 1, m)
     bs = np.zeros(m)
     ol.csr_spmv(orc, rp2, c2, v2, xs, bs)
     sol = ctx.vector(m)
-    iters, relres = ctx.cg(S, ctx.vector_from(bs), sol, max_iter=200, rel_tol=1e-12, check_every=4)
-    assert relres <= 1e-12 and np.max(np.abs(sol.download() - xs)) < 1e-9, (iters, relres)
+    for k in (capi.CSR_SEGSCAN, capi.CSR_SPLIT):
+        S.set_kernel(k)
+        sol.fill(0.0)
+        iters, relres = ctx.cg(S, ctx.vector_from(bs), sol, max_iter=200, rel_tol=1e-12, check_every=4)
+        assert relres <= 1e-12 and np.max(np.abs(sol.download() - xs)) < 1e-9, (k, iters, relres)
     # a CSC handle of the arrow: its row-grouped copy may pick the scan; a COO handle's copy never does (the handle has it itself)
     rows = np.repeat(np.arange(n, dtype=np.int32), lens)
     cp, cr, cw = ol.coo_to_csc(orc, n, rows, cc, cv)
     C = ctx.csc(n, n, cp, cr, cw)
-    assert C.info.kernel == capi.CSR_PANEL and C.get_param("rowgrouped_kernel") == capi.CSR_SEGSCAN
+    assert C.info.kernel == capi.CSR_PANEL and C.get_param("rowgrouped_kernel") in (capi.CSR_SEGSCAN, capi.CSR_SPLIT)
     product(C, "arrow as CSC, AUTO")
     O = ctx.coo(n, n, rows, cc, cv)
     assert O.get_param("rowgrouped_kernel") != capi.CSR_SEGSCAN
@@ -1105,7 +1132,7 @@ def test_rows_that_hold_most_of_the_entries_go_through_the_scan(ctx, orc, pkg, m
     # the model alone
     monkeypatch.setenv("SPMV_PANEL_TRIAL", "0")
     B = ctx.csr(n, n, rp, cc, cv)
-    assert B.get_param("select_candidates") == 0 and B.info.kernel == capi.CSR_SEGSCAN
+    assert B.get_param("select_candidates") == 0 and B.info.kernel == capi.CSR_SPLIT and B.get_param("split_long_rows") == 1
     product(B, "arrow, model only")
 
 
@@ -1385,7 +1412,7 @@ def test_large_csc_is_regrouped_by_row_and_matches_oracle(ctx, orc, pkg):
     A = ctx.csc(n, n, cp, cr, cw)
     # 4.8M entries: AUTO times the scatter against the copy grouped by row (round 5; rounds 1-4: the model alone, the panel
     # layout forced on the copy); the copy wins on any box (one atomic on y per entry against a row-grouped product)
-    assert A.info.kernel == capi.CSR_PANEL and A.get_param("rowgrouped_kernel") in (1, 2, 3, 4, 5, 6)
+    assert A.info.kernel == capi.CSR_PANEL and A.get_param("rowgrouped_kernel") in (1, 2, 3, 4, 5, 6, 7)
     assert A.info.device_bytes > 12 * n * k + 12 * n * k - 1  # CSC arrays + the copy (12-byte entries, or CSR's own 12)
     for kernel, what in ((None, "AUTO"), (capi.CSR_VECTOR, "scatter forced"), (capi.CSR_PANEL, "panel layout forced on the copy"), (capi.CSR_AUTO, "AUTO again")):
         if kernel is not None:

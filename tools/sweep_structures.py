@@ -25,7 +25,7 @@ sys.path.insert(0, str(ROOT))
 from __graft_entry__ import load_package  # noqa: E402
 
 capi = load_package().capi
-NAMES = {0: "auto", 1: "vector", 2: "ldswin", 3: "scalar", 4: "panel", 5: "twophase", 6: "segscan"}
+NAMES = {0: "auto", 1: "vector", 2: "ldswin", 3: "scalar", 4: "panel", 5: "twophase", 6: "segscan", 7: "split"}
 
 
 # ---------------------------------------------------------------------------------------------- generators (host, numpy)
@@ -236,15 +236,15 @@ def run_case(ctx, name, build, out):
     auto_k = int(A.info.kernel)
     check(ctx, A, x, y, ref, scale, f"{name} csr auto")
     res = {"auto": timed(ctx, A, x, y, reps)}
-    for kern in (1, 2, 3, 4, 5, 6):
-        if kern == 5 and nnz < 2_000_000:
+    for kern in (1, 2, 3, 4, 5, 6, 7):
+        if (kern == 5 and nnz < 2_000_000) or (kern == 7 and ln.max() < 4096):
             continue
         ms = try_kernel(ctx, A, kern, 0, x, y, ref, scale, reps, f"{name} csr {NAMES[kern]}")
         if ms is not None:
             res[NAMES[kern]] = ms
     A.set_kernel(0)
     res["auto"] = min(res["auto"], timed(ctx, A, x, y, reps))
-    rows.append(("csr", NAMES[int(A.info.kernel)], res, trial_record(A).replace("variant1", "segscan")))
+    rows.append(("csr", NAMES[int(A.info.kernel)], res, trial_record(A).replace("variant1", "segscan").replace("variant2", "split")))
     del A
 
     # ---- COO handle (row-sorted, as .mtx files converted by the reference arrive)
