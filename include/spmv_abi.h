@@ -74,7 +74,9 @@ typedef enum spmv_format
  *   what was timed is on record: spmv_mat_get_param "select_candidates", "select_us_vector" / "_ldswin" / "_scalar" / "_panel" /
  *   "_twophase" (microseconds per product, 0 = not timed; COO / ELL: "_vector" the format's own kernel, "_panel" the copy; ELL
  *   also "_variant1" one row per lane, "_variant2" two rows per lane reading every index), "rowgrouped_kernel" (the kernel the
- *   copy of a COO / ELL / CSC handle runs, 0 = no copy in use), "ell_variant", "contiguous_permille".
+ *   copy of a COO / ELL / CSC handle runs, 0 = no copy in use), "ell_variant", "contiguous_permille"; CSR handles also
+ *   "select_us_segscan" / "_split", and for kernel SPLIT "split_row_threshold" (get: in effect; set: 0 = default, read at the
+ *   next spmv_mat_set_kernel), "split_long_rows", "split_long_entries", "split_inner_kernel" (what the short rows' copy runs).
  *   Audit on stencils, dense blocks, R-MAT graphs, rectangles, permutations: tools/sweep_structures.py, profiles/r05_sweep_structures_*.
  *
  * Order of the additions (all within the parity tolerance of 1e-10):
