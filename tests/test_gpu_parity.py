@@ -985,7 +985,8 @@ def test_auto_times_its_candidates_and_keeps_the_fastest(ctx, orc, pkg, monkeypa
     C = ctx.coo(n, n, rows, cc, cv)
     assert C.get_param("select_candidates") == 2 and C.get_param("select_us_vector") > 0 and C.get_param("select_us_panel") > 0
     if C.info.kernel == capi.CSR_PANEL:
-        assert C.get_param("rowgrouped_kernel") in names and C.get_param("select_us_panel") < C.get_param("select_us_vector")
+        # (whole microseconds: the copy won by 2 % and more, which may round to the same number)
+        assert C.get_param("rowgrouped_kernel") in names and C.get_param("select_us_panel") <= C.get_param("select_us_vector")
     else:
         assert C.get_param("rowgrouped_kernel") == 0 and C.get_param("device_bytes") <= 16 * int(rp[-1]) + 4096  # the copy went back
     product(C, "hub row, COO AUTO")
