@@ -763,6 +763,13 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         SPMV_REQUIRE(value >= 0 && value <= INT32_MAX, "split_row_threshold must be 0 (default) or a row length, got %lld", (long long)value);
         m->split_threshold = (int32_t)value;
     }
+    else if (!strcmp(name, "split_mode"))
+    {
+        // how kernel SPLIT runs its long rows: 1 chunks of 4096 entries over the handle's own arrays, 2 virtual rows of 64 entries in a
+        // matrix of their own, 0 by their density (kernels_csr_split.hip); takes effect at the next spmv_mat_set_kernel
+        SPMV_REQUIRE(value >= 0 && value <= 2, "split_mode must be 0 (by density), 1 (chunks) or 2 (virtual rows), got %lld", (long long)value);
+        m->split_mode = (int32_t)value;
+    }
     else if (!strcmp(name, "panel_keep_csr"))
     {
         // 0: release col_ind / values of a CSR handle whose product runs from the panel layout (which holds the same
@@ -992,6 +999,12 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         *value = m->format == SPMV_FMT_CSR ? csr_split_threshold(m) : 0;
     else if (!strcmp(name, "split_long_rows"))
         *value = m->split_long_rows;
+    else if (!strcmp(name, "split_mode"))
+        *value = m->split_built_mode ? m->split_built_mode : m->split_mode;
+    else if (!strcmp(name, "split_virtual_rows"))
+        *value = m->split_vrows;
+    else if (!strcmp(name, "split_long_kernel"))
+        *value = m->split_long ? m->split_long->kernel : 0;
     else if (!strcmp(name, "split_long_entries"))
         *value = m->split_long_nnz;
     else if (!strcmp(name, "split_inner_kernel"))

@@ -12,6 +12,16 @@
 // A product is the copy's product followed by the long-row kernel on the same stream.  Rows that cross chunks are joined by
 // atomic adds in arrival order (the last bits of a LONG row's y may differ between two calls, as with PANEL).
 //
+// That is "split_mode" 1, right for DENSE long rows (an entry in most 128-byte lines of x they span).  Long rows of a power law
+// or an R-MAT graph are long AND sparse: 8192 entries spread over 1M columns gather a line of x per entry, in row order, from
+// an x beyond L2 - what the panel layout exists to avoid (tools/probe_split_threshold.py: the more rows went through the
+// chunks, the slower the product).  "split_mode" 2 therefore turns every long row into V = ceil(len / 64) VIRTUAL rows with
+// the entries dealt out in turn (entry j of the row goes to virtual row j % V): neighbours in x land in different virtual
+// rows, every virtual row looks like an ordinary short row, and the virtual rows of all long rows form a second CSR matrix
+// with a handle - and a kernel, as a rule the panel layout - of its own.  Its product goes to a scratch vector (overwrite),
+// and one wavefront per long row adds the V partial sums up in a fixed order and onto y.  Mode 0 picks: chunks where the long
+// rows hold an entry per 2 columns on average, virtual rows otherwise.
+//
 // The reference has nothing to mirror here: its CSR loop gives a row to one thread whatever its length (src/mat_vec.cpp:57-65).
 #include <algorithm>
 #include <vector>
@@ -24,6 +34,7 @@ namespace spmv
 namespace
 {
 constexpr int kLongChunk = 4096;  // entries per workgroup: 16 per lane, 4 loads in flight each
+constexpr int kVirtualLen = 64;  // mode 2: entries per virtual row
 
 __global__ __launch_bounds__(kBlock) void csr_long_rows_kernel(const int32_t* __restrict__ chunk_row, const int32_t* __restrict__ chunk_beg,
                                                                const int32_t* __restrict__ chunk_end, const int32_t* __restrict__ col,
@@ -73,6 +84,38 @@ __global__ __launch_bounds__(kBlock) void split_copy_kernel(int nrow, const int3
         out_val[d + j] = val[s + j];
     }
 }
+
+// mode 2: deal the entries of the long rows out to their virtual rows.  One workgroup per chunk of a long row (the chunk
+// table's row column holds the INDEX of the long row here); lrow = first entry | V | first virtual row, per long row
+__global__ __launch_bounds__(kBlock) void split_deal_kernel(const int32_t* __restrict__ chunk_long, const int32_t* __restrict__ chunk_beg,
+                                                            const int32_t* __restrict__ chunk_end, const int32_t* __restrict__ lbeg,
+                                                            const int32_t* __restrict__ lv, const int32_t* __restrict__ lbase,
+                                                            const int32_t* __restrict__ vptr, const int32_t* __restrict__ col, const double* __restrict__ val,
+                                                            int32_t* __restrict__ out_col, double* __restrict__ out_val)
+{
+    const int c = blockIdx.x, li = chunk_long[c];
+    const int first = lbeg[li], V = lv[li], base = lbase[li];
+    for (int j = chunk_beg[c] + (int)threadIdx.x; j < chunk_end[c]; j += kBlock)
+    {
+        const int k = j - first;
+        const int d = vptr[base + k % V] + k / V;
+        out_col[d]  = col[j];
+        out_val[d]  = val[j];
+    }
+}
+
+// mode 2: y[row] += the partial sums of the row's virtual rows, one wavefront per long row, a fixed order
+__global__ __launch_bounds__(kBlock) void split_combine_kernel(int nlong, const int32_t* __restrict__ lrow, const int32_t* __restrict__ lv,
+                                                               const int32_t* __restrict__ lbase, const double* __restrict__ yl, double* __restrict__ y)
+{
+    const int li = (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
+    if (li >= nlong) return;  // (uniform over the wavefront)
+    const int V = lv[li], base = lbase[li];
+    double    s = 0.0;
+    for (int v = lane_id(); v < V; v += kWave) s += yl[base + v];
+    s = wave_sum(s);
+    if (lane_id() == 0) y[lrow[li]] += s;
+}
 }  // namespace
 
 void csr_split_free(spmv_mat* m)
@@ -90,6 +133,26 @@ void csr_split_free(spmv_mat* m)
         mat_free(m->coo_csr);
         m->coo_csr = nullptr;
     }
+    if (m->split_long)
+    {
+        m->device_bytes -= m->split_long->device_bytes;
+        mat_free(m->split_long);
+        m->split_long = nullptr;
+    }
+    if (m->split_yl)
+    {
+        (void)hipFree(m->split_yl);
+        m->device_bytes -= (int64_t)sizeof(double) * m->split_vrows;
+        m->split_yl = nullptr;
+    }
+    if (m->split_rows)
+    {
+        (void)hipFree(m->split_rows);
+        m->device_bytes -= (int64_t)sizeof(int32_t) * 4 * m->split_long_rows;
+        m->split_rows = nullptr;
+    }
+    m->split_vrows = 0;
+    m->split_built_mode = 0;
     m->split_nchunks = 0;
     m->split_long_rows = 0;
     m->split_long_nnz = 0;
@@ -107,39 +170,70 @@ int csr_split_build(spmv_mat* m)
 {
     SPMV_REQUIRE(m->format == SPMV_FMT_CSR && m->a && m->b && m->v, "the long-row split is built from a CSR handle's own arrays");
     const int T = csr_split_threshold(m);
-    if (m->coo_csr && m->split_built_threshold == T) return SPMV_OK;
+    if (m->coo_csr && m->split_built_threshold == T && (m->split_mode == 0 || m->split_mode == m->split_built_mode)) return SPMV_OK;
     (void)hipStreamSynchronize(m->ctx->stream);
     csr_split_free(m);
     spmv_ctx*   ctx = m->ctx;
     hipStream_t s   = ctx->stream;
     const int   n   = m->nrow;
     // row lengths through the host: one pass, one-off (8M rows: 32 MB)
-    std::vector<int32_t> rp((size_t)n + 1), dst((size_t)n + 1), chunks;
+    std::vector<int32_t> rp((size_t)n + 1), dst((size_t)n + 1);
     SPMV_HIP(hipMemcpyAsync(rp.data(), m->a, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, s));
     SPMV_HIP(hipStreamSynchronize(s));
-    std::vector<int32_t> crow, cbeg, cend;
+    std::vector<int32_t> lrow;  // the long rows
     int64_t              kept = 0, long_nnz = 0;
-    int                  long_rows = 0;
     for (int r = 0; r < n; ++r)
     {
         const int len  = rp[(size_t)r + 1] - rp[(size_t)r];
         dst[(size_t)r] = (int32_t)kept;
         if (len >= T)
         {
-            ++long_rows;
+            lrow.push_back(r);
             long_nnz += len;
-            for (int b = rp[(size_t)r]; b < rp[(size_t)r + 1]; b += kLongChunk)
-            {
-                crow.push_back(r);
-                cbeg.push_back(b);
-                cend.push_back(std::min(b + kLongChunk, rp[(size_t)r + 1]));
-            }
         }
         else
             kept += len;
     }
-    dst[(size_t)n] = (int32_t)kept;
-    spmv_mat* rest = nullptr;
+    dst[(size_t)n]     = (int32_t)kept;
+    const size_t nlong = lrow.size();
+    // chunks or virtual rows: dense long rows read x nearly coalesced in row order; sparse ones want the panel layout's order
+    int mode = m->split_mode;
+    // (1M rows, lengths min(500000, 8 / u): the 260 longest rows hold an entry per 9 columns - chunks 0.46 ms, virtual rows 0.28;
+    // 8 rows with an entry in every column among 500000 of 32: chunks 0.079, virtual rows 0.119)
+    if (mode != 1 && mode != 2) mode = (double)long_nnz * 2.0 >= (double)nlong * (double)m->ncol ? 1 : 2;
+    // chunk table (mode 1: row | begin | end; mode 2: index of the long row | begin | end, for the deal kernel)
+    std::vector<int32_t> crow, cbeg, cend, lbeg(nlong), lv(nlong), lbase(nlong), vptr;
+    int64_t              nv = 0;
+    for (size_t i = 0; i < nlong; ++i)
+    {
+        const int r = lrow[i], b0 = rp[(size_t)r], e0 = rp[(size_t)r + 1];
+        for (int b = b0; b < e0; b += kLongChunk)
+        {
+            crow.push_back(mode == 1 ? r : (int32_t)i);
+            cbeg.push_back(b);
+            cend.push_back(std::min(b + kLongChunk, e0));
+        }
+        lbeg[i]  = b0;
+        lv[i]    = (int32_t)ceil_div((int64_t)(e0 - b0), kVirtualLen);
+        lbase[i] = (int32_t)nv;
+        nv += lv[i];
+    }
+    if (mode == 2)
+    {
+        vptr.resize((size_t)nv + 1);
+        int64_t at = 0;
+        for (size_t i = 0; i < nlong; ++i)
+        {
+            const int len = rp[(size_t)lrow[i] + 1] - rp[(size_t)lrow[i]], V = lv[i];
+            for (int v = 0; v < V; ++v)
+            {
+                vptr[(size_t)lbase[i] + (size_t)v] = (int32_t)at;
+                at += len / V + (v < len % V ? 1 : 0);
+            }
+        }
+        vptr[(size_t)nv] = (int32_t)at;
+    }
+    spmv_mat *rest = nullptr, *lng = nullptr;
     SPMV_TRY(mat_alloc(ctx, SPMV_FMT_CSR, n, m->ncol, kept, 0, (size_t)n + 1, (size_t)kept, (size_t)kept, &rest));
     int rc = SPMV_OK;
     do
@@ -162,59 +256,115 @@ int csr_split_build(spmv_mat* m)
                                const_cast<int32_t*>(rest->b), const_cast<double*>(rest->v));
         }
         const size_t nc = crow.size();
-        if (nc > 0)
+        if (nc == 0) break;
+        if (hipMalloc(&m->split_chunks, sizeof(int32_t) * 3 * nc) != hipSuccess)
         {
-            if (hipMalloc(&m->split_chunks, sizeof(int32_t) * 3 * nc) != hipSuccess)
-            {
-                m->split_chunks = nullptr;
-                rc              = SPMV_ERR_ALLOC;
-                break;
-            }
-            m->split_nchunks = (int32_t)nc;
-            m->device_bytes += (int64_t)sizeof(int32_t) * 3 * (int64_t)nc;
-            if (hipMemcpyAsync(m->split_chunks, crow.data(), sizeof(int32_t) * nc, hipMemcpyHostToDevice, s) != hipSuccess ||
-                hipMemcpyAsync(m->split_chunks + nc, cbeg.data(), sizeof(int32_t) * nc, hipMemcpyHostToDevice, s) != hipSuccess ||
-                hipMemcpyAsync(m->split_chunks + 2 * nc, cend.data(), sizeof(int32_t) * nc, hipMemcpyHostToDevice, s) != hipSuccess)
-                rc = SPMV_ERR_HIP;
+            m->split_chunks = nullptr;
+            rc              = SPMV_ERR_ALLOC;
+            break;
         }
-        if (hipGetLastError() != hipSuccess) rc = SPMV_ERR_HIP;
+        m->split_nchunks = (int32_t)nc;
+        m->device_bytes += (int64_t)sizeof(int32_t) * 3 * (int64_t)nc;
+        if (hipMemcpyAsync(m->split_chunks, crow.data(), sizeof(int32_t) * nc, hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(m->split_chunks + nc, cbeg.data(), sizeof(int32_t) * nc, hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(m->split_chunks + 2 * nc, cend.data(), sizeof(int32_t) * nc, hipMemcpyHostToDevice, s) != hipSuccess)
+        {
+            rc = SPMV_ERR_HIP;
+            break;
+        }
+        if (mode == 1) break;
+        // mode 2: the virtual rows as a CSR matrix of their own
+        if (hipMalloc(&m->split_rows, sizeof(int32_t) * 4 * nlong) != hipSuccess)
+        {
+            m->split_rows = nullptr;
+            rc            = SPMV_ERR_ALLOC;
+            break;
+        }
+        m->split_long_rows = (int32_t)nlong;  // (csr_split_free accounts for split_rows with it)
+        m->device_bytes += (int64_t)sizeof(int32_t) * 4 * (int64_t)nlong;
+        if (hipMalloc(&m->split_yl, sizeof(double) * (size_t)nv) != hipSuccess)
+        {
+            m->split_yl = nullptr;
+            rc          = SPMV_ERR_ALLOC;
+            break;
+        }
+        m->split_vrows = (int32_t)nv;
+        m->device_bytes += (int64_t)sizeof(double) * nv;
+        if ((rc = mat_alloc(ctx, SPMV_FMT_CSR, (int32_t)nv, m->ncol, long_nnz, 0, (size_t)nv + 1, (size_t)long_nnz, (size_t)long_nnz, &lng)) != SPMV_OK) break;
+        int32_t* sr = m->split_rows;
+        if (hipMemcpyAsync(sr, lrow.data(), sizeof(int32_t) * nlong, hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(sr + nlong, lbeg.data(), sizeof(int32_t) * nlong, hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(sr + 2 * nlong, lv.data(), sizeof(int32_t) * nlong, hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(sr + 3 * nlong, lbase.data(), sizeof(int32_t) * nlong, hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(const_cast<int32_t*>(lng->a), vptr.data(), sizeof(int32_t) * ((size_t)nv + 1), hipMemcpyHostToDevice, s) != hipSuccess)
+        {
+            rc = SPMV_ERR_HIP;
+            break;
+        }
+        hipLaunchKernelGGL(split_deal_kernel, dim3((unsigned)nc), dim3(kBlock), 0, s, m->split_chunks, m->split_chunks + nc, m->split_chunks + 2 * nc, sr + nlong,
+                           sr + 2 * nlong, sr + 3 * nlong, lng->a, m->b, m->v, const_cast<int32_t*>(lng->b), const_cast<double*>(lng->v));
     } while (0);
+    if (rc == SPMV_OK && hipGetLastError() != hipSuccess) rc = SPMV_ERR_HIP;
     if (hipStreamSynchronize(s) != hipSuccess && rc == SPMV_OK) rc = SPMV_ERR_HIP;  // (the host vectors go out of scope below)
-    if (rc == SPMV_OK)
-    {
-        rest->row_begin      = m->row_begin;
-        rest->pb_trial       = m->pb_trial;
-        rest->sel_no_split   = true;  // (its longest row is below the threshold by construction; and no split of a split)
-        rest->sel_no_segscan = true;  // what the scan is for went out with the long rows
-        rc                   = csr_analyse(rest);  // picks the copy's kernel and builds its layout
-    }
+    for (spmv_mat* part : {rest, lng})
+        if (rc == SPMV_OK && part)
+        {
+            part->row_begin      = part == rest ? m->row_begin : 0;
+            part->pb_trial       = m->pb_trial;
+            part->sel_no_split   = true;  // (their longest rows are short by construction; and no split of a split)
+            part->sel_no_segscan = true;  // what the scan is for went out with the long rows
+            rc                   = csr_analyse(part);  // picks the part's kernel and builds its layout
+            // the panel and two-phase layouts read row_ptr and their own arrays only
+            if (rc == SPMV_OK && (part->kernel == SPMV_CSR_PANEL || part->kernel == SPMV_CSR_TWOPHASE) && part->b && part->v && part->nnz > 0)
+            {
+                (void)hipFree(const_cast<int32_t*>(part->b));
+                (void)hipFree(const_cast<double*>(part->v));
+                part->device_bytes -= part->nnz * 12;
+                part->b = nullptr;
+                part->v = nullptr;
+            }
+        }
     if (rc != SPMV_OK)
     {
         mat_free(rest);
+        if (lng) mat_free(lng);
         csr_split_free(m);
         if (rc == SPMV_ERR_HIP) set_error("building the long-row split failed: %s", hipGetErrorString(hipGetLastError()));
         if (rc == SPMV_ERR_ALLOC) set_error("no device memory for the long-row split of %lld entries", (long long)m->nnz);
         return rc;
     }
-    // the panel and two-phase layouts read row_ptr and their own arrays only
-    if ((rest->kernel == SPMV_CSR_PANEL || rest->kernel == SPMV_CSR_TWOPHASE) && rest->b && rest->v && kept > 0)
+    m->coo_csr = rest;
+    m->device_bytes += rest->device_bytes;
+    if (lng)
     {
-        (void)hipFree(const_cast<int32_t*>(rest->b));
-        (void)hipFree(const_cast<double*>(rest->v));
-        rest->device_bytes -= kept * 12;
-        rest->b = nullptr;
-        rest->v = nullptr;
+        m->split_long = lng;
+        m->device_bytes += lng->device_bytes;
+        // the chunk table was for the deal kernel only
+        (void)hipFree(m->split_chunks);
+        m->device_bytes -= (int64_t)sizeof(int32_t) * 3 * m->split_nchunks;
+        m->split_chunks  = nullptr;
+        m->split_nchunks = 0;
     }
-    m->coo_csr               = rest;
-    m->device_bytes         += rest->device_bytes;
-    m->split_long_rows       = long_rows;
+    m->split_long_rows       = (int32_t)nlong;
     m->split_long_nnz        = long_nnz;
     m->split_built_threshold = T;
+    m->split_built_mode      = mode;
     return SPMV_OK;
 }
 
 int csr_split_long_rows_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
 {
+    if (A->split_long)
+    {
+        const size_t nl = (size_t)A->split_long_rows;
+        apply_extra  over;
+        over.overwrite = true;
+        SPMV_TRY(mat_apply_ex(ctx, A->split_long, x, A->split_yl, over));
+        hipLaunchKernelGGL(split_combine_kernel, dim3((unsigned)ceil_div((int64_t)nl * kWave, kBlock)), dim3(kBlock), 0, ctx->stream, (int)nl, A->split_rows,
+                           A->split_rows + 2 * nl, A->split_rows + 3 * nl, A->split_yl, y);
+        SPMV_HIP(hipGetLastError());
+        return SPMV_OK;
+    }
     if (A->split_nchunks == 0) return SPMV_OK;
     const size_t nc = (size_t)A->split_nchunks;
     hipLaunchKernelGGL(csr_long_rows_kernel, dim3((unsigned)nc), dim3(kBlock), 0, ctx->stream, A->split_chunks, A->split_chunks + nc, A->split_chunks + 2 * nc,

@@ -158,6 +158,11 @@ int csr_select_kernel(spmv_mat* m)
             add(SPMV_CSR_PANEL);
             if (m->win_max_span > 0 && m->win_max_span <= csr_ldswin_capacity()) add(SPMV_CSR_LDSWIN);  // (64 x 64 blocks: 0.092 against 0.094 / 0.113)
         }
+        // the two-phase model was measured on 10M rows x 32 under an x of 80 .. 640 MB (C5's shards); on other shapes below that
+        // size it has been wrong by 4x (12.7M entries in 200000 rows of 64 over 4M columns: 0.80 ms, panel 0.06): time the panel
+        // layout beside it.  From 64M entries on its word stands (a shard of C5 keeps the set-up - and the allocation history
+        // its piece search starts from - it was measured with).
+        if (m->nnz >= kSelectMaxNnz && model == SPMV_CSR_TWOPHASE && m->nnz < ((int64_t)64 << 20)) add(SPMV_CSR_PANEL);
     }
     if (cand.size() == 1) return build(model);
 

@@ -76,7 +76,8 @@ typedef enum spmv_format
  *   also "_variant1" one row per lane, "_variant2" two rows per lane reading every index), "rowgrouped_kernel" (the kernel the
  *   copy of a COO / ELL / CSC handle runs, 0 = no copy in use), "ell_variant", "contiguous_permille"; CSR handles also
  *   "select_us_segscan" / "_split", and for kernel SPLIT "split_row_threshold" (get: in effect; set: 0 = default, read at the
- *   next spmv_mat_set_kernel), "split_long_rows", "split_long_entries", "split_inner_kernel" (what the short rows' copy runs).
+ *   next spmv_mat_set_kernel), "split_mode" (likewise; get: the mode in effect), "split_long_rows", "split_long_entries",
+ *   "split_inner_kernel" (what the short rows' copy runs), "split_long_kernel" / "split_virtual_rows" (mode 2).
  *   Audit on stencils, dense blocks, R-MAT graphs, rectangles, permutations: tools/sweep_structures.py, profiles/r05_sweep_structures_*.
  *
  * Order of the additions (all within the parity tolerance of 1e-10):
@@ -88,8 +89,9 @@ typedef enum spmv_format
  *                       need run-to-run identical bits select VECTOR (spmv_mat_set_kernel(A, SPMV_CSR_VECTOR, 0));
  *   SEGSCAN             a fixed tree inside a wavefront's 512 entries; rows that cross into another wavefront's entries are joined by
  *                       atomic adds on y in arrival order (like the COO scan);
- *   SPLIT               the long rows: a fixed tree per chunk of 4096 entries, chunks joined by atomic adds in arrival order; the
- *                       other rows: as the inner kernel. */
+ *   SPLIT               the long rows: mode 1 a fixed tree per chunk of 4096 entries, chunks joined by atomic adds in arrival order;
+ *                       mode 2 as the virtual rows' kernel, then a fixed order over a row's partial sums; the other rows: as the
+ *                       inner kernel. */
 typedef enum spmv_csr_kernel
 {
     SPMV_CSR_AUTO     = 0,
@@ -104,11 +106,15 @@ typedef enum spmv_csr_kernel
                               kernel leaves that row to ONE wavefront or workgroup (1M entries in one row: 1.26 ms there, 0.045 here).
                               CSR handles only; AUTO times it where the longest row exceeds 1/128 of the entries */
     SPMV_CSR_SPLIT    = 7  /* the rows of "split_row_threshold" entries and more (default: a sixteenth of the longest row, at least
-                              4096) stay in the handle's own arrays and run in chunks of 4096 entries, one workgroup and one atomic
-                              add on y each; every other row goes into a copy without them, which picks its own kernel (reported
-                              as "split_inner_kernel"; the panel layout as a rule).  For LARGE handles with a few dense rows, where
-                              SEGSCAN makes every entry pay for them (1M rows x 32 + one dense row: panel 1.26 ms, scan 0.47,
-                              split 0.15).  CSR handles only; AUTO times it beside SEGSCAN from 1M entries on */
+                              4096) leave the matrix; every other row goes into a copy without them, which picks its own kernel
+                              ("split_inner_kernel"; the panel layout as a rule).  The long rows ("split_mode": 0 by their density):
+                              1 = in chunks of 4096 entries over the handle's own arrays, one workgroup and one atomic add on y each
+                              (dense rows: an entry per 2 columns); 2 = dealt out to virtual rows of 64 entries (entry j of a row to
+                              virtual row j mod V) that form a CSR matrix with a handle and a kernel of its own ("split_long_kernel",
+                              "split_virtual_rows"), its product summed per long row in a fixed order (long AND sparse rows: power
+                              laws, graph hubs).  1M rows x 32 + one dense row: panel 1.26 ms, scan 0.47, split 0.11; 1M rows of
+                              min(500000, 8/u) entries: panel 0.64, split 0.29.  CSR handles only; AUTO times it where the longest
+                              row is >= 4096 and 32x the mean */
 } spmv_csr_kernel;
 
 /* Tuning bits for spmv_mat_set_flags (speed only; results stay within the parity tolerance). */

@@ -406,7 +406,10 @@ def test_random_large_csr_shapes(ctx, orc, pkg, seed):
             ("two-phase", lambda: A.set_kernel(capi.CSR_TWOPHASE)), ("scan", lambda: A.set_kernel(capi.CSR_SEGSCAN)),
             ("split, default threshold", lambda: A.set_kernel(capi.CSR_SPLIT)),
             ("split, rows of 3 and more are long", lambda: (A.set_param("split_row_threshold", 3), A.set_kernel(capi.CSR_SPLIT))),
-            ("split, every row is long", lambda: (A.set_param("split_row_threshold", 1), A.set_kernel(capi.CSR_SPLIT)))]
+            ("split, every row is long", lambda: (A.set_param("split_row_threshold", 1), A.set_kernel(capi.CSR_SPLIT))),
+            ("split, rows of 3 and more as virtual rows", lambda: (A.set_param("split_row_threshold", 3), A.set_param("split_mode", 2), A.set_kernel(capi.CSR_SPLIT))),
+            ("split, every row as virtual rows", lambda: (A.set_param("split_row_threshold", 1), A.set_kernel(capi.CSR_SPLIT))),
+            ("split, rows of 3 and more in chunks", lambda: (A.set_param("split_row_threshold", 3), A.set_param("split_mode", 1), A.set_kernel(capi.CSR_SPLIT)))]
     for name, setup in runs:
         setup()
         dy.fill(0.0)
@@ -444,7 +447,8 @@ def test_random_spd_systems_through_cg_and_the_fused_dot(ctx, orc, pkg, seed):
     ol.csr_spmv(orc, rp, cc, vv, xh, ref)
     ol.csr_abs_row_sums(orc, rp, cc, vv, xh, scale)
     x, w, y = ctx.vector_from(xh), ctx.vector_from(wh), ctx.vector(n)
-    A.set_param("split_row_threshold", 4)  # (kernel SPLIT below: rows of 4 entries and more in chunks, the others through the copy)
+    A.set_param("split_row_threshold", 4)  # (kernel SPLIT below: rows of 4 entries and more on their own, the others through the copy)
+    A.set_param("split_mode", 1 + seed % 2)  # ... in chunks / as virtual rows
     for kernel in (capi.CSR_AUTO, capi.CSR_VECTOR, capi.CSR_SCALAR, capi.CSR_PANEL, capi.CSR_TWOPHASE, capi.CSR_SEGSCAN, capi.CSR_SPLIT):
         if kernel == capi.CSR_TWOPHASE and len(vv) < 1000:
             continue

@@ -510,7 +510,10 @@ def test_csr_twophase_kernel_on_wide_and_ragged_matrices(ctx, orc, pkg):
         ol.assert_parity(dy.download(), ref, scale, f"twophase panel {cols} unroll {unroll}")
     # the automatic choice: a shard far wider than tall takes it when its runs (panel x row group) are long enough to
     # pad to whole lines; a sparser one and a square matrix of the same size do not
+    # (the MODEL's choice: between 8M and 64M entries a handle it sends to the two phases also times the panel layout, select.hip)
+    os.environ["SPMV_PANEL_TRIAL"] = "0"
     wide = ctx.gen_csr_uniform(0, 2_500_000, 40_000_000, 16, seed=3)
+    os.environ.pop("SPMV_PANEL_TRIAL")
     assert wide.info.kernel == capi.CSR_TWOPHASE
     assert wide.info.nnz <= wide.get_param("twophase_padded") <= 1.25 * wide.info.nnz
     xw, yw, yv = ctx.gen_vector(40_000_000, seed=3), ctx.vector(2_500_000), ctx.vector(2_500_000)
@@ -532,8 +535,16 @@ def test_csr_twophase_kernel_on_wide_and_ragged_matrices(ctx, orc, pkg):
     band = ctx.gen_csr_uniform(0, 3_000_000, 3_000_000, 4, band=4096, seed=3)
     assert band.info.kernel == capi.CSR_PANEL
     del band
+    os.environ["SPMV_PANEL_TRIAL"] = "0"
     sparse = ctx.gen_csr_uniform(0, 3_000_000, 3_000_000, 4, seed=3)  # the same shape with uniform columns takes the two phases
+    os.environ.pop("SPMV_PANEL_TRIAL")
     assert sparse.info.kernel == capi.CSR_TWOPHASE
+    del sparse
+    # ... and with the trials on, the two phases and the panel layout are both timed there and the faster one stays
+    sparse = ctx.gen_csr_uniform(0, 3_000_000, 3_000_000, 4, seed=3)
+    t2, tp = sparse.get_param("select_us_twophase"), sparse.get_param("select_us_panel")
+    assert sparse.get_param("select_candidates") == 2 and t2 > 0 and tp > 0
+    assert sparse.info.kernel == (capi.CSR_TWOPHASE if t2 <= tp else capi.CSR_PANEL) or abs(t2 - tp) <= 0.03 * tp + 1
     del sparse
     os.environ["SPMV_PANEL_TRIAL"] = "0"
     square = ctx.gen_csr_uniform(0, 600_000, 600_000, 8, seed=3)
@@ -643,7 +654,7 @@ def test_large_coo_handle_keeps_one_layout_only(ctx, pkg):
     capi = pkg.capi
     n, k = 2_500_000, 4
     C = ctx.gen_csr_uniform(0, n, n, k, seed=41)
-    assert C.info.kernel == capi.CSR_TWOPHASE  # (what the policy picks for this shape as CSR)
+    assert C.info.kernel in (capi.CSR_TWOPHASE, capi.CSR_PANEL)  # (the model says two phases for this shape as CSR; at 10M entries both are timed)
     rp, col, val = C.download()
     del C
     rows = np.repeat(np.arange(n, dtype=np.int32), k)
@@ -1086,12 +1097,19 @@ def test_rows_that_hold_most_of_the_entries_go_through_the_scan(ctx, orc, pkg, m
     # the row index of the scan went back; the copy holds the short rows only (the panel layout forced above stays until AUTO or a re-build)
     assert A.info.device_bytes < base + A.get_param("panel_bytes") + 16 * (int(rp[-1]) - n) + (2 << 20)
     product(A, "arrow, long-row split")
-    for T in (2, 1, 1 << 30):  # every row with entries is "long" (the copy is empty); the same; none is (no chunk at all)
-        A.set_param("split_row_threshold", T)
-        A.set_kernel(capi.CSR_SPLIT)
-        assert A.get_param("split_long_rows") == (n - 2000 if T <= 2 else 0)
-        product(A, f"arrow, split at {T}")
+    assert A.get_param("split_mode") == 1 and A.get_param("split_virtual_rows") == 0  # a dense row: chunks of the handle's own arrays
+    for mode in (1, 2):  # 2: every long row dealt out to virtual rows of 64 entries, a CSR matrix with a handle of its own
+        A.set_param("split_mode", mode)
+        for T in (0, 2, 1, 1 << 30):  # default; every row with entries is "long" (the copy is empty); the same; none is
+            A.set_param("split_row_threshold", T)
+            A.set_kernel(capi.CSR_SPLIT)
+            assert A.get_param("split_long_rows") == (1 if T == 0 else n - 2000 if T <= 2 else 0) and A.get_param("split_mode") == mode
+            if mode == 2:
+                assert A.get_param("split_virtual_rows") == ((n + 63) // 64 + (n - 2001 if 0 < T <= 2 else 0) if T < 1 << 30 else 0)
+                assert (A.get_param("split_long_kernel") > 0) == (T < 1 << 30)
+            product(A, f"arrow, split at {T}, mode {mode}")
     A.set_param("split_row_threshold", 0)
+    A.set_param("split_mode", 0)
     A.set_kernel(capi.CSR_VECTOR)
     assert A.info.device_bytes <= base + (1 << 20) + A.get_param("panel_bytes")
     # the solver's fused extras (y = A x, w . y) on a kernel that has no write-back of its own: CG on an SPD arrow
@@ -1114,11 +1132,12 @@ def test_rows_that_hold_most_of_the_entries_go_through_the_scan(ctx, orc, pkg, m
     bs = np.zeros(m)
     ol.csr_spmv(orc, rp2, c2, v2, xs, bs)
     sol = ctx.vector(m)
-    for k in (capi.CSR_SEGSCAN, capi.CSR_SPLIT):
+    for k, mode in ((capi.CSR_SEGSCAN, 0), (capi.CSR_SPLIT, 1), (capi.CSR_SPLIT, 2)):
+        S.set_param("split_mode", mode)
         S.set_kernel(k)
         sol.fill(0.0)
         iters, relres = ctx.cg(S, ctx.vector_from(bs), sol, max_iter=200, rel_tol=1e-12, check_every=4)
-        assert relres <= 1e-12 and np.max(np.abs(sol.download() - xs)) < 1e-9, (k, iters, relres)
+        assert relres <= 1e-12 and np.max(np.abs(sol.download() - xs)) < 1e-9, (k, mode, iters, relres)
     # a CSC handle of the arrow: its row-grouped copy may pick the scan; a COO handle's copy never does (the handle has it itself)
     rows = np.repeat(np.arange(n, dtype=np.int32), lens)
     cp, cr, cw = ol.coo_to_csc(orc, n, rows, cc, cv)

@@ -23,13 +23,7 @@ spec.loader.exec_module(ss)
 capi = ss.capi
 
 
-def powerlaw(n, cap, seed=21):
-    """row length min(cap, 8 / u), u uniform (BASELINE C4's law with another cap), uniform columns"""
-    rng = np.random.default_rng(seed)
-    ln = np.minimum(cap, (8.0 / np.maximum(rng.random(n), 1e-12)).astype(np.int64))
-    r = np.repeat(np.arange(n, dtype=np.int64), ln)
-    c = rng.integers(0, n, r.size)
-    return ss._finish(n, n, r, c, 22)
+powerlaw = ss.powerlaw
 
 
 CASES = {
@@ -74,12 +68,16 @@ def main():
                 A.set_kernel(k)
                 ss.check(ctx, A, x, y, ref, scale, f"{name} {nm}")
                 say(f"    {nm}: {ss.timed(ctx, A, x, y, 20):.4f} ms")
-            for T in (512, 1024, 2048, 4096, 8192, 16384, 65536, 0):
-                A.set_param("split_row_threshold", T)
-                A.set_kernel(7)
-                ss.check(ctx, A, x, y, ref, scale, f"{name} split at {T}")
-                say(f"    split, rows >= {A.get_param('split_row_threshold'):>7d} long ({A.get_param('split_long_rows'):>6d} rows, {A.get_param('split_long_entries'):>10d} entries; "
-                    f"inner kernel {A.get_param('split_inner_kernel')}): {ss.timed(ctx, A, x, y, 20):.4f} ms" + ("   <- the default" if T == 0 else ""))
+            for mode, what in ((1, "chunks of 4096 entries"), (2, "virtual rows of 64 entries")):
+                A.set_param("split_mode", mode)
+                for T in (256, 512, 1024, 2048, 4096, 8192, 16384, 65536, 0):
+                    A.set_param("split_row_threshold", T)
+                    A.set_kernel(7)
+                    ss.check(ctx, A, x, y, ref, scale, f"{name} split at {T} mode {mode}")
+                    say(f"    split ({what}), rows >= {A.get_param('split_row_threshold'):>7d} long ({A.get_param('split_long_rows'):>6d} rows, "
+                        f"{A.get_param('split_long_entries'):>10d} entries; short rows' kernel {A.get_param('split_inner_kernel')}, long rows' {A.get_param('split_long_kernel')}): "
+                        f"{ss.timed(ctx, A, x, y, 20):.4f} ms" + ("   <- the default threshold" if T == 0 else ""))
+            A.set_param("split_mode", 0)
             del A
 
 

@@ -133,6 +133,15 @@ def mostly_empty(n, frac, k, seed=13):
     return _finish(n, n, r, c, 14)
 
 
+def powerlaw(n, cap, seed=21):
+    """row length min(cap, 8 / u), u uniform (BASELINE C4's law with another cap), uniform columns: long AND sparse rows"""
+    rng = np.random.default_rng(seed)
+    ln = np.minimum(cap, (8.0 / np.maximum(rng.random(n), 1e-12)).astype(np.int64))
+    r = np.repeat(np.arange(n, dtype=np.int64), ln)
+    c = rng.integers(0, n, r.size)
+    return _finish(n, n, r, c, 22)
+
+
 def permutation(n, seed=7):
     p = np.random.default_rng(seed).permutation(n)
     return _finish(n, n, np.arange(n, dtype=np.int64), p, 8)
@@ -162,6 +171,8 @@ CASES = {
     "dense_rows_200k": ("odd", lambda: few_dense_rows(200_000, 16, 4)),
     "dense_row_in_32M": ("odd", lambda: few_dense_rows(1_000_000, 32, 1)),
     "dense_rows_in_16M": ("odd", lambda: few_dense_rows(500_000, 32, 8)),
+    "powerlaw_500k_cap_200k": ("odd", lambda: powerlaw(500_000, 200_000)),
+    "powerlaw_1M_cap_500k": ("odd", lambda: powerlaw(1_000_000, 500_000)),
     "tridiagonal_8M": ("odd", lambda: banded_contiguous(8_000_000, 1)),
     "band33_2M": ("odd", lambda: banded_contiguous(2_000_000, 16)),
     "band33_small": ("odd", lambda: banded_contiguous(30_000, 16)),
