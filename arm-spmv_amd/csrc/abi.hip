@@ -710,8 +710,9 @@ int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
     }
     else
     {
-        m->kernel        = kernel;
-        m->kernel_forced = true;
+        m->kernel         = kernel;
+        m->kernel_forced  = true;
+        m->split_auto_low = false;  // (a forced SPLIT takes "split_row_threshold" or its default, not what AUTO found)
     }
     if (m->kernel != SPMV_CSR_SEGSCAN) csr_segscan_free(m);
     if (m->format == SPMV_FMT_CSR && m->kernel != SPMV_CSR_SPLIT) csr_split_free(m);
@@ -988,7 +989,8 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
             if (!strcmp(name + 10, kNames[i])) slot = i;
         if (!strcmp(name + 10, "segscan")) slot = SPMV_CSR_SEGSCAN;  // (CSR handles; the slots are an ELL handle's "variant1" / "variant2")
         if (!strcmp(name + 10, "split")) slot = SPMV_CSR_SPLIT;
-        SPMV_REQUIRE(slot > 0, "unknown parameter '%s'", name);
+        if (!strcmp(name + 10, "split_low")) slot = 0;  // kernel SPLIT with rows of 256 entries and more split off (timed from 8M entries on)
+        SPMV_REQUIRE(slot >= 0, "unknown parameter '%s'", name);
         *value = (int64_t)(m->sel_us[slot] + 0.5f);
     }
     else if (!strcmp(name, "rowgrouped_kernel"))

@@ -247,6 +247,7 @@ struct spmv_mat
     int32_t  split_nchunks = 0;
     int32_t  split_threshold = 0;         // rows of this many entries and more are long (0: max(4096, longest / 16))
     int32_t  split_built_threshold = 0;   // what the split in memory was built with
+    bool     split_auto_low = false;      // AUTO timed a threshold of 256 faster than the default on this handle (select.hip)
     int32_t  split_long_rows = 0;
     int64_t  split_long_nnz = 0;
     bool     sel_no_split = false;        // the handle is the short-row part of a split

@@ -162,6 +162,7 @@ void csr_split_free(spmv_mat* m)
 int csr_split_threshold(const spmv_mat* m)
 {
     if (m->split_threshold > 0) return m->split_threshold;
+    if (m->split_auto_low) return 256;  // what AUTO found faster on this handle (select.hip)
     // a sixteenth of the longest row, at least a chunk: what stays behind is at most a few workgroup-chunks of work per row
     return std::max(kLongChunk, m->max_row_nnz / 16);
 }

@@ -112,12 +112,19 @@ int csr_select_kernel(spmv_mat* m)
     select_reset(m);
     csr_choose_kernel(m);  // the model (no launches)
     const int model = m->kernel;
+    constexpr int kSplitLow = 8;  // a candidate of this function only: kernel SPLIT with every row of 256 entries and more split off
+    m->split_auto_low = false;
     auto build = [&](int kernel) -> int {
+        if (kernel == kSplitLow || kernel == SPMV_CSR_SPLIT)
+        {
+            m->split_auto_low = kernel == kSplitLow;
+            m->kernel         = SPMV_CSR_SPLIT;
+            return csr_split_build(m);
+        }
         m->kernel = kernel;
         if (kernel == SPMV_CSR_PANEL) return csr_panel_build(m);
         if (kernel == SPMV_CSR_TWOPHASE) return csr_twophase_build(m);
         if (kernel == SPMV_CSR_SEGSCAN) return csr_segscan_build(m);
-        if (kernel == SPMV_CSR_SPLIT) return csr_split_build(m);
         return SPMV_OK;
     };
     if (m->nrow == 0 || m->nnz == 0 || !m->b || !m->v) return build(model);
@@ -142,6 +149,11 @@ int csr_select_kernel(spmv_mat* m)
             add(SPMV_CSR_PANEL);  // (also beyond 8M entries, where the model is otherwise taken at its word)
         }
         if (hub_rows) add(SPMV_CSR_SPLIT);
+        // large graphs whose long rows also share their hub COLUMNS (R-MAT): neighbouring lanes of the panel kernel then add
+        // into the same LDS accumulator, and it pays to turn every row of 256 entries and more into virtual rows (scale 22, 67M
+        // entries: 0.327 -> 0.250 ms) - where two launches instead of one are not what decides (scale 20, 16.8M: 0.074 ->
+        // 0.085).  No statistic at hand tells the two apart: both thresholds are timed.
+        if (hub_rows && m->nnz >= kSelectMaxNnz && m->split_threshold == 0 && csr_split_threshold(m) > 256) add(kSplitLow);
         if (m->nnz < kSelectMaxNnz)
         {
             add(SPMV_CSR_PANEL);
@@ -174,7 +186,10 @@ int csr_select_kernel(spmv_mat* m)
     // two passes in the same order, the minimum per candidate: a transient (the driver still unmapping what the caller freed a
     // moment ago, clocks ramping) hits whoever is being timed at that moment, not the same candidate twice.  The second pass
     // leaves out only what was 8x behind (a disturbed first measurement was seen 6x off: tools/probe_ell_trial.py).  Layouts stay resident between the passes; the losers' are freed at the end.
-    for (int pass = 0; pass < 2 && rc == SPMV_OK; ++pass)
+    // (From 8M entries on one pass: a product takes tens of microseconds there, and the split in its two variants is built anew
+    // for every timing.)
+    const int passes = m->nnz < kSelectMaxNnz ? 2 : 1;
+    for (int pass = 0; pass < passes && rc == SPMV_OK; ++pass)
         for (size_t i = 0; i < cand.size() && rc == SPMV_OK; ++i)
         {
             const int k = cand[i];
@@ -199,7 +214,7 @@ int csr_select_kernel(spmv_mat* m)
     for (size_t i = 0; i < cand.size(); ++i)  // the model's pick first; a later candidate has to win by 2 %
         if (t[i] >= 0.f)
         {
-            select_note(m, cand[i], t[i]);
+            select_note(m, cand[i] == kSplitLow ? 0 : cand[i], t[i]);
             if (t[i] < best_ms * (best >= 0 ? 0.98f : 1.0f))
             {
                 best    = cand[i];
@@ -210,7 +225,7 @@ int csr_select_kernel(spmv_mat* m)
     if (best != SPMV_CSR_PANEL) csr_panel_free(m);
     if (best != SPMV_CSR_TWOPHASE) csr_twophase_free(m);
     if (best != SPMV_CSR_SEGSCAN) csr_segscan_free(m);
-    if (best != SPMV_CSR_SPLIT) csr_split_free(m);
+    if (best != SPMV_CSR_SPLIT && best != kSplitLow) csr_split_free(m);
     return build(best);  // (a layout that is already in memory with the current parameters is kept as it is)
 }
 

@@ -1154,6 +1154,36 @@ def test_rows_that_hold_most_of_the_entries_go_through_the_scan(ctx, orc, pkg, m
     B = ctx.csr(n, n, rp, cc, cv)
     assert B.get_param("select_candidates") == 0 and B.info.kernel == capi.CSR_SPLIT and B.get_param("split_long_rows") == 1
     product(B, "arrow, model only")
+    monkeypatch.delenv("SPMV_PANEL_TRIAL")
+    del A, B, C, O, S
+    # from 8M entries on the split is timed at TWO thresholds (its default and 256: graphs whose long rows share hub columns want
+    # the low one, R-MAT scale 22: 0.327 -> 0.250 ms); 500000 rows x 16, 2000 rows of 600 and one dense row: 9.7M entries
+    nb, kb = 500_000, 16
+    lb = np.full(nb, kb, np.int64)
+    mid = rng.choice(np.arange(1, nb), 2000, replace=False)
+    lb[mid] = 600
+    lb[0] = nb
+    rpb = np.concatenate(([0], np.cumsum(lb))).astype(np.int32)
+    cb = rng.integers(0, nb, rpb[-1]).astype(np.int32)
+    cb[:nb] = np.arange(nb)
+    vb = rng.uniform(-1, 1, rpb[-1])
+    xb = rng.uniform(0, 1, nb)
+    rowsb = np.repeat(np.arange(nb), lb)
+    refb = np.bincount(rowsb, weights=vb * xb[cb], minlength=nb)
+    scb = np.bincount(rowsb, weights=np.abs(vb) * xb[cb], minlength=nb)
+    G = ctx.csr(nb, nb, rpb, cb, vb)
+    t_def, t_low = G.get_param("select_us_split"), G.get_param("select_us_split_low")
+    assert G.get_param("select_candidates") == 4 and t_def > 0 and t_low > 0 and G.get_param("select_us_panel") > 0 and G.get_param("select_us_segscan") > 0
+    assert G.info.kernel == capi.CSR_SPLIT and G.get_param("split_row_threshold") in (256, nb // 16)
+    assert (G.get_param("split_row_threshold") == 256) == (t_low < 0.98 * t_def) or abs(t_low - t_def) <= 0.03 * t_def + 1, (t_def, t_low)
+    assert G.get_param("split_long_rows") == (2001 if G.get_param("split_row_threshold") == 256 else 1)
+    dxb, dyb = ctx.vector_from(xb), ctx.vector(nb)
+    dyb.fill(0.0)
+    ctx.apply(G, dxb, dyb)
+    ctx.sync()
+    ol.assert_parity(dyb.download(), refb, scb, "8M entries with long rows, AUTO")
+    G.set_kernel(capi.CSR_SPLIT)  # forced: the default threshold, whatever AUTO found
+    assert G.get_param("split_row_threshold") == nb // 16 and G.get_param("split_long_rows") == 1
 
 
 # ---------------------------------------------------------------------------------- full-size properties
