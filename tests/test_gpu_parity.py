@@ -50,7 +50,7 @@ def test_csr_matches_reference_golden(ctx, orc, pkg, make):
     capi = pkg.capi
     for kernel, lanes in ((capi.CSR_AUTO, 0), (capi.CSR_VECTOR, 1), (capi.CSR_VECTOR, 2), (capi.CSR_VECTOR, 4),
                           (capi.CSR_VECTOR, 8), (capi.CSR_VECTOR, 16), (capi.CSR_VECTOR, 32), (capi.CSR_VECTOR, 64),
-                          (capi.CSR_SCALAR, 0), (capi.CSR_TWOPHASE, 0), (capi.CSR_SEGSCAN, 0)):
+                          (capi.CSR_SCALAR, 0), (capi.CSR_TWOPHASE, 0), (capi.CSR_SEGSCAN, 0), (capi.CSR_SPLIT, 0)):
         for flags in (0, capi.FLAG_DPP_REDUCE, capi.FLAG_XCD_REMAP):
             if kernel != capi.CSR_VECTOR and flags:
                 continue
