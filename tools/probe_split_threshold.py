@@ -40,6 +40,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=str(ROOT / "gpurun_out" / "probe_split_threshold.txt"))
     ap.add_argument("--cases", default="")
+    ap.add_argument("--low", action="store_true", help="also thresholds of 32, 64 and 128 entries")
     args = ap.parse_args()
     ctx = capi.Context(0)
     Path(args.out).parent.mkdir(parents=True, exist_ok=True)
@@ -70,7 +71,7 @@ def main():
                 say(f"    {nm}: {ss.timed(ctx, A, x, y, 20):.4f} ms")
             for mode, what in ((1, "chunks of 4096 entries"), (2, "virtual rows of 64 entries")):
                 A.set_param("split_mode", mode)
-                for T in (256, 512, 1024, 2048, 4096, 8192, 16384, 65536, 0):
+                for T in ((32, 64, 128) if args.low else ()) + (256, 512, 1024, 2048, 4096, 8192, 16384, 65536, 0):
                     A.set_param("split_row_threshold", T)
                     A.set_kernel(7)
                     ss.check(ctx, A, x, y, ref, scale, f"{name} split at {T} mode {mode}")
