@@ -758,6 +758,11 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         m->pb_pipe = (int32_t)value;
     else if (!strcmp(name, "panel_two_per_cu"))
         m->pb_two_per_cu = (int32_t)value;
+    else if (!strcmp(name, "panel_rounds"))
+    {
+        SPMV_REQUIRE(value >= 0 && value <= 16, "panel_rounds must be 0 (automatic), 1 (the fewest groups) or a multiple up to 16, got %lld", (long long)value);
+        m->pb_rounds_req = (int32_t)value;
+    }
     else if (!strcmp(name, "split_row_threshold"))
     {
         // rows of this many entries and more are "long" under kernel SPLIT (0: the default); takes effect at the next spmv_mat_set_kernel
@@ -997,6 +1002,12 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         *value = m->coo_csr && m->kernel == SPMV_CSR_PANEL ? m->coo_csr->kernel : 0;
     else if (!strcmp(name, "ell_variant"))
         *value = m->ell_variant;
+    else if (!strcmp(name, "panel_rounds"))
+        *value = m->pb_built_rounds;
+    else if (!strcmp(name, "panel_rounds_us_one"))
+        *value = (int64_t)(m->pb_rounds_us[0] + 0.5f);
+    else if (!strcmp(name, "panel_rounds_us_more"))
+        *value = (int64_t)(m->pb_rounds_us[1] + 0.5f);
     else if (!strcmp(name, "split_row_threshold"))
         *value = m->format == SPMV_FMT_CSR ? csr_split_threshold(m) : 0;
     else if (!strcmp(name, "split_long_rows"))

@@ -208,6 +208,10 @@ struct spmv_mat
     int32_t   pb_trial       = -1;       // timing launches when the layout is built: 1 yes, 0 no, -1 = SPMV_PANEL_TRIAL (default yes)
     int32_t   pb_two_per_cu  = 1;        // allow two workgroups per CU when the accumulators fit twice
     int32_t   pb_ngroups     = 0;
+    int32_t   pb_rounds_req  = 0;        // groups for k rounds of 256 workgroups instead of the fewest the LDS cap allows (0: one round's worth unless
+                                         // skewed rows make a finer cut worth a timing, 1: never)
+    int32_t   pb_built_rounds = 0;       // what the layout in memory was cut for
+    float     pb_rounds_us[2] = {0.f, 0.f};  // the timing that decided: the single round, the finer cut (microseconds per product; 0 = not timed)
     int32_t   pb_max_rows    = 0;        // rows of the fullest group (sizes the LDS accumulators)
     int32_t   pb_built_rows = 0, pb_built_width = 0, pb_built_sort = -1;  // parameters of the layout in memory
     int64_t   pb_bytes       = 0;

@@ -636,7 +636,8 @@ int csr_panel_build(spmv_mat* m)
     while (ceil_div(m->ncol, W) > 8192) W *= 2;  // the per-group histogram lives in LDS
     const bool sort = m->pb_sort != 0;
     const bool pack = (m->pb_aos == 3 || m->pb_aos == 4) && sort;  // 12-byte entries (needs the line order); kept only if every slice fits
-    if (m->pb_val && m->pb_built_rows == G && m->pb_built_width == W && m->pb_built_sort == (int)sort && m->pb_built_layout == m->pb_aos)
+    if (m->pb_val && m->pb_built_rows == G && m->pb_built_width == W && m->pb_built_sort == (int)sort && m->pb_built_layout == m->pb_aos &&
+        (m->pb_rounds_req == 0 || m->pb_rounds_req == m->pb_built_rounds))
         return panel_choose_pace(m);  // the layout in memory was built with these parameters
     if (!m->b || !m->v) SPMV_FAIL(SPMV_ERR_INVALID, "the panel layout cannot be re-built: this handle gave up its CSR arrays (panel_keep_csr = 0)");
     csr_panel_free(m);
@@ -645,6 +646,7 @@ int csr_panel_build(spmv_mat* m)
     // (C4's power-law rows: equal-row groups differ by 15 %) — under the row cap that LDS imposes.  Smallest bound T
     // such that a greedy cut (entries <= T, rows <= cap) needs no more groups than equal groups of G rows would.
     std::vector<int32_t> gstart;
+    int                  try_rounds = 0;  // groups for this many rounds are worth a timing against the single round
     {
         std::vector<int32_t> rp((size_t)m->nrow + 1);
         SPMV_HIP(hipMemcpyAsync(rp.data(), m->a, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost, ctx->stream));
@@ -670,20 +672,51 @@ int csr_panel_build(spmv_mat* m)
             }
             return groups;
         };
-        if (m->pb_group_rows > 0)
-            cut((int64_t)INT32_MAX, &gstart);  // equal groups of G rows
-        else
-        {
-            int64_t lo = ceil_div(m->nnz, want), hi = m->nnz;
+        // the cut into at most `groups` groups with the smallest bound; returns what the busiest CU gets over the mean (workgroup
+        // b takes the groups b, b + 256, ...: csr_panel_pp_kernel's loop)
+        auto balanced = [&](int groups, std::vector<int32_t>* out) {
+            int64_t lo = ceil_div(m->nnz, groups), hi = m->nnz;
             while (lo < hi)
             {
                 const int64_t mid = lo + (hi - lo) / 2;
-                if (cut(mid, nullptr) <= want)
+                if (cut(mid, nullptr) <= groups)
                     hi = mid;
                 else
                     lo = mid + 1;
             }
-            cut(lo, &gstart);
+            cut(lo, out);
+            std::vector<int64_t> load((size_t)kNumCu, 0);
+            for (size_t g = 0; g + 1 < out->size(); ++g) load[g % (size_t)kNumCu] += (int64_t)rp[(size_t)(*out)[g + 1]] - (int64_t)rp[(size_t)(*out)[g]];
+            return (double)*std::max_element(load.begin(), load.end()) * (double)kNumCu / (double)m->nnz;
+        };
+        if (m->pb_group_rows > 0)
+            cut((int64_t)INT32_MAX, &gstart);  // equal groups of G rows
+        else
+        {
+            double busiest = balanced(want, &gstart);
+            // Many rows AND skewed lengths (R-MAT scale 22: 4.2M rows, 210 groups' worth of rows under the LDS cap, so 256 groups
+            // leave the heavy rows 46 to spread over): the busiest group holds 2.24x the mean and sets the product's time.  More
+            // groups than one round let the heavy stretches be cut finer (512: 1.21x; the pairing b, b + 256 puts a heavy and a
+            // light stretch on the same CU) - but every further round is another sweep of x by workgroups that are no longer in
+            // step, and entries per CU are not the whole cost: that matrix went from 0.333 to 0.267 ms, what is left of it after
+            // its 254 longest rows were split off (1.97x) from 0.327 to 0.402.  So the alternative is TIMED against one round
+            // (below, after the build); "panel_rounds" k forces k rounds' worth of groups, 1 the single round.
+            if (m->pb_rounds_req > 1)
+                (void)balanced(want * m->pb_rounds_req, &gstart);
+            else if (m->pb_rounds_req == 0 && busiest > 1.15 && select_trials_enabled(m))
+            {
+                double q_best = 0.9 * busiest;
+                for (int rounds = 2; rounds <= 4; ++rounds)
+                {
+                    std::vector<int32_t> alt;
+                    const double         q = balanced(want * rounds, &alt);
+                    if (q < q_best)
+                    {
+                        try_rounds = rounds;
+                        q_best     = 0.9 * q;
+                    }
+                }
+            }
         }
     }
     const int ngroups = (int)gstart.size() - 1;
@@ -762,7 +795,38 @@ int csr_panel_build(spmv_mat* m)
     m->pb_built_layout = m->pb_aos;
     if (pack) panel_pack(m, ngroups, max_rows, m->pb_aos == 4);  // keeps the three arrays when packing does not pay
     m->device_bytes += m->pb_bytes;
-    return panel_choose_pace(m);
+    m->pb_built_rounds = m->pb_rounds_req > 1 ? m->pb_rounds_req : 1;
+    SPMV_TRY(panel_choose_pace(m));
+    if (try_rounds > 1)
+    {
+        // one round (just built) against `try_rounds`: the layout is built again for the timing, and a third time if the
+        // single round wins (one-off; 0.05-0.1 s each at 67M entries)
+        select_scratch sv;
+        if (sv.alloc(ctx, m->ncol, m->nrow) != SPMV_OK) return SPMV_OK;  // no room to try: the single round stays
+        float t_one = 0.f, t_more = 0.f;
+        int   rc    = select_time(ctx, [&] { return csr_panel_apply(ctx, m, sv.x, sv.y); }, 1e30f, &t_one);
+        if (rc != SPMV_OK) return rc;
+        m->pb_rounds_req = try_rounds;
+        if ((rc = csr_panel_build(m)) != SPMV_OK)
+        {
+            (void)hipGetLastError();
+            m->pb_rounds_req = 1;  // (no memory for the finer cut: back to the single round)
+            rc               = csr_panel_build(m);
+            m->pb_rounds_req = 0;
+            return rc;
+        }
+        rc = select_time(ctx, [&] { return csr_panel_apply(ctx, m, sv.x, sv.y); }, 1e30f, &t_more);
+        if (rc == SPMV_OK && !(t_more < 0.97f * t_one))
+        {
+            m->pb_rounds_req = 1;
+            rc               = csr_panel_build(m);
+        }
+        m->pb_rounds_req = 0;  // (automatic again; the layout in memory stays until a parameter changes)
+        m->pb_rounds_us[0] = t_one * 1000.f;
+        m->pb_rounds_us[1] = t_more * 1000.f;
+        return rc;
+    }
+    return SPMV_OK;
 }
 
 static int panel_launch(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y, bool trial, const apply_extra& ex);

@@ -251,6 +251,9 @@ int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
  * timing a handful of launches (about 0.1 s for 320M entries; SPMV_PANEL_TRIAL=0 or "panel_trial" 0: no launches, the
  * choice that wins on scattered columns).  Panel-kernel parameters take effect with the next spmv_mat_set_kernel:
  *   "panel_rows"     rows per group (0 = choose, entry-balanced; at most 20000)
+ *   "panel_rounds"   0 (default) = the fewest groups the cap of 20000 rows allows, a whole number of rounds of 256 workgroups; where
+ *                    skewed rows leave the busiest CU more than 1.15x the mean, a cut for 2-4 rounds is timed against it (get:
+ *                    "panel_rounds" what was built, "panel_rounds_us_one" / "_more" the timing); 1 = never, k = groups for k rounds
  *   "panel_width"    columns per panel (0 = 131072)
  *   "panel_sort"     1 = bucket the entries of a panel by 128-byte line of x (default), 0 = leave unordered
  *   "panel_aos"      entry layout: 4 = 12-byte packed entries, slices of 1024 stored in interleaved pairs and read with 8- and

@@ -1186,6 +1186,41 @@ def test_rows_that_hold_most_of_the_entries_go_through_the_scan(ctx, orc, pkg, m
     assert G.get_param("split_row_threshold") == nb // 16 and G.get_param("split_long_rows") == 1
 
 
+def test_panel_layout_cut_for_more_than_one_round_of_workgroups(ctx, orc, pkg):
+    """Round 5: with many rows AND skewed lengths the fewest groups the LDS cap allows leave the heavy rows too few groups to
+    spread over (R-MAT scale 22: the busiest group 2.24x the mean); csr_panel_build then times a cut for 2-4 rounds of 256
+    workgroups against the single round (tools/probe_split_threshold.py: 0.333 -> 0.267 ms there).  "panel_rounds" forces
+    either; whatever the cut, the product is the oracle's."""
+    capi = pkg.capi
+    rng = np.random.default_rng(31)
+    n = 700_000  # 600000 rows of 2 entries, then 100000 of 40: the light rows alone need 30 groups of 20000 rows
+    lens = np.concatenate((np.full(600_000, 2, np.int64), np.full(100_000, 40, np.int64)))
+    rp = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    cc = rng.integers(0, n, rp[-1]).astype(np.int32)
+    cv = rng.uniform(-1, 1, rp[-1])
+    x = rng.uniform(0, 1, n)
+    ref, scale = np.zeros(n), np.zeros(n)
+    ol.csr_spmv(orc, rp, cc, cv, x, ref)
+    ol.csr_abs_row_sums(orc, rp, cc, cv, x, scale)
+    dx, dy = ctx.vector_from(x), ctx.vector(n)
+    A = ctx.csr(n, n, rp, cc, cv)
+    seen = {}
+    for rounds in (1, 2, 3, 0):
+        A.set_param("panel_rounds", rounds)
+        A.set_kernel(capi.CSR_PANEL)
+        built = A.get_param("panel_rounds")
+        assert built == rounds or (rounds == 0 and built >= 1)
+        seen[rounds] = A.get_param("panel_groups")
+        dy.fill(0.0)
+        ctx.apply(A, dx, dy)
+        ctx.sync()
+        ol.assert_parity(dy.download(), ref, scale, f"panel layout cut for {rounds} round(s): {seen[rounds]} groups")
+    assert seen[1] <= 256 < seen[2] <= 512 < seen[3] <= 768, seen
+    if A.get_param("panel_rounds_us_more"):  # the automatic cut timed an alternative: what stayed is what was faster (3 % for the finer one)
+        one, more = A.get_param("panel_rounds_us_one"), A.get_param("panel_rounds_us_more")
+        assert (A.get_param("panel_rounds") > 1) == (more < 0.97 * one) or abs(more - one) <= 0.04 * one + 1, (one, more)
+
+
 # ---------------------------------------------------------------------------------- full-size properties
 
 def _abs_row_scale(ctx, pkg, A, x):
