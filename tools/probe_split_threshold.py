@@ -62,7 +62,10 @@ def main():
             x, y = ctx.vector_from(x_h), ctx.vector(nrow)
             say(f"{name}: {nrow} x {ncol}, {nnz} entries, rows mean {ln.mean():.1f} max {ln.max()}, "
                 f"rows >= 1024 / 4096 / 16384: {(ln >= 1024).sum()} / {(ln >= 4096).sum()} / {(ln >= 16384).sum()} (built in {time.perf_counter() - t0:.1f}s)")
+            t1 = time.perf_counter()
             A = ctx.csr(nrow, ncol, rp, c, v)
+            ctx.sync()
+            say(f"    handle created in {time.perf_counter() - t1:.2f} s (upload, analysis, every candidate's layout and timing)")
             say(f"    AUTO = kernel {A.info.kernel}" + (f" (threshold {A.get_param('split_row_threshold')}, {A.get_param('split_long_rows')} long rows, "
                 f"inner kernel {A.get_param('split_inner_kernel')})" if A.info.kernel == 7 else "") + f": {ss.timed(ctx, A, x, y, 20):.4f} ms")
             for k, nm in ((4, "panel"), (6, "scan")):
