@@ -42,6 +42,7 @@
 #include <atomic>
 
 #include "common.hpp"
+#include "panel_groups.hpp"
 #include "wave.hpp"
 
 namespace spmv
@@ -652,48 +653,12 @@ int csr_panel_build(spmv_mat* m)
         SPMV_HIP(hipMemcpyAsync(rp.data(), m->a, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost, ctx->stream));
         SPMV_HIP(hipStreamSynchronize(ctx->stream));
         const int want = (int)ceil_div(m->nrow, G);
-        auto cut = [&](int64_t T, std::vector<int32_t>* out) {
-            int groups = 0;
-            int r      = 0;
-            if (out) out->assign(1, 0);
-            while (r < m->nrow)
-            {
-                // a requested size is exact; otherwise light groups may take up to the LDS cap so heavy ones can shrink
-                const int     r_cap = std::min(m->nrow, r + (m->pb_group_rows > 0 ? G : kCapRows));
-                const int64_t limit = (int64_t)rp[(size_t)r] + T;
-                // last row index e in (r, r_cap] with rp[e] <= limit; at least one row
-                int e = (int)(std::upper_bound(rp.begin() + r + 1, rp.begin() + r_cap + 1, limit,
-                                               [](int64_t v, int32_t x) { return v < (int64_t)x; }) -
-                              rp.begin()) - 1;
-                if (e <= r) e = r + 1;
-                r = e;
-                ++groups;
-                if (out) out->push_back(r);
-            }
-            return groups;
-        };
-        // the cut into at most `groups` groups with the smallest bound; returns what the busiest CU gets over the mean (workgroup
-        // b takes the groups b, b + 256, ...: csr_panel_pp_kernel's loop)
-        auto balanced = [&](int groups, std::vector<int32_t>* out) {
-            int64_t lo = ceil_div(m->nnz, groups), hi = m->nnz;
-            while (lo < hi)
-            {
-                const int64_t mid = lo + (hi - lo) / 2;
-                if (cut(mid, nullptr) <= groups)
-                    hi = mid;
-                else
-                    lo = mid + 1;
-            }
-            cut(lo, out);
-            std::vector<int64_t> load((size_t)kNumCu, 0);
-            for (size_t g = 0; g + 1 < out->size(); ++g) load[g % (size_t)kNumCu] += (int64_t)rp[(size_t)(*out)[g + 1]] - (int64_t)rp[(size_t)(*out)[g]];
-            return (double)*std::max_element(load.begin(), load.end()) * (double)kNumCu / (double)m->nnz;
-        };
         if (m->pb_group_rows > 0)
-            cut((int64_t)INT32_MAX, &gstart);  // equal groups of G rows
+            (void)panel_cut(rp, m->nrow, (int64_t)INT32_MAX, G, &gstart);  // a requested size is exact: equal groups of G rows
         else
         {
-            double busiest = balanced(want, &gstart);
+            // light groups may take up to the LDS cap so heavy ones can shrink (panel_groups.hpp)
+            const double busiest = panel_balanced_cut(rp, m->nrow, want, kCapRows, kNumCu, &gstart);
             // Many rows AND skewed lengths (R-MAT scale 22: 4.2M rows, 210 groups' worth of rows under the LDS cap, so 256 groups
             // leave the heavy rows 46 to spread over): the busiest group holds 2.24x the mean and sets the product's time.  More
             // groups than one round let the heavy stretches be cut finer (512: 1.21x; the pairing b, b + 256 puts a heavy and a
@@ -702,21 +667,9 @@ int csr_panel_build(spmv_mat* m)
             // its 254 longest rows were split off (1.97x) from 0.327 to 0.402.  So the alternative is TIMED against one round
             // (below, after the build); "panel_rounds" k forces k rounds' worth of groups, 1 the single round.
             if (m->pb_rounds_req > 1)
-                (void)balanced(want * m->pb_rounds_req, &gstart);
-            else if (m->pb_rounds_req == 0 && busiest > 1.15 && select_trials_enabled(m))
-            {
-                double q_best = 0.9 * busiest;
-                for (int rounds = 2; rounds <= 4; ++rounds)
-                {
-                    std::vector<int32_t> alt;
-                    const double         q = balanced(want * rounds, &alt);
-                    if (q < q_best)
-                    {
-                        try_rounds = rounds;
-                        q_best     = 0.9 * q;
-                    }
-                }
-            }
+                (void)panel_balanced_cut(rp, m->nrow, want * m->pb_rounds_req, kCapRows, kNumCu, &gstart);
+            else if (m->pb_rounds_req == 0 && select_trials_enabled(m))
+                try_rounds = panel_rounds_worth_a_trial(rp, m->nrow, want, kCapRows, kNumCu, busiest);
         }
     }
     const int ngroups = (int)gstart.size() - 1;

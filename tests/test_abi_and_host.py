@@ -164,3 +164,21 @@ def test_placement_spread_arithmetic_holds_for_every_fp32_time(tmp_path):
     words = r.stdout.split()
     assert int(words[1]) > 2_000_000_000 and words[3] == "0" and words[5] == "0"
     assert int(words[7]) > 1_000_000  # the old form really had the hole this test closes
+
+
+def test_panel_row_groups_cover_the_rows_and_ask_for_a_finer_cut_only_when_skewed(tmp_path):
+    """The panel layout's row groups (csrc/panel_groups.hpp, used by csr_panel_build): every cut covers all rows once under the
+    LDS cap of 20000 rows; the busiest-CU figure is what a direct count gives; a profile of many light rows and one heavy
+    stretch (the shape of an R-MAT graph's row lengths: round 5) leaves the single round of 256 groups far from even
+    and asks for a trial of more rounds, a uniform profile does not.  tests/panel_groups_check.cpp, 300 cuts."""
+    import shutil
+    import subprocess
+
+    if not shutil.which("g++"):
+        pytest.skip("no g++ here")
+    exe = tmp_path / "panel_groups_check"
+    subprocess.run(["g++", "-O2", "-std=c++17", f"-I{ROOT / 'arm-spmv_amd' / 'csrc'}", str(ROOT / "tests" / "panel_groups_check.cpp"), "-o", str(exe)],
+                   check=True, timeout=120)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and " 0 violations" in r.stdout, r.stdout + r.stderr
+    assert "uniform: trial of 0" in r.stdout
