@@ -256,7 +256,8 @@ struct spmv_mat
     int64_t  split_long_nnz = 0;
     bool     sel_no_split = false;        // the handle is the short-row part of a split
     int32_t  split_mode = 0;              // how the long rows run: 1 chunks of the handle's own arrays, 2 virtual rows in a matrix of their own, 0 = by their density
-    int32_t  split_built_mode = 0;
+    int32_t  split_built_mode = 0;         // the mode in effect (1 or 2)
+    int32_t  split_built_for_mode = 0;     // the "split_mode" request the split in memory was built under
     spmv_mat* split_long = nullptr;       // mode 2: the virtual rows (a CSR handle with a kernel of its own); owned
     double*  split_yl = nullptr;          // mode 2: [split_vrows] the virtual rows' sums of one product
     int32_t* split_rows = nullptr;        // mode 2: [4 * long rows] row | first entry | virtual rows V | first virtual row

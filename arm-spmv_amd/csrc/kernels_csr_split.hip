@@ -153,6 +153,7 @@ void csr_split_free(spmv_mat* m)
     }
     m->split_vrows = 0;
     m->split_built_mode = 0;
+    m->split_built_for_mode = 0;
     m->split_nchunks = 0;
     m->split_long_rows = 0;
     m->split_long_nnz = 0;
@@ -171,7 +172,7 @@ int csr_split_build(spmv_mat* m)
 {
     SPMV_REQUIRE(m->format == SPMV_FMT_CSR && m->a && m->b && m->v, "the long-row split is built from a CSR handle's own arrays");
     const int T = csr_split_threshold(m);
-    if (m->coo_csr && m->split_built_threshold == T && (m->split_mode == 0 || m->split_mode == m->split_built_mode)) return SPMV_OK;
+    if (m->coo_csr && m->split_built_threshold == T && m->split_mode == m->split_built_for_mode) return SPMV_OK;  // (the request it was built for)
     (void)hipStreamSynchronize(m->ctx->stream);
     csr_split_free(m);
     spmv_ctx*   ctx = m->ctx;
@@ -350,6 +351,7 @@ int csr_split_build(spmv_mat* m)
     m->split_long_nnz        = long_nnz;
     m->split_built_threshold = T;
     m->split_built_mode      = mode;
+    m->split_built_for_mode  = m->split_mode;
     return SPMV_OK;
 }
 
