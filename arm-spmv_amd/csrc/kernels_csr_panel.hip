@@ -633,7 +633,7 @@ int csr_panel_build(spmv_mat* m)
     int G = m->pb_group_rows > 0 ? std::min(m->pb_group_rows, kCapRows) : pick_group_rows(m->nrow, kCapRows);
     G     = std::max<int64_t>(G, ceil_div(m->nrow, (int64_t)1 << 21));  // at most 2M groups: one workgroup of 256 per group in the build kernels
     int W = m->pb_panel_width > 0 ? m->pb_panel_width : 128 * 1024;
-    W     = std::max(kLineDoubles, (W / kLineDoubles) * kLineDoubles);
+    W     = std::min(524288, std::max(kLineDoubles, (W / kLineDoubles) * kLineDoubles));  // (the line sort keeps W / 16 + 1 counters of a panel in LDS)
     while (ceil_div(m->ncol, W) > 8192) W *= 2;  // the per-group histogram lives in LDS
     const bool sort = m->pb_sort != 0;
     const bool pack = (m->pb_aos == 3 || m->pb_aos == 4) && sort;  // 12-byte entries (needs the line order); kept only if every slice fits
