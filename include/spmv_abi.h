@@ -254,7 +254,7 @@ int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
  *   "panel_rounds"   0 (default) = the fewest groups the cap of 20000 rows allows, a whole number of rounds of 256 workgroups; where
  *                    skewed rows leave the busiest CU more than 1.15x the mean, a cut for 2-4 rounds is timed against it (get:
  *                    "panel_rounds" what was built, "panel_rounds_us_one" / "_more" the timing); 1 = never, k = groups for k rounds
- *   "panel_width"    columns per panel (0 = 131072)
+ *   "panel_width"    columns per panel (0 = 131072; at most 524288, rounded down to whole 128-byte lines of x)
  *   "panel_sort"     1 = bucket the entries of a panel by 128-byte line of x (default), 0 = leave unordered
  *   "panel_aos"      entry layout: 4 = 12-byte packed entries, slices of 1024 stored in interleaved pairs and read with 8- and
  *                    16-byte loads (default; falls back to 0 where padding would outweigh it), 3 = the same without the
