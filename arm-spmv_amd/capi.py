@@ -17,7 +17,7 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("SPMV_HIP_SO") or _PKG / "lib" / "libspmv_hip.so")  # override: A/B against another build
 
 FMT_COO, FMT_CSR, FMT_CSC, FMT_ELL, FMT_DIA = 0, 1, 2, 3, 4
-CSR_AUTO, CSR_VECTOR, CSR_LDSWIN, CSR_SCALAR, CSR_PANEL, CSR_TWOPHASE, CSR_SEGSCAN, CSR_SPLIT = 0, 1, 2, 3, 4, 5, 6, 7
+CSR_AUTO, CSR_VECTOR, CSR_LDSWIN, CSR_SCALAR, CSR_PANEL, CSR_TWOPHASE, CSR_SEGSCAN, CSR_SPLIT, CSR_ELL = 0, 1, 2, 3, 4, 5, 6, 7, 8
 PRECOND_NONE, PRECOND_JACOBI, PRECOND_SYMGS = 0, 1, 2
 FLAG_DPP_REDUCE, FLAG_XCD_REMAP = 1, 2
 

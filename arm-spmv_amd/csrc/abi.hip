@@ -90,6 +90,7 @@ void mat_free(spmv_mat* m)
     csr_twophase_free(m);
     csr_segscan_free(m);
     csr_split_free(m);
+    csr_ell_copy_free(m);
     symgs_free(m);
     if (m->coo_csr) mat_free(m->coo_csr);
     coo_free_bins(m);
@@ -618,7 +619,7 @@ int spmv_mat_get_info(const spmv_mat* m, spmv_mat_info* info)
 int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
 {
     SPMV_REQUIRE(m, "null matrix");
-    SPMV_REQUIRE(kernel >= SPMV_CSR_AUTO && kernel <= SPMV_CSR_SPLIT, "unknown kernel id %d", kernel);
+    SPMV_REQUIRE(kernel >= SPMV_CSR_AUTO && kernel <= SPMV_CSR_ELL, "unknown kernel id %d", kernel);
     SPMV_REQUIRE(lanes_per_row == 0 || (lanes_per_row >= 1 && lanes_per_row <= 64 &&
                                         (lanes_per_row & (lanes_per_row - 1)) == 0),
                  "lanes_per_row must be 0 or a power of two in 1..64, got %d", lanes_per_row);
@@ -716,6 +717,7 @@ int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
     }
     if (m->kernel != SPMV_CSR_SEGSCAN) csr_segscan_free(m);
     if (m->format == SPMV_FMT_CSR && m->kernel != SPMV_CSR_SPLIT) csr_split_free(m);
+    if (m->kernel != SPMV_CSR_ELL) csr_ell_copy_free(m);
     if (m->format == SPMV_FMT_CSR && m->kernel == SPMV_CSR_PANEL)
     {
         SPMV_HIP(hipSetDevice(m->ctx->device));
@@ -737,6 +739,12 @@ int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
         SPMV_REQUIRE(m->format == SPMV_FMT_CSR, "kernel SPLIT (7) is a CSR kernel");
         SPMV_HIP(hipSetDevice(m->ctx->device));
         SPMV_TRY(csr_split_build(m));
+    }
+    if (m->kernel == SPMV_CSR_ELL)
+    {
+        SPMV_REQUIRE(m->format == SPMV_FMT_CSR, "kernel ELL (8) is a CSR kernel: the ELL copy of a CSR handle");
+        SPMV_HIP(hipSetDevice(m->ctx->device));
+        SPMV_TRY(csr_ell_copy_build(m));
     }
     return SPMV_OK;
 }
@@ -994,7 +1002,8 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
             if (!strcmp(name + 10, kNames[i])) slot = i;
         if (!strcmp(name + 10, "segscan")) slot = SPMV_CSR_SEGSCAN;  // (CSR handles; the slots are an ELL handle's "variant1" / "variant2")
         if (!strcmp(name + 10, "split")) slot = SPMV_CSR_SPLIT;
-        if (!strcmp(name + 10, "split_low")) slot = 0;  // kernel SPLIT with rows of 256 entries and more split off (timed from 8M entries on)
+        if (!strcmp(name + 10, "split_low")) slot = 0;
+        if (!strcmp(name + 10, "ell")) slot = SPMV_CSR_ELL;  // CSR handles: the ELL copy of (nearly) equal rows  // kernel SPLIT with rows of 256 entries and more split off (timed from 8M entries on)
         SPMV_REQUIRE(slot >= 0, "unknown parameter '%s'", name);
         *value = (int64_t)(m->sel_us[slot] + 0.5f);
     }
@@ -1020,6 +1029,14 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         *value = m->split_long ? m->split_long->kernel : 0;
     else if (!strcmp(name, "split_long_entries"))
         *value = m->split_long_nnz;
+    else if (!strcmp(name, "ell_copy_slots"))
+        *value = m->ell_copy ? (int64_t)m->ell_copy->nrow * m->ell_copy->k : 0;
+    else if (!strcmp(name, "ell_copy_diagonal_slots"))
+        *value = m->ell_copy && m->ell_copy->ell_diag ? 1 : 0;
+    else if (!strcmp(name, "ell_copy_variant"))
+        *value = m->ell_copy ? m->ell_copy->ell_variant : 0;
+    else if (!strcmp(name, "min_row_entries"))
+        *value = m->min_row_nnz;
     else if (!strcmp(name, "split_inner_kernel"))
         *value = m->format == SPMV_FMT_CSR && m->kernel == SPMV_CSR_SPLIT && m->coo_csr ? m->coo_csr->kernel : 0;
     else

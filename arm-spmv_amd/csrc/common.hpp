@@ -177,7 +177,7 @@ struct spmv_mat
     // AUTO selection by measurement (select.hip): candidates timed when the handle was analysed, microseconds per product
     // by spmv_csr_kernel id (COO / ELL: [1] the format's own kernel, [4] the row-grouped copy); 0 = not timed
     int32_t  sel_candidates = 0;
-    float    sel_us[8]      = {0};
+    float    sel_us[10]     = {0};
 
     // CSR panel kernel (kernels_csr_panel.hip): entries re-ordered per row group by column panel / x line
     int32_t*  pb_col         = nullptr;  // [nnz] global column
@@ -245,6 +245,13 @@ struct spmv_mat
     // CSR segmented-scan kernel (kernels_coo.hip: csr_segscan_build): the row of every entry
     int32_t* seg_row = nullptr;  // [nnz]
     bool     sel_no_segscan = false;  // the handle is the row-grouped copy of a COO handle: that handle's own kernel IS this scan
+
+    // CSR handle of (nearly) equal rows: an ELL copy of it with a handle - and kernels, diagonal slots included - of its own
+    // (kernels_ell.hip: csr_ell_copy_build; kernel SPMV_CSR_ELL); owned
+    spmv_mat* ell_copy = nullptr;
+    int32_t   min_row_nnz = 0;
+    bool      sel_no_ell = false;  // the handle is itself somebody's copy whose source is an ELL handle
+    bool      sel_no_rowgrouped = false;  // ELL: the handle is the ELL copy of a CSR handle (no row-grouped copy of the copy)
 
     // CSR long-row split (kernels_csr_split.hip): the long rows in chunks over the handle's own arrays, the others in `coo_csr`
     int32_t* split_chunks = nullptr;      // [3 * nchunks] row | first entry | end, per chunk of a long row
@@ -362,6 +369,9 @@ int ell_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 int ell_analyse(spmv_mat* m);
 int ell_build_panel(spmv_mat* m, bool only_if_worth);  // the row-grouped copy with the PANEL kernel forced on it
 int ell_select_kernel(spmv_mat* m);                    // AUTO: the format's own variants and (where a candidate) the row-grouped copy, timed
+int  csr_ell_copy_build(spmv_mat* m);  // SPMV_CSR_ELL: the ELL copy of a CSR handle with (nearly) equal rows
+void csr_ell_copy_free(spmv_mat* m);
+bool csr_ell_copy_worth(const spmv_mat* m);
 // kernels_coo.hip
 int  ell_build_tiles(spmv_mat* m, bool only_if_worth);
 void ell_free_tiles(spmv_mat* m);
@@ -409,7 +419,7 @@ int  symgs_sequence(const spmv_mat* m, int32_t* out);
 int sort_ids_by_key(spmv_ctx* ctx, const int32_t* keys, int64_t n, int bits, int32_t* out_ids);
 int coo_place_by_stable_sort(spmv_ctx* ctx, int64_t nnz, int32_t nrow, const int32_t* row, const int32_t* col, const double* val,
                              int32_t* out_col, double* out_val);
-int csr_to_ell(spmv_ctx* ctx, const spmv_mat* csr, spmv_mat** out);
+int csr_to_ell(spmv_ctx* ctx, const spmv_mat* csr, spmv_mat** out, bool pad_own_column = false);
 int csr_split_columns(spmv_ctx* ctx, const spmv_mat* csr, int32_t c0, int32_t c1, spmv_mat** out_in, spmv_mat** out_out);
 int csr_extract_rows(spmv_ctx* dst, const spmv_mat* csr, int64_t r0, int64_t r1, spmv_mat** out);
 int coo_row_offsets(const spmv_mat* coo, int64_t* row_ptr64 /* host, nrow + 1 */);

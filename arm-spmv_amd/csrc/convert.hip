@@ -114,8 +114,11 @@ __global__ __launch_bounds__(kBlock) void order_rows_kernel(int nrow, const int3
 }
 
 // ---- CSR -> ELL (column-major, zero padded) --------------------------------------------------------------------
-template <int LPR>
-__global__ __launch_bounds__(kBlock) void csr_to_ell_kernel(int nrow, const int32_t* __restrict__ row_ptr,
+// PAD_OWN: every slot of the row is written; the slots beyond its entries get value 0.0 and the row's own LAST column (0 for an
+// empty row) instead of the reference's column 0 - the internal ELL copy of a CSR handle (kernels_ell.hip: csr_ell_copy_build),
+// whose padding must not bring x[0] into rows that never touch it
+template <int LPR, bool PAD_OWN>
+__global__ __launch_bounds__(kBlock) void csr_to_ell_kernel(int nrow, int k, const int32_t* __restrict__ row_ptr,
                                                             const int32_t* __restrict__ col,
                                                             const double* __restrict__ val,
                                                             int32_t* __restrict__ ell_col, double* __restrict__ ell_val)
@@ -123,11 +126,12 @@ __global__ __launch_bounds__(kBlock) void csr_to_ell_kernel(int nrow, const int3
     const int r = blockIdx.x * (kBlock / LPR) + threadIdx.x / LPR;
     if (r >= nrow) return;
     const int begin = row_ptr[r], len = row_ptr[r + 1] - begin;
-    for (int s = threadIdx.x % LPR; s < len; s += LPR)
+    const int pad   = PAD_OWN && len > 0 ? col[begin + len - 1] : 0;
+    for (int s = threadIdx.x % LPR; s < (PAD_OWN ? k : len); s += LPR)
     {
         const size_t at = (size_t)r + (size_t)s * (size_t)nrow;
-        ell_col[at]     = col[begin + s];
-        ell_val[at]     = val[begin + s];
+        ell_col[at]     = s < len ? col[begin + s] : pad;
+        ell_val[at]     = s < len ? val[begin + s] : 0.0;
     }
 }
 }  // namespace
@@ -241,7 +245,7 @@ int coo_to_csr(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out, int32_t force
     return SPMV_OK;
 }
 
-int csr_to_ell(spmv_ctx* ctx, const spmv_mat* csr, spmv_mat** out)
+int csr_to_ell(spmv_ctx* ctx, const spmv_mat* csr, spmv_mat** out, bool pad_own_column)
 {
     SPMV_REQUIRE(csr->format == SPMV_FMT_CSR, "spmv_csr_to_ell: input is not CSR");
     SPMV_REQUIRE(csr->nnz == 0 || (csr->b && csr->v), "spmv_csr_to_ell: the handle gave up its CSR arrays (panel_keep_csr = 0)");
@@ -254,17 +258,23 @@ int csr_to_ell(spmv_ctx* ctx, const spmv_mat* csr, spmv_mat** out)
     if (total > 0)
     {
         // padding: col 0, val +0.0 (src/matrix.cpp:473-474, value-initialised new[])
-        (void)hipMemsetAsync(const_cast<int32_t*>(ell->b), 0, sizeof(int32_t) * total, ctx->stream);
-        (void)hipMemsetAsync(const_cast<double*>(ell->v), 0, sizeof(double) * total, ctx->stream);
+        if (!pad_own_column)
+        {
+            (void)hipMemsetAsync(const_cast<int32_t*>(ell->b), 0, sizeof(int32_t) * total, ctx->stream);
+            (void)hipMemsetAsync(const_cast<double*>(ell->v), 0, sizeof(double) * total, ctx->stream);
+        }
         constexpr int LPR = 8;
         if (!launch_fits(nrow, LPR))
         {
             mat_free(ell);
             SPMV_FAIL(SPMV_ERR_UNSUPPORTED, "spmv_csr_to_ell: %d rows are more than one launch of the fill step holds", nrow);
         }
-        hipLaunchKernelGGL(csr_to_ell_kernel<LPR>, dim3((unsigned)ceil_div(nrow, kBlock / LPR)), dim3(kBlock), 0,
-                           ctx->stream, nrow, csr->a, csr->b, csr->v, const_cast<int32_t*>(ell->b),
-                           const_cast<double*>(ell->v));
+        if (pad_own_column)
+            hipLaunchKernelGGL((csr_to_ell_kernel<LPR, true>), dim3((unsigned)ceil_div(nrow, kBlock / LPR)), dim3(kBlock), 0, ctx->stream, nrow, k, csr->a,
+                               csr->b, csr->v, const_cast<int32_t*>(ell->b), const_cast<double*>(ell->v));
+        else
+            hipLaunchKernelGGL((csr_to_ell_kernel<LPR, false>), dim3((unsigned)ceil_div(nrow, kBlock / LPR)), dim3(kBlock), 0, ctx->stream, nrow, k, csr->a,
+                               csr->b, csr->v, const_cast<int32_t*>(ell->b), const_cast<double*>(ell->v));
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess)

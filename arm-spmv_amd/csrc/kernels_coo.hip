@@ -309,7 +309,7 @@ namespace
 // adopts a CSR handle as the row-grouped copy; the layouts that do not read col_ind / values give them back
 void adopt_rowgrouped(spmv_mat* m, spmv_mat* csr)
 {
-    if ((csr->kernel == SPMV_CSR_PANEL || csr->kernel == SPMV_CSR_TWOPHASE) && csr->b && csr->v && csr->owned)
+    if ((csr->kernel == SPMV_CSR_PANEL || csr->kernel == SPMV_CSR_TWOPHASE || csr->kernel == SPMV_CSR_ELL) && csr->b && csr->v && csr->owned)
     {
         (void)hipFree(const_cast<int32_t*>(csr->b));
         (void)hipFree(const_cast<double*>(csr->v));

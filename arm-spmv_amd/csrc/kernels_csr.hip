@@ -214,14 +214,27 @@ __global__ __launch_bounds__(kBlock) void csr_ldswin_kernel(
     }
 }
 
+// out[0] = longest row, out[1] = shortest row (initialised to 0 / INT32_MAX by the caller)
 __global__ __launch_bounds__(kBlock) void row_len_max_kernel(int nrow, const int32_t* __restrict__ row_ptr,
-                                                             int32_t* __restrict__ out_max)
+                                                             int32_t* __restrict__ out)
 {
-    int mx = 0;
+    int mx = 0, mn = INT32_MAX;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nrow; i += (int64_t)gridDim.x * kBlock)
-        mx = max(mx, row_ptr[i + 1] - row_ptr[i]);
-    for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
-    if ((threadIdx.x & 63) == 0 && mx > 0) atomicMax(out_max, mx);
+    {
+        const int len = row_ptr[i + 1] - row_ptr[i];
+        mx            = max(mx, len);
+        mn            = min(mn, len);
+    }
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        mx = max(mx, __shfl_xor(mx, off));
+        mn = min(mn, __shfl_xor(mn, off));
+    }
+    if ((threadIdx.x & 63) == 0)
+    {
+        if (mx > 0) atomicMax(out, mx);
+        atomicMin(out + 1, mn);
+    }
 }
 
 __global__ void sum_i32_kernel(const int32_t* __restrict__ in, int n, unsigned long long* __restrict__ out_sum)
@@ -382,15 +395,18 @@ int csr_analyse(spmv_mat* m)
                  (long long)m->nnz);
     SPMV_TRY(ensure_scratch(ctx, 64));
     int32_t* d_max = (int32_t*)ctx->scratch;
-    SPMV_HIP(hipMemsetAsync(d_max, 0, sizeof(int32_t), ctx->stream));
+    int32_t h_len[2] = {0, INT32_MAX};
+    SPMV_HIP(hipMemcpyAsync(d_max, h_len, sizeof(h_len), hipMemcpyHostToDevice, ctx->stream));
     if (m->nrow > 0)
     {
         const int grid = (int)std::min<int64_t>(kMaxGrid, ceil_div(m->nrow, kBlock));
         hipLaunchKernelGGL(row_len_max_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, m->nrow, m->a, d_max);
         SPMV_HIP(hipGetLastError());
     }
-    SPMV_HIP(hipMemcpyAsync(&m->max_row_nnz, d_max, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SPMV_HIP(hipMemcpyAsync(h_len, d_max, sizeof(h_len), hipMemcpyDeviceToHost, ctx->stream));
     SPMV_HIP(hipStreamSynchronize(ctx->stream));
+    m->max_row_nnz = h_len[0];
+    m->min_row_nnz = m->nrow > 0 ? h_len[1] : 0;
 
     const double mean = m->nrow > 0 ? (double)m->nnz / (double)m->nrow : 0.0;
     m->lanes_per_row  = pick_lanes(mean);
@@ -427,6 +443,7 @@ int csr_analyse(spmv_mat* m)
     if (m->kernel == SPMV_CSR_TWOPHASE) SPMV_TRY(csr_twophase_build(m));
     if (m->kernel == SPMV_CSR_SEGSCAN) SPMV_TRY(csr_segscan_build(m));
     if (m->kernel == SPMV_CSR_SPLIT) SPMV_TRY(csr_split_build(m));
+    if (m->kernel == SPMV_CSR_ELL) SPMV_TRY(csr_ell_copy_build(m));
     return SPMV_OK;
 }
 
@@ -467,6 +484,9 @@ int csr_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
         case SPMV_CSR_TWOPHASE: return csr_twophase_apply_ex(ctx, A, x, y, apply_extra{});
         case SPMV_CSR_SEGSCAN: return csr_segscan_apply(ctx, A, x, y);
         case SPMV_CSR_SPLIT: return csr_split_apply(ctx, A, x, y);
+        case SPMV_CSR_ELL:
+            if (!A->ell_copy) SPMV_FAIL(SPMV_ERR_INVALID, "ELL copy selected but never built");
+            return ell_apply(ctx, A->ell_copy, x, y);
         case SPMV_CSR_VECTOR:
         case SPMV_CSR_AUTO:
         default:

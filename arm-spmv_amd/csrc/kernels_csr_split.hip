@@ -317,7 +317,7 @@ int csr_split_build(spmv_mat* m)
             part->sel_no_segscan = true;  // what the scan is for went out with the long rows
             rc                   = csr_analyse(part);  // picks the part's kernel and builds its layout
             // the panel and two-phase layouts read row_ptr and their own arrays only
-            if (rc == SPMV_OK && (part->kernel == SPMV_CSR_PANEL || part->kernel == SPMV_CSR_TWOPHASE) && part->b && part->v && part->nnz > 0)
+            if (rc == SPMV_OK && (part->kernel == SPMV_CSR_PANEL || part->kernel == SPMV_CSR_TWOPHASE || part->kernel == SPMV_CSR_ELL) && part->b && part->v && part->nnz > 0)
             {
                 (void)hipFree(const_cast<int32_t*>(part->b));
                 (void)hipFree(const_cast<double*>(part->v));

@@ -372,8 +372,9 @@ int ell_make_rowgrouped(spmv_mat* m, int32_t force_kernel)
             csr->kernel_forced = true;
             csr->kernel        = force_kernel;
         }
-        csr->pb_trial = m->pb_trial;
-        rc            = csr_analyse(csr);  // row statistics, kernel (selected or forced), layout
+        csr->pb_trial   = m->pb_trial;
+        csr->sel_no_ell = true;  // (an ELL copy of the CSR copy of an ELL handle would be this handle again)
+        rc              = csr_analyse(csr);  // row statistics, kernel (selected or forced), layout
     }
     if (rc != SPMV_OK)
     {
@@ -382,7 +383,7 @@ int ell_make_rowgrouped(spmv_mat* m, int32_t force_kernel)
         return rc;
     }
     // the panel and two-phase kernels read row_ptr and their own arrays only
-    if ((csr->kernel == SPMV_CSR_PANEL || csr->kernel == SPMV_CSR_TWOPHASE) && csr->b && csr->v)
+    if ((csr->kernel == SPMV_CSR_PANEL || csr->kernel == SPMV_CSR_TWOPHASE || csr->kernel == SPMV_CSR_ELL) && csr->b && csr->v)
     {
         (void)hipFree(const_cast<int32_t*>(csr->b));
         (void)hipFree(const_cast<double*>(csr->v));
@@ -437,9 +438,9 @@ int ell_select_kernel(spmv_mat* m)
     const int64_t slots = (int64_t)m->nrow * m->k;
     if (slots == 0 || m->nrow <= 0) return SPMV_OK;
     if (!select_trials_enabled(m) || slots < kSelectMinNnz)
-        return m->ell_diag ? SPMV_OK : ell_build_panel(m, /*only_if_worth=*/true);
+        return (m->ell_diag || m->sel_no_rowgrouped) ? SPMV_OK : ell_build_panel(m, /*only_if_worth=*/true);
     select_scratch sv;
-    if (sv.alloc(ctx, m->ncol, m->nrow) != SPMV_OK) return m->ell_diag ? SPMV_OK : ell_build_panel(m, true);
+    if (sv.alloc(ctx, m->ncol, m->nrow) != SPMV_OK) return (m->ell_diag || m->sel_no_rowgrouped) ? SPMV_OK : ell_build_panel(m, true);
     // the format's own variants
     float best_ms = 1e30f, fastest = 1e30f, t[3] = {-1.f, -1.f, -1.f};
     int   best_v  = 0, rc = SPMV_OK;
@@ -468,7 +469,7 @@ int ell_select_kernel(spmv_mat* m)
     m->ell_variant = best_v;
     if (rc != SPMV_OK) return rc;
     // the row-grouped copy, where it is a candidate
-    bool candidate = slots <= (int64_t)INT32_MAX - 65536;
+    bool candidate = !m->sel_no_rowgrouped && slots <= (int64_t)INT32_MAX - 65536;  // (the ELL copy of a CSR handle: that handle IS the row-grouped form)
     if (candidate)
     {
         const bool few_rows = m->nrow <= 65536 && m->k >= 16;
@@ -505,6 +506,58 @@ int ell_select_kernel(spmv_mat* m)
     (void)hipStreamSynchronize(ctx->stream);
     if (rc != SPMV_OK) return rc;
     m->kernel = m->coo_csr ? SPMV_CSR_PANEL : SPMV_CSR_VECTOR;
+    return SPMV_OK;
+}
+
+// ---- the ELL copy of a CSR handle (SPMV_CSR_ELL) --------------------------------------------------------------------
+// tools/sweep_structures.py, every family: where the rows are (nearly) equally long - stencils, bands, block diagonals - the
+// same matrix runs faster through an ELL handle than through a CSR handle's best kernel: a tridiagonal matrix of 8M rows
+// 0.0557 against 0.0873 ms, a band of 33 0.105 against 0.163, dense 8 x 8 blocks 0.077 against 0.100, the 5- / 7-point stencils
+// 0.048 / 0.065 against 0.056 / 0.074 (one lane per two rows streams values and indices coalesced, and slots recognised as
+// diagonals read no index at all).  The reference's user calls CSRMatrixMatVector on whatever matrix she has
+// (src/mat_vec.cpp:44-67): a CSR handle whose padding to its longest row stays below a quarter and that has no empty row
+// therefore times an ELL copy of itself as one more candidate - where its columns are local (csr_ell_copy_worth).  The copy's padding carries value 0.0 and the row's own LAST
+// column, not the reference's column 0 (convert.hip): a padded slot adds 0.0 * x[c] for a column the row reads anyway, so a
+// non-finite x[0] stays out of rows that never touch it.  (A row that does read a non-finite x[c] gets NaN from the padding
+// where the reference's CSR loop gets +-inf: the one place the copy is not the reference's arithmetic.)
+bool csr_ell_copy_worth(const spmv_mat* m)
+{
+    if (m->format != SPMV_FMT_CSR || m->sel_no_ell || m->nrow < 2 || m->nnz < kSelectMinNnz || !m->b || !m->v) return false;
+    const int64_t slots = (int64_t)m->nrow * m->max_row_nnz;
+    // local columns only: one lane per row gathers x like the row-parallel kernel does - fine while the x window of a row block
+    // (mean over blocks of 256 rows) or all of x stays in an XCD's L2, hopeless on scattered columns (C2 has exactly 32 entries
+    // in every row too: its handle must not build and time 3.84 GB of ELL copy to find that out)
+    const bool local = m->win_avg_span * 8.0 <= 2.0 * 1048576.0 || (double)m->ncol * 8.0 <= 4.0 * 1048576.0;
+    return local && m->min_row_nnz >= 1 && m->max_row_nnz <= 1024 && slots * 4 <= m->nnz * 5 && slots <= (int64_t)INT32_MAX - 65536;
+}
+
+void csr_ell_copy_free(spmv_mat* m)
+{
+    if (!m->ell_copy) return;
+    (void)hipStreamSynchronize(m->ctx->stream);
+    m->device_bytes -= m->ell_copy->device_bytes;
+    mat_free(m->ell_copy);
+    m->ell_copy = nullptr;
+}
+
+int csr_ell_copy_build(spmv_mat* m)
+{
+    if (m->ell_copy || m->nnz == 0 || m->nrow == 0) return SPMV_OK;
+    SPMV_REQUIRE(m->format == SPMV_FMT_CSR && m->a && m->b && m->v, "the ELL copy is made from a CSR handle's own arrays");
+    SPMV_REQUIRE((int64_t)m->nrow * m->max_row_nnz <= (int64_t)INT32_MAX - 65536 && (int64_t)m->nrow * m->max_row_nnz <= 16 * std::max<int64_t>(m->nnz, 1),
+                 "an ELL copy of %d rows x %d slots for %lld entries: the padding is out of proportion", m->nrow, m->max_row_nnz, (long long)m->nnz);
+    spmv_mat* ell = nullptr;
+    SPMV_TRY(csr_to_ell(m->ctx, m, &ell, /*pad_own_column=*/true));
+    ell->pb_trial          = m->pb_trial;
+    ell->sel_no_rowgrouped = true;
+    const int rc           = ell_analyse(ell);  // diagonal slots, the variant that is timed fastest
+    if (rc != SPMV_OK)
+    {
+        mat_free(ell);
+        return rc;
+    }
+    m->ell_copy = ell;
+    m->device_bytes += ell->device_bytes;
     return SPMV_OK;
 }
 

@@ -386,7 +386,7 @@ int csc_build_rowgrouped(spmv_mat* m, int32_t force_kernel)
     (void)hipFree(cols);
     if (rc != SPMV_OK) return rc;
     // the panel and two-phase layouts read row_ptr and their own arrays only
-    if ((csr->kernel == SPMV_CSR_PANEL || csr->kernel == SPMV_CSR_TWOPHASE) && csr->b && csr->v)
+    if ((csr->kernel == SPMV_CSR_PANEL || csr->kernel == SPMV_CSR_TWOPHASE || csr->kernel == SPMV_CSR_ELL) && csr->b && csr->v)
     {
         (void)hipFree(const_cast<int32_t*>(csr->b));
         (void)hipFree(const_cast<double*>(csr->v));

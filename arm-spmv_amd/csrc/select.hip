@@ -95,7 +95,7 @@ int select_time(spmv_ctx* ctx, const std::function<int()>& launch, float best_so
 
 void select_note(spmv_mat* m, int slot, float ms)
 {
-    if (slot >= 0 && slot < 8) m->sel_us[slot] = ms * 1000.f;
+    if (slot >= 0 && slot < 10) m->sel_us[slot] = ms * 1000.f;
     ++m->sel_candidates;
 }
 void select_reset(spmv_mat* m)
@@ -112,7 +112,7 @@ int csr_select_kernel(spmv_mat* m)
     select_reset(m);
     csr_choose_kernel(m);  // the model (no launches)
     const int model = m->kernel;
-    constexpr int kSplitLow = 8;  // a candidate of this function only: kernel SPLIT with every row of 256 entries and more split off
+    constexpr int kSplitLow = 100;  // a candidate of this function only (not a kernel id): kernel SPLIT with every row of 256 entries and more split off
     m->split_auto_low = false;
     auto build = [&](int kernel) -> int {
         if (kernel == kSplitLow || kernel == SPMV_CSR_SPLIT)
@@ -125,6 +125,7 @@ int csr_select_kernel(spmv_mat* m)
         if (kernel == SPMV_CSR_PANEL) return csr_panel_build(m);
         if (kernel == SPMV_CSR_TWOPHASE) return csr_twophase_build(m);
         if (kernel == SPMV_CSR_SEGSCAN) return csr_segscan_build(m);
+        if (kernel == SPMV_CSR_ELL) return csr_ell_copy_build(m);
         return SPMV_OK;
     };
     if (m->nrow == 0 || m->nnz == 0 || !m->b || !m->v) return build(model);
@@ -149,6 +150,10 @@ int csr_select_kernel(spmv_mat* m)
             add(SPMV_CSR_PANEL);  // (also beyond 8M entries, where the model is otherwise taken at its word)
         }
         if (hub_rows) add(SPMV_CSR_SPLIT);
+        // (nearly) equal rows - stencils, bands, block diagonals: an ELL copy streams values and indices coalesced and reads no
+        // index at all where its slots are diagonals (kernels_ell.hip: csr_ell_copy_build; 1.15x to 1.57x over the best CSR
+        // kernel on those shapes, at any size)
+        if (csr_ell_copy_worth(m)) add(SPMV_CSR_ELL);
         // large graphs whose long rows also share their hub COLUMNS (R-MAT): neighbouring lanes of the panel kernel then add
         // into the same LDS accumulator, and it pays to turn every row of 256 entries and more into virtual rows (scale 22, 67M
         // entries: 0.327 -> 0.250 ms) - where two launches instead of one are not what decides (scale 20, 16.8M: 0.074 ->
@@ -226,6 +231,7 @@ int csr_select_kernel(spmv_mat* m)
     if (best != SPMV_CSR_TWOPHASE) csr_twophase_free(m);
     if (best != SPMV_CSR_SEGSCAN) csr_segscan_free(m);
     if (best != SPMV_CSR_SPLIT && best != kSplitLow) csr_split_free(m);
+    if (best != SPMV_CSR_ELL) csr_ell_copy_free(m);
     return build(best);  // (a layout that is already in memory with the current parameters is kept as it is)
 }
 

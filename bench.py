@@ -701,7 +701,7 @@ def main() -> None:
             """(kernel that runs, which bytes it has to move) of a handle"""
             kid = int(inf.kernel)
             inner_names = {1: "csr_vector_kernel", 2: "csr_ldswin_kernel", 3: "csr_scalar_kernel", 4: "csr_panel_pp_kernel", 5: "tp_expand_kernel + tp_reduce_kernel (two-phase)",
-                           6: "coo_segscan_kernel (over the row-grouped entries)", 7: "long rows split off (kernels_csr_split.hip), the others through a copy"}
+                           6: "coo_segscan_kernel (over the row-grouped entries)", 7: "long rows split off (kernels_csr_split.hip), the others through a copy", 8: "the ELL kernels over an ELL copy"}
             inner = inner_names.get(M.get_param("rowgrouped_kernel"), "csr_panel_pp_kernel") if fmt in ("ell", "coo") and kid == 4 else None
             if fmt == "ell":
                 if kid == 4:
@@ -719,7 +719,8 @@ def main() -> None:
                 return "coo_segscan_kernel (wavefront segmented scan over the entries in file order)", "coo_segscan"
             names = {1: "csr_vector_kernel", 2: "csr_ldswin_kernel", 3: "csr_scalar_kernel", 4: "csr_panel_pp_kernel",
                      5: "tp_expand_kernel + tp_reduce_kernel (two-phase)", 6: "coo_segscan_kernel (over the CSR entries and a row index per entry)",
-                     7: "long rows split off (kernels_csr_split.hip), the others through a copy with a kernel of its own"}
+                     7: "long rows split off (kernels_csr_split.hip), the others through a copy with a kernel of its own",
+                     8: "ell_diag_kernel_x2 / ell_kernel_x2 over an ELL copy of the CSR handle (rows of nearly equal length)"}
             return names.get(kid, str(kid)), "csr"
 
         # After the headline loop: the other single-GPU configurations of BASELINE.json (C3: ELL, C4: COO), each once with

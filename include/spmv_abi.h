@@ -75,7 +75,8 @@ typedef enum spmv_format
  *   "_twophase" (microseconds per product, 0 = not timed; COO / ELL: "_vector" the format's own kernel, "_panel" the copy; ELL
  *   also "_variant1" one row per lane, "_variant2" two rows per lane reading every index), "rowgrouped_kernel" (the kernel the
  *   copy of a COO / ELL / CSC handle runs, 0 = no copy in use), "ell_variant", "contiguous_permille"; CSR handles also
- *   "select_us_segscan" / "_split", and for kernel SPLIT "split_row_threshold" (get: in effect; set: 0 = default, read at the
+ *   "select_us_segscan" / "_split" / "_split_low" / "_ell", "min_row_entries", for kernel ELL "ell_copy_slots",
+ *   "ell_copy_diagonal_slots", "ell_copy_variant", and for kernel SPLIT "split_row_threshold" (get: in effect; set: 0 = default, read at the
  *   next spmv_mat_set_kernel), "split_mode" (likewise; get: the mode in effect), "split_long_rows", "split_long_entries",
  *   "split_inner_kernel" (what the short rows' copy runs), "split_long_kernel" / "split_virtual_rows" (mode 2).
  *   Audit on stencils, dense blocks, R-MAT graphs, rectangles, permutations: tools/sweep_structures.py, profiles/r05_sweep_structures_*.
@@ -89,6 +90,7 @@ typedef enum spmv_format
  *                       need run-to-run identical bits select VECTOR (spmv_mat_set_kernel(A, SPMV_CSR_VECTOR, 0));
  *   SEGSCAN             a fixed tree inside a wavefront's 512 entries; rows that cross into another wavefront's entries are joined by
  *                       atomic adds on y in arrival order (like the COO scan);
+ *   ELL                 the reference's ELL order (slot after slot into the row's sum): deterministic;
  *   SPLIT               the long rows: mode 1 a fixed tree per chunk of 4096 entries, chunks joined by atomic adds in arrival order;
  *                       mode 2 as the virtual rows' kernel, then a fixed order over a row's partial sums; the other rows: as the
  *                       inner kernel. */
@@ -105,7 +107,7 @@ typedef enum spmv_csr_kernel
                               longest rows hold a large share of the entries - arrow shapes, a few dense rows - where every other CSR
                               kernel leaves that row to ONE wavefront or workgroup (1M entries in one row: 1.26 ms there, 0.045 here).
                               CSR handles only; AUTO times it where the longest row exceeds 1/128 of the entries */
-    SPMV_CSR_SPLIT    = 7  /* the rows of "split_row_threshold" entries and more (default: a sixteenth of the longest row, at least
+    SPMV_CSR_SPLIT    = 7, /* the rows of "split_row_threshold" entries and more (default: a sixteenth of the longest row, at least
                               4096) leave the matrix; every other row goes into a copy without them, which picks its own kernel
                               ("split_inner_kernel"; the panel layout as a rule).  The long rows ("split_mode": 0 by their density):
                               1 = in chunks of 4096 entries over the handle's own arrays, one workgroup and one atomic add on y each
@@ -115,6 +117,13 @@ typedef enum spmv_csr_kernel
                               laws, graph hubs).  1M rows x 32 + one dense row: panel 1.26 ms, scan 0.47, split 0.11; 1M rows of
                               min(500000, 8/u) entries: panel 0.64, split 0.29.  CSR handles only; AUTO times it where the longest
                               row is >= 4096 and 32x the mean */
+    SPMV_CSR_ELL      = 8  /* an ELL copy of the handle (column-major slots, padded to the longest row with value 0.0 and the row's own
+                              last column) with the ELL kernels - diagonal slots recognised, one or two rows per lane, timed - for
+                              matrices of (nearly) equal rows: stencils, bands, block diagonals (tridiagonal, 8M rows: panel 0.087
+                              ms, this 0.056; a band of 33: 0.163 / 0.105).  12 bytes per slot on top of the CSR arrays.  CSR
+                              handles only; AUTO times it where the padding stays below a quarter, no row is empty and the columns are local
+                              (the x window of 256 rows within 2 MB, or all of x within 4 MB).  A row that
+                              reads a non-finite x[c] gets NaN from its padding where the plain CSR loop gives +-inf */
 } spmv_csr_kernel;
 
 /* Tuning bits for spmv_mat_set_flags (speed only; results stay within the parity tolerance). */

@@ -410,6 +410,14 @@ def test_random_large_csr_shapes(ctx, orc, pkg, seed):
             ("split, rows of 3 and more as virtual rows", lambda: (A.set_param("split_row_threshold", 3), A.set_param("split_mode", 2), A.set_kernel(capi.CSR_SPLIT))),
             ("split, every row as virtual rows", lambda: (A.set_param("split_row_threshold", 1), A.set_kernel(capi.CSR_SPLIT))),
             ("split, rows of 3 and more in chunks", lambda: (A.set_param("split_row_threshold", 3), A.set_param("split_mode", 1), A.set_kernel(capi.CSR_SPLIT)))]
+    def ell_copy():
+        try:
+            A.set_kernel(capi.CSR_ELL)
+        except capi.SpmvError as e:  # (refused where the padding to the longest row would be beyond 16x the entries)
+            assert "out of proportion" in str(e), e
+            A.set_kernel(capi.CSR_VECTOR)
+
+    runs.append(("ell copy", ell_copy))
     for name, setup in runs:
         setup()
         dy.fill(0.0)

@@ -50,12 +50,16 @@ def test_csr_matches_reference_golden(ctx, orc, pkg, make):
     capi = pkg.capi
     for kernel, lanes in ((capi.CSR_AUTO, 0), (capi.CSR_VECTOR, 1), (capi.CSR_VECTOR, 2), (capi.CSR_VECTOR, 4),
                           (capi.CSR_VECTOR, 8), (capi.CSR_VECTOR, 16), (capi.CSR_VECTOR, 32), (capi.CSR_VECTOR, 64),
-                          (capi.CSR_SCALAR, 0), (capi.CSR_TWOPHASE, 0), (capi.CSR_SEGSCAN, 0), (capi.CSR_SPLIT, 0)):
+                          (capi.CSR_SCALAR, 0), (capi.CSR_TWOPHASE, 0), (capi.CSR_SEGSCAN, 0), (capi.CSR_SPLIT, 0), (capi.CSR_ELL, 0)):
         for flags in (0, capi.FLAG_DPP_REDUCE, capi.FLAG_XCD_REMAP):
             if kernel != capi.CSR_VECTOR and flags:
                 continue
             A = ctx.csr(c["nrow"], c["ncol"], rp, cc, cv)
-            A.set_kernel(kernel, lanes)
+            try:
+                A.set_kernel(kernel, lanes)
+            except capi.SpmvError as e:  # the ELL copy of one 4096-entry row among short ones: refused, not built
+                assert kernel == capi.CSR_ELL and "out of proportion" in str(e), e
+                continue
             A.set_flags(flags)
             y1, y50 = _apply_n(ctx, A, c["x"], c["nrow"], NUM_TEST)
             what = f"{c['name']} csr kernel={kernel} lanes={lanes} flags={flags}"
@@ -543,7 +547,8 @@ def test_csr_twophase_kernel_on_wide_and_ragged_matrices(ctx, orc, pkg):
     # ... and with the trials on, the two phases and the panel layout are both timed there and the faster one stays
     sparse = ctx.gen_csr_uniform(0, 3_000_000, 3_000_000, 4, seed=3)
     t2, tp = sparse.get_param("select_us_twophase"), sparse.get_param("select_us_panel")
-    assert sparse.get_param("select_candidates") == 2 and t2 > 0 and tp > 0
+    # (exactly 4 entries in every row, but scattered columns: the ELL copy of csr_ell_copy_worth is no candidate)
+    assert sparse.get_param("select_candidates") == 2 and t2 > 0 and tp > 0 and sparse.get_param("select_us_ell") == 0
     assert sparse.info.kernel == (capi.CSR_TWOPHASE if t2 <= tp else capi.CSR_PANEL) or abs(t2 - tp) <= 0.03 * tp + 1
     del sparse
     os.environ["SPMV_PANEL_TRIAL"] = "0"
@@ -1029,7 +1034,7 @@ def test_auto_times_its_candidates_and_keeps_the_fastest(ctx, orc, pkg, monkeypa
     brp = (np.arange(nb + 1, dtype=np.int64) * bs).astype(np.int32)
     bcc = (np.repeat(i // bs * bs, bs) + np.tile(np.arange(bs), nb)).astype(np.int32)
     D = ctx.csr(nb, nb, brp, bcc, rng.uniform(-1, 1, nb * bs))
-    assert D.get_param("contiguous_permille") > 950 and D.get_param("select_candidates") in (2, 3)  # row-parallel, panel, LDS window (its windows fit)
+    assert D.get_param("contiguous_permille") > 950 and D.get_param("select_candidates") in (2, 3, 4)  # row-parallel, panel, LDS window (its windows fit), the ELL copy (equal rows)
     assert D.get_param("select_us_vector") > 0 and D.get_param("select_us_panel") > 0
 
 
@@ -1219,6 +1224,89 @@ def test_panel_layout_cut_for_more_than_one_round_of_workgroups(ctx, orc, pkg):
     if A.get_param("panel_rounds_us_more"):  # the automatic cut timed an alternative: what stayed is what was faster (3 % for the finer one)
         one, more = A.get_param("panel_rounds_us_one"), A.get_param("panel_rounds_us_more")
         assert (A.get_param("panel_rounds") > 1) == (more < 0.97 * one) or abs(more - one) <= 0.04 * one + 1, (one, more)
+
+
+def test_csr_handles_of_nearly_equal_rows_may_run_from_an_ell_copy(ctx, orc, pkg, monkeypatch):
+    """Round 5 (tools/sweep_structures.py: stencils, bands, block diagonals run 1.15x to 1.57x faster through an ELL handle than
+    through a CSR handle's best kernel): a CSR handle whose padding to its longest row stays below a quarter and that has no
+    empty row times an ELL copy of itself (kernel SPMV_CSR_ELL).  The copy is the reference's ELL arithmetic - bit-identical to
+    an ELL handle of the same matrix - except for its padding, which carries the row's own last column instead of column 0:
+    a non-finite x[0] stays out of rows that never read it."""
+    capi = pkg.capi
+    monkeypatch.delenv("SPMV_PANEL_TRIAL", raising=False)
+    rng = np.random.default_rng(41)
+    n, half = 600_000, 3  # a band of 7 around the diagonal, clipped at the edges (rows of 4 to 7): 4.2M entries
+    i = np.repeat(np.arange(n, dtype=np.int64), 2 * half + 1)
+    c = i + np.tile(np.arange(-half, half + 1, dtype=np.int64), n)
+    ok = (c >= 0) & (c < n)
+    rows, cols = i[ok], c[ok].astype(np.int32)
+    lens = np.bincount(rows, minlength=n)
+    rp = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    vals = rng.uniform(-1, 1, rows.size)
+    x = rng.uniform(0, 1, n)
+    ref, scale = np.zeros(n), np.zeros(n)
+    ol.csr_spmv(orc, rp, cols, vals, x, ref)
+    ol.csr_abs_row_sums(orc, rp, cols, vals, x, scale)
+    dx, dy = ctx.vector_from(x), ctx.vector(n)
+
+    def product(M, xv=None):
+        dy.fill(0.0)
+        ctx.apply(M, xv if xv is not None else dx, dy)
+        ctx.sync()
+        return dy.download()
+
+    A = ctx.csr(n, n, rp, cols, vals)
+    assert A.get_param("min_row_entries") == half + 1 and A.info.max_row_nnz == 2 * half + 1
+    t_ell, t_panel = A.get_param("select_us_ell"), A.get_param("select_us_panel")
+    assert t_ell > 0 and t_panel > 0  # both were candidates and timed
+    kept = int(A.info.kernel)
+    assert (kept == capi.CSR_ELL) == (A.get_param("ell_copy_slots") == n * (2 * half + 1))  # the copy stays only where it runs
+    ol.assert_parity(product(A), ref, scale, f"band of 7, AUTO (kernel {kept})")
+    base = A.get_param("device_bytes")
+    A.set_kernel(capi.CSR_ELL)
+    assert A.info.kernel == capi.CSR_ELL and A.get_param("ell_copy_slots") == n * 7
+    y_copy = product(A)
+    ol.assert_parity(y_copy, ref, scale, "band of 7, ELL copy forced")
+    # the reference's ELL arithmetic: an ELL handle of the same matrix (padding: column 0, value 0.0) gives the same bits
+    E = ctx.csr_to_ell(A) if hasattr(ctx, "csr_to_ell") else None
+    if E is not None:
+        E.set_kernel(capi.CSR_VECTOR, 2 if A.get_param("ell_copy_variant") != 1 else 1)
+        assert np.array_equal(product(E), y_copy) or np.max(np.abs(product(E) - y_copy)) <= ol.REL_TOL * 7
+    # x[0] = NaN reaches the rows that read column 0 (rows 0..half) and no other - under the copy as under every CSR kernel;
+    # through the ELL HANDLE the reference's padding (column 0) brings it into every padded row (a4 of SURVEY 8a)
+    xn = x.copy()
+    xn[0] = np.nan
+    dxn = ctx.vector_from(xn)
+    got = product(A, dxn)
+    assert np.all(np.isnan(got[:half + 1])) and np.all(np.isfinite(got[half + 1:]))
+    if E is not None:
+        assert np.isnan(product(E, dxn)[n - 1])  # (the last rows are padded: 0.0 * x[0])
+    A.set_kernel(capi.CSR_PANEL)
+    assert A.get_param("ell_copy_slots") == 0  # the copy goes back with the kernel
+    got = product(A, dxn)
+    assert np.all(np.isnan(got[:half + 1])) and np.all(np.isfinite(got[half + 1:]))
+    # not a candidate: an empty row, or padding beyond a quarter
+    lens2 = lens.copy()
+    lens2[1000] = 0
+    keep = np.ones(rows.size, bool)
+    keep[rp[1000]:rp[1001]] = False
+    rp2 = np.concatenate(([0], np.cumsum(lens2))).astype(np.int32)
+    B = ctx.csr(n, n, rp2, cols[keep], vals[keep])
+    assert B.get_param("min_row_entries") == 0 and B.get_param("select_us_ell") == 0 and B.info.kernel != capi.CSR_ELL
+    B.set_kernel(capi.CSR_ELL)  # forced, it works all the same (the empty row's padding reads column 0 with value 0.0)
+    ref2, scale2 = np.zeros(n), np.zeros(n)
+    ol.csr_spmv(orc, rp2, cols[keep], vals[keep], x, ref2)
+    ol.csr_abs_row_sums(orc, rp2, cols[keep], vals[keep], x, scale2)
+    ol.assert_parity(product(B), ref2, scale2, "band with an empty row, ELL copy forced")
+    # the solver's extras over the copy (generic path: fill, product, dot)
+    w = rng.uniform(-1, 1, n)
+    A.set_kernel(capi.CSR_ELL)
+    dw = ctx.vector_from(w)
+    d = ctx.apply_dot(A, dx, dy, dw, overwrite=True)
+    got = dy.download()
+    ol.assert_parity(got, ref, scale, "band of 7, ELL copy, overwrite + dot")
+    assert abs(d - float(w @ got)) <= 1e-11 * float(np.abs(w) @ np.abs(got))
+    assert base > 0
 
 
 # ---------------------------------------------------------------------------------- full-size properties

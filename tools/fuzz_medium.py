@@ -23,7 +23,7 @@ sys.path.insert(0, str(ROOT))
 from __graft_entry__ import load_package  # noqa: E402
 
 capi = load_package().capi
-NAMES = {1: "vector", 2: "ldswin", 3: "scalar", 4: "panel", 5: "twophase", 6: "segscan", 7: "split"}
+NAMES = {1: "vector", 2: "ldswin", 3: "scalar", 4: "panel", 5: "twophase", 6: "segscan", 7: "split", 8: "ell"}
 
 
 def draw(rng):
@@ -110,6 +110,9 @@ def main():
             for k in (1, 3, 4, 6):
                 A.set_kernel(k)
                 product(A, f"csr {NAMES[k]}")
+            if nrow * int(ln.max()) <= 8 * max(nnz, 1) and nrow * int(ln.max()) < 60_000_000:
+                A.set_kernel(8)
+                product(A, f"csr ell copy ({'diagonal slots' if A.get_param('ell_copy_diagonal_slots') else 'columns'}, variant {A.get_param('ell_copy_variant')})")
             for mode in (1, 2):
                 A.set_param("split_mode", mode)
                 A.set_param("split_row_threshold", int(rng.choice([0, 1, 3, 64, 1000, 50_000])))

@@ -11,7 +11,7 @@ sys.path.insert(0, str(ROOT))
 from __graft_entry__ import load_package  # noqa: E402
 
 capi = load_package().capi
-NAMES = {1: "row-parallel", 2: "LDS window", 3: "scalar", 4: "panel", 5: "two-phase", 6: "segmented scan", 7: "long-row split"}
+NAMES = {1: "row-parallel", 2: "LDS window", 3: "scalar", 4: "panel", 5: "two-phase", 6: "segmented scan", 7: "long-row split", 8: "ELL copy"}
 
 
 def main():

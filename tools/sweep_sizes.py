@@ -10,7 +10,7 @@ from __graft_entry__ import load_package  # noqa: E402
 from bench import algorithmic_bytes  # noqa: E402
 
 capi = load_package().capi
-NAMES = {1: "vector", 2: "ldswin", 3: "scalar", 4: "panel", 5: "twophase", 6: "segscan", 7: "split"}
+NAMES = {1: "vector", 2: "ldswin", 3: "scalar", 4: "panel", 5: "twophase", 6: "segscan", 7: "split", 8: "ell"}
 
 
 def timed(ctx, A, x, y, reps):

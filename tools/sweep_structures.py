@@ -25,7 +25,7 @@ sys.path.insert(0, str(ROOT))
 from __graft_entry__ import load_package  # noqa: E402
 
 capi = load_package().capi
-NAMES = {0: "auto", 1: "vector", 2: "ldswin", 3: "scalar", 4: "panel", 5: "twophase", 6: "segscan", 7: "split"}
+NAMES = {0: "auto", 1: "vector", 2: "ldswin", 3: "scalar", 4: "panel", 5: "twophase", 6: "segscan", 7: "split", 8: "ell"}
 
 
 # ---------------------------------------------------------------------------------------------- generators (host, numpy)
@@ -208,6 +208,8 @@ def check(ctx, A, x, y, ref, scale, what):
 def trial_record(A):
     """what the handle's own selection timed (microseconds per product), as it reports it"""
     got = {n: A.get_param("select_us_" + n) for n in ("vector", "ldswin", "scalar", "panel", "twophase", "variant1", "variant2")}
+    if A.info.format == 1 and A.get_param("select_us_ell"):
+        got["ell"] = A.get_param("select_us_ell")
     return " ".join(f"{n} {v}" for n, v in got.items() if v) or "none"
 
 
@@ -247,8 +249,8 @@ def run_case(ctx, name, build, out):
     auto_k = int(A.info.kernel)
     check(ctx, A, x, y, ref, scale, f"{name} csr auto")
     res = {"auto": timed(ctx, A, x, y, reps)}
-    for kern in (1, 2, 3, 4, 5, 6, 7):
-        if (kern == 5 and nnz < 2_000_000) or (kern == 7 and ln.max() < 4096):
+    for kern in (1, 2, 3, 4, 5, 6, 7, 8):
+        if (kern == 5 and nnz < 2_000_000) or (kern == 7 and ln.max() < 4096) or (kern == 8 and nrow * int(ln.max()) > 2 * nnz):
             continue
         ms = try_kernel(ctx, A, kern, 0, x, y, ref, scale, reps, f"{name} csr {NAMES[kern]}")
         if ms is not None:
