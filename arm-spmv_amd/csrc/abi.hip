@@ -697,8 +697,8 @@ int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
         return SPMV_OK;
     }
     if (m->format == SPMV_FMT_CSR && m->nnz > 0 && (!m->b || !m->v))
-        SPMV_REQUIRE((kernel == SPMV_CSR_PANEL && m->pb_val) || (kernel == SPMV_CSR_TWOPHASE && m->tp_val) ||
-                         (kernel == SPMV_CSR_AUTO && (m->kernel == SPMV_CSR_PANEL || m->kernel == SPMV_CSR_TWOPHASE)),
+        SPMV_REQUIRE((kernel == SPMV_CSR_PANEL && m->pb_val) || (kernel == SPMV_CSR_TWOPHASE && m->tp_val) || (kernel == SPMV_CSR_ELL && m->ell_copy) ||
+                         (kernel == SPMV_CSR_AUTO && (m->kernel == SPMV_CSR_PANEL || m->kernel == SPMV_CSR_TWOPHASE || m->kernel == SPMV_CSR_ELL)),
                      "this handle gave up its CSR arrays (panel_keep_csr = 0): only the product it was built for is left");
     if (kernel == SPMV_CSR_AUTO)
     {
@@ -793,8 +793,9 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         if (value == 0 && m->b && m->v)
         {
             SPMV_REQUIRE(m->format == SPMV_FMT_CSR && m->owned &&
-                             ((m->kernel == SPMV_CSR_PANEL && m->pb_val) || (m->kernel == SPMV_CSR_TWOPHASE && m->tp_val)),
-                         "panel_keep_csr = 0 needs an owned CSR handle whose panel or two-phase layout is built");
+                             ((m->kernel == SPMV_CSR_PANEL && m->pb_val) || (m->kernel == SPMV_CSR_TWOPHASE && m->tp_val) ||
+                              (m->kernel == SPMV_CSR_ELL && m->ell_copy)),
+                         "panel_keep_csr = 0 needs an owned CSR handle whose panel or two-phase layout or ELL copy is built");
             SPMV_HIP(hipSetDevice(m->ctx->device));
             SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
             // a two-phase handle first offers the gigabytes it is about to release to its product stream's piece search

@@ -279,7 +279,7 @@ int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
  *                    Round 1's clock throttle and what hung on it - "panel_pace_ns", "panel_guard", "panel_stagger", the trace build
  *                    "panel_trace", the A/B switch "panel_legacy" - were deleted in round 5 with the kernel that carried them
  *                    inside its chunk loop (the headline's schedule had come to depend on that dead code: DESIGN.md 4.2).
- *   "panel_keep_csr" 0 = release col_ind / values of a CSR handle whose product runs from the panel or two-phase layout
+ *   "panel_keep_csr" 0 = release col_ind / values of a CSR handle whose product runs from the panel or two-phase layout or from its ELL copy
  *                    (memory 2x -> 1x the matrix; download, other kernels, re-builds and conversions are then refused)
  *   "panel_trial"    1 / 0 = timing launches when the layout is built, yes / no (-1 = environment, default yes)
  *   "dia_col_bound"  DIA handles: columns >= this are skipped (row shards keep the bound of the whole matrix)

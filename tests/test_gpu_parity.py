@@ -1307,6 +1307,15 @@ def test_csr_handles_of_nearly_equal_rows_may_run_from_an_ell_copy(ctx, orc, pkg
     ol.assert_parity(got, ref, scale, "band of 7, ELL copy, overwrite + dot")
     assert abs(d - float(w @ got)) <= 1e-11 * float(np.abs(w) @ np.abs(got))
     assert base > 0
+    # panel_keep_csr = 0 under the ELL copy: col_ind / values go back (the copy holds every entry), the product stays
+    before = A.get_param("device_bytes")
+    A.set_param("panel_keep_csr", 0)
+    assert A.get_param("device_bytes") == before - 12 * rows.size and A.get_param("panel_keep_csr") == 0
+    ol.assert_parity(product(A), ref, scale, "band of 7, ELL copy, CSR arrays released")
+    A.set_kernel(capi.CSR_AUTO)  # stays what it is
+    assert A.info.kernel == capi.CSR_ELL
+    with pytest.raises(capi.SpmvError, match="gave up its CSR arrays"):
+        A.set_kernel(capi.CSR_VECTOR)  # (a kernel that reads them; the panel layout built above would still run)
 
 
 # ---------------------------------------------------------------------------------- full-size properties
