@@ -473,7 +473,11 @@ int ell_select_kernel(spmv_mat* m)
     if (candidate)
     {
         const bool few_rows = m->nrow <= 65536 && m->k >= 16;
-        if (!few_rows)
+        // rows of unequal length (a finite-element mesh: 16 to 64 entries per row in 64 slots): a lane per row walks the padding
+        // of the short rows while its neighbours work - 200000 rows, 8M entries in 12.8M slots: 0.046 ms against 0.032 through
+        // the copy, which carries the same padding but spreads it over a workgroup
+        const bool ragged = m->nnz > 0 && slots * 5 > m->nnz * 6;
+        if (!few_rows && !ragged)
         {
             if (m->ell_diag)
                 candidate = false;

@@ -142,6 +142,16 @@ def powerlaw(n, cap, seed=21):
     return _finish(n, n, r, c, 22)
 
 
+def fem_like(n, lo, hi, window, seed=31):
+    """row lengths uniform in [lo, hi], columns random within +-window of the diagonal (sorted, distinct per row mostly): a
+    finite-element mesh's matrix - variable rows, local columns"""
+    rng = np.random.default_rng(seed)
+    ln = rng.integers(lo, hi + 1, n)
+    r = np.repeat(np.arange(n, dtype=np.int64), ln)
+    c = np.clip(r + rng.integers(-window, window + 1, r.size), 0, n - 1)
+    return _finish(n, n, r, c, 32)
+
+
 def permutation(n, seed=7):
     p = np.random.default_rng(seed).permutation(n)
     return _finish(n, n, np.arange(n, dtype=np.int64), p, 8)
@@ -173,6 +183,9 @@ CASES = {
     "dense_rows_in_16M": ("odd", lambda: few_dense_rows(500_000, 32, 8)),
     "powerlaw_500k_cap_200k": ("odd", lambda: powerlaw(500_000, 200_000)),
     "powerlaw_1M_cap_500k": ("odd", lambda: powerlaw(1_000_000, 500_000)),
+    "fem_like_2M": ("fem", lambda: fem_like(2_000_000, 16, 64, 3000)),
+    "fem_like_200k": ("fem", lambda: fem_like(200_000, 16, 64, 1500)),
+    "fem_like_narrow_2M": ("fem", lambda: fem_like(2_000_000, 8, 24, 300)),
     "tridiagonal_8M": ("odd", lambda: banded_contiguous(8_000_000, 1)),
     "band33_2M": ("odd", lambda: banded_contiguous(2_000_000, 16)),
     "band33_small": ("odd", lambda: banded_contiguous(30_000, 16)),
