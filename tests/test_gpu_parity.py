@@ -1318,6 +1318,56 @@ def test_csr_handles_of_nearly_equal_rows_may_run_from_an_ell_copy(ctx, orc, pkg
         A.set_kernel(capi.CSR_VECTOR)  # (a kernel that reads them; the panel layout built above would still run)
 
 
+def test_row_grouped_copy_of_a_ragged_ell_handle_keeps_one_padding_term_per_row(ctx, orc, pkg):
+    """The copy of an ELL handle drops the padding slots (column 0, value 0.0) beyond the first of every row: the reference's sum
+    adds 0.0 * x[0] once per padded slot (src/mat_vec.cpp:108-117), and once says what many say.  A mesh-like matrix (rows of
+    4 to 40 entries in 40 slots): the copy holds ~entries + rows, not rows x 40; the product is the oracle's ELL product; and
+    with x[0] = NaN exactly the rows that have padding (or read column 0) turn NaN - under the copy as under the format's own
+    kernel."""
+    capi = pkg.capi
+    rng = np.random.default_rng(53)
+    n, K = 150_000, 40
+    lens = rng.integers(4, K + 1, n)
+    lens[::1000] = K  # some rows without padding
+    cols = np.zeros((K, n), np.int32)
+    vals = np.zeros((K, n))
+    for s in range(K):
+        live = lens > s
+        cols[s, live] = np.clip(np.flatnonzero(live) + rng.integers(1, 2000, int(live.sum())), 1, n - 1)  # (never column 0)
+        vals[s, live] = rng.uniform(0.5, 1.5, int(live.sum()))
+    nnz = int(lens.sum())
+    x = rng.uniform(0.5, 1.5, n)
+    ref = np.zeros(n)
+    ol.ell_spmv(orc, n, K, cols.ravel(), vals.ravel(), x, ref)
+    scale = np.abs(ref) + 1e-300
+    E = ctx.ell(n, n, K, nnz, cols.ravel(), vals.ravel())
+    dx, dy = ctx.vector_from(x), ctx.vector(n)
+
+    def product(M, xv):
+        dy.fill(0.0)
+        ctx.apply(M, xv, dy)
+        ctx.sync()
+        return dy.download()
+
+    E.set_kernel(capi.CSR_VECTOR, 1)
+    own = product(E, dx)
+    ol.assert_parity(own, ref, scale, "ragged ELL, one row per lane")
+    base = E.get_param("device_bytes")
+    E.set_kernel(capi.CSR_PANEL)  # the row-grouped copy, panel layout forced on it
+    assert E.get_param("rowgrouped_kernel") == capi.CSR_PANEL
+    held = E.get_param("device_bytes") - base
+    assert held < 17 * (nnz + n) + (1 << 20), (held, nnz, n * K)  # (row_ptr + the panel layout of entries + one pad per row; n K = 6M slots)
+    ol.assert_parity(product(E, dx), ref, scale, "ragged ELL, row-grouped copy")
+    xn = x.copy()
+    xn[0] = np.nan
+    dxn = ctx.vector_from(xn)
+    padded = lens < K
+    for kernel, lanes, what in ((capi.CSR_PANEL, 0, "copy"), (capi.CSR_VECTOR, 1, "own kernel")):
+        E.set_kernel(kernel, lanes)
+        got = product(E, dxn)
+        assert np.array_equal(np.isnan(got), padded), what
+
+
 # ---------------------------------------------------------------------------------- full-size properties
 
 def _abs_row_scale(ctx, pkg, A, x):
