@@ -18,7 +18,7 @@ all: engine host oracle
 
 engine: $(LIBDIR)/libspmv_hip.so
 
-$(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/common.hpp $(CSRC)/wave.hpp $(CSRC)/placement_math.hpp $(CSRC)/panel_groups.hpp include/spmv_abi.h
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/common.hpp $(CSRC)/wave.hpp $(CSRC)/placement_math.hpp $(CSRC)/panel_groups.hpp $(CSRC)/split_rows.hpp include/spmv_abi.h
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

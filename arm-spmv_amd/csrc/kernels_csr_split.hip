@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "split_rows.hpp"
 #include "wave.hpp"
 
 namespace spmv
@@ -204,8 +205,8 @@ int csr_split_build(spmv_mat* m)
     // 8 rows with an entry in every column among 500000 of 32: chunks 0.079, virtual rows 0.119)
     if (mode != 1 && mode != 2) mode = (double)long_nnz * 2.0 >= (double)nlong * (double)m->ncol ? 1 : 2;
     // chunk table (mode 1: row | begin | end; mode 2: index of the long row | begin | end, for the deal kernel)
-    std::vector<int32_t> crow, cbeg, cend, lbeg(nlong), lv(nlong), lbase(nlong), vptr;
-    int64_t              nv = 0;
+    std::vector<int32_t> crow, cbeg, cend, lbeg(nlong), lv, lbase, vptr;
+    std::vector<int64_t> llen(nlong);
     for (size_t i = 0; i < nlong; ++i)
     {
         const int r = lrow[i], b0 = rp[(size_t)r], e0 = rp[(size_t)r + 1];
@@ -215,26 +216,11 @@ int csr_split_build(spmv_mat* m)
             cbeg.push_back(b);
             cend.push_back(std::min(b + kLongChunk, e0));
         }
-        lbeg[i]  = b0;
-        lv[i]    = (int32_t)ceil_div((int64_t)(e0 - b0), kVirtualLen);
-        lbase[i] = (int32_t)nv;
-        nv += lv[i];
+        lbeg[i] = b0;
+        llen[i] = e0 - b0;
     }
-    if (mode == 2)
-    {
-        vptr.resize((size_t)nv + 1);
-        int64_t at = 0;
-        for (size_t i = 0; i < nlong; ++i)
-        {
-            const int len = rp[(size_t)lrow[i] + 1] - rp[(size_t)lrow[i]], V = lv[i];
-            for (int v = 0; v < V; ++v)
-            {
-                vptr[(size_t)lbase[i] + (size_t)v] = (int32_t)at;
-                at += len / V + (v < len % V ? 1 : 0);
-            }
-        }
-        vptr[(size_t)nv] = (int32_t)at;
-    }
+    split_virtual_row_ptr(llen, kVirtualLen, &lv, &lbase, &vptr);  // (split_rows.hpp: V = ceil(len / 64) virtual rows per long row)
+    const int64_t nv = (int64_t)vptr.size() - 1;
     spmv_mat *rest = nullptr, *lng = nullptr;
     SPMV_TRY(mat_alloc(ctx, SPMV_FMT_CSR, n, m->ncol, kept, 0, (size_t)n + 1, (size_t)kept, (size_t)kept, &rest));
     int rc = SPMV_OK;

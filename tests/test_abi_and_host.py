@@ -182,3 +182,19 @@ def test_panel_row_groups_cover_the_rows_and_ask_for_a_finer_cut_only_when_skewe
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and " 0 violations" in r.stdout, r.stdout + r.stderr
     assert "uniform: trial of 0" in r.stdout
+
+
+def test_split_virtual_rows_hold_every_entry_once_in_order(tmp_path):
+    """Kernel SPLIT, mode 2 (csrc/split_rows.hpp, used by csr_split_build): a long row's entries are dealt out to V = ceil(len / 64)
+    virtual rows, entry k to row k mod V at position k / V.  tests/split_rows_check.cpp: the dealing is a bijection, keeps the
+    order inside every virtual row, balances their lengths to within one, and parts neighbouring entries."""
+    import shutil
+    import subprocess
+
+    if not shutil.which("g++"):
+        pytest.skip("no g++ here")
+    exe = tmp_path / "split_rows_check"
+    subprocess.run(["g++", "-O2", "-std=c++17", f"-I{ROOT / 'arm-spmv_amd' / 'csrc'}", str(ROOT / "tests" / "split_rows_check.cpp"), "-o", str(exe)],
+                   check=True, timeout=120)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and " 0 violations" in r.stdout, r.stdout + r.stderr
