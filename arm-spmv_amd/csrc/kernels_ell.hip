@@ -14,6 +14,9 @@
 #include <algorithm>
 #include <vector>
 
+#include <chrono>
+#include <thread>
+
 #include "common.hpp"
 #include "wave.hpp"
 
@@ -495,6 +498,14 @@ int ell_select_kernel(spmv_mat* m)
         return (m->ell_diag || m->sel_no_rowgrouped) ? SPMV_OK : ell_build_panel(m, /*only_if_worth=*/true);
     select_scratch sv;
     if (sv.alloc(ctx, m->ncol, m->nrow) != SPMV_OK) return (m->ell_diag || m->sel_no_rowgrouped) ? SPMV_OK : ell_build_panel(m, true);
+    // (small handles: 2 ms of quiet first - products launched within a millisecond of a hipMalloc / hipFree run up to 2x slower
+    // whichever kernel they are (select.hip), and a copy built a moment ago for somebody's trial is timed right after both; at 4-5
+    // us per product that has decided between one and two rows per lane the wrong way round)
+    if (slots < ((int64_t)4 << 20))
+    {
+        (void)hipStreamSynchronize(ctx->stream);
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    }
     // the format's own variants
     float best_ms = 1e30f, fastest = 1e30f, t[3] = {-1.f, -1.f, -1.f};
     int   best_v  = 0, rc = SPMV_OK;
