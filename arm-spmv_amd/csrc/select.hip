@@ -20,6 +20,10 @@
 //      row-parallel kernel on C2 would cost 60 ms for a kernel that loses 5x) unless a statistic says the model may be
 //      wrong: long contiguous rows (dense blocks) also time the row-parallel kernel;
 //   3. layouts built for candidates that lost are freed before the call returns.
+// Later in round 5 three more CSR kernels joined the candidates at ANY size where a statistic asks for them - the segmented
+// scan and the long-row split for rows that dwarf the others (kernels_coo.hip: csr_segscan_build, kernels_csr_split.hip), the
+// ELL copy for (nearly) equal rows with local columns (kernels_ell.hip: csr_ell_copy_build) - and the two-phase model is timed
+// against the panel layout below 64M entries.
 // "panel_trial" 0 / SPMV_PANEL_TRIAL=0 (no timing launches at all) leaves step 1 alone.  What was timed is reported:
 // spmv_mat_get_param "select_candidates" and "select_us_<kernel>" (include/spmv_abi.h).
 #include <algorithm>

@@ -68,7 +68,12 @@ typedef enum spmv_format
  *               model's pick): 1 warm-up + 2 x 4 products each on zeroed scratch vectors (8 * (nrow + ncol) bytes, freed
  *               before the call returns), a candidate 3x behind after its first product is dropped at once, the fastest
  *               stays, layouts built for the others are freed.  Larger handles keep the model's pick without a launch, unless
- *               their rows are contiguous runs (then VECTOR and PANEL are timed).  COO and ELL handles time their own
+ *               a statistic casts doubt on it: rows that are contiguous runs (then VECTOR and PANEL are timed), the model's
+ *               TWOPHASE below 64M entries (PANEL is timed beside it).  At ANY size: a longest row with 1/128 of the entries
+ *               adds SEGSCAN, rows 32x the mean (and >= 4096; from 8M entries on >= 1/512 of the entries) add SPLIT - from 8M
+ *               entries on at two thresholds -, (nearly) equal rows with local columns add ELL (the kernels' own comments
+ *               below).  The panel layout itself times a cut for more rounds of workgroups where skewed rows leave its
+ *               busiest row group far above the mean ("panel_rounds").  COO and ELL handles time their own
  *               kernel(s) against a row-grouped CSR copy of themselves - which picks ITS kernel the same way - where that copy
  *               is a candidate (below).  "panel_trial" 0 / SPMV_PANEL_TRIAL=0: no timing launch anywhere, the model alone.
  *   what was timed is on record: spmv_mat_get_param "select_candidates", "select_us_vector" / "_ldswin" / "_scalar" / "_panel" /
@@ -79,7 +84,8 @@ typedef enum spmv_format
  *   "ell_copy_diagonal_slots", "ell_copy_variant", and for kernel SPLIT "split_row_threshold" (get: in effect; set: 0 = default, read at the
  *   next spmv_mat_set_kernel), "split_mode" (likewise; get: the mode in effect), "split_long_rows", "split_long_entries",
  *   "split_inner_kernel" (what the short rows' copy runs), "split_long_kernel" / "split_virtual_rows" (mode 2).
- *   Audit on stencils, dense blocks, R-MAT graphs, rectangles, permutations: tools/sweep_structures.py, profiles/r05_sweep_structures_*.
+ *   Audit on stencils, dense blocks, R-MAT graphs, rectangles, permutations, arrow and dense-row shapes, power laws, bands and meshes:
+ *   tools/sweep_structures.py, tools/fuzz_medium.py, profiles/r05_sweep_structures_*, profiles/r05_fuzz_medium_sizes.txt.
  *
  * Order of the additions (all within the parity tolerance of 1e-10):
  *   SCALAR              the reference's own order (left to right inside a row): bit-identical to its fma flavour;
