@@ -54,6 +54,7 @@ SIGNATURES = {
     "spmv_sync": (C.c_int, [_vp]),
     "spmv_ctx_mem_info": (C.c_int, [_vp, _i64p, _i64p]),
     "spmv_ctx_device": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "spmv_ctx_get_param": (C.c_int, [_vp, C.c_char_p, _i64p]),
     "spmv_vec_create": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp)]),
     "spmv_vec_wrap_device": (C.c_int, [_vp, C.c_int64, _vp, C.POINTER(_vp)]),
     "spmv_vec_destroy": (C.c_int, [_vp]),
@@ -217,6 +218,12 @@ class Context:
         if x_host.size != i.ncol or y_host.size != i.nrow:
             raise ValueError(f"apply_host: x has {x_host.size} entries (ncol {i.ncol}), y {y_host.size} (nrow {i.nrow})")
         _check(self._lib.spmv_apply_host(self.h, A.h, x_host.ctypes.data, y_host.ctypes.data))
+
+    def get_param(self, name: str) -> int:
+        """what the context found out about its platform (spmv_ctx_get_param): "host_stores", "xcd_round_robin", ..."""
+        v = C.c_int64(0)
+        _check(self._lib.spmv_ctx_get_param(self.h, name.encode(), C.byref(v)))
+        return v.value
 
     def xcd_round_robin(self) -> tuple[int, int]:
         """(1 / 0 / -1, distinct XCD ids seen): the start-up probe of workgroup placement (spmv_ctx_xcd_round_robin)"""

@@ -147,6 +147,35 @@ static int finish(spmv_mat* m, spmv_mat** out)
     *out = m;
     return SPMV_OK;
 }
+// Does a product of this handle add into y with device atomics (global_atomic_add_f64)?  Decided by the kernel that RUNS,
+// followed through the copies a handle may run from: the COO scan (in place or over column bins) and the CSC scatter; CSR
+// handles under SPMV_CSR_SEGSCAN (the same scan over a row index per entry) and SPMV_CSR_SPLIT in chunk mode (one atomic add
+// per chunk of a long row; the virtual-row mode adds its partial sums up in a scratch vector of its own and onto y with a plain
+// read and store); and any handle whose row-grouped copy, short-row copy or ELL copy runs one of those.  Everything else
+// touches every y_i once with a plain read and a plain store.  spmv_apply_host decides from this where y may live.
+bool adds_into_y_with_atomics(const spmv_mat* A)
+{
+    if (!A) return false;
+    switch (A->format)
+    {
+        case SPMV_FMT_COO:
+        case SPMV_FMT_CSC:
+            return A->coo_csr && A->kernel == SPMV_CSR_PANEL ? adds_into_y_with_atomics(A->coo_csr) : true;
+        case SPMV_FMT_ELL: return A->coo_csr && A->kernel == SPMV_CSR_PANEL ? adds_into_y_with_atomics(A->coo_csr) : false;
+        case SPMV_FMT_CSR:
+            switch (A->kernel)
+            {
+                case SPMV_CSR_SEGSCAN: return true;
+                case SPMV_CSR_SPLIT:
+                    // the short rows' copy picks a kernel of its own; long rows: chunks add atomically, virtual rows do not
+                    return adds_into_y_with_atomics(A->coo_csr) || (!A->split_long && A->split_nchunks > 0);
+                case SPMV_CSR_ELL: return adds_into_y_with_atomics(A->ell_copy);
+                default: return false;
+            }
+        default: return false;  // DIA
+    }
+}
+
 }  // namespace spmv
 
 using namespace spmv;
@@ -171,6 +200,7 @@ int spmv_device_count(int* count)
 }
 
 static void xcd_probe(spmv_ctx* ctx);
+static bool host_stores_reach_kernels(spmv_ctx* ctx);
 static int ctx_create_common(int device, void* borrowed_stream, bool borrow, spmv_ctx** out)
 {
     SPMV_REQUIRE(out, "out is null");
@@ -216,6 +246,9 @@ static int ctx_create_common(int device, void* borrowed_stream, bool borrow, spm
             if (hipDeviceGetAttribute((int*)&reg, hipDeviceAttributeHdpMemFlushCntl, device) == hipSuccess) ctx->hdp_flush = reg;
             const char* off = getenv("SPMV_HOST_STORES");  // SPMV_HOST_STORES=0: never store into device memory from the CPU (A/B; read once per context)
             ctx->large_bar  = !(off && off[0] == '0');
+            // ... and only where this context has SEEN it work: CPU stores into a device buffer, read by a kernel, twice (the second
+            // round right after a kernel read the first contents - the case a stale cache line would get wrong)
+            if (ctx->large_bar && !host_stores_reach_kernels(ctx)) ctx->large_bar = 0;
         }
         (void)hipGetLastError();
     }
@@ -269,11 +302,80 @@ static void xcd_probe(spmv_ctx* ctx)
     ctx->xcd_round_robin = ok ? 1 : 0;
 }
 
+// ---- may the CPU store x straight into device memory? --------------------------------------------------------------------------
+// spmv_apply_host writes a small x into its device buffer with memcpy where the device reports a large BAR.  The attribute says
+// the memory is mapped; that a KERNEL sees such stores (write-combining buffers drained, HDP flushed, no stale line in L2) is
+// checked here once per context before the path is switched on: 512 doubles stored by the CPU, summed by a kernel, twice with
+// different contents.  A mismatch (or any error) leaves large_bar off and x goes through the pinned staging buffer instead.
+namespace
+{
+__global__ void host_store_probe_kernel(const double* __restrict__ in, int n, double* __restrict__ out)
+{
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) s += in[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (threadIdx.x == 0) *out = s;
+}
+}  // namespace
+
+static bool host_stores_reach_kernels(spmv_ctx* ctx)
+{
+    constexpr int kN = 512;
+    double* buf = nullptr;
+    if (hipMalloc((void**)&buf, sizeof(double) * kN) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return false;
+    }
+    bool   ok = true;
+    double host[kN];
+    for (int round = 0; round < 2 && ok; ++round)
+    {
+        double want = 0.0;
+        for (int i = 0; i < kN; ++i)
+        {
+            host[i] = (double)((i * 7 + round * 13) % 32) + (round ? 0.5 : 0.25);  // (sums of these are exact in fp64 in any order)
+            want += host[i];
+        }
+        memcpy(buf, host, sizeof(host));
+        __sync_synchronize();
+        if (ctx->hdp_flush) *ctx->hdp_flush = 1u;
+        hipLaunchKernelGGL(host_store_probe_kernel, dim3(1), dim3(64), 0, ctx->stream, buf, kN, ctx->dev_scalars);
+        double got = -1.0;
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&got, ctx->dev_scalars, sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            ok = false;
+        }
+        else
+            ok = got == want;
+    }
+    (void)hipFree(buf);
+    return ok;
+}
+
 int spmv_ctx_xcd_round_robin(spmv_ctx* ctx, int32_t* round_robin, int32_t* xcds_seen)
 {
     SPMV_REQUIRE(ctx, "ctx is null");
     if (round_robin) *round_robin = ctx->xcd_round_robin;
     if (xcds_seen) *xcds_seen = ctx->xcds_seen;
+    return SPMV_OK;
+}
+
+int spmv_ctx_get_param(const spmv_ctx* ctx, const char* name, int64_t* value)
+{
+    SPMV_REQUIRE(ctx && name && value, "spmv_ctx_get_param: null argument");
+    if (!strcmp(name, "host_stores"))
+        *value = ctx->large_bar ? 1 : 0;
+    else if (!strcmp(name, "xcd_round_robin"))
+        *value = ctx->xcd_round_robin;
+    else if (!strcmp(name, "xcds_seen"))
+        *value = ctx->xcds_seen;
+    else if (!strcmp(name, "trial_arena_bytes"))
+        *value = (int64_t)ctx->arena_bytes;
+    else
+        SPMV_FAIL(SPMV_ERR_INVALID, "unknown context parameter '%s'", name);
     return SPMV_OK;
 }
 
@@ -289,6 +391,7 @@ int spmv_ctx_destroy(spmv_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->stage_x) (void)hipFree(ctx->stage_x);
     if (ctx->stage_y) (void)hipFree(ctx->stage_y);
     if (ctx->stage_pinned) (void)hipHostFree(ctx->stage_pinned);
@@ -1038,6 +1141,8 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         *value = m->ell_copy ? m->ell_copy->ell_variant : 0;
     else if (!strcmp(name, "min_row_entries"))
         *value = m->min_row_nnz;
+    else if (!strcmp(name, "adds_into_y_with_atomics"))  // 1: the product adds into y with device atomics (spmv_apply_host stages y in device memory)
+        *value = adds_into_y_with_atomics(m) ? 1 : 0;
     else if (!strcmp(name, "split_inner_kernel"))
         *value = m->format == SPMV_FMT_CSR && m->kernel == SPMV_CSR_SPLIT && m->coo_csr ? m->coo_csr->kernel : 0;
     else
@@ -1207,11 +1312,17 @@ int spmv_apply_host(spmv_ctx* ctx, const spmv_mat* A, const double* x_host, doub
         if (nx && !ctx->large_bar) memcpy(hx, x_host, sizeof(double) * nx);
         memcpy(hy, y_host, sizeof(double) * ny);
         // Kernels that touch every y_i once with a plain read and a plain store (the row-parallel, LDS-window, scalar, panel and
-        // two-phase CSR kernels, the ELL kernels, and COO / ELL / CSC handles running from their row-grouped CSR copy) update y
-        // IN the staging buffer over the host link: two launches.  The COO scan and the CSC scatter add into y with device
-        // atomics, which host memory may not support: y goes through a device buffer there, three launches.
-        const bool from_copy = A->coo_csr && A->kernel == SPMV_CSR_PANEL;
-        const bool y_in_place = A->format == SPMV_FMT_CSR || A->format == SPMV_FMT_ELL || ((A->format == SPMV_FMT_COO || A->format == SPMV_FMT_CSC) && from_copy);
+        // two-phase CSR kernels, the ELL and DIA kernels, and handles running from a copy that runs one of those) update y IN
+        // the staging buffer over the host link: two launches.  Kernels that add into y with device atomics (the COO scan, the
+        // CSC scatter, CSR under SEGSCAN or SPLIT's chunks - whether the handle's own or its copy's: adds_into_y_with_atomics)
+        // get y through a device buffer: fp64 atomics on host memory over the link are platform behaviour, not a HIP guarantee.
+        // (experiment, tools/probe_apply_host_atomics.py: SPMV_EXPERIMENTS=1 SPMV_HOST_Y_IN_PLACE=1 keeps y in the staging buffer
+        // whatever the kernel - to SEE what device atomics on mapped host memory do on a given box; never a product's path)
+        static const bool kForceInPlace = [] {
+            const char *e = getenv("SPMV_EXPERIMENTS"), *f = getenv("SPMV_HOST_Y_IN_PLACE");
+            return e && e[0] == '1' && f && f[0] == '1';
+        }();
+        const bool y_in_place = kForceInPlace || !adds_into_y_with_atomics(A);
         // x: where the CPU can store into device memory (large BAR) it writes x into the device buffer itself - 80 KB in 2 us,
         // no launch (tools/probe_host_write_vram.hip: the next kernel sees the stores, also right after a kernel that read the
         // previous contents; the HDP flush register is written behind them as the platform prescribes for such stores).

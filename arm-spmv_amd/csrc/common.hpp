@@ -122,6 +122,10 @@ struct spmv_ctx
     // hdp_flush: the HDP flush register (hipDeviceAttributeHdpMemFlushCntl), written after such stores
     int32_t            large_bar = 0;
     volatile unsigned* hdp_flush = nullptr;
+    // the trial arena (select.hip): ONE allocation that the timing launches of AUTO carve their scratch vectors from, so that no
+    // hipMalloc / hipFree falls between a candidate's build and its timing window; grown between trials, freed with the context
+    void*  arena       = nullptr;
+    size_t arena_bytes = 0;
 };
 
 namespace spmv
@@ -438,4 +442,5 @@ int gen_vec_uniform(spmv_ctx* ctx, double* d, int64_t n, int64_t index_offset, u
 int  mat_alloc(spmv_ctx* ctx, int32_t format, int32_t nrow, int32_t ncol, int64_t nnz, int32_t k,
                size_t a_count, size_t b_count, size_t v_count, spmv_mat** out);
 void mat_free(spmv_mat* m);
+bool adds_into_y_with_atomics(const spmv_mat* A);  // global_atomic_add_f64 on y, by the kernel (of the handle or its copies) that runs
 }  // namespace spmv

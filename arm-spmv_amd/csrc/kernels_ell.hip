@@ -615,6 +615,9 @@ int csr_ell_copy_build(spmv_mat* m)
     SPMV_REQUIRE(m->format == SPMV_FMT_CSR && m->a && m->b && m->v, "the ELL copy is made from a CSR handle's own arrays");
     SPMV_REQUIRE((int64_t)m->nrow * m->max_row_nnz <= (int64_t)INT32_MAX - 65536 && (int64_t)m->nrow * m->max_row_nnz <= 16 * std::max<int64_t>(m->nnz, 1),
                  "an ELL copy of %d rows x %d slots for %lld entries: the padding is out of proportion", m->nrow, m->max_row_nnz, (long long)m->nnz);
+    // an EMPTY row has no column of its own to pad with: its slots would carry column 0, and y += 0.0 * x[0] writes NaN into a row
+    // the reference's CSR loop never touches when x[0] is not finite (src/mat_vec.cpp:57-65) - what pad_own_column exists to prevent
+    SPMV_REQUIRE(m->min_row_nnz >= 1, "an ELL copy of a CSR handle with an empty row: its padding would read x[0] for a row without entries");
     spmv_mat* ell = nullptr;
     SPMV_TRY(csr_to_ell(m->ctx, m, &ell, /*pad_own_column=*/true));
     ell->pb_trial          = m->pb_trial;

@@ -177,6 +177,12 @@ int spmv_ctx_device(const spmv_ctx* ctx, int* device);
  * ("coo_column_bins") - are built only when it is 1 (otherwise the scan runs in place and the library says so once on stderr);
  * nothing leans on it for correctness.  Either pointer may be NULL. */
 int spmv_ctx_xcd_round_robin(spmv_ctx* ctx, int32_t* round_robin, int32_t* xcds_seen);
+/* What a context found out about its platform when it was created (read-only):
+ *   "host_stores"      1 = spmv_apply_host stores a small x straight into device memory from the CPU (large BAR reported, a
+ *                      self-check passed at creation - CPU stores summed by a kernel, twice - and SPMV_HOST_STORES is not 0)
+ *   "xcd_round_robin", "xcds_seen"   as spmv_ctx_xcd_round_robin
+ *   "trial_arena_bytes"  bytes of the arena that timing launches of AUTO take their scratch vectors from (0 until a trial ran) */
+int spmv_ctx_get_param(const spmv_ctx* ctx, const char* name, int64_t* value);
 /* free and total device memory in bytes (sizing shards for 288 GB of HBM; checking that handles give memory back) */
 int spmv_ctx_mem_info(spmv_ctx* ctx, int64_t* free_bytes, int64_t* total_bytes);
 

