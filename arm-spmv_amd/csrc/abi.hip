@@ -1098,6 +1098,8 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         *value = (int64_t)(m->contig_frac * 1000.0 + 0.5);
     else if (!strcmp(name, "select_candidates"))
         *value = m->sel_candidates;
+    else if (!strcmp(name, "select_rounds"))  // rounds the handle's last trial went through until its candidates' minima stood still (2 .. 6; 0: no trial)
+        *value = m->sel_rounds;
     else if (!strncmp(name, "select_us_", 10))
     {
         static const char* const kNames[] = {"", "vector", "ldswin", "scalar", "panel", "twophase", "variant1", "variant2"};

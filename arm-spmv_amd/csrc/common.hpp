@@ -126,6 +126,7 @@ struct spmv_ctx
     // hipMalloc / hipFree falls between a candidate's build and its timing window; grown between trials, freed with the context
     void*  arena       = nullptr;
     size_t arena_bytes = 0;
+    int    arena_users = 0;  // trials holding pointers into it (it is not re-allocated while > 0)
 };
 
 namespace spmv
@@ -182,6 +183,7 @@ struct spmv_mat
     // by spmv_csr_kernel id (COO / ELL: [1] the format's own kernel, [4] the row-grouped copy); 0 = not timed
     int32_t  sel_candidates = 0;
     float    sel_us[10]     = {0};
+    int32_t  sel_rounds     = 0;  // rounds the last trial went through until its minima stood still ("select_rounds")
 
     // CSR panel kernel (kernels_csr_panel.hip): entries re-ordered per row group by column panel / x line
     int32_t*  pb_col         = nullptr;  // [nnz] global column
@@ -320,10 +322,14 @@ int  csr_select_kernel(spmv_mat* m);
 struct select_scratch
 {
     double *x = nullptr, *y = nullptr;
+    spmv_ctx* ctx        = nullptr;
+    bool      from_arena = false;  // x / y lie in the context's trial arena (select.hip), not in allocations of their own
     int  alloc(spmv_ctx* ctx, int64_t ncol, int64_t nrow);
     void release();
     ~select_scratch() { release(); }
 };
+// candidates 0 .. n-1 timed in rounds until no minimum moves (select.hip); t[i] < 0: not timed yet
+int  select_rounds(spmv_ctx* ctx, int n, const std::function<int(int)>& launch, float* t, int* rounds_run);
 // ms per product of `launch`: 1 warm-up + 1 product, and 2 x 4 more (the minimum) unless that one was 3x behind best_so_far
 int  select_time(spmv_ctx* ctx, const std::function<int()>& launch, float best_so_far, float* ms);
 void select_note(spmv_mat* m, int slot, float ms);  // records a timed candidate (sel_us[slot], sel_candidates)

@@ -348,44 +348,39 @@ int coo_select_kernel(spmv_mat* m)
     if (!select_trials_enabled(m) || m->nnz < kSelectMinNnz) return model_copy ? build_copy() : SPMV_OK;
     select_scratch sv;
     if (sv.alloc(ctx, m->ncol, m->nrow) != SPMV_OK) return model_copy ? build_copy() : SPMV_OK;
-    float t_scan = 1e30f, t_copy = 1e30f;
-    int   rc     = SPMV_OK;
-    // the model's pick first: the other one is dropped after a single product when it is 3x behind
-    for (int pass = 0; pass < 2 && rc == SPMV_OK; ++pass)
+    // the copy is built first, then the two are timed in rounds - the model's pick first - until their minima stand still
+    // (select.hip: no allocation between two timings)
+    int rc = build_copy();
+    if (rc == SPMV_ERR_ALLOC && !model_copy)
     {
-        if ((pass == 0) == model_copy)
+        (void)hipGetLastError();
+        rc = SPMV_OK;  // no memory for the copy: the scan runs
+    }
+    if (rc != SPMV_OK) return rc;
+    float t_scan = 1e30f, t_copy = 1e30f;
+    {
+        // candidate 0 is the model's pick; without a copy the scan is timed alone (its figure is reported)
+        const bool copy_first = model_copy && m->coo_csr;
+        float      t[2]       = {-1.f, -1.f};
+        const int  n          = m->coo_csr ? 2 : 1;
+        rc = select_rounds(ctx, n,
+                           [&](int j) {
+                               const bool copy = m->coo_csr && ((j == 0) == copy_first);
+                               return copy ? csr_apply(ctx, m->coo_csr, sv.x, sv.y) : coo_scan_apply(ctx, m, sv.x, sv.y);
+                           },
+                           t, &m->sel_rounds);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (rc != SPMV_OK) return rc;
+        if (m->coo_csr)
         {
-            rc = build_copy();
-            if (rc == SPMV_ERR_ALLOC && !model_copy)
-            {
-                (void)hipGetLastError();
-                rc = SPMV_OK;  // no memory for the copy: the scan runs
-                continue;
-            }
-            if (rc != SPMV_OK) break;
-            rc = select_time(ctx, [&] { return csr_apply(ctx, m->coo_csr, sv.x, sv.y); }, t_scan, &t_copy);
-            if (rc == SPMV_OK) select_note(m, SPMV_CSR_PANEL, t_copy);
+            t_copy = copy_first ? t[0] : t[1];
+            t_scan = copy_first ? t[1] : t[0];
+            if (t_copy >= 0.f) select_note(m, SPMV_CSR_PANEL, t_copy); else t_copy = 1e30f;
         }
         else
-        {
-            rc = select_time(ctx, [&] { return coo_scan_apply(ctx, m, sv.x, sv.y); }, t_copy, &t_scan);
-            if (rc == SPMV_OK) select_note(m, SPMV_CSR_VECTOR, t_scan);
-        }
+            t_scan = t[0];
+        if (t_scan >= 0.f) select_note(m, SPMV_CSR_VECTOR, t_scan); else t_scan = 1e30f;
     }
-    // once more round, the minimum per candidate (select.hip: a transient hits whoever is being timed, not the same one twice)
-    if (rc == SPMV_OK && m->coo_csr && t_scan < 8.0f * t_copy && t_copy < 8.0f * t_scan)
-    {
-        float again = 0.f;
-        if ((rc = select_time(ctx, [&] { return csr_apply(ctx, m->coo_csr, sv.x, sv.y); }, t_scan, &again)) == SPMV_OK) t_copy = std::min(t_copy, again);
-        if (rc == SPMV_OK && (rc = select_time(ctx, [&] { return coo_scan_apply(ctx, m, sv.x, sv.y); }, t_copy, &again)) == SPMV_OK) t_scan = std::min(t_scan, again);
-        if (rc == SPMV_OK)
-        {
-            m->sel_us[SPMV_CSR_PANEL]  = t_copy * 1000.f;
-            m->sel_us[SPMV_CSR_VECTOR] = t_scan * 1000.f;
-        }
-    }
-    (void)hipStreamSynchronize(ctx->stream);
-    if (rc != SPMV_OK) return rc;
     // Third candidate: the scan over a copy of the entries in column bins, one per XCD (coo_build_bins; 16 bytes per entry).
     // Worth a try where the scan in place is gather-bound but not hopeless (within 4x of the row-grouped copy; C4's is 6.5x behind, and its scan over bins loses too): local
     // columns under an x beyond an XCD's L2 - dense blocks, bands (8 x 8 blocks, 32M entries: 0.097 ms against the copy's 0.108).
@@ -395,17 +390,20 @@ int coo_select_kernel(spmv_mat* m)
         rc = coo_build_bins(m, 0, /*only_if_worth=*/true);
         if (rc == SPMV_OK && m->cb_bins)
         {
-            // timed twice with the copy re-timed in between: the first timing follows the build of the bins (allocations and
-            // frees a moment ago: products run slower for the next millisecond, select.hip), the second does not
-            float again = 0.f;
-            rc = select_time(ctx, [&] { return coo_scan_apply(ctx, m, sv.x, sv.y); }, std::min(t_scan, t_copy), &t_bins);
-            if (rc == SPMV_OK && m->coo_csr && (rc = select_time(ctx, [&] { return csr_apply(ctx, m->coo_csr, sv.x, sv.y); }, t_bins, &again)) == SPMV_OK)
-                t_copy = std::min(t_copy, again);
-            if (rc == SPMV_OK && (rc = select_time(ctx, [&] { return coo_scan_apply(ctx, m, sv.x, sv.y); }, t_copy, &again)) == SPMV_OK) t_bins = std::min(t_bins, again);
+            // the scan over the bins and (again, as a minimum to improve on) the copy, in rounds: the bins' first timing follows
+            // their build - allocations and frees a moment ago - the later ones do not
+            float     t[2] = {-1.f, m->coo_csr && t_copy < 1e29f ? t_copy : -1.f};
+            const int n    = m->coo_csr ? 2 : 1;
+            rc = select_rounds(ctx, n, [&](int j) { return j == 0 ? coo_scan_apply(ctx, m, sv.x, sv.y) : csr_apply(ctx, m->coo_csr, sv.x, sv.y); }, t, nullptr);
             if (rc == SPMV_OK)
             {
-                select_note(m, 6, t_bins);  // "select_us_variant1"
-                m->sel_us[SPMV_CSR_PANEL] = t_copy * 1000.f;
+                t_bins = t[0] >= 0.f ? t[0] : 1e30f;
+                if (t[0] >= 0.f) select_note(m, 6, t_bins);  // "select_us_variant1"
+                if (m->coo_csr && t[1] >= 0.f)
+                {
+                    t_copy                    = t[1];
+                    m->sel_us[SPMV_CSR_PANEL] = t_copy * 1000.f;
+                }
             }
         }
         else if (rc == SPMV_ERR_ALLOC)

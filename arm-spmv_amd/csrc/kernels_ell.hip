@@ -14,8 +14,6 @@
 #include <algorithm>
 #include <vector>
 
-#include <chrono>
-#include <thread>
 
 #include "common.hpp"
 #include "wave.hpp"
@@ -498,42 +496,8 @@ int ell_select_kernel(spmv_mat* m)
         return (m->ell_diag || m->sel_no_rowgrouped) ? SPMV_OK : ell_build_panel(m, /*only_if_worth=*/true);
     select_scratch sv;
     if (sv.alloc(ctx, m->ncol, m->nrow) != SPMV_OK) return (m->ell_diag || m->sel_no_rowgrouped) ? SPMV_OK : ell_build_panel(m, true);
-    // (small handles: 2 ms of quiet first - products launched within a millisecond of a hipMalloc / hipFree run up to 2x slower
-    // whichever kernel they are (select.hip), and a copy built a moment ago for somebody's trial is timed right after both; at 4-5
-    // us per product that has decided between one and two rows per lane the wrong way round)
-    if (slots < ((int64_t)4 << 20))
-    {
-        (void)hipStreamSynchronize(ctx->stream);
-        std::this_thread::sleep_for(std::chrono::milliseconds(2));
-    }
-    // the format's own variants
-    float best_ms = 1e30f, fastest = 1e30f, t[3] = {-1.f, -1.f, -1.f};
-    int   best_v  = 0, rc = SPMV_OK;
-    for (int pass = 0; pass < 2 && rc == SPMV_OK; ++pass)  // twice round, the minimum per variant (select.hip: transients)
-        for (int v = 0; v < 3 && rc == SPMV_OK; ++v)
-        {
-            if (v == 2 && !(m->ell_diag && m->ell_diag_mask)) continue;  // (without diagonal slots variant 0 reads the indices already)
-            if (pass == 1 && t[v] > 8.0f * fastest) continue;
-            m->ell_variant = v;
-            float ms       = 0.f;
-            rc             = select_time(ctx, [&] { return ell_own_apply(ctx, m, sv.x, sv.y); }, fastest, &ms);
-            if (rc != SPMV_OK) break;
-            t[v]    = t[v] < 0.f ? ms : std::min(t[v], ms);
-            fastest = std::min(fastest, t[v]);
-        }
-    for (int v = 0; v < 3 && rc == SPMV_OK; ++v)
-        if (t[v] >= 0.f)
-        {
-            select_note(m, v == 0 ? SPMV_CSR_VECTOR : 5 + v, t[v]);  // slots 1, 6 ("variant1"), 7 ("variant2")
-            if (t[v] < best_ms * (v ? 0.98f : 1.0f))
-            {
-                best_ms = t[v];
-                best_v  = v;
-            }
-        }
-    m->ell_variant = best_v;
-    if (rc != SPMV_OK) return rc;
-    // the row-grouped copy, where it is a candidate
+    // is the row-grouped copy a candidate?  (decided from the matrix, not from a timing: it is built BEFORE anything is timed, so
+    // that no allocation falls between two timings - select.hip)
     bool candidate = !m->sel_no_rowgrouped && slots <= (int64_t)INT32_MAX - 65536;  // (the ELL copy of a CSR handle: that handle IS the row-grouped form)
     if (candidate)
     {
@@ -553,27 +517,55 @@ int ell_select_kernel(spmv_mat* m)
             }
         }
     }
+    int rc = SPMV_OK;
     if (candidate)
     {
         rc = ell_make_rowgrouped(m, SPMV_CSR_AUTO);
         if (rc == SPMV_ERR_ALLOC)
         {
             (void)hipGetLastError();
-            rc = SPMV_OK;  // no memory for the copy: the format's own kernel runs
+            rc = SPMV_OK;  // no memory for the copy: the format's own kernels are the candidates
         }
-        else if (rc == SPMV_OK)
-        {
-            float t_copy = 0.f;
-            rc           = select_time(ctx, [&] { return csr_apply(ctx, m->coo_csr, sv.x, sv.y); }, best_ms, &t_copy);
-            if (rc == SPMV_OK)
-            {
-                select_note(m, SPMV_CSR_PANEL, t_copy);
-                if (!(t_copy < best_ms * 0.98f)) ell_drop_rowgrouped(m);
-            }
-        }
+        if (rc != SPMV_OK) return rc;
     }
+    // candidates 0 .. 2: the format's own variants; 3: the copy.  Timed in rounds until their minima stand still (select.hip:
+    // this is what replaced round 5's 2 ms of sleep in front of small handles' trials)
+    const bool has_v2 = m->ell_diag && m->ell_diag_mask;  // (without diagonal slots variant 0 reads the indices already)
+    int        ids[4], n = 0;
+    ids[n++] = 0;
+    ids[n++] = 1;
+    if (has_v2) ids[n++] = 2;
+    if (m->coo_csr) ids[n++] = 3;
+    float t[4] = {-1.f, -1.f, -1.f, -1.f};
+    rc = select_rounds(ctx, n,
+                       [&](int j) {
+                           if (ids[j] == 3) return csr_apply(ctx, m->coo_csr, sv.x, sv.y);
+                           m->ell_variant = ids[j];
+                           return ell_own_apply(ctx, m, sv.x, sv.y);
+                       },
+                       t, &m->sel_rounds);
     (void)hipStreamSynchronize(ctx->stream);
     if (rc != SPMV_OK) return rc;
+    float best_ms = 1e30f;
+    int   best_v  = 0;
+    for (int j = 0; j < n; ++j)
+    {
+        if (ids[j] == 3 || t[j] < 0.f) continue;
+        const int v = ids[j];
+        select_note(m, v == 0 ? SPMV_CSR_VECTOR : 5 + v, t[j]);  // slots 1, 6 ("variant1"), 7 ("variant2")
+        if (t[j] < best_ms * (v ? 0.98f : 1.0f))  // two rows per lane is the model's pick: another variant has to win by 2 %
+        {
+            best_ms = t[j];
+            best_v  = v;
+        }
+    }
+    m->ell_variant = best_v;
+    if (m->coo_csr)
+    {
+        const float t_copy = t[n - 1];
+        if (t_copy >= 0.f) select_note(m, SPMV_CSR_PANEL, t_copy);
+        if (!(t_copy >= 0.f && t_copy < best_ms * 0.98f)) ell_drop_rowgrouped(m);
+    }
     m->kernel = m->coo_csr ? SPMV_CSR_PANEL : SPMV_CSR_VECTOR;
     return SPMV_OK;
 }

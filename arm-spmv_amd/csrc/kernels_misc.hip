@@ -422,14 +422,15 @@ int csc_select_kernel(spmv_mat* m)
     }
     if (rc != SPMV_OK) return rc;
     if (!m->coo_csr) return SPMV_OK;
-    for (int pass = 0; pass < 2 && rc == SPMV_OK; ++pass)  // twice round, the minimum per candidate (select.hip: transients)
     {
-        float t = 0.f;
-        if ((rc = select_time(ctx, [&] { return csr_apply(ctx, m->coo_csr, sv.x, sv.y); }, t_own, &t)) != SPMV_OK) break;
-        t_copy = std::min(t_copy, t);
-        if (pass == 1 && t_own > 8.0f * t_copy) break;
-        if ((rc = select_time(ctx, [&] { return csc_scatter_apply(ctx, m, sv.x, sv.y); }, t_copy, &t)) != SPMV_OK) break;
-        t_own = std::min(t_own, t);
+        // the copy is built; the two are timed in rounds until their minima stand still (select.hip)
+        float t[2] = {-1.f, -1.f};
+        rc = select_rounds(ctx, 2, [&](int j) { return j == 0 ? csr_apply(ctx, m->coo_csr, sv.x, sv.y) : csc_scatter_apply(ctx, m, sv.x, sv.y); }, t, &m->sel_rounds);
+        if (rc == SPMV_OK)
+        {
+            t_copy = t[0] >= 0.f ? t[0] : 1e30f;
+            t_own  = t[1] >= 0.f ? t[1] : 1e30f;
+        }
     }
     (void)hipStreamSynchronize(ctx->stream);
     if (rc != SPMV_OK) return rc;

@@ -42,23 +42,77 @@ bool select_trials_enabled(const spmv_mat* m)
     return !(e && e[0] == '0');
 }
 
-int select_scratch::alloc(spmv_ctx* ctx, int64_t ncol, int64_t nrow)
+// ---- the trial arena ----------------------------------------------------------------------------------------------
+// Round 5 found products launched within a millisecond or two of a hipMalloc / hipFree running up to 2x slower, whichever
+// kernel they are (the driver is still mapping / unmapping), and answered with a 2 ms sleep in front of the ELL trial.  Round 6
+// removes the allocations it can and stops trusting a single moment for the rest:
+//   * the zeroed x and y that every trial multiplies with come from ONE allocation of the context (ctx->arena: x in its first
+//     half, y in its second - nothing ever writes the first half, and y += A * 0 leaves the second what it was), made before the
+//     first trial of a context and kept: no hipMalloc / hipFree per trial, nested trials (a handle's copy selecting its own
+//     kernel) share it.  Up to 4M entries per vector (64 MB in all) - the sizes where a product takes microseconds and a
+//     transient decides; larger vectors get allocations of their own as before (their products take tens of microseconds up);
+//   * the candidates of a small handle are BUILT first and timed afterwards (csr_select_kernel), and every trial goes round
+//     until no candidate's minimum moves any more (select_rounds): whatever the allocations of a build stirred up has died
+//     down by the time the minima agree, without anybody sleeping.
+constexpr size_t kArenaHalfMax = (size_t)4 << 20;  // doubles per half
+
+int select_scratch::alloc(spmv_ctx* c, int64_t ncol, int64_t nrow)
 {
-    if (hipMalloc(&x, sizeof(double) * (size_t)std::max<int64_t>(ncol, 1)) != hipSuccess ||
-        hipMalloc(&y, sizeof(double) * (size_t)std::max<int64_t>(nrow, 1)) != hipSuccess)
+    const size_t nx = (size_t)std::max<int64_t>(ncol, 1), ny = (size_t)std::max<int64_t>(nrow, 1);
+    const size_t half = std::max(nx, ny);
+    if (half <= kArenaHalfMax)
+    {
+        if (c->arena_bytes < 2 * half * sizeof(double) && c->arena_users == 0)
+        {
+            size_t want = (size_t)1 << 17;  // doubles per half: 1 MB at least, powers of two
+            while (want < half) want <<= 1;
+            (void)hipStreamSynchronize(c->stream);
+            if (c->arena) (void)hipFree(c->arena);
+            c->arena       = nullptr;
+            c->arena_bytes = 0;
+            if (hipMalloc(&c->arena, 2 * want * sizeof(double)) == hipSuccess && hipMemsetAsync(c->arena, 0, 2 * want * sizeof(double), c->stream) == hipSuccess)
+                c->arena_bytes = 2 * want * sizeof(double);
+            else
+            {
+                (void)hipGetLastError();
+                if (c->arena) (void)hipFree(c->arena);
+                c->arena = nullptr;
+            }
+        }
+        if (c->arena_bytes >= 2 * half * sizeof(double))
+        {
+            x          = (double*)c->arena;
+            y          = (double*)c->arena + c->arena_bytes / sizeof(double) / 2;
+            ctx        = c;
+            from_arena = true;
+            ++c->arena_users;
+            return SPMV_OK;
+        }
+    }
+    // beyond the arena (or the arena is in use and too small: a nested trial of another shape): allocations of its own
+    if (hipMalloc(&x, sizeof(double) * nx) != hipSuccess || hipMalloc(&y, sizeof(double) * ny) != hipSuccess)
     {
         (void)hipGetLastError();
         release();
         return SPMV_ERR_ALLOC;
     }
-    (void)hipMemsetAsync(x, 0, sizeof(double) * (size_t)std::max<int64_t>(ncol, 1), ctx->stream);
-    (void)hipMemsetAsync(y, 0, sizeof(double) * (size_t)std::max<int64_t>(nrow, 1), ctx->stream);
+    (void)hipMemsetAsync(x, 0, sizeof(double) * nx, c->stream);
+    (void)hipMemsetAsync(y, 0, sizeof(double) * ny, c->stream);
     return SPMV_OK;
 }
 void select_scratch::release()
 {
-    if (x) (void)hipFree(x);
-    if (y) (void)hipFree(y);
+    if (from_arena)
+    {
+        if (ctx && ctx->arena_users > 0) --ctx->arena_users;
+        from_arena = false;
+        ctx        = nullptr;
+    }
+    else
+    {
+        if (x) (void)hipFree(x);
+        if (y) (void)hipFree(y);
+    }
     x = y = nullptr;
 }
 
@@ -97,6 +151,40 @@ int select_time(spmv_ctx* ctx, const std::function<int()>& launch, float best_so
     return SPMV_OK;
 }
 
+// The candidates 0 .. n-1 timed in rounds, the minimum per candidate, until a round moves no minimum by 3 % or more (at least
+// two rounds, at most six; two where a product takes 50 us and more - a transient of a millisecond is noise there and a round
+// costs milliseconds).  t[i] < 0 on entry: not timed yet; t[i] >= 0: a timing from before, kept as a minimum to improve on.
+// A candidate 8x behind the fastest is left out of later rounds.  This replaces "time twice and hope" and round 5's sleep: what a
+// build's allocations stirred up a moment ago shows as a minimum that still moves, and the rounds go on until it does not.
+int select_rounds(spmv_ctx* ctx, int n, const std::function<int(int)>& launch, float* t, int* rounds_run)
+{
+    constexpr int kMaxRounds = 6;
+    float fastest = 1e30f;
+    for (int i = 0; i < n; ++i)
+        if (t[i] >= 0.f) fastest = std::min(fastest, t[i]);
+    int r = 0;
+    for (; r < kMaxRounds; ++r)
+    {
+        bool moved = false;
+        for (int i = 0; i < n; ++i)
+        {
+            if (t[i] >= 0.f && t[i] > 8.0f * fastest) continue;
+            float ms = 0.f;
+            SPMV_TRY(select_time(ctx, [&] { return launch(i); }, fastest, &ms));
+            if (t[i] < 0.f || ms < 0.97f * t[i]) moved = true;
+            t[i]    = t[i] < 0.f ? ms : std::min(t[i], ms);
+            fastest = std::min(fastest, t[i]);
+        }
+        if (r >= 1 && (!moved || fastest > 0.05f))
+        {
+            ++r;
+            break;
+        }
+    }
+    if (rounds_run) *rounds_run = r;
+    return SPMV_OK;
+}
+
 void select_note(spmv_mat* m, int slot, float ms)
 {
     if (slot >= 0 && slot < 10) m->sel_us[slot] = ms * 1000.f;
@@ -105,6 +193,7 @@ void select_note(spmv_mat* m, int slot, float ms)
 void select_reset(spmv_mat* m)
 {
     m->sel_candidates = 0;
+    m->sel_rounds     = 0;
     for (float& v : m->sel_us) v = 0.f;
 }
 
@@ -192,17 +281,39 @@ int csr_select_kernel(spmv_mat* m)
     int                rc = SPMV_OK;
     float              fastest = 1e30f;
     std::vector<float> t(cand.size(), -1.f);
-    // two passes in the same order, the minimum per candidate: a transient (the driver still unmapping what the caller freed a
-    // moment ago, clocks ramping) hits whoever is being timed at that moment, not the same candidate twice.  The second pass
-    // leaves out only what was 8x behind (a disturbed first measurement was seen 6x off: tools/probe_ell_trial.py).  Layouts stay resident between the passes; the losers' are freed at the end.
-    // (From 8M entries on one pass: a product takes tens of microseconds there, and the split in its two variants is built anew
-    // for every timing.)
-    const int passes = m->nnz < kSelectMaxNnz ? 2 : 1;
-    for (int pass = 0; pass < passes && rc == SPMV_OK; ++pass)
+    // (a transient - the driver still unmapping what the caller freed a moment ago, clocks ramping - hits whoever is being timed
+    // at that moment; a disturbed first measurement was seen 6x off, tools/probe_ell_trial.py: hence rounds, and minima)
+    if (m->nnz < kSelectMaxNnz)
+    {
+        // every candidate's layout is built first (at most 8M entries: a few layouts of 100 MB side by side), then they are timed
+        // in rounds with no allocation in between, until their minima stand still (select_rounds)
+        std::vector<int> built;
+        for (size_t i = 0; i < cand.size(); ++i)
+        {
+            if ((rc = build(cand[i])) != SPMV_OK)
+            {
+                if (cand[i] == model) return rc;
+                (void)hipGetLastError();
+                rc = SPMV_OK;  // a candidate that cannot be built (no memory for another layout) is not a candidate
+                continue;
+            }
+            built.push_back((int)i);
+        }
+        std::vector<float> tb(built.size(), -1.f);
+        rc = select_rounds(ctx, (int)built.size(),
+                           [&](int j) {
+                               m->kernel = cand[(size_t)built[(size_t)j]];  // (no split at two thresholds below 8M entries: the kernel id says which layout runs)
+                               return csr_apply(ctx, m, sv.x, sv.y);
+                           },
+                           tb.data(), &m->sel_rounds);
+        for (size_t j = 0; j < built.size(); ++j) t[(size_t)built[j]] = tb[j];
+    }
+    else
+        // (from 8M entries on: one pass, build and time in turn - a product takes tens of microseconds there, the layouts are
+        // hundreds of megabytes each, and the split in its two variants is built anew for every timing)
         for (size_t i = 0; i < cand.size() && rc == SPMV_OK; ++i)
         {
             const int k = cand[i];
-            if (pass == 1 && (t[i] < 0.f || t[i] > 8.0f * fastest)) continue;
             if ((rc = build(k)) != SPMV_OK)
             {
                 if (k == model) return rc;
@@ -213,7 +324,7 @@ int csr_select_kernel(spmv_mat* m)
             float ms = 0.f;
             rc       = select_time(ctx, [&] { return csr_apply(ctx, m, sv.x, sv.y); }, fastest, &ms);
             if (rc != SPMV_OK) break;
-            t[i]    = t[i] < 0.f ? ms : std::min(t[i], ms);
+            t[i]    = ms;
             fastest = std::min(fastest, t[i]);
         }
     (void)hipStreamSynchronize(ctx->stream);
