@@ -84,6 +84,9 @@ SIGNATURES = {
     "spmv_mat_set_flags": (C.c_int, [_vp, C.c_uint32]),
     "spmv_mat_set_param": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
     "spmv_mat_get_param": (C.c_int, [_vp, C.c_char_p, _i64p]),
+    "spmv_mat_get_plan": (C.c_int, [_vp, _vp, _i64p]),
+    "spmv_mat_set_plan": (C.c_int, [_vp, _vp, C.c_int64]),
+    "spmv_ctx_set_plan": (C.c_int, [_vp, _vp, C.c_int64]),
     "spmv_mat_download": (C.c_int, [_vp, _vp, _vp, _vp]),
     "spmv_mat_device_ptrs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "spmv_apply": (C.c_int, [_vp, _vp, _vp, _vp]),
@@ -224,6 +227,13 @@ class Context:
         v = C.c_int64(0)
         _check(self._lib.spmv_ctx_get_param(self.h, name.encode(), C.byref(v)))
         return v.value
+
+    def set_plan(self, plan: bytes | None) -> None:
+        """handles of the plan's format created on this context from now on take `plan` instead of selecting; None clears it"""
+        if plan is None:
+            _check(self._lib.spmv_ctx_set_plan(self.h, None, 0))
+        else:
+            _check(self._lib.spmv_ctx_set_plan(self.h, plan, len(plan)))
 
     def xcd_round_robin(self) -> tuple[int, int]:
         """(1 / 0 / -1, distinct XCD ids seen): the start-up probe of workgroup placement (spmv_ctx_xcd_round_robin)"""
@@ -520,6 +530,18 @@ class Matrix:
         v = C.c_int64(0)
         _check(self.ctx._lib.spmv_mat_get_param(self.h, name.encode(), C.byref(v)))
         return v.value
+
+    def get_plan(self) -> bytes:
+        """the handle's set-up decisions (kernel, layout, tuned parameters; its copies' too) as a POD blob (spmv_mat_get_plan)"""
+        n = C.c_int64(0)
+        _check(self.ctx._lib.spmv_mat_get_plan(self.h, None, C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        _check(self.ctx._lib.spmv_mat_get_plan(self.h, buf, C.byref(n)))
+        return buf.raw[: n.value]
+
+    def set_plan(self, plan: bytes) -> None:
+        """build exactly the kernel and layout of `plan` (from get_plan of a handle of the same format), no timing launch"""
+        _check(self.ctx._lib.spmv_mat_set_plan(self.h, plan, len(plan)))
 
     def set_flags(self, flags: int) -> None:
         _check(self.ctx._lib.spmv_mat_set_flags(self.h, flags))

@@ -130,6 +130,21 @@ static int wrap(spmv_ctx* ctx, int32_t format, int32_t nrow, int32_t ncol, int64
     return SPMV_OK;
 }
 
+// spmv_ctx_set_plan: the handle a public entry point is about to create takes the context's plan (plan.hip: plan_take_armed, at
+// the handle's analysis); whatever the entry point does, the flag is down again when it returns
+struct plan_arm
+{
+    spmv_ctx* c;
+    explicit plan_arm(spmv_ctx* ctx) : c(ctx)
+    {
+        if (c && !c->plan_blob.empty()) c->plan_armed = true;
+    }
+    ~plan_arm()
+    {
+        if (c) c->plan_armed = false;
+    }
+};
+
 static int finish(spmv_mat* m, spmv_mat** out)
 {
     // The analysis and layout builders index by row and column (histograms in LDS, scatter cursors): a malformed
@@ -525,6 +540,7 @@ int spmv_csr_upload(spmv_ctx* ctx, int32_t nrow, int32_t ncol, const int32_t* ro
     SPMV_REQUIRE(row_ptr[0] == 0 && nnz >= 0 && (nnz == 0 || (col_ind && values)),
                  "spmv_csr_upload: row_ptr[0]=%d, nnz=%lld", row_ptr[0], (long long)nnz);
     SPMV_TRY(use_device(ctx));
+    plan_arm arm(ctx);
     spmv_mat* m = nullptr;
     SPMV_TRY(mat_alloc(ctx, SPMV_FMT_CSR, nrow, ncol, nnz, 0, (size_t)nrow + 1, (size_t)nnz, (size_t)nnz, &m));
     int rc = upload(const_cast<int32_t*>(m->a), row_ptr, sizeof(int32_t) * ((size_t)nrow + 1), ctx);
@@ -543,6 +559,7 @@ int spmv_csr_wrap_device(spmv_ctx* ctx, int32_t nrow, int32_t ncol, const int32_
 {
     SPMV_REQUIRE(ctx && out && nrow >= 0 && ncol >= 0 && d_row_ptr, "spmv_csr_wrap_device: bad argument");
     SPMV_TRY(use_device(ctx));
+    plan_arm arm(ctx);
     int32_t ends[2] = {0, 0};
     SPMV_HIP(hipMemcpyAsync(&ends[0], d_row_ptr, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     SPMV_HIP(hipMemcpyAsync(&ends[1], d_row_ptr + nrow, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -564,6 +581,7 @@ int spmv_csr_upload_shard(spmv_ctx* ctx, int64_t row_begin, int64_t row_end, int
     SPMV_REQUIRE(nnz >= 0 && nnz <= INT32_MAX, "spmv_csr_upload_shard: shard holds %lld entries (int32 offsets)",
                  (long long)nnz);
     SPMV_TRY(use_device(ctx));
+    plan_arm arm(ctx);
     // rebase exactly like src/mat_vec.cpp:260-263
     std::vector<int32_t> sub((size_t)nrow + 1);
     for (int32_t j = 0; j <= nrow; ++j) sub[j] = (int32_t)(row_ptr64[row_begin + j] - base);
@@ -587,6 +605,7 @@ int spmv_coo_upload(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int64_t nnz, cons
     SPMV_REQUIRE(ctx && out && nrow >= 0 && ncol >= 0 && nnz >= 0 && (nnz == 0 || (row_ind && col_ind && values)),
                  "spmv_coo_upload: bad argument");
     SPMV_TRY(use_device(ctx));
+    plan_arm arm(ctx);
     spmv_mat* m = nullptr;
     SPMV_TRY(mat_alloc(ctx, SPMV_FMT_COO, nrow, ncol, nnz, 0, (size_t)nnz, (size_t)nnz, (size_t)nnz, &m));
     int rc = upload(const_cast<int32_t*>(m->a), row_ind, sizeof(int32_t) * (size_t)nnz, ctx);
@@ -605,6 +624,7 @@ int spmv_coo_wrap_device(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int64_t nnz,
 {
     SPMV_REQUIRE(ctx && out && nrow >= 0 && ncol >= 0 && nnz >= 0, "spmv_coo_wrap_device: bad argument");
     SPMV_TRY(use_device(ctx));
+    plan_arm arm(ctx);
     spmv_mat* m = nullptr;
     SPMV_TRY(wrap(ctx, SPMV_FMT_COO, nrow, ncol, nnz, 0, d_row_ind, d_col_ind, d_values, &m));
     return finish(m, out);
@@ -617,6 +637,7 @@ int spmv_ell_upload(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t k, int64_
     const size_t total = (size_t)nrow * (size_t)k;
     SPMV_REQUIRE(total == 0 || (col_ind && values), "spmv_ell_upload: null arrays");
     SPMV_TRY(use_device(ctx));
+    plan_arm arm(ctx);
     spmv_mat* m = nullptr;
     SPMV_TRY(mat_alloc(ctx, SPMV_FMT_ELL, nrow, ncol, nnz, k, 0, total, total, &m));
     int rc = upload(const_cast<int32_t*>(m->b), col_ind, sizeof(int32_t) * total, ctx);
@@ -634,6 +655,7 @@ int spmv_ell_wrap_device(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t k, i
                          const double* d_values, spmv_mat** out)
 {
     SPMV_REQUIRE(ctx && out && nrow >= 0 && ncol >= 0 && k >= 0, "spmv_ell_wrap_device: bad argument");
+    plan_arm arm(ctx);
     spmv_mat* m = nullptr;
     SPMV_TRY(wrap(ctx, SPMV_FMT_ELL, nrow, ncol, nnz, k, nullptr, d_col_ind, d_values, &m));
     m->max_row_nnz = k;
@@ -647,6 +669,7 @@ int spmv_csc_upload(spmv_ctx* ctx, int32_t nrow, int32_t ncol, const int32_t* co
     const int64_t nnz = (int64_t)col_ptr[ncol];
     SPMV_REQUIRE(col_ptr[0] == 0 && nnz >= 0 && (nnz == 0 || (row_ind && values)), "spmv_csc_upload: bad col_ptr");
     SPMV_TRY(use_device(ctx));
+    plan_arm arm(ctx);
     spmv_mat* m = nullptr;
     SPMV_TRY(mat_alloc(ctx, SPMV_FMT_CSC, nrow, ncol, nnz, 0, (size_t)ncol + 1, (size_t)nnz, (size_t)nnz, &m));
     int rc = upload(const_cast<int32_t*>(m->a), col_ptr, sizeof(int32_t) * ((size_t)ncol + 1), ctx);
@@ -1473,6 +1496,7 @@ int spmv_coo_to_csr(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out_csr)
 {
     SPMV_REQUIRE(ctx && coo && out_csr, "spmv_coo_to_csr: null argument");
     SPMV_TRY(use_device(ctx));
+    plan_arm arm(ctx);
     return coo_to_csr(ctx, coo, out_csr);
 }
 
@@ -1480,6 +1504,7 @@ int spmv_csr_to_ell(spmv_ctx* ctx, const spmv_mat* csr, spmv_mat** out_ell)
 {
     SPMV_REQUIRE(ctx && csr && out_ell, "spmv_csr_to_ell: null argument");
     SPMV_TRY(use_device(ctx));
+    plan_arm arm(ctx);
     SPMV_TRY(csr_to_ell(ctx, csr, out_ell));
     return analyse_new_ell(out_ell);
 }
@@ -1514,6 +1539,7 @@ int spmv_coo_to_ell(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out_ell)
     SPMV_TRY(coo_to_csr(ctx, coo, &csr));
     int rc = csr_to_ell(ctx, csr, out_ell);
     mat_free(csr);
+    plan_arm arm(ctx);  // (for the ELL handle: the intermediate CSR form above selected as usual)
     return rc == SPMV_OK ? analyse_new_ell(out_ell) : rc;
 }
 
@@ -1588,6 +1614,7 @@ int spmv_csr_extract_rows(spmv_ctx* dst_ctx, const spmv_mat* csr, int64_t row_be
     int before = -1;
     if (hipGetDevice(&before) != hipSuccess) before = -1;
     spmv_mat* m  = nullptr;
+    plan_arm  arm(dst_ctx);
     int       rc = csr_extract_rows(dst_ctx, csr, row_begin, row_end, &m);
     if (rc == SPMV_OK) rc = finish(m, out);  // validates and analyses like an uploaded shard (frees on failure)
     if (before >= 0) (void)hipSetDevice(before);
@@ -1600,6 +1627,7 @@ int spmv_gen_csr_uniform(spmv_ctx* ctx, int64_t row_begin, int64_t row_end, int3
 {
     SPMV_REQUIRE(ctx && out, "spmv_gen_csr_uniform: null argument");
     SPMV_TRY(use_device(ctx));
+    plan_arm arm(ctx);
     return gen_csr_uniform(ctx, row_begin, row_end, ncol, k, band, seed, out);
 }
 
@@ -1607,6 +1635,7 @@ int spmv_gen_ell_banded(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t k, ui
 {
     SPMV_REQUIRE(ctx && out, "spmv_gen_ell_banded: null argument");
     SPMV_TRY(use_device(ctx));
+    plan_arm arm(ctx);
     SPMV_TRY(gen_ell_banded(ctx, nrow, ncol, k, seed, out));
     return analyse_new_ell(out);
 }
@@ -1622,6 +1651,7 @@ int spmv_gen_coo_powerlaw(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t max
 {
     SPMV_REQUIRE(ctx && out, "spmv_gen_coo_powerlaw: null argument");
     SPMV_TRY(use_device(ctx));
+    plan_arm arm(ctx);
     return gen_coo_powerlaw(ctx, nrow, ncol, max_len, seed, false, out);
 }
 
@@ -1629,6 +1659,7 @@ int spmv_gen_coo_powerlaw_sorted(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int3
 {
     SPMV_REQUIRE(ctx && out, "spmv_gen_coo_powerlaw_sorted: null argument");
     SPMV_TRY(use_device(ctx));
+    plan_arm arm(ctx);
     return gen_coo_powerlaw(ctx, nrow, ncol, max_len, seed, true, out);
 }
 

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <vector>
 
 #include "spmv_abi.h"
 
@@ -117,6 +118,10 @@ struct spmv_ctx
     double* stage_x = nullptr;
     double* stage_y = nullptr;
     size_t  stage_x_n = 0, stage_y_n = 0;
+    // spmv_ctx_set_plan: handles created on this context take this plan instead of selecting (plan.hip); `plan_armed` is set by
+    // the public entry point that creates a handle and consumed by that handle's analysis (its children get theirs handed down)
+    std::vector<unsigned char> plan_blob;
+    bool                       plan_armed = false;
     // can the CPU store straight into device memory (large BAR: hipDeviceAttributeIsLargeBar)?  Then spmv_apply_host writes a
     // small x into its device buffer itself (80 KB in 2 us) instead of launching a kernel that pulls it over the host link;
     // hdp_flush: the HDP flush register (hipDeviceAttributeHdpMemFlushCntl), written after such stores
@@ -132,6 +137,29 @@ struct spmv_ctx
 namespace spmv
 {
 struct symgs_plan;
+// ---- plans (plan.hip): the decisions a handle's set-up made - by model or by timing - as plain data ------------------------------
+// One node per handle, children by index (the row-grouped copy of a COO / CSC / ELL handle or the short-row copy of a split,
+// the long rows' matrix of a split in virtual-row mode, the ELL copy of a CSR handle).  32 four-byte fields, no pointers:
+// the blob of spmv_mat_get_plan is a plan_header followed by nnodes plan_node, node 0 the handle itself.
+struct plan_node
+{
+    int32_t  format, kernel, lanes_per_row;
+    uint32_t flags;
+    int32_t  pb_group_rows, pb_width, pb_sort, pb_aos, pb_unroll, pb_pipe, pb_sync, pb_two_per_cu, pb_rounds;
+    int32_t  split_threshold, split_mode;
+    int32_t  tp_pcols, tp_rotate;
+    int32_t  ell_variant, ell_tiled;
+    int32_t  coo_bins_per_xcd;
+    int32_t  child_rowgrouped, child_long, child_ell;  // node indices, -1: none
+    int32_t  reserved[9];
+};
+static_assert(sizeof(plan_node) == 128, "plan_node is 32 four-byte fields");
+struct plan_header
+{
+    uint32_t magic, version, bytes, nnodes;
+};
+constexpr uint32_t kPlanMagic = 0x4e4c5053u;  // "SPLN"
+constexpr uint32_t kPlanVersion = 1;
 }
 
 struct spmv_vec
@@ -300,6 +328,11 @@ struct spmv_mat
     int32_t  cb_chunks[8] = {0};      // chunks of the XCD's bins
     int64_t  cb_padded = 0;           // entries of the copy with its padding
 
+    // a plan being applied (plan.hip): the node array and this handle's node in it; set only while spmv_mat_set_plan or the
+    // analysis of a handle created under spmv_ctx_set_plan runs, handed down to the copies that are built meanwhile
+    const spmv::plan_node* plan_base = nullptr;
+    int32_t                plan_at   = -1;
+
     // symmetric Gauss-Seidel (symgs.hip): L / D / U copies, rows by level, launch schedule; built by symgs_setup
     struct spmv::symgs_plan* gs = nullptr;
     int32_t                  gs_order = 1;  // sweep order: 1 multicolour (default), 0 the matrix's own row order
@@ -444,6 +477,24 @@ int gen_coo_powerlaw(spmv_ctx* ctx, int32_t nrow, int32_t ncol, int32_t max_len,
                      spmv_mat** out);
 int gen_vec_uniform(spmv_ctx* ctx, double* d, int64_t n, int64_t index_offset, uint64_t seed);
 
+// plan.hip
+inline const plan_node* plan_of(const spmv_mat* m) { return m->plan_base && m->plan_at >= 0 ? m->plan_base + m->plan_at : nullptr; }
+enum plan_child { kPlanChildRowgrouped, kPlanChildLong, kPlanChildEll };
+inline void plan_hand_down(const spmv_mat* parent, spmv_mat* child, plan_child which)
+{
+    const plan_node* p = plan_of(parent);
+    if (!p) return;
+    const int32_t at = which == kPlanChildRowgrouped ? p->child_rowgrouped : (which == kPlanChildLong ? p->child_long : p->child_ell);
+    child->plan_base = at >= 0 ? parent->plan_base : nullptr;
+    child->plan_at   = at;
+}
+bool plan_take_armed(spmv_mat* m);   // a handle under analysis takes the context's armed plan (if its format is the plan's); true: it did
+void plan_clear(spmv_mat* m);
+int  csr_apply_plan(spmv_mat* m);    // select.hip
+void plan_reset_requests(spmv_mat* m);  // the parameters a plan sets explicitly, back to "choose" (a plan that did not fit)
+int  ell_apply_plan(spmv_mat* m);    // kernels_ell.hip
+int  coo_apply_plan(spmv_mat* m);    // kernels_coo.hip
+int  csc_apply_plan(spmv_mat* m);    // kernels_misc.hip
 // abi.hip helpers used by the other units
 int  mat_alloc(spmv_ctx* ctx, int32_t format, int32_t nrow, int32_t ncol, int64_t nnz, int32_t k,
                size_t a_count, size_t b_count, size_t v_count, spmv_mat** out);

@@ -236,6 +236,7 @@ int coo_to_csr(spmv_ctx* ctx, const spmv_mat* coo, spmv_mat** out, int32_t force
         csr->kernel        = force_kernel;
     }
     csr->pb_trial = coo->pb_trial;  // ("panel_trial" of the source handle holds for what is built from it)
+    plan_hand_down(coo, csr, kPlanChildRowgrouped);  // (a source that is being built from a plan: the copy takes its node)
     if ((rc = csr_analyse(csr)) != SPMV_OK)
     {
         mat_free(csr);

@@ -290,6 +290,14 @@ int coo_analyse(spmv_mat* m)
     SPMV_HIP(hipStreamSynchronize(ctx->stream));
     m->sorted_rows = unsorted ? 0 : 1;
     m->kernel      = SPMV_CSR_VECTOR;  // reported for COO as "segmented scan"
+    const bool from_ctx = plan_take_armed(m);
+    if (plan_of(m))
+    {
+        const int rc = coo_apply_plan(m);
+        plan_clear(m);
+        if (rc == SPMV_OK || !from_ctx) return rc;
+        (void)hipGetLastError();  // (a context's plan that does not fit this matrix: the handle selects by itself)
+    }
     if (!m->kernel_forced) SPMV_TRY(coo_select_kernel(m));
     return SPMV_OK;
 }
@@ -422,6 +430,34 @@ int coo_select_kernel(spmv_mat* m)
     else
         coo_free_bins(m);
     m->kernel = m->coo_csr ? SPMV_CSR_PANEL : SPMV_CSR_VECTOR;
+    return SPMV_OK;
+}
+
+// A plan on a COO handle (plan.hip): the scan in place, the scan over column bins, or the row-grouped copy whose own node says
+// which kernel and layout IT runs - no timing launch.
+int coo_apply_plan(spmv_mat* m)
+{
+    const plan_node& p = *plan_of(m);
+    spmv_ctx*        ctx = m->ctx;
+    select_reset(m);
+    coo_drop_rowgrouped(m);
+    (void)hipStreamSynchronize(ctx->stream);
+    coo_free_bins(m);
+    m->kernel = SPMV_CSR_VECTOR;
+    if (m->nnz == 0 || m->nrow <= 0) return SPMV_OK;
+    if (p.kernel == SPMV_CSR_PANEL)
+    {
+        SPMV_REQUIRE(m->nnz <= (int64_t)INT32_MAX - 65536, "plan: a row-grouped copy of %lld COO entries does not fit int32 offsets", (long long)m->nnz);
+        spmv_mat* csr = nullptr;
+        SPMV_TRY(coo_to_csr(ctx, m, &csr, kCsrAutoNoSegscan));  // (hands the copy's node down)
+        adopt_rowgrouped(m, csr);
+    }
+    else if (p.coo_bins_per_xcd > 0)
+    {
+        const int rc = coo_build_bins(m, p.coo_bins_per_xcd, /*only_if_worth=*/false);
+        if (rc != SPMV_OK && rc != SPMV_ERR_ALLOC) return rc;  // (no room for the copy: the scan runs over the handle's own arrays)
+        (void)hipGetLastError();
+    }
     return SPMV_OK;
 }
 

@@ -438,6 +438,16 @@ int csr_analyse(spmv_mat* m)
         SPMV_HIP(hipStreamSynchronize(ctx->stream));
         m->win_avg_span = (double)total / nblocks;
     }
+    // (a handle created under spmv_ctx_set_plan takes the context's plan; copies get their node handed down by whoever builds them)
+    const bool from_ctx = plan_take_armed(m);
+    if (plan_of(m))
+    {
+        const int rc = csr_apply_plan(m);  // the plan's kernel and layout, no timing launch (select.hip)
+        plan_clear(m);
+        if (rc == SPMV_OK || !from_ctx) return rc;
+        (void)hipGetLastError();  // a context's plan that does not fit THIS matrix is no reason to refuse the handle: it selects by itself
+        plan_reset_requests(m);
+    }
     if (!m->kernel_forced) return csr_select_kernel(m);  // the model, and where it pays a trial of the candidates (select.hip)
     if (m->kernel == SPMV_CSR_PANEL) SPMV_TRY(csr_panel_build(m));
     if (m->kernel == SPMV_CSR_TWOPHASE) SPMV_TRY(csr_twophase_build(m));

@@ -818,15 +818,9 @@ int panel_choose_pace(spmv_mat* m)
         m->pb_tuned_key    = key;
         return SPMV_OK;
     }
-    double *x = nullptr, *y = nullptr;
-    if (hipMalloc(&x, sizeof(double) * (size_t)m->ncol) != hipSuccess || hipMalloc(&y, sizeof(double) * (size_t)m->nrow) != hipSuccess)
-    {
-        if (x) (void)hipFree(x);
-        (void)hipGetLastError();
-        return SPMV_OK;  // no room to try: defaults
-    }
-    (void)hipMemsetAsync(x, 0, sizeof(double) * (size_t)m->ncol, ctx->stream);
-    (void)hipMemsetAsync(y, 0, sizeof(double) * (size_t)m->nrow, ctx->stream);
+    select_scratch sv;  // zeroed x and y: from the context's trial arena where they fit (select.hip), else allocations of their own
+    if (sv.alloc(ctx, m->ncol, m->nrow) != SPMV_OK) return SPMV_OK;  // no room to try: defaults
+    double *x = sv.x, *y = sv.y;
     int  rc    = SPMV_OK;
     auto timed = [&](int launches, float* ms) -> int {
         int r = panel_launch(ctx, m, x, y, true, apply_extra{});  // warm
@@ -876,8 +870,7 @@ int panel_choose_pace(spmv_mat* m)
         }
     }
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(x);
-    (void)hipFree(y);
+    sv.release();
     m->pb_unroll_tuned = rc == SPMV_OK && m->pb_unroll <= 0 ? best.unroll : 0;
     m->pb_pipe_tuned   = rc == SPMV_OK ? best.pipe : 0;
     m->pb_sync_tuned   = rc == SPMV_OK ? best.sync : 0;

@@ -301,6 +301,7 @@ int csr_split_build(spmv_mat* m)
             part->pb_trial       = m->pb_trial;
             part->sel_no_split   = true;  // (their longest rows are short by construction; and no split of a split)
             part->sel_no_segscan = true;  // what the scan is for went out with the long rows
+            plan_hand_down(m, part, part == rest ? kPlanChildRowgrouped : kPlanChildLong);
             rc                   = csr_analyse(part);  // picks the part's kernel and builds its layout
             // the panel and two-phase layouts read row_ptr and their own arrays only
             if (rc == SPMV_OK && (part->kernel == SPMV_CSR_PANEL || part->kernel == SPMV_CSR_TWOPHASE || part->kernel == SPMV_CSR_ELL) && part->b && part->v && part->nnz > 0)

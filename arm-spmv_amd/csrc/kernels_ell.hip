@@ -429,6 +429,7 @@ int ell_make_rowgrouped(spmv_mat* m, int32_t force_kernel)
         }
         csr->pb_trial   = m->pb_trial;
         csr->sel_no_ell = true;  // (an ELL copy of the CSR copy of an ELL handle would be this handle again)
+        plan_hand_down(m, csr, kPlanChildRowgrouped);
         rc              = csr_analyse(csr);  // row statistics, kernel (selected or forced), layout
     }
     if (rc != SPMV_OK)
@@ -614,6 +615,7 @@ int csr_ell_copy_build(spmv_mat* m)
     SPMV_TRY(csr_to_ell(m->ctx, m, &ell, /*pad_own_column=*/true));
     ell->pb_trial          = m->pb_trial;
     ell->sel_no_rowgrouped = true;
+    plan_hand_down(m, ell, kPlanChildEll);
     const int rc           = ell_analyse(ell);  // diagonal slots, the variant that is timed fastest
     if (rc != SPMV_OK)
     {
@@ -774,7 +776,43 @@ int ell_analyse(spmv_mat* m)
 {
     m->kernel = SPMV_CSR_VECTOR;  // reported for ELL as "one lane per row"
     SPMV_TRY(ell_detect_diagonals(m));
+    const bool from_ctx = plan_take_armed(m);
+    if (plan_of(m))
+    {
+        const int rc = ell_apply_plan(m);
+        plan_clear(m);
+        if (rc == SPMV_OK || !from_ctx) return rc;
+        (void)hipGetLastError();  // (a context's plan that does not fit this matrix: the handle selects by itself)
+    }
     if (!m->kernel_forced) SPMV_TRY(ell_select_kernel(m));
+    return SPMV_OK;
+}
+
+// A plan on an ELL handle (plan.hip): the variant of the format's own kernel, the tiled values, or the row-grouped copy with
+// the kernel and layout its own node names - no timing launch.  (Whether the slots are diagonals is found out from the matrix
+// as always: that is analysis, not a decision.)
+int ell_apply_plan(spmv_mat* m)
+{
+    const plan_node& p = *plan_of(m);
+    select_reset(m);
+    ell_drop_rowgrouped(m);
+    m->kernel        = SPMV_CSR_VECTOR;
+    m->ell_variant   = p.ell_variant >= 0 && p.ell_variant <= 2 ? p.ell_variant : 0;
+    m->lanes_per_row = p.lanes_per_row;
+    m->flags         = p.flags;
+    if ((int64_t)m->nrow * m->k == 0) return SPMV_OK;
+    if (p.kernel == SPMV_CSR_PANEL)
+    {
+        SPMV_TRY(ell_make_rowgrouped(m, SPMV_CSR_AUTO));  // (hands the copy's node down)
+        m->kernel = m->coo_csr ? SPMV_CSR_PANEL : SPMV_CSR_VECTOR;
+    }
+    if (p.ell_tiled)
+        SPMV_TRY(ell_build_tiles(m, /*only_if_worth=*/false));
+    else
+    {
+        (void)hipStreamSynchronize(m->ctx->stream);
+        ell_free_tiles(m);
+    }
     return SPMV_OK;
 }
 

@@ -380,6 +380,8 @@ int csc_build_rowgrouped(spmv_mat* m, int32_t force_kernel)
     view.pb_trial      = m->pb_trial;
     view.kernel_forced = true;  // nothing is selected or built for the temporary view itself
     int       rc  = coo_analyse(&view);  // sortedness of the row indices
+    view.plan_base = m->plan_base;  // (a CSC handle built from a plan: spmv_coo_to_csr hands the copy's node down from the view -
+    view.plan_at   = m->plan_at;    // set only now: the view itself is nobody's handle and must not act on the plan)
     spmv_mat* csr = nullptr;
     if (rc == SPMV_OK) rc = coo_to_csr(ctx, &view, &csr, force_kernel);
     (void)hipStreamSynchronize(ctx->stream);
@@ -445,8 +447,29 @@ int csc_select_kernel(spmv_mat* m)
 int csc_analyse(spmv_mat* m)
 {
     m->kernel = SPMV_CSR_VECTOR;  // reported for CSC as "scatter over the columns"
+    const bool from_ctx = plan_take_armed(m);
+    if (plan_of(m))
+    {
+        const int rc = csc_apply_plan(m);
+        plan_clear(m);
+        if (rc == SPMV_OK || !from_ctx) return rc;
+        (void)hipGetLastError();  // (a context's plan that does not fit this matrix: the handle selects by itself)
+    }
     if (m->kernel_forced) return SPMV_OK;
     return csc_select_kernel(m);
+}
+
+// A plan on a CSC handle (plan.hip): the scatter, or the row-grouped copy with the kernel and layout its own node names
+int csc_apply_plan(spmv_mat* m)
+{
+    const plan_node& p = *plan_of(m);
+    select_reset(m);
+    csc_drop_rowgrouped(m);
+    m->kernel = SPMV_CSR_VECTOR;
+    if (m->nnz == 0 || m->nrow <= 0 || m->ncol <= 0 || p.kernel != SPMV_CSR_PANEL) return SPMV_OK;
+    SPMV_TRY(csc_build_rowgrouped(m, SPMV_CSR_AUTO));
+    m->kernel = m->coo_csr ? SPMV_CSR_PANEL : SPMV_CSR_VECTOR;
+    return SPMV_OK;
 }
 
 int csc_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)

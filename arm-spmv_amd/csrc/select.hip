@@ -197,6 +197,82 @@ void select_reset(spmv_mat* m)
     for (float& v : m->sel_us) v = 0.f;
 }
 
+// ---- a plan on a CSR handle (plan.hip) ------------------------------------------------------------------------------
+// The kernel and every parameter a trial would have chosen come from the node; nothing is timed (pb_trial = 0 for the duration:
+// no pace trial, no rounds trial, no piece search of the two-phase layout - "twophase_choose_pieces" runs that afterwards, it is
+// about where the pieces lie in THIS device's memory and no part of a plan).  Layouts of other kernels are released.
+int csr_apply_plan(spmv_mat* m)
+{
+    const plan_node& p = *plan_of(m);
+    SPMV_REQUIRE(p.kernel >= SPMV_CSR_VECTOR && p.kernel <= SPMV_CSR_ELL, "plan: CSR kernel id %d", p.kernel);
+    SPMV_REQUIRE((m->b && m->v) || m->nnz == 0, "plan: this handle gave up its CSR arrays (panel_keep_csr = 0)");
+    select_reset(m);
+    (void)hipStreamSynchronize(m->ctx->stream);
+    if (p.kernel != SPMV_CSR_PANEL) csr_panel_free(m);
+    if (p.kernel != SPMV_CSR_TWOPHASE) csr_twophase_free(m);
+    if (p.kernel != SPMV_CSR_SEGSCAN) csr_segscan_free(m);
+    csr_split_free(m);     // (rebuilt from the plan: its parts carry decisions of their own)
+    csr_ell_copy_free(m);  // (idem)
+    const int32_t trial_before = m->pb_trial;
+    m->pb_trial       = 0;
+    m->kernel         = p.kernel;
+    m->kernel_forced  = false;
+    m->split_auto_low = false;
+    if (p.lanes_per_row > 0) m->lanes_per_row = p.lanes_per_row;
+    m->flags = p.flags;
+    int rc   = SPMV_OK;
+    if (m->nrow > 0 && m->nnz > 0) switch (p.kernel)
+        {
+            case SPMV_CSR_PANEL:
+                m->pb_group_rows  = p.pb_group_rows;
+                m->pb_panel_width = p.pb_width;
+                m->pb_sort        = p.pb_sort;
+                m->pb_aos         = p.pb_aos;
+                m->pb_unroll      = p.pb_unroll;
+                m->pb_pipe        = p.pb_pipe;
+                m->pb_sync        = p.pb_sync;
+                m->pb_two_per_cu  = p.pb_two_per_cu;
+                m->pb_rounds_req  = std::max(1, p.pb_rounds);
+                rc                = csr_panel_build(m);
+                break;
+            case SPMV_CSR_TWOPHASE:
+                m->tp_pcols_req = p.tp_pcols;
+                m->tp_rotate    = p.tp_rotate;
+                rc              = csr_twophase_build(m);
+                break;
+            case SPMV_CSR_SEGSCAN: rc = csr_segscan_build(m); break;
+            case SPMV_CSR_SPLIT:
+                m->split_threshold = p.split_threshold;
+                m->split_mode      = p.split_mode;
+                rc                 = csr_split_build(m);  // (hands the parts' nodes down)
+                break;
+            case SPMV_CSR_ELL: rc = csr_ell_copy_build(m); break;
+            case SPMV_CSR_LDSWIN:
+                if (m->win_max_span <= 0 || m->win_max_span > csr_ldswin_capacity())
+                {
+                    set_error("plan: the LDS-window kernel does not fit this matrix (widest block window %d columns, the tile holds %d)", m->win_max_span,
+                              csr_ldswin_capacity());
+                    rc = SPMV_ERR_UNSUPPORTED;
+                }
+                break;
+            default: break;  // VECTOR, SCALAR: the CSR arrays as they are
+        }
+    m->pb_trial = trial_before;
+    return rc;
+}
+
+void plan_reset_requests(spmv_mat* m)
+{
+    m->pb_group_rows = m->pb_panel_width = m->pb_unroll = m->pb_rounds_req = 0;
+    m->pb_sort       = 1;
+    m->pb_aos        = 4;
+    m->pb_pipe = m->pb_sync = -1;
+    m->pb_two_per_cu        = 1;
+    m->split_threshold = m->split_mode = m->tp_pcols_req = 0;
+    m->tp_rotate                                       = 256;
+    m->kernel_forced                                   = false;
+}
+
 // ---- CSR ----------------------------------------------------------------------------------------------------------
 // Leaves m->kernel chosen and its layout built; layouts of candidates that lost are freed.
 int csr_select_kernel(spmv_mat* m)

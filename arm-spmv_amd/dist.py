@@ -88,6 +88,38 @@ def max_over_ranks(value: float, device, group=None) -> float:
     return float(t.item())
 
 
+# ---- plans across ranks (spmv_mat_get_plan / spmv_ctx_set_plan) -------------------------------------------------
+def broadcast_plan(plan: bytes | None, device, src: int = 0, group=None) -> bytes:
+    """rank `src`'s plan blob on every rank.  The reference builds all its shards the same way (src/mat_vec.cpp:240-268); with
+    AUTO a measurement, every rank would otherwise draw its own kernel.  Typical use: rank `src` builds its shard with AUTO,
+    takes `A.get_plan()`, every other rank passes None here, calls `ctx.set_plan(blob)` and builds its shard under it."""
+    rank = dist.get_rank(group)
+    g_src = dist.get_global_rank(group, src) if group is not None else src
+    n = torch.tensor([len(plan) if (rank == src and plan is not None) else 0], dtype=torch.int64, device=device)
+    dist.broadcast(n, src=g_src, group=group)
+    size = int(n.item())
+    if size == 0:
+        return b""
+    if rank == src:
+        buf = torch.frombuffer(bytearray(plan), dtype=torch.uint8).to(device)
+    else:
+        buf = torch.empty(size, dtype=torch.uint8, device=device)
+    dist.broadcast(buf, src=g_src, group=group)
+    return bytes(buf.cpu().numpy().tobytes())
+
+
+def plans_equal(plan: bytes, device, group=None) -> bool:
+    """True on every rank iff every rank holds the same plan blob (a 64-bit digest is compared: min == max over the ranks)"""
+    import hashlib
+
+    d = int.from_bytes(hashlib.sha256(plan).digest()[:7], "little")  # 56 bits: exact in int64
+    lo = torch.tensor([d], dtype=torch.int64, device=device)
+    hi = lo.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    return int(lo.item()) == int(hi.item())
+
+
 # ---- solver step across shards (SURVEY.md 8f rank 3) ----------------------------------------------------------
 def sum_over_ranks(value: float, device, group=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)

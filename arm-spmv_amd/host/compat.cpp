@@ -846,9 +846,27 @@ void CSRMatrixMatVectorNuma(const CSRMatrix& A, const Vector& x, Vector& y, int 
     Engine&              E      = Engine::get();
     std::vector<int64_t> rp64(A.row_ptr, A.row_ptr + A.nrow + 1);
     std::vector<Shard>   shards = plan_shards(A.nrow, nthreads, rp64.data());
+    // The first shard selects its kernel (AUTO: a measurement); the others are built under ITS plan - the reference builds every
+    // shard the same way (src/mat_vec.cpp:240-268), and shards that draw different kernels would differ in their last bits and
+    // in their step times for no reason the user can see
+    std::vector<unsigned char> plan;
     for (Shard& s : shards)  // rebased row_ptr, global columns (src/mat_vec.cpp:250-265) — done inside the ABI call
-        check(spmv_csr_upload_shard(E.ctx(s.device), s.row0, s.row1, A.ncol, rp64.data(), A.col_ind, A.values, &s.mat),
-              "spmv_csr_upload_shard");
+    {
+        spmv_ctx* c = E.ctx(s.device);
+        if (!plan.empty()) (void)spmv_ctx_set_plan(c, plan.data(), (int64_t)plan.size());
+        check(spmv_csr_upload_shard(c, s.row0, s.row1, A.ncol, rp64.data(), A.col_ind, A.values, &s.mat), "spmv_csr_upload_shard");
+        if (!plan.empty())
+            (void)spmv_ctx_set_plan(c, nullptr, 0);
+        else
+        {
+            int64_t len = 0;
+            if (spmv_mat_get_plan(s.mat, nullptr, &len) == SPMV_OK && len > 0)
+            {
+                plan.resize((size_t)len);
+                if (spmv_mat_get_plan(s.mat, plan.data(), &len) != SPMV_OK) plan.clear();
+            }
+        }
+    }
     run_shards("CSR", shards, x, y, 2.0 * (double)A.row_ptr[A.nrow]);
 }
 

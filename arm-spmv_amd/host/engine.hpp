@@ -34,13 +34,26 @@ public:
     spmv_mat* cached(const void* key, int device, uint64_t fingerprint, const void* owner, Make make)
     {
         auto it = cache_.find({key, device});
+        std::vector<unsigned char> plan;  // what the stale copy had decided (kernel, layout, tuned parameters: spmv_mat_get_plan)
         if (it != cache_.end())
         {
             if (it->second.fingerprint == fingerprint) return it->second.mat;
-            spmv_mat_destroy(it->second.mat);  // stale: the host arrays changed under the key
+            // stale: the host arrays changed under the key.  The container is the same object with edited contents: its
+            // replacement is built under the old copy's PLAN (no timing launches; the same kernel as before the edit) - a plan
+            // that no longer fits the edited matrix is dropped by the engine, which then selects afresh
+            int64_t len = 0;
+            if (spmv_mat_get_plan(it->second.mat, nullptr, &len) == SPMV_OK && len > 0)
+            {
+                plan.resize((size_t)len);
+                if (spmv_mat_get_plan(it->second.mat, plan.data(), &len) != SPMV_OK) plan.clear();
+            }
+            spmv_mat_destroy(it->second.mat);
             cache_.erase(it);
         }
-        spmv_mat* m = make(ctx(device));
+        spmv_ctx* c = ctx(device);
+        if (!plan.empty()) (void)spmv_ctx_set_plan(c, plan.data(), (int64_t)plan.size());
+        spmv_mat* m = make(c);
+        if (!plan.empty()) (void)spmv_ctx_set_plan(c, nullptr, 0);
         cache_[{key, device}] = Entry{m, fingerprint, owner};
         return m;
     }

@@ -533,6 +533,7 @@ def main() -> None:
     ap.add_argument("--partition", choices=("rows", "nnz", "both"), default="both",
                     help="the skewed extra (C4's row lengths sorted by length, the heavy rows at one end): cut into shards by equal rows "
                          "(the reference's split, src/mat_vec.cpp:245-246), by stored entries (spmv_partition_rows_balanced), or both")
+    ap.add_argument("--no-shared-plan", action="store_true", help="N > 1: every rank selects its kernel by itself (A/B against rank 0's plan broadcast)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
@@ -591,7 +592,19 @@ def main() -> None:
         ncol = n * world
         row_begin, row_end = shard.shard_rows(ncol, world, rank)  # equal rows per rank (src/mat_vec.cpp:245-246)
         t_setup = time.perf_counter()
+        # N > 1: the ranks hold same-shape shards, and AUTO is a measurement - every rank would draw its own kernel.  Rank 0
+        # builds its shard first and its PLAN (spmv_mat_get_plan: kernel, layout, tuned parameters) is broadcast; the other
+        # ranks build theirs under it (spmv_ctx_set_plan: no timing launch), as the reference builds all its shards the same
+        # way (src/mat_vec.cpp:240-268).  `plans_equal` on the line says what the ranks ended up with.
+        shared_plan = None
+        if grouped and rank != 0 and not (args.kernel or args.lanes) and not args.no_shared_plan:
+            shared_plan = shard.broadcast_plan(None, dev, src=0)
+            if shared_plan:
+                ctx.set_plan(shared_plan)
         A = ctx.gen_csr_uniform(row_begin, row_end, ncol, k, band=args.band, seed=args.seed)
+        if grouped and rank == 0 and not (args.kernel or args.lanes) and not args.no_shared_plan:
+            shared_plan = shard.broadcast_plan(A.get_plan(), dev, src=0)
+        ctx.set_plan(None)
         if args.kernel or args.lanes:
             A.set_kernel(args.kernel, args.lanes)
         if args.flags:
@@ -612,6 +625,9 @@ def main() -> None:
             A.set_param("panel_keep_csr", 0)
         bytes_held = A.get_param("device_bytes")
         setup_no_trial_s = None
+        setup_with_plan_s = None
+        my_plan = A.get_plan()
+        plans_equal = shard.plans_equal(my_plan, dev) if grouped else None
         if world == 1 and int(info.kernel) == 4 and not args.no_extra:
             os.environ["SPMV_PANEL_TRIAL"] = "0"
             t1 = time.perf_counter()
@@ -620,6 +636,15 @@ def main() -> None:
             setup_no_trial_s = time.perf_counter() - t1
             del B
             os.environ.pop("SPMV_PANEL_TRIAL")
+            # ... and under the plan of the handle that is measured: the same kernel, layout and tuned parameters, no timing launch
+            ctx.set_plan(my_plan)
+            t1 = time.perf_counter()
+            B = ctx.gen_csr_uniform(row_begin, row_end, ncol, k, band=args.band, seed=args.seed)
+            ctx.sync()
+            setup_with_plan_s = time.perf_counter() - t1
+            ctx.set_plan(None)
+            assert B.get_plan() == my_plan and B.get_param("select_candidates") == 0
+            del B
 
         # x: every rank draws its own slice; the replica is assembled by an RCCL all-gather over xGMI
         x_full = torch.empty(ncol, dtype=torch.float64, device=dev)
@@ -964,6 +989,11 @@ def main() -> None:
                 "lanes_per_row": int(info.lanes_per_row),
                 "setup_seconds": round(setup_s, 3),
                 "setup_seconds_without_trials": round(setup_no_trial_s, 3) if setup_no_trial_s is not None else None,
+                "setup_seconds_with_plan": round(setup_with_plan_s, 3) if setup_with_plan_s is not None else None,
+                "plan": {"bytes": len(my_plan), "shared_from_rank_0": bool(shared_plan), "plans_equal": plans_equal,
+                         "note": "N > 1: rank 0's plan (spmv_mat_get_plan) is broadcast and the other ranks build their shards under it "
+                                 "(spmv_ctx_set_plan), so same-shape shards cannot end on different kernels; the two-phase piece search "
+                                 "stays per rank (physical placement is no part of a plan)"},
                 "device_bytes": {"held_during_the_timed_loop": int(bytes_held), "with_the_csr_copy": int(bytes_with_csr),
                                  "matrix_csr": 12 * nnz_rank + 4 * (n + 1),
                                  "ratio_to_matrix": round(bytes_held / (12 * nnz_rank + 4 * (n + 1)), 3)},

@@ -343,7 +343,10 @@ int spmv_mat_set_flags(spmv_mat* m, uint32_t flags);
  *   "panel_two_per_cu"   0 = never two workgroups per CU (default 1: two when their accumulators fit the LDS twice) */
 int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value);
 /* What is in effect: "panel_rows", "panel_width", "panel_sort", "panel_groups", "panel_layout", "panel_unroll",
- * "panel_pipe", "panel_sync",
+ * "panel_pipe", "panel_sync", "select_candidates" / "select_us_<kernel>" (what AUTO timed, microseconds per product; 0 = not timed),
+ * "select_rounds" (rounds the last trial took until its candidates' minima stood still), "adds_into_y_with_atomics" (1: the product
+ * adds into y with device atomics - the COO scan, the CSC scatter, CSR under SEGSCAN or SPLIT's chunks, or a copy that runs one of
+ * those; spmv_apply_host then stages y in device memory),
  * "panel_bytes", "panel_keep_csr", "device_bytes", "window_max_span", "window_avg_span", "twophase_panel_cols",
  * "twophase_padded" (entries of the two-phase layout with its padding), "twophase_pieces" (1 GB pieces of its product stream),
  * "twophase_pieces_carved" (how many of them lie inside allocations taken over from the released CSR copy),
@@ -356,6 +359,29 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value);
  * "symgs_levels_forward", "symgs_levels_backward", "symgs_launches", "symgs_bytes", "symgs_fused" (1: the colouring is proper and
  * the sweep takes one launch per colour). */
 int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value);
+/* ---- plans: a handle's set-up decisions as plain data (plan.hip) ------------------------------------------------------------
+ * AUTO is a measurement (spmv_mat_set_kernel above): which kernel a handle runs, in which layout, with which chunk size,
+ * barrier placement, split threshold or ELL variant is found by timing candidates when the handle is created.  Consequences:
+ * NON-DETERMINISM - two handles of one matrix, or two ranks holding statistically identical shards, may end on different
+ * kernels (candidates within 2 % of each other swap places between two trials) and with them on different last bits of y (every
+ * kernel stays within the parity tolerance; the order of a row's additions differs) and different step times - and set-up
+ * time (C2: 0.2 s with the timing launches, 0.05 s without).  The reference builds its shards once, the same way every time
+ * (src/mat_vec.cpp:240-268).  Three ways to get that back:
+ *   - spmv_mat_set_kernel with an explicit kernel, or SPMV_PANEL_TRIAL=0 / "panel_trial" 0: the model alone, no launches;
+ *   - a PLAN: spmv_mat_get_plan writes what a handle decided - for itself and for the copies it runs from - into a POD blob
+ *     (16-byte header + 128 bytes per handle; pass buf = NULL to learn the size in *len); spmv_mat_set_plan builds exactly
+ *     that kernel and layout on another handle of the same format, with NO timing launch;
+ *   - spmv_ctx_set_plan: every handle of the plan's format created on the context afterwards (uploads, wraps, generators,
+ *     conversions, spmv_csr_extract_rows) takes the plan instead of selecting; buf = NULL clears it.
+ * A plan holds decisions, nothing about the matrix: row cuts, column panels and slot descriptors are derived again from the
+ * handle's own arrays, so the plan of one shard fits a shard of another size (arm-spmv_amd/dist.py broadcasts rank 0's).  It
+ * does not hold where a two-phase product stream lies in a device's physical memory: run "twophase_choose_pieces" afterwards
+ * where that search is wanted.  A plan that does not fit the handle's matrix (an LDS window too wide, an ELL copy of a matrix
+ * with an empty row) is an error of spmv_mat_set_plan; the handle then selects by itself.  Blobs are validated (magic, version,
+ * sizes, ids, child indices) before anything is read from them. */
+int spmv_mat_get_plan(const spmv_mat* m, void* buf, int64_t* len);
+int spmv_mat_set_plan(spmv_mat* m, const void* buf, int64_t len);
+int spmv_ctx_set_plan(spmv_ctx* ctx, const void* buf, int64_t len);
 /* Copy the arrays of a handle back to the host (any pointer may be NULL to skip it).
  *   CSR: a=row_ptr[nrow+1]  b=col_ind[nnz]      v=values[nnz]
  *   COO: a=row_ind[nnz]     b=col_ind[nnz]      v=values[nnz]

@@ -266,3 +266,51 @@ def test_sharded_cg_over_gloo(world, m, overlap, symgs):
     assert all(0 < r[1] < 500 and r[2] <= 1e-10 and r[3] <= 1e-9 for r in results), results
     if symgs:  # (1-D Laplacian with diagonal 2.5: plain CG needs ~30 iterations to 1e-10, the sweep about half)
         assert results[0][1] <= 20, results
+
+
+def _worker_plans(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    sys.path[:0] = [str(root), str(root / "tests")]
+    from __graft_entry__ import load_package
+    import importlib
+
+    load_package()
+    dmod = importlib.import_module("arm_spmv_amd.dist")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cpu")
+        # a blob the size of a three-node plan (16-byte header + 3 x 128): the bytes travel unchanged, whoever holds them first
+        blob = bytes((7 * i + 3) % 251 for i in range(16 + 3 * 128))
+        got0 = dmod.broadcast_plan(blob if rank == 0 else None, dev, src=0)
+        same0 = dmod.plans_equal(got0, dev)
+        last = world - 1
+        got1 = dmod.broadcast_plan(blob[::-1] if rank == last else None, dev, src=last)
+        same1 = dmod.plans_equal(got1, dev)
+        # ranks that built different plans are told so
+        differ = dmod.plans_equal(blob if rank == 0 else blob[:-1] + b"\x00", dev)
+        empty = dmod.broadcast_plan(None, dev, src=0)  # nobody has one: an empty blob everywhere
+        q.put((rank, got0 == blob, same0, got1 == blob[::-1], same1, differ, empty == b""))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_plan_blob_broadcast_and_equality_over_gloo(world):
+    """rank 0's plan reaches every rank byte for byte (dist.broadcast_plan: what `bench.py --gpus N` and the sharded drivers use so
+    that ranks holding same-shape shards cannot diverge in their kernel), and plans_equal tells equal from different"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_plans, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in results:
+        assert r[1] and r[2] and r[3] and r[4] and (not r[5]) and r[6], r
