@@ -86,6 +86,7 @@ void mat_free(spmv_mat* m)
     if (m->ell_diag) (void)hipFree(m->ell_diag);
     if (m->ell_diag_mask) (void)hipFree(m->ell_diag_mask);
     ell_free_tiles(m);
+    ell_free_dia_order(m);
     csr_panel_free(m);
     csr_twophase_free(m);
     csr_segscan_free(m);
@@ -812,6 +813,11 @@ int spmv_mat_set_kernel(spmv_mat* m, int32_t kernel, int32_t lanes_per_row)
         {
             m->kernel      = SPMV_CSR_VECTOR;
             m->ell_variant = 0;  // lanes_per_row (below) picks the variant of the format's own kernel
+            if (m->ell_dia_order_req < 0 && m->ell_rval)
+            {
+                SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
+                ell_free_dia_order(m);  // (a DIA-order copy the trial had kept: 8 bytes per slot nobody multiplies from now)
+            }
         }
         else if (kernel == SPMV_CSR_AUTO)
             SPMV_TRY(ell_select_kernel(m));  // the format's own kernels and, where it is a candidate, the row-grouped copy: timed
@@ -947,6 +953,23 @@ int spmv_mat_set_param(spmv_mat* m, const char* name, int64_t value)
         else
             SPMV_TRY(ell_build_tiles(m, /*only_if_worth=*/false));
     }
+    else if (!strcmp(name, "ell_dia_order"))
+    {
+        // ELL whose slots are diagonals: 1 = keep the values once more in DIA order (row-major) and multiply with the DIA kernel,
+        // now; 0 = drop the copy and never build it; -1 = a candidate of AUTO's trial (the default).  8 bytes per slot.
+        SPMV_REQUIRE(m->format == SPMV_FMT_ELL && value >= -1 && value <= 1, "ell_dia_order: an ELL handle and -1, 0 or 1");
+        SPMV_HIP(hipSetDevice(m->ctx->device));
+        SPMV_HIP(hipStreamSynchronize(m->ctx->stream));
+        m->ell_dia_order_req = (int32_t)value;
+        if (value == 1)
+        {
+            SPMV_TRY(ell_build_dia_order(m, /*only_if_worth=*/false));
+            if (m->coo_csr && m->kernel == SPMV_CSR_PANEL) m->kernel = SPMV_CSR_VECTOR;  // (the format's own kernel runs: this variant of it)
+            m->ell_variant = 3;
+        }
+        else
+            ell_free_dia_order(m);
+    }
     else if (!strcmp(name, "coo_column_bins"))
     {
         // COO, segmented scan: bins per XCD of the copy the scan runs over (1..8), 0 = no copy (the scan reads the handle's
@@ -1070,6 +1093,10 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         *value = m->device_bytes;
     else if (!strcmp(name, "ell_tiled_values"))  // ELL: 1 if the product reads the values from the copy in tiles of 512 rows
         *value = m->ell_tval ? 1 : 0;
+    else if (!strcmp(name, "ell_dia_order"))  // ELL: 1 if the product runs the DIA kernel over the DIA-order copy of the values
+        *value = m->ell_variant == 3 && m->ell_rval ? 1 : 0;
+    else if (!strcmp(name, "ell_non_conforming_rows"))  // ... and the rows the side kernel does
+        *value = m->ell_rval ? m->ell_nc_count : 0;
     else if (!strcmp(name, "coo_column_bins"))  // bins of the copy the segmented scan runs over (8 x bins per XCD), 0: none
         *value = m->cb_bins;
     else if (!strcmp(name, "coo_bins_padded"))
@@ -1132,6 +1159,7 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value)
         if (!strcmp(name + 10, "segscan")) slot = SPMV_CSR_SEGSCAN;  // (CSR handles; the slots are an ELL handle's "variant1" / "variant2")
         if (!strcmp(name + 10, "split")) slot = SPMV_CSR_SPLIT;
         if (!strcmp(name + 10, "split_low")) slot = 0;
+        if (!strcmp(name + 10, "dia_order")) slot = 9;  // ELL handles: the DIA-order copy of the values
         if (!strcmp(name + 10, "ell")) slot = SPMV_CSR_ELL;  // CSR handles: the ELL copy of (nearly) equal rows  // kernel SPLIT with rows of 256 entries and more split off (timed from 8M entries on)
         SPMV_REQUIRE(slot >= 0, "unknown parameter '%s'", name);
         *value = (int64_t)(m->sel_us[slot] + 0.5f);

@@ -313,6 +313,16 @@ struct spmv_mat
     int32_t  ell_variant  = 0;  // which of the format's own kernels AUTO timed fastest: 0 two rows per lane (diagonal slots where found),
                                 // 1 one row per lane, 2 two rows per lane reading every column index
     double*  ell_tval = nullptr;  // the values in tiles of 512 rows, (tile * k + slot) * 512 + row (ell_build_tiles); owned
+    // ELL whose slots are diagonals, DIA-ORDER copy (kernels_ell.hip: ell_build_dia_order; ell_variant 3): the values once more
+    // ROW-major, row * k + slot, multiplied by the DIA kernel (a workgroup streams one contiguous stretch and x goes through an
+    // LDS window); rows in which any slot is not its diagonal are skipped there (ell_skip: a bit per row) and done by a side
+    // kernel over the handle's own arrays (ell_nc_rows: their indices), in the same slot order: the same bits.  All owned.
+    double*             ell_rval     = nullptr;
+    unsigned long long* ell_skip     = nullptr;
+    int32_t*            ell_nc_rows  = nullptr;
+    int32_t             ell_nc_count = 0;
+    int32_t             ell_off_min = 0, ell_off_max = 0;
+    int32_t             ell_dia_order_req = -1;  // "ell_dia_order": -1 a candidate of the trial, 0 never, 1 built and used
 
     // COO / CSC / ELL: internal row-grouped copy in the panel layout (coo_build_panel, csc_analyse, ell_build_panel); owned.
     // CSR with kernel SPLIT: the copy without the long rows
@@ -418,6 +428,8 @@ bool csr_ell_copy_worth(const spmv_mat* m);
 // kernels_coo.hip
 int  ell_build_tiles(spmv_mat* m, bool only_if_worth);
 void ell_free_tiles(spmv_mat* m);
+int  ell_build_dia_order(spmv_mat* m, bool only_if_worth);  // the DIA-order copy of the values (ell_variant 3)
+void ell_free_dia_order(spmv_mat* m);
 int coo_analyse(spmv_mat* m);
 int coo_build_panel(spmv_mat* m, bool only_if_worth);  // the row-grouped copy with the PANEL kernel forced on it
 int coo_select_kernel(spmv_mat* m);                    // AUTO: the segmented scan or the row-grouped copy (which picks its own kernel), timed
@@ -441,6 +453,8 @@ int csc_select_kernel(spmv_mat* m);                       // AUTO: the scatter o
 int csc_build_rowgrouped(spmv_mat* m, int32_t force_kernel);
 void csc_drop_rowgrouped(spmv_mat* m);
 int dia_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
+int dia_rows_apply(spmv_ctx* ctx, int nrow, int jmax, int k, const int32_t* offsets, const double* values, const double* x, double* y, bool off_known,
+                   int off_min, int off_max, uint32_t flags, const unsigned long long* skip_rows);
 int vec_fill(spmv_ctx* ctx, double* d, int64_t n, double a);
 int vec_copy2(spmv_ctx* ctx, double* dst0, const double* src0, int64_t n0, double* dst1, const double* src1, int64_t n1);  // two copies, one launch
 int vec_dot(spmv_ctx* ctx, const double* x, const double* y, int64_t n, double* result);

@@ -532,16 +532,19 @@ int ell_select_kernel(spmv_mat* m)
     // candidates 0 .. 2: the format's own variants; 3: the copy.  Timed in rounds until their minima stand still (select.hip:
     // this is what replaced round 5's 2 ms of sleep in front of small handles' trials)
     const bool has_v2 = m->ell_diag && m->ell_diag_mask;  // (without diagonal slots variant 0 reads the indices already)
-    int        ids[4], n = 0;
+    // the DIA-order copy of the values (variant 3), where the slots are diagonals and it is not forbidden ("ell_dia_order" 0)
+    if (m->ell_dia_order_req != 0) SPMV_TRY(ell_build_dia_order(m, /*only_if_worth=*/m->ell_dia_order_req < 0));
+    int        ids[5], n = 0;  // 0, 1, 2: the format's own variants; 4: the DIA-order copy (variant 3); 3: the row-grouped copy, last
     ids[n++] = 0;
     ids[n++] = 1;
     if (has_v2) ids[n++] = 2;
+    if (m->ell_rval) ids[n++] = 4;
     if (m->coo_csr) ids[n++] = 3;
-    float t[4] = {-1.f, -1.f, -1.f, -1.f};
+    float t[5] = {-1.f, -1.f, -1.f, -1.f, -1.f};
     rc = select_rounds(ctx, n,
                        [&](int j) {
                            if (ids[j] == 3) return csr_apply(ctx, m->coo_csr, sv.x, sv.y);
-                           m->ell_variant = ids[j];
+                           m->ell_variant = ids[j] == 4 ? 3 : ids[j];
                            return ell_own_apply(ctx, m, sv.x, sv.y);
                        },
                        t, &m->sel_rounds);
@@ -552,15 +555,18 @@ int ell_select_kernel(spmv_mat* m)
     for (int j = 0; j < n; ++j)
     {
         if (ids[j] == 3 || t[j] < 0.f) continue;
-        const int v = ids[j];
-        select_note(m, v == 0 ? SPMV_CSR_VECTOR : 5 + v, t[j]);  // slots 1, 6 ("variant1"), 7 ("variant2")
-        if (t[j] < best_ms * (v ? 0.98f : 1.0f))  // two rows per lane is the model's pick: another variant has to win by 2 %
+        const int v = ids[j] == 4 ? 3 : ids[j];
+        select_note(m, v == 0 ? SPMV_CSR_VECTOR : (v == 3 ? 9 : 5 + v), t[j]);  // slots 1, 6 ("variant1"), 7 ("variant2"), 9 ("dia_order")
+        // two rows per lane is the model's pick: another variant has to win by 2 % - the DIA-order copy, which costs 8 bytes per
+        // slot of memory, by 5 %
+        if (t[j] < best_ms * (v == 3 ? 0.95f : (v ? 0.98f : 1.0f)))
         {
             best_ms = t[j];
             best_v  = v;
         }
     }
     m->ell_variant = best_v;
+    if (best_v != 3 && m->ell_dia_order_req < 0) ell_free_dia_order(m);  // (a copy that was asked for stays, used or not)
     if (m->coo_csr)
     {
         const float t_copy = t[n - 1];
@@ -772,6 +778,138 @@ int ell_build_tiles(spmv_mat* m, bool only_if_worth)
     return SPMV_OK;
 }
 
+// ---- the DIA-order copy of an ELL handle whose slots are diagonals (ell_variant 3) -------------------------------------------
+// BASELINE's C3 (4M rows x 64 slots, a circulant band) in one process, handles interleaved (tools/probe_c3_layouts.py,
+// profiles/r06_probe_c3_layouts.txt): the ELL kernel over the column-major values 0.373-0.394 ms, over the values in tiles of
+// 512 rows 0.338-0.393, the engine's DIA kernel over ROW-major values of the same band 0.316-0.336 - in memory allocated at the
+// same moment.  A workgroup of the DIA kernel streams ONE contiguous stretch (256 rows x k values) in 128-byte lines through
+// an LDS tile and takes x from an LDS window; the ELL kernel reads k stretches that lie nrow * 8 bytes apart.  So an ELL handle
+// whose slots are diagonals may keep its values once more in DIA order - row * k + slot - and run the DIA kernel over them
+// (kernels_misc.hip: dia_rows_apply).  Rows in which ANY slot is not its diagonal (C3: the 64 wrap-around rows; boundary rows of
+// a stencil with their padding) are skipped there - a bit per row - and done by a side kernel over the handle's own column-major
+// arrays.  Either way a row's products are added in slot order onto y[i] with fma: bit-identical to the ELL kernels and to the
+// oracle's orc_ell_spmv_fma.  Cost: 8 bytes per slot of device memory (C3: +2.05 GB on 3.07 GB).  A candidate of the trial
+// (ell_select_kernel), never a default by model; "ell_dia_order" 1 / 0 forces / forbids it.
+namespace
+{
+constexpr int kRmChunk = 16;  // slots per tile of the transposition
+
+// rval[i * k + s] = val[i + s * nrow]: tiles of 256 rows x 16 slots through LDS, both sides in whole 128-byte lines
+__global__ __launch_bounds__(kBlock) void ell_rowmajor_kernel(int nrow, int k, const double* __restrict__ val, double* __restrict__ rval)
+{
+    __shared__ double tile[kBlock * (kRmChunk + 1)];
+    const int r0 = blockIdx.x * kBlock, s0 = blockIdx.y * kRmChunk;
+    const int i  = r0 + (int)threadIdx.x;
+    for (int j = 0; j < kRmChunk; ++j) tile[threadIdx.x * (kRmChunk + 1) + j] = (i < nrow && s0 + j < k) ? val[(size_t)i + (size_t)(s0 + j) * nrow] : 0.0;
+    __syncthreads();
+    const int d = threadIdx.x % kRmChunk, rr = threadIdx.x / kRmChunk;
+    for (int p = 0; p < kRmChunk; ++p)
+    {
+        const int r = rr + p * (kBlock / kRmChunk);
+        if (r0 + r < nrow && s0 + d < k) rval[(size_t)(r0 + r) * k + s0 + d] = tile[r * (kRmChunk + 1) + d];
+    }
+}
+
+// skip[i / 64] bit i % 64 = row i has a slot that is not its diagonal (col != i + off[s]); the grid covers whole words
+__global__ __launch_bounds__(kBlock) void ell_row_conform_kernel(int nrow, int k, const int32_t* __restrict__ col, const int32_t* __restrict__ off,
+                                                                 u64* __restrict__ skip)
+{
+    const int i  = blockIdx.x * kBlock + (int)threadIdx.x;
+    bool      nc = false;
+    if (i < nrow)
+        for (int s = 0; s < k; ++s) nc |= col[(size_t)i + (size_t)s * nrow] != i + off[s];
+    const u64 b = __ballot(nc);
+    if ((threadIdx.x & 63) == 0 && (i >> 6) < (nrow + 63) / 64) skip[i >> 6] = b;
+}
+
+// the rows the DIA pass skipped: one lane per listed row over the column-major arrays, in slot order
+__global__ __launch_bounds__(kBlock) void ell_rows_list_kernel(int nlist, const int32_t* __restrict__ rows, int nrow, int k, const int32_t* __restrict__ col,
+                                                               const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y)
+{
+    const int t = blockIdx.x * kBlock + (int)threadIdx.x;
+    if (t >= nlist) return;
+    const int i   = rows[t];
+    double    acc = y[i];
+    for (int s = 0; s < k; ++s) acc = fma(val[(size_t)i + (size_t)s * nrow], x[col[(size_t)i + (size_t)s * nrow]], acc);
+    y[i] = acc;
+}
+}  // namespace
+
+void ell_free_dia_order(spmv_mat* m)
+{
+    if (m->format != SPMV_FMT_ELL || !m->ell_rval) return;
+    (void)hipFree(m->ell_rval);
+    if (m->ell_skip) (void)hipFree(m->ell_skip);
+    if (m->ell_nc_rows) (void)hipFree(m->ell_nc_rows);
+    m->device_bytes -= (int64_t)sizeof(double) * m->nrow * m->k + (int64_t)sizeof(u64) * ((m->nrow + 63) / 64) + (int64_t)sizeof(int32_t) * std::max(m->ell_nc_count, 1);
+    m->ell_rval     = nullptr;
+    m->ell_skip     = nullptr;
+    m->ell_nc_rows  = nullptr;
+    m->ell_nc_count = 0;
+    if (m->ell_variant == 3) m->ell_variant = 0;
+}
+
+// only_if_worth: the trial's gate - diagonal slots found, a million slots and more (below, a product is launch latency),
+// at most 1/16 of the rows non-conforming, and device memory to spare (the copy is 8 bytes per slot)
+int ell_build_dia_order(spmv_mat* m, bool only_if_worth)
+{
+    if (m->ell_rval) return SPMV_OK;
+    spmv_ctx*     ctx   = m->ctx;
+    const int64_t slots = (int64_t)m->nrow * m->k;
+    if (!m->ell_diag || slots == 0 || !m->b || !m->v)
+    {
+        if (only_if_worth) return SPMV_OK;
+        SPMV_FAIL(SPMV_ERR_UNSUPPORTED, "ell_dia_order: the slots of this ELL handle were not found to be diagonals");
+    }
+    if (only_if_worth)
+    {
+        if (slots < ((int64_t)1 << 20) || m->k > 1024) return SPMV_OK;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (size_t)slots * 8 * 4 > free_b) return SPMV_OK;
+    }
+    const int         k = m->k, nrow = m->nrow;
+    const size_t      words = (size_t)(nrow + 63) / 64;
+    std::vector<int32_t> h_off((size_t)k);
+    std::vector<u64>     h_skip(words);
+    double*   rval = nullptr;
+    u64*      skip = nullptr;
+    int32_t*  list = nullptr;
+    int       rc   = SPMV_OK;
+    do
+    {
+        if (hipMemcpyAsync(h_off.data(), m->ell_diag, sizeof(int32_t) * (size_t)k, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { rc = SPMV_ERR_HIP; break; }
+        if (hipMalloc(&skip, sizeof(u64) * words) != hipSuccess) { skip = nullptr; rc = SPMV_ERR_ALLOC; break; }
+        hipLaunchKernelGGL(ell_row_conform_kernel, dim3((unsigned)ceil_div((int64_t)words * 64, kBlock)), dim3(kBlock), 0, ctx->stream, nrow, k, m->b, m->ell_diag, skip);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(h_skip.data(), skip, sizeof(u64) * words, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = SPMV_ERR_HIP; break; }
+        std::vector<int32_t> nc;
+        for (size_t w = 0; w < words; ++w)
+            for (u64 b = h_skip[w]; b; b &= b - 1) nc.push_back((int32_t)(w * 64 + (size_t)__builtin_ctzll(b)));
+        if (only_if_worth && (int64_t)nc.size() * 16 > nrow) break;  // too many rows for the side kernel: not a candidate (rc OK, nothing built)
+        if (hipMalloc(&rval, sizeof(double) * (size_t)slots) != hipSuccess) { rval = nullptr; rc = SPMV_ERR_ALLOC; break; }
+        if (hipMalloc(&list, sizeof(int32_t) * std::max<size_t>(nc.size(), 1)) != hipSuccess) { list = nullptr; rc = SPMV_ERR_ALLOC; break; }
+        if (!nc.empty() && hipMemcpyAsync(list, nc.data(), sizeof(int32_t) * nc.size(), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = SPMV_ERR_HIP; break; }
+        hipLaunchKernelGGL(ell_rowmajor_kernel, dim3((unsigned)ceil_div(nrow, kBlock), (unsigned)ceil_div(k, kRmChunk)), dim3(kBlock), 0, ctx->stream, nrow, k, m->v, rval);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = SPMV_ERR_HIP; break; }  // (nc, host, goes out of scope)
+        m->ell_rval     = rval;
+        m->ell_skip     = skip;
+        m->ell_nc_rows  = list;
+        m->ell_nc_count = (int32_t)nc.size();
+        m->ell_off_min  = *std::min_element(h_off.begin(), h_off.end());
+        m->ell_off_max  = *std::max_element(h_off.begin(), h_off.end());
+        m->device_bytes += (int64_t)sizeof(double) * slots + (int64_t)sizeof(u64) * (int64_t)words + (int64_t)sizeof(int32_t) * std::max(m->ell_nc_count, 1);
+        return SPMV_OK;
+    } while (0);
+    if (rval) (void)hipFree(rval);
+    if (skip) (void)hipFree(skip);
+    if (list) (void)hipFree(list);
+    if (rc == SPMV_OK) return SPMV_OK;  // not worth it
+    (void)hipGetLastError();
+    if (only_if_worth && rc == SPMV_ERR_ALLOC) return SPMV_OK;  // no room: not a candidate
+    if (rc == SPMV_ERR_ALLOC) SPMV_FAIL(rc, "out of device memory for the DIA-order copy of an ELL handle (%lld bytes)", (long long)(slots * 8));
+    SPMV_FAIL(rc, "building the DIA-order copy of an ELL handle failed");
+}
+
 int ell_analyse(spmv_mat* m)
 {
     m->kernel = SPMV_CSR_VECTOR;  // reported for ELL as "one lane per row"
@@ -797,7 +935,17 @@ int ell_apply_plan(spmv_mat* m)
     select_reset(m);
     ell_drop_rowgrouped(m);
     m->kernel        = SPMV_CSR_VECTOR;
-    m->ell_variant   = p.ell_variant >= 0 && p.ell_variant <= 2 ? p.ell_variant : 0;
+    m->ell_variant   = p.ell_variant >= 0 && p.ell_variant <= 3 ? p.ell_variant : 0;
+    if (m->ell_variant == 3)
+    {
+        SPMV_TRY(ell_build_dia_order(m, /*only_if_worth=*/false));  // (refused where the slots are no diagonals: the plan does not fit)
+        m->ell_variant = 3;
+    }
+    else
+    {
+        (void)hipStreamSynchronize(m->ctx->stream);
+        ell_free_dia_order(m);
+    }
     m->lanes_per_row = p.lanes_per_row;
     m->flags         = p.flags;
     if ((int64_t)m->nrow * m->k == 0) return SPMV_OK;
@@ -827,6 +975,19 @@ namespace
 {
 int ell_own_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
 {
+    if (A->ell_variant == 3 && A->ell_rval && A->ell_diag && !(A->flags & SPMV_FLAG_ELL_READ_COLUMNS))
+    {
+        // the DIA kernel over the row-major copy (every row whose slots are all diagonals), then the few other rows from the
+        // column-major arrays; every column of a conforming row is a real column: the bound is ncol
+        SPMV_TRY(dia_rows_apply(ctx, A->nrow, A->ncol, A->k, A->ell_diag, A->ell_rval, x, y, true, A->ell_off_min, A->ell_off_max, A->flags, A->ell_skip));
+        if (A->ell_nc_count > 0)
+        {
+            hipLaunchKernelGGL(ell_rows_list_kernel, dim3((unsigned)ceil_div(A->ell_nc_count, kBlock)), dim3(kBlock), 0, ctx->stream, A->ell_nc_count, A->ell_nc_rows,
+                               A->nrow, A->k, A->b, A->v, x, y);
+            SPMV_HIP(hipGetLastError());
+        }
+        return SPMV_OK;
+    }
     const bool aligned = (A->nrow % 2 == 0) && (((uintptr_t)A->b % 8) == 0) && (((uintptr_t)A->v % 16) == 0) &&
                          (((uintptr_t)y % 16) == 0);
     // lanes_per_row == 1 (spmv_mat_set_kernel) or the variant AUTO timed fastest (ell_variant 1) select the one-row kernel

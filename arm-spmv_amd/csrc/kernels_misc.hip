@@ -141,10 +141,13 @@ constexpr int kDiaChunk = 16;
 // XWIN: the offsets lie within a narrow band (off_min .. off_max): the stretch x[r0 + off_min .. r0 + 255 + off_max] the
 // 256 rows of the workgroup multiply with is copied into LDS once, and the ndiags reads of x per row come from there
 // instead of from global memory (64 vector loads per row otherwise: the vector memory pipe, not HBM, was the limit).
+// skip_rows (may be null): bit i set = row i is somebody else's (the DIA-order copy of an ELL handle leaves its non-conforming
+// rows to a side kernel, kernels_ell.hip): its y is neither read nor written here.
 template <bool WIDE, bool XWIN>
 __global__ __launch_bounds__(kBlock) void dia_kernel(int nrow, int jmax, int ndiags, const int32_t* __restrict__ offsets,
                                                      const double* __restrict__ val, const double* __restrict__ x,
-                                                     double* __restrict__ y, int off_min, int off_max)
+                                                     double* __restrict__ y, int off_min, int off_max,
+                                                     const unsigned long long* __restrict__ skip_rows)
 {
     __shared__ double tile[kBlock * (kDiaChunk + 1)];
     extern __shared__ double xs[];  // XWIN: kBlock + off_max - off_min entries of x
@@ -154,7 +157,8 @@ __global__ __launch_bounds__(kBlock) void dia_kernel(int nrow, int jmax, int ndi
     constexpr int NPASS = kBlock / RPP;                  // passes per tile
     const int r0 = blockIdx.x * kBlock;
     const int i  = r0 + threadIdx.x;
-    double    acc = i < nrow ? y[i] : 0.0;
+    const bool mine = i < nrow && !(skip_rows && ((skip_rows[i >> 6] >> (i & 63)) & 1ull));
+    double    acc = mine ? y[i] : 0.0;
     // element j of this lane's share of a chunk: tile position (r, d) = (r_mine + RPP j, d_mine [+ 1])
     const int d_mine = (threadIdx.x % LPR) * PER;
     const int r_mine = threadIdx.x / LPR;
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void dia_kernel(int nrow, int jmax, int ndi
             for (int e = 0; e < PER; ++e) tile[(r_mine + j * RPP) * (kDiaChunk + 1) + d_mine + e] = stage[PER * j + e];
         __syncthreads();
         if (d0 + kDiaChunk < ndiags) fetch(d0 + kDiaChunk);  // in flight while this chunk is consumed
-        if (i < nrow)
+        if (mine)
             for (int d = 0; d < dn; ++d)
             {
                 const int off = offsets[d0 + d];  // wave-uniform address: scalar load
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void dia_kernel(int nrow, int jmax, int ndi
                     acc = fma(tile[threadIdx.x * (kDiaChunk + 1) + d], XWIN ? xs[(int)threadIdx.x + off - off_min] : x[j], acc);
             }
     }
-    if (i < nrow) y[i] = acc;
+    if (mine) y[i] = acc;
 }
 
 inline int stream_grid(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(kMaxGrid, ceil_div(n, kBlock))); }
@@ -482,17 +486,24 @@ int csc_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
 int dia_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
 {
     if (A->nrow == 0 || A->k == 0) return SPMV_OK;
-    const dim3 grid((unsigned)ceil_div(A->nrow, kBlock));
     // a row shard (offsets shifted by its first row) keeps the bound of the whole matrix; never past the end of x
     const int jmax = std::min(A->dia_col_bound > 0 ? A->dia_col_bound : std::min(A->nrow, A->ncol), A->ncol);
-    const bool wide = A->k % 2 == 0 && (((uintptr_t)A->v) & 15) == 0;
+    return dia_rows_apply(ctx, A->nrow, jmax, A->k, A->a, A->v, x, y, A->dia_off_known, A->dia_off_min, A->dia_off_max, A->flags, nullptr);
+}
+
+// the DIA product over row-major values (a DIA handle's own, or the DIA-order copy of an ELL handle's values: kernels_ell.hip)
+int dia_rows_apply(spmv_ctx* ctx, int nrow, int jmax, int k, const int32_t* offsets, const double* values, const double* x, double* y, bool off_known,
+                   int off_min, int off_max, uint32_t flags, const unsigned long long* skip_rows)
+{
+    if (nrow == 0 || k == 0) return SPMV_OK;
+    const dim3 grid((unsigned)ceil_div(nrow, kBlock));
+    const bool wide = k % 2 == 0 && (((uintptr_t)values) & 15) == 0;
     // offsets within a band of at most 1792 (known from the upload / the generator): x goes through LDS
-    const bool   xwin = A->dia_off_known && A->dia_off_min <= A->dia_off_max && (int64_t)A->dia_off_max - A->dia_off_min <= 1792 &&
-                      !(A->flags & SPMV_FLAG_DIA_GLOBAL_X);
-    const size_t lds  = xwin ? sizeof(double) * (size_t)(kBlock + A->dia_off_max - A->dia_off_min) : 0;
-#define SPMV_DIA(W, X)                                                                                                         \
-    hipLaunchKernelGGL((dia_kernel<W, X>), grid, dim3(kBlock), lds, ctx->stream, A->nrow, jmax, A->k, A->a, A->v, x, y, \
-                       xwin ? A->dia_off_min : 0, xwin ? A->dia_off_max : 0)
+    const bool   xwin = off_known && off_min <= off_max && (int64_t)off_max - off_min <= 1792 && !(flags & SPMV_FLAG_DIA_GLOBAL_X);
+    const size_t lds  = xwin ? sizeof(double) * (size_t)(kBlock + off_max - off_min) : 0;
+#define SPMV_DIA(W, X)                                                                                                 \
+    hipLaunchKernelGGL((dia_kernel<W, X>), grid, dim3(kBlock), lds, ctx->stream, nrow, jmax, k, offsets, values, x, y, \
+                       xwin ? off_min : 0, xwin ? off_max : 0, skip_rows)
     if (wide && xwin)
         SPMV_DIA(true, true);
     else if (wide)

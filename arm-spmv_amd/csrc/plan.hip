@@ -90,7 +90,7 @@ int check_blob(const void* buf, int64_t len, const plan_node** nodes, int* nnode
         if (n[i].child_long >= 0) SPMV_REQUIRE(n[n[i].child_long].format == SPMV_FMT_CSR, "plan: node %u: the long rows' matrix is a CSR handle", i);
         if (n[i].child_ell >= 0) SPMV_REQUIRE(n[n[i].child_ell].format == SPMV_FMT_ELL, "plan: node %u: an ELL copy is an ELL handle", i);
         SPMV_REQUIRE(n[i].pb_rounds >= 0 && n[i].pb_rounds <= 16 && n[i].split_mode >= 0 && n[i].split_mode <= 2 && n[i].split_threshold >= 0 &&
-                         n[i].coo_bins_per_xcd >= 0 && n[i].coo_bins_per_xcd <= 8 && n[i].ell_variant >= 0 && n[i].ell_variant <= 2 && n[i].tp_pcols >= 0,
+                         n[i].coo_bins_per_xcd >= 0 && n[i].coo_bins_per_xcd <= 8 && n[i].ell_variant >= 0 && n[i].ell_variant <= 3 && n[i].tp_pcols >= 0,
                      "plan: node %u holds a parameter out of range", i);
     }
     *nodes  = n;

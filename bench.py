@@ -731,6 +731,9 @@ def main() -> None:
             if fmt == "ell":
                 if kid == 4:
                     return f"{inner} on the row-grouped copy of the ELL slots", "panel"
+                if M.get_param("ell_dia_order") and not (flags & 8):
+                    return ("dia_kernel over the DIA-order (row-major) copy of the values: no column index read, x through an LDS window, "
+                            f"{M.get_param('ell_non_conforming_rows')} non-conforming rows by a side kernel over the column-major arrays; +8 bytes per slot of device memory"), "ell_diagonals"
                 if M.get_param("ell_diagonal_slots") and not (flags & 8):  # 8 = SPMV_FLAG_ELL_READ_COLUMNS
                     return ("ell_diag_kernel_x2 (slots recognised as diagonals: conforming rows read no column index"
                             + ("; values read from the copy in tiles of 512 rows)" if M.get_param("ell_tiled_values") else ")")), "ell_diagonals"

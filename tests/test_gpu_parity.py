@@ -187,6 +187,44 @@ def test_ell_slots_that_are_diagonals_need_no_column_stream(ctx, orc, pkg, shape
     assert A.get_param("ell_tiled_values") == 0 and A.get_param("device_bytes") == held
     y1, _ = _apply_n(ctx, A, x, nrow, 1)
     assert np.array_equal(y1, ref), (shape, "tiles dropped")
+    # Round 6: the values once more in DIA ORDER (row-major) under the DIA kernel - a workgroup streams one contiguous stretch and
+    # x goes through an LDS window where the offsets lie within 1792 of each other; rows in which any slot is not its diagonal
+    # (padding, wrap-around, arbitrary columns) are skipped there and done by a side kernel over the column-major arrays.  The
+    # same products in the same order: the fma oracle bit for bit.  8 bytes per slot; a candidate of AUTO's trial from 1M slots on
+    capi = pkg.capi
+    if shape == "mostly_irregular":
+        with pytest.raises(capi.SpmvError, match="diagonals"):
+            A.set_param("ell_dia_order", 1)
+        assert A.get_param("ell_dia_order") == 0 and A.get_param("device_bytes") == held
+        return
+    A.set_param("ell_dia_order", 1)
+    nc = A.get_param("ell_non_conforming_rows")
+    conforming = np.all(col.reshape(k, nrow) == (np.arange(nrow)[None, :] + offs[:, None]), axis=0)
+    assert A.get_param("ell_dia_order") == 1 and A.get_param("ell_variant") == 3 and nc == int((~conforming).sum()) >= len(odd)
+    assert A.get_param("device_bytes") == held + 8 * k * nrow + 8 * -(-nrow // 64) + 4 * max(nc, 1)
+    y1, y50 = _apply_n(ctx, A, x, nrow, NUM_TEST)
+    assert np.array_equal(y1, ref), (shape, "DIA order")
+    ref50 = np.zeros(nrow)
+    for _ in range(NUM_TEST):
+        ol.ell_spmv(orc, nrow, k, col, val, x, ref50, fma=True)
+    assert np.array_equal(y50, ref50), (shape, "DIA order, 50 calls")
+    if shape == "stencil":  # the padding's 0.0 * x[0] with x[0] = inf: padded rows are non-conforming rows, done in slot order
+        yn, _ = _apply_n(ctx, A, xn, nrow, 1)
+        assert np.array_equal(np.isnan(yn), np.isnan(refn)) and np.array_equal(yn[~np.isnan(refn)], refn[~np.isnan(refn)])
+    got = A.download()
+    assert np.array_equal(got[-1], val) and np.array_equal(got[-2], col)
+    # it travels in a plan: another handle of the same matrix built from it runs the same variant and gives the same bits
+    plan = A.get_plan()
+    B = ctx.ell(nrow, ncol, k, nrow * k, col, val)
+    assert B.get_param("ell_dia_order") == 0  # (180K slots at most: no candidate of the trial)
+    B.set_plan(plan)
+    assert B.get_param("ell_dia_order") == 1 and B.get_plan() == plan
+    yb, _ = _apply_n(ctx, B, x, nrow, 1)
+    assert np.array_equal(yb, ref), (shape, "DIA order from a plan")
+    A.set_param("ell_dia_order", 0)
+    assert A.get_param("ell_dia_order") == 0 and A.get_param("ell_variant") == 0 and A.get_param("device_bytes") == held
+    y1, _ = _apply_n(ctx, A, x, nrow, 1)
+    assert np.array_equal(y1, ref), (shape, "DIA-order copy dropped")
 
 
 @pytest.mark.parametrize("make", cases.ALL_CASES, ids=lambda f: f.__name__)
@@ -2151,6 +2189,20 @@ def test_full_size_c3_ell_and_c4_coo_row_samples(ctx, orc, pkg):
         ol.csr_spmv(orc, rp, cc, cv, hx, ref)
         ol.csr_abs_row_sums(orc, rp, cc, cv, hx, scale)
         ol.assert_parity(hy[r0:r0 + 3000], ref, scale, f"C3 rows {r0}..")
+    # the format's own variants and the DIA-order copy add a row's products in the same (slot) order: the whole vector, bit for bit
+    variant = E.get_param("ell_variant")
+    E.set_param("ell_dia_order", 1)
+    assert E.get_param("ell_dia_order") == 1 and E.get_param("ell_non_conforming_rows") == k - 1  # the wrap-around rows of the circulant band: 32 at the top, 31 at the bottom
+    yd = ctx.vector(n)
+    yd.fill(0.0)
+    ctx.apply(E, x, yd)
+    E.set_kernel(1, 2)  # two rows per lane over the column-major values (a copy that was ASKED for stays allocated; one the trial kept would go back)
+    yv = ctx.vector(n)
+    yv.fill(0.0)
+    ctx.apply(E, x, yv)
+    ctx.sync()
+    assert np.array_equal(yd.download(), hy) and np.array_equal(yv.download(), hy), f"C3: AUTO ran variant {variant}"
+    del yd, yv
     x2, y2 = ctx.vector(n), ctx.vector(n)
     ctx.axpby(2.0, x, 0.0, x, x2)
     y2.fill(0.0)

@@ -335,7 +335,7 @@ def run_case(ctx, name, build, out):
         A.set_kernel(0)
         res["auto"] = min(res["auto"], timed(ctx, A, x, y, reps))
         inner, variant = A.get_param("rowgrouped_kernel"), A.get_param("ell_variant")
-        what = f"copy:{NAMES.get(inner, inner)}" if inner else (("lane/row", "lane/2rows+idx")[variant - 1] if variant else
+        what = f"copy:{NAMES.get(inner, inner)}" if inner else (("lane/row", "lane/2rows+idx", "dia-order")[variant - 1] if variant else
                                                                  ("diag-slots" if A.get_param("ell_diagonal_slots") else "lane/2rows"))
         rows.append((f"ell K={K}", what, res, trial_record(A)))
         del A
