@@ -1318,6 +1318,18 @@ static int grow(double** p, size_t* have, size_t want)
     return SPMV_OK;
 }
 
+// The end of a staged call: hipStreamSynchronize.  Measured for an empty kernel (tools/probe_launch_floor.hip,
+// profiles/r06_probe_launch_floor.txt): launch + hipStreamQuery spin (round 5) 16.9 us, launch + hipStreamSynchronize 10.5,
+// launch + a word of pinned host memory the kernel writes and the host spins on 6.4.  The last one does not survive contact with a
+// real call: the word has to come AFTER the product's stores, i.e. from a second launch (23.9 us per C1 call against 22.2 with
+// the plain synchronize, same box, profiles/r06_dropin_small_products.txt) or from the product's own last workgroup behind
+// system-wide fences of every lane (32 us).  So: the call HIP guarantees, and nothing to go wrong.
+static int host_wait(spmv_ctx* ctx)
+{
+    SPMV_HIP(hipStreamSynchronize(ctx->stream));
+    return SPMV_OK;
+}
+
 int spmv_apply_host(spmv_ctx* ctx, const spmv_mat* A, const double* x_host, double* y_host)
 {
     SPMV_REQUIRE(ctx && A && (x_host || A->ncol == 0) && (y_host || A->nrow == 0), "spmv_apply_host: null argument");
@@ -1325,7 +1337,9 @@ int spmv_apply_host(spmv_ctx* ctx, const spmv_mat* A, const double* x_host, doub
     SPMV_TRY(use_device(ctx));
     const size_t nx = (size_t)A->ncol, ny = (size_t)A->nrow;
     if (ny == 0) return SPMV_OK;
-    SPMV_HIP(hipStreamSynchronize(ctx->stream));  // (the staging buffers may still be in use by work queued earlier)
+    // (No wait for the stream here: the staging buffers are touched by this function alone, and it returns only when its own
+    // launches are done with them; work queued earlier by others runs before ours by stream order.  Growing a buffer waits.)
+    if (ctx->stage_x_n < std::max<size_t>(nx, 1) || ctx->stage_y_n < ny) SPMV_HIP(hipStreamSynchronize(ctx->stream));
     SPMV_TRY(grow(&ctx->stage_x, &ctx->stage_x_n, std::max<size_t>(nx, 1)));
     SPMV_TRY(grow(&ctx->stage_y, &ctx->stage_y_n, ny));
     spmv_vec vx, vy;
@@ -1344,6 +1358,7 @@ int spmv_apply_host(spmv_ctx* ctx, const spmv_mat* A, const double* x_host, doub
     {
         if (ctx->stage_pinned_n < nx + ny)
         {
+            SPMV_HIP(hipStreamSynchronize(ctx->stream));
             if (ctx->stage_pinned) (void)hipHostFree(ctx->stage_pinned);
             ctx->stage_pinned     = nullptr;
             ctx->stage_pinned_dev = nullptr;
@@ -1362,8 +1377,6 @@ int spmv_apply_host(spmv_ctx* ctx, const spmv_mat* A, const double* x_host, doub
         }
         double* hx = ctx->stage_pinned;
         double* hy = ctx->stage_pinned + nx;
-        if (nx && !ctx->large_bar) memcpy(hx, x_host, sizeof(double) * nx);
-        memcpy(hy, y_host, sizeof(double) * ny);
         // Kernels that touch every y_i once with a plain read and a plain store (the row-parallel, LDS-window, scalar, panel and
         // two-phase CSR kernels, the ELL and DIA kernels, and handles running from a copy that runs one of those) update y IN
         // the staging buffer over the host link: two launches.  Kernels that add into y with device atomics (the COO scan, the
@@ -1376,10 +1389,23 @@ int spmv_apply_host(spmv_ctx* ctx, const spmv_mat* A, const double* x_host, doub
             return e && e[0] == '1' && f && f[0] == '1';
         }();
         const bool y_in_place = kForceInPlace || !adds_into_y_with_atomics(A);
+        // Round 6 (tools/probe_launch_floor.hip, tools/probe_small_host_calls.py; profiles/r06_dropin_small_products.txt):
+        //   * the call ends in hipStreamSynchronize, not in a hipStreamQuery spin (host_wait above), and does not begin with one;
+        //   * y NEED NOT TRAVEL TO THE DEVICE.  The CSR kernels that form a row's sum and add it to y in one step - row-parallel,
+        //     panel, two-phase: y_i = y_i + sum_i, the reference's own shape (src/mat_vec.cpp:59-64: private sum, one +=) - write
+        //     sum_i alone (their "overwrite" mode) and the host does y_host[i] += sum_i while it copies out: the same IEEE add,
+        //     bit for bit what the kernel would have stored, one memcpy and one crossing of the host link less.  Kernels whose
+        //     accumulator starts AT y_i (ELL, DIA, scalar CSR: the reference's order y0 + p0 + p1 + ...) keep y in place.
+        const spmv_mat* K = A;  // the handle whose kernel runs
+        while (K->format != SPMV_FMT_CSR && K->coo_csr && K->kernel == SPMV_CSR_PANEL) K = K->coo_csr;
+        const bool sum_then_add = y_in_place && !kForceInPlace && K->format == SPMV_FMT_CSR && K->nnz > 0 &&
+                                  (K->kernel == SPMV_CSR_VECTOR || K->kernel == SPMV_CSR_AUTO || K->kernel == SPMV_CSR_PANEL || K->kernel == SPMV_CSR_TWOPHASE);
+        if (nx && !ctx->large_bar) memcpy(hx, x_host, sizeof(double) * nx);
+        if (!sum_then_add) memcpy(hy, y_host, sizeof(double) * ny);
         // x: where the CPU can store into device memory (large BAR) it writes x into the device buffer itself - 80 KB in 2 us,
         // no launch (tools/probe_host_write_vram.hip: the next kernel sees the stores, also right after a kernel that read the
-        // previous contents; the HDP flush register is written behind them as the platform prescribes for such stores).
-        // Elsewhere one kernel pulls x out of the staging buffer over the host link.
+        // previous contents; the HDP flush register is written behind them as the platform prescribes for such stores; the
+        // context checked it once for itself when it was created).  Elsewhere one kernel pulls x out of the staging buffer.
         const bool direct = ctx->large_bar != 0;
         if (direct && nx)
         {
@@ -1391,7 +1417,14 @@ int spmv_apply_host(spmv_ctx* ctx, const spmv_mat* A, const double* x_host, doub
         {
             vy.d = ctx->stage_pinned_dev + nx;
             if (!direct) SPMV_TRY(vec_copy2(ctx, ctx->stage_x, ctx->stage_pinned_dev, (int64_t)nx, nullptr, nullptr, 0));
-            SPMV_TRY(apply_checked(ctx, A, &vx, &vy));
+            if (sum_then_add)
+            {
+                apply_extra ex;
+                ex.overwrite = true;
+                SPMV_TRY(mat_apply_ex(ctx, A, vx.d, vy.d, ex));
+            }
+            else
+                SPMV_TRY(apply_checked(ctx, A, &vx, &vy));
         }
         else
         {
@@ -1399,16 +1432,11 @@ int spmv_apply_host(spmv_ctx* ctx, const spmv_mat* A, const double* x_host, doub
             SPMV_TRY(apply_checked(ctx, A, &vx, &vy));
             SPMV_TRY(vec_copy2(ctx, ctx->stage_pinned_dev + nx, ctx->stage_y, (int64_t)ny, nullptr, nullptr, 0));
         }
-        // poll instead of sleeping on an interrupt: the whole call is a few tens of microseconds
-        hipError_t e = hipErrorNotReady;
-        for (int spins = 0; (e = hipStreamQuery(ctx->stream)) == hipErrorNotReady; ++spins)
-            if (spins > 200000)
-            {
-                e = hipStreamSynchronize(ctx->stream);
-                break;
-            }
-        if (e != hipSuccess) SPMV_FAIL(SPMV_ERR_HIP, "spmv_apply_host: %s", hipGetErrorString(e));
-        memcpy(y_host, hy, sizeof(double) * ny);
+        SPMV_TRY(host_wait(ctx));
+        if (sum_then_add)
+            for (size_t i = 0; i < ny; ++i) y_host[i] += hy[i];
+        else
+            memcpy(y_host, hy, sizeof(double) * ny);
         return SPMV_OK;
     }
     if (nx) SPMV_HIP(hipMemcpyAsync(ctx->stage_x, x_host, sizeof(double) * nx, hipMemcpyHostToDevice, ctx->stream));

@@ -402,12 +402,17 @@ int spmv_apply_timed(spmv_ctx* ctx, const spmv_mat* A, const spmv_vec* x, spmv_v
 
 /* y_host += A * x_host with the caller's HOST vectors, synchronous - the reference's own call shape (include/mat_vec.h:7-11:
  * every CSRMatrixMatVector(A, x, y) hands over host arrays; main.cpp:56-59 does it 50 times), as ONE entry point so that the
- * hand-over can be done the cheapest way for its size: vectors of up to 1 MB together go through a pinned, device-mapped
- * staging buffer of the context that the GPU reads and writes itself, x by CPU stores straight into device memory where the
- * platform has a large BAR (one launch on the context's stream - three for the kernels that add into y with atomics -, no
- * hipMemcpy, the host polls; SPMV_HOST_STORES=0: x through the staging buffer and a second launch); larger ones through asynchronous copies.  x_host has ncol entries, y_host
- * nrow.  The caller's arrays are neither registered nor mapped (they may be freed or moved between calls).  Never part of a
- * throughput figure: resident vectors (spmv_apply) are what the roofline numbers are measured with. */
+ * hand-over can be done the cheapest way for its size.  Vectors of up to 1 MB together: x by CPU stores straight into device
+ * memory where the platform has a large BAR and the context's self-check of such stores passed (SPMV_HOST_STORES=0: through a
+ * pinned staging buffer and one more launch); y stays on the HOST where the kernel that runs forms a row's sum before it adds it
+ * to y (row-parallel, panel and two-phase CSR: the kernel writes the sums into the pinned buffer, the host adds them to y while
+ * it copies out - the same IEEE addition, bit for bit), is updated in place in the pinned buffer over the host link where the
+ * accumulator starts at y_i (ELL, DIA, scalar and LDS-window CSR), and goes through a device buffer for the kernels that add
+ * into y with atomics (spmv_mat_get_param "adds_into_y_with_atomics"; two more launches).  The call ends in hipStreamSynchronize.
+ * Larger vectors: asynchronous copies.  x_host has ncol entries, y_host nrow.  The caller's arrays are neither registered nor
+ * mapped (they may be freed or moved between calls).  C1 (10000 x 10000 x 16): 22 us per call, of which the kernel takes 3 - the
+ * rest is one launch and its completion (10.5 us for an empty kernel on this platform), 80 KB each way and the runtime; never
+ * part of a throughput figure: resident vectors (spmv_apply) are what the roofline numbers are measured with. */
 int spmv_apply_host(spmv_ctx* ctx, const spmv_mat* A, const double* x_host, double* y_host);
 
 /* ---- BLAS-1 (include/vec_vec.h:6-7) ---------------------------------------------------------- */
