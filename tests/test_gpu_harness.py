@@ -194,6 +194,7 @@ def test_bench_contract_one_rank_and_two_rank_rehearsal(tmp_path):
     rl = line["roofline"]
     assert "traffic_gbs" in rl and "traffic_source" in rl and (rl["traffic"] is None or abs(rl["traffic_gbs"] - rl["traffic"] / rl["kernel_ms"] / 1e6) < 1.0)
     assert len(line["config"]["per_rank"]) == 1 and line["config"]["per_rank"][0]["kernel_ms"] > 0 and "y_concatenate_ms" not in line
+    assert line["config"]["plan"]["plans_equal"] is None and line["config"]["plan"]["shared_from_rank_0"] is False  # (no process group: nothing to share)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -212,6 +213,10 @@ def test_bench_contract_one_rank_and_two_rank_rehearsal(tmp_path):
     ranks = line["config"]["per_rank"]
     assert [r_["rank"] for r_ in ranks] == [0, 1] and all(r_["kernel_ms"] > 0 and r_["kernel_id"] in (1, 2, 4, 5) for r_ in ranks)
     assert line["config"]["kernel_ms_per_rank"] == [r_["kernel_ms"] for r_ in ranks]
+    # rank 0's plan was broadcast and rank 1 built its shard under it: the two cannot have drawn different kernels or parameters
+    plan = line["config"]["plan"]
+    assert plan["shared_from_rank_0"] is True and plan["plans_equal"] is True and plan["bytes"] >= 16 + 128
+    assert ranks[0]["kernel_id"] == ranks[1]["kernel_id"]
     skew = {e["partition"]: e for e in line["extra"] if "partition" in e}  # one shard per rank, both partitions, every rank's time on rank 0's line
     assert set(skew) == {"rows", "entries"} and all(e["shards"] == 2 and all(sh["ms"] > 0 for sh in e["per_shard"]) for e in skew.values())
     assert skew["rows"]["entries_per_shard_max_over_mean"] > 1.5 and skew["entries"]["entries_per_shard_max_over_mean"] <= 1.02

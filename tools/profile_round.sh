@@ -39,7 +39,7 @@ if cur:
 with open(O + "/timed_region.txt", "w") as out:
     for run in runs:
         name = run[0]["Kernel_Name"]
-        if len(run) < 50 or is_trial(name) or not any(k in name for k in ("csr_panel_kernel", "csr_panel_pp_kernel", "ell_kernel", "ell_diag_kernel", "coo_segscan_kernel", "coo_segscan_bins_kernel")):
+        if len(run) < 50 or is_trial(name) or not any(k in name for k in ("csr_panel_kernel", "csr_panel_pp_kernel", "ell_kernel", "ell_diag_kernel", "coo_segscan_kernel", "coo_segscan_bins_kernel", "dia_kernel")):
             continue
         d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in run]
         tail = d[-50:]
