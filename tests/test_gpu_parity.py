@@ -1476,6 +1476,10 @@ def test_full_size_csr_linearity_and_row_sample(ctx, orc, pkg):
     n, k = 10_000_000, 32
     A = ctx.gen_csr_uniform(0, n, n, k, band=0, seed=1)
     assert A.info.nnz == n * k
+    # the kernel BASELINE's headline is measured with (the model's pick at this size; a change here is a change of the headline)
+    assert A.info.kernel == pkg.capi.CSR_PANEL and A.get_param("panel_layout") == 4, (A.info.kernel, A.get_param("panel_layout"))
+    perf_expect((A.get_param("panel_unroll"), A.get_param("panel_pipe"), A.get_param("panel_sync")) == (8, 2, 1),
+                f"C2: the panel trial kept chunk / order / barrier {A.get_param('panel_unroll')}, {A.get_param('panel_pipe')}, {A.get_param('panel_sync')} (bench records: 8, 2, 1)")
     x1 = ctx.gen_vector(n, seed=1)
     x2 = ctx.gen_vector(n, seed=2)
     y1, y2, y3 = ctx.vector(n), ctx.vector(n), ctx.vector(n)
@@ -2171,6 +2175,10 @@ def test_full_size_c3_ell_and_c4_coo_row_samples(ctx, orc, pkg):
     # ---- C3
     n, k = 4_000_000, 64
     E = ctx.gen_ell_banded(n, n, k, seed=1)
+    # C3 runs the format's own kernel over slots recognised as diagonals (which variant of it - two rows per lane, or the DIA-order
+    # copy - is the trial's to say: both add in slot order)
+    assert E.info.kernel == pkg.capi.CSR_VECTOR and E.get_param("ell_diagonal_slots") == 1 and E.get_param("ell_variant") in (0, 1, 2, 3)
+    perf_expect(E.get_param("ell_variant") in (0, 3), f"C3: the trial kept variant {E.get_param('ell_variant')}")
     x = ctx.gen_vector(n, seed=1)
     hx = synth.vec_uniform(n, seed=1)
     y = ctx.vector(n)
@@ -2215,6 +2223,8 @@ def test_full_size_c3_ell_and_c4_coo_row_samples(ctx, orc, pkg):
     P = ctx.gen_coo_powerlaw(n, n, max_len, seed=1)
     lens = synth.powerlaw_lengths(n, max_len, 1).astype(np.int64)
     assert P.info.nnz == int(lens.sum()) and P.info.sorted_rows == 1
+    perf_expect(P.info.kernel == pkg.capi.CSR_PANEL and P.get_param("rowgrouped_kernel") == pkg.capi.CSR_PANEL,
+                f"C4: AUTO kept kernel {P.info.kernel}, the copy runs {P.get_param('rowgrouped_kernel')} (bench records: the panel layout on the row-grouped copy)")
     x = ctx.gen_vector(n, seed=1)
     hx = synth.vec_uniform(n, seed=1)
     y = ctx.vector(n)
