@@ -822,16 +822,30 @@ __global__ __launch_bounds__(kBlock) void ell_row_conform_kernel(int nrow, int k
     if ((threadIdx.x & 63) == 0 && (i >> 6) < (nrow + 63) / 64) skip[i >> 6] = b;
 }
 
-// the rows the DIA pass skipped: one lane per listed row over the column-major arrays, in slot order
+// the rows the DIA pass skipped, over the column-major arrays: one WAVEFRONT per listed row.  The 64 lanes fetch 64 slots' values,
+// columns and x at once; the sum is then formed in slot order - acc = fma(v_s, x_s, acc), s = 0, 1, ... - from lane to lane, so
+// that the bits are the ELL kernels' (one lane per row walking its slots alone took 25 us for C3's 63 rows x 64 slots: a chain of
+// 64 dependent gathers - a twelfth of the DIA pass it follows; this form takes the 3 us of a launch)
 __global__ __launch_bounds__(kBlock) void ell_rows_list_kernel(int nlist, const int32_t* __restrict__ rows, int nrow, int k, const int32_t* __restrict__ col,
                                                                const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y)
 {
-    const int t = blockIdx.x * kBlock + (int)threadIdx.x;
-    if (t >= nlist) return;
+    const int t = (int)((blockIdx.x * kBlock + threadIdx.x) >> 6), lane = (int)(threadIdx.x & 63);
+    if (t >= nlist) return;  // (uniform over the wavefront)
     const int i   = rows[t];
     double    acc = y[i];
-    for (int s = 0; s < k; ++s) acc = fma(val[(size_t)i + (size_t)s * nrow], x[col[(size_t)i + (size_t)s * nrow]], acc);
-    y[i] = acc;
+    for (int s0 = 0; s0 < k; s0 += kWave)
+    {
+        const int s = s0 + lane;
+        double    v = 0.0, xv = 0.0;
+        if (s < k)
+        {
+            v  = val[(size_t)i + (size_t)s * nrow];
+            xv = x[col[(size_t)i + (size_t)s * nrow]];
+        }
+        const int n = min(kWave, k - s0);
+        for (int j = 0; j < n; ++j) acc = fma(__shfl(v, j), __shfl(xv, j), acc);  // every lane forms the same sum, in slot order
+    }
+    if (lane == 0) y[i] = acc;
 }
 }  // namespace
 
@@ -982,7 +996,7 @@ int ell_own_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
         SPMV_TRY(dia_rows_apply(ctx, A->nrow, A->ncol, A->k, A->ell_diag, A->ell_rval, x, y, true, A->ell_off_min, A->ell_off_max, A->flags, A->ell_skip));
         if (A->ell_nc_count > 0)
         {
-            hipLaunchKernelGGL(ell_rows_list_kernel, dim3((unsigned)ceil_div(A->ell_nc_count, kBlock)), dim3(kBlock), 0, ctx->stream, A->ell_nc_count, A->ell_nc_rows,
+            hipLaunchKernelGGL(ell_rows_list_kernel, dim3((unsigned)ceil_div((int64_t)A->ell_nc_count * kWave, kBlock)), dim3(kBlock), 0, ctx->stream, A->ell_nc_count, A->ell_nc_rows,
                                A->nrow, A->k, A->b, A->v, x, y);
             SPMV_HIP(hipGetLastError());
         }
