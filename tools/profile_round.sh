@@ -27,6 +27,10 @@ def is_trial(n):  # csr_panel_kernel<U, LAYOUT, PIPE, TRIAL, TRACE, SYNCT>
     m = re.search(r"csr_panel(?:_pp)?_kernel<([^>]*)>", n)
     return bool(m) and m.group(1).split(",")[3].strip() == "true"
 rows = sorted(trace, key=lambda r: int(r["Start_Timestamp"]))
+# (an ELL handle running from its DIA-order copy launches two kernels per product: dia_kernel and, for the few rows that are not
+# pure diagonals, ell_rows_list_kernel; the side kernel is reported by itself and left out of the runs)
+side = [r for r in rows if "ell_rows_list_kernel" in r["Kernel_Name"]]
+rows_all, rows = rows, [r for r in rows if "ell_rows_list_kernel" not in r["Kernel_Name"]]
 # runs of consecutive dispatches of one kernel: bench.py launches every workload's product 5 + 50 times back to back
 runs, cur = [], []
 for r in rows:
@@ -47,12 +51,16 @@ with open(O + "/timed_region.txt", "w") as out:
         out.write(f"{short(name)}: run of {len(d)} consecutive dispatches; mean {statistics.mean(d):.4f} ms, median {statistics.median(d):.4f}, "
                   f"min {min(d):.4f}, max {max(d):.4f}; the last 50: mean {statistics.mean(tail):.4f} ms.  (kernel_stats.csv row of this name, all its "
                   f"dispatches in the process: Calls {st[0]['Calls'] if st else '?'}, AverageNs {float(st[0]['AverageNs']) if st else 0:.0f})\n")
+if side:
+    with open(O + "/timed_region.txt", "a") as out:
+        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in side]
+        out.write(f"ell_rows_list_kernel (the side kernel of the DIA-order product, one launch behind every dia_kernel above): {len(d)} dispatches, mean {statistics.mean(d):.4f} ms\n")
 with open(O + "/timed_region.txt", "a") as out:
     # two-phase: the phases alternate (no runs); piece searches launch 3 products per configuration, each C5-shard extra 5 + 50.
     # Since round 5 small matrices run two-phase products too (the skewed extra's shards, trial candidates): only dispatches of
     # the C5 shard's size count here (expand > 0.9 ms, reduce > 0.4 ms).
     for key, floor in (("tp_expand_kernel", 0.9), ("tp_reduce_kernel", 0.4)):
-        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows if key in r["Kernel_Name"]]
+        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows_all if key in r["Kernel_Name"]]
         d = [t for t in d if t > floor]
         if d:
             out.write(f"{key}: {len(d)} dispatches of the C5 shard's size in the process (piece searches: 3 products per configuration; then 5 + 50 products per "
@@ -60,5 +68,5 @@ with open(O + "/timed_region.txt", "a") as out:
 print(open(O + "/timed_region.txt").read())
 PY
 # product launches only (the trial launches carry `true` as their fourth template argument); per workload: 1 warm-up + 5
-for d in pmc_fetch pmc_write pmc_tcc pmc_req; do echo "== $d"; python3 tools/pmc_summary.py "$O/$d" csr_panel --runs | grep -v ", true," ; python3 tools/pmc_summary.py "$O/$d" ell_ --runs; python3 tools/pmc_summary.py "$O/$d" coo_segscan --runs; python3 tools/pmc_summary.py "$O/$d" tp_ | tail -4; done > "$O/pmc_summary.txt" 2>&1
+for d in pmc_fetch pmc_write pmc_tcc pmc_req; do echo "== $d"; python3 tools/pmc_summary.py "$O/$d" csr_panel --runs | grep -v ", true," ; python3 tools/pmc_summary.py "$O/$d" ell_ --runs; python3 tools/pmc_summary.py "$O/$d" dia_kernel --runs; python3 tools/pmc_summary.py "$O/$d" coo_segscan --runs; python3 tools/pmc_summary.py "$O/$d" tp_ | tail -4; done > "$O/pmc_summary.txt" 2>&1
 cat "$O/pmc_summary.txt"
