@@ -54,8 +54,17 @@ def draw(rng):
         ln = ln // 2
     nnz = int(ln.sum())
     r = np.repeat(np.arange(nrow, dtype=np.int64), ln)
-    claw = rng.choice(["uniform", "band", "hubs", "runs"])
-    if claw == "uniform" or ncol < 64:
+    claw = rng.choice(["uniform", "band", "hubs", "runs", "diagonals"])
+    if claw == "diagonals" and ncol >= 64 and int(ln.max()) <= 512:
+        # slot s of every row holds column i' + off[s] (i' = the row scaled to the columns): a stencil / band as ELL stores it;
+        # wrapped at the edges, and a few rows with arbitrary columns (round 6: diagonal slots, the DIA-order copy)
+        offs = np.sort(rng.choice(np.arange(-min(ncol // 2, 3000), min(ncol // 2, 3000)), size=int(ln.max()), replace=False))
+        rp0 = np.concatenate(([0], np.cumsum(ln)))
+        slot = np.arange(nnz) - np.repeat(rp0[:-1], ln)
+        c = (r * ncol // nrow + offs[slot]) % ncol
+        odd = rng.random(nnz) < 0.0005
+        c[odd] = rng.integers(0, ncol, int(odd.sum()))
+    elif claw == "uniform" or ncol < 64:
         c = rng.integers(0, ncol, nnz)
     elif claw == "band":
         w = int(rng.integers(8, max(9, ncol // 10)))
@@ -105,12 +114,22 @@ def main():
                     raise AssertionError(f"case {case} ({what}, {nnz} entries) {label}: |dy| / (|A||x| + |y0|) = {err:.3e}")
                 done.append(label)
 
+            def from_plan(A, make, label):
+                # round 6: another handle of the same matrix built from A's plan runs A's kernel (and its copies' kernels) - no trial
+                plan = A.get_plan()
+                B = make()
+                B.set_plan(plan)
+                if B.get_plan() != plan or int(B.info.kernel) != int(A.info.kernel) or B.get_param("select_candidates") != 0:
+                    raise AssertionError(f"case {case} ({what}) {label}: the handle built from the plan differs from the one the plan came from")
+                product(B, label + " from its plan")
+
             A = ctx.csr(nrow, ncol, rp, c.astype(np.int32), v)
             product(A, f"csr auto={NAMES.get(int(A.info.kernel), A.info.kernel)}")
+            from_plan(A, lambda: ctx.csr(nrow, ncol, rp, c.astype(np.int32), v), "csr")
             for k in (1, 3, 4, 6):
                 A.set_kernel(k)
                 product(A, f"csr {NAMES[k]}")
-            if nrow * int(ln.max()) <= 8 * max(nnz, 1) and nrow * int(ln.max()) < 60_000_000:
+            if nrow * int(ln.max()) <= 8 * max(nnz, 1) and nrow * int(ln.max()) < 60_000_000 and int(ln.min()) >= 1:  # (refused with an empty row)
                 A.set_kernel(8)
                 product(A, f"csr ell copy ({'diagonal slots' if A.get_param('ell_copy_diagonal_slots') else 'columns'}, variant {A.get_param('ell_copy_variant')})")
             for mode in (1, 2):
@@ -123,11 +142,13 @@ def main():
             perm = {"rows": np.arange(nnz), "columns": np.lexsort((r, c)), "shuffled": rng.permutation(nnz)}[order]
             A = ctx.coo(nrow, ncol, r[perm].astype(np.int32), c[perm].astype(np.int32), v[perm])
             product(A, f"coo ({order}) auto={'copy:' + NAMES.get(A.get_param('rowgrouped_kernel'), '?') if int(A.info.kernel) == 4 else 'scan'}")
+            from_plan(A, lambda: ctx.coo(nrow, ncol, r[perm].astype(np.int32), c[perm].astype(np.int32), v[perm]), "coo")
             del A
             cs = np.lexsort((r, c))
             cp = np.concatenate(([0], np.cumsum(np.bincount(c, minlength=ncol)))).astype(np.int32)
             A = ctx.csc(nrow, ncol, cp, r[cs].astype(np.int32), v[cs])
             product(A, f"csc auto={'copy:' + NAMES.get(A.get_param('rowgrouped_kernel'), '?') if int(A.info.kernel) == 4 else 'scatter'}")
+            from_plan(A, lambda: ctx.csc(nrow, ncol, cp, r[cs].astype(np.int32), v[cs]), "csc")
             del A
             K = int(ln.max()) if nrow else 0
             if 0 < K and nrow * K <= 4 * max(nnz, 1) and nrow * K < 40_000_000:
@@ -136,7 +157,21 @@ def main():
                 ec[pos * nrow + r] = c
                 ev[pos * nrow + r] = v
                 A = ctx.ell(nrow, ncol, K, nnz, ec, ev)
-                product(A, f"ell K={K} auto={'copy:' + NAMES.get(A.get_param('rowgrouped_kernel'), '?') if int(A.info.kernel) == 4 else 'own'}")
+                product(A, f"ell K={K} auto={'copy:' + NAMES.get(A.get_param('rowgrouped_kernel'), '?') if int(A.info.kernel) == 4 else 'own variant ' + str(A.get_param('ell_variant'))}")
+                from_plan(A, lambda: ctx.ell(nrow, ncol, K, nnz, ec, ev), "ell")
+                if A.get_param("ell_diagonal_slots"):
+                    # the DIA-order copy against two rows per lane over the column-major values: the same slot order, the same bits
+                    def bits(M):
+                        yy = ctx.vector_from(y0)
+                        ctx.apply(M, x, yy)
+                        ctx.sync()
+                        return yy.download()
+                    A.set_kernel(1, 2)
+                    own = bits(A)
+                    A.set_param("ell_dia_order", 1)
+                    if not np.array_equal(bits(A), own):
+                        raise AssertionError(f"case {case} ({what}): the DIA-order copy of an ELL handle differs from the ELL kernel in some bit")
+                    product(A, f"ell DIA order ({A.get_param('ell_non_conforming_rows')} rows off their diagonals)")
                 del A
             say(f"case {case:3d}: {what}; {nnz} entries, longest row {int(ln.max())}: " + "; ".join(done))
         say(f"# {args.cases} cases, {nprod} products, all within 1e-10 (worst {worst:.2e}); {time.perf_counter() - t0:.0f} s")
