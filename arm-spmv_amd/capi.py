@@ -87,6 +87,7 @@ SIGNATURES = {
     "spmv_mat_get_plan": (C.c_int, [_vp, _vp, _i64p]),
     "spmv_mat_set_plan": (C.c_int, [_vp, _vp, C.c_int64]),
     "spmv_ctx_set_plan": (C.c_int, [_vp, _vp, C.c_int64]),
+    "spmv_plan_check": (C.c_int, [_vp, C.c_int64, _i32p, _i32p, _i32p]),
     "spmv_mat_download": (C.c_int, [_vp, _vp, _vp, _vp]),
     "spmv_mat_device_ptrs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "spmv_apply": (C.c_int, [_vp, _vp, _vp, _vp]),
@@ -170,6 +171,13 @@ def device_count() -> int:
     n = C.c_int(0)
     rc = load().spmv_device_count(C.byref(n))
     return n.value if rc == 0 else 0
+
+
+def plan_check(plan: bytes) -> tuple[int, int, int]:
+    """(root format, root kernel, number of nodes) of a plan blob, or SpmvError with the reason; needs no device (spmv_plan_check)"""
+    f, k, n = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    _check(load().spmv_plan_check(plan, len(plan), C.byref(f), C.byref(k), C.byref(n)))
+    return f.value, k.value, n.value
 
 
 def partition_rows(nrow: int, nparts: int, part: int) -> tuple[int, int]:

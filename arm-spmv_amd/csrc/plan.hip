@@ -67,7 +67,7 @@ int collect(const spmv_mat* m, std::vector<plan_node>& out)
 }
 
 // a blob is trusted with nothing: sizes, ids and child indices are checked before a node is read by anybody
-int check_blob(const void* buf, int64_t len, const plan_node** nodes, int* nnodes)
+int check_blob(const void* buf, int64_t len, std::vector<plan_node>* out)
 {
     SPMV_REQUIRE(buf && len >= (int64_t)sizeof(plan_header), "plan: %lld bytes are not a plan", (long long)len);
     plan_header h;
@@ -76,7 +76,9 @@ int check_blob(const void* buf, int64_t len, const plan_node** nodes, int* nnode
     SPMV_REQUIRE(h.version == kPlanVersion, "plan: version %u, this library reads version %u", h.version, kPlanVersion);
     SPMV_REQUIRE(h.nnodes >= 1 && h.nnodes <= 64 && h.bytes == sizeof(plan_header) + (size_t)h.nnodes * sizeof(plan_node) && (int64_t)h.bytes <= len,
                  "plan: %u nodes in %u bytes (%lld given)", h.nnodes, h.bytes, (long long)len);
-    const plan_node* n = (const plan_node*)((const unsigned char*)buf + sizeof(plan_header));
+    // (copied out before anything is read: the caller's buffer need not be aligned for 4-byte fields)
+    std::vector<plan_node> n(h.nnodes);
+    memcpy(n.data(), (const unsigned char*)buf + sizeof(plan_header), (size_t)h.nnodes * sizeof(plan_node));
     for (uint32_t i = 0; i < h.nnodes; ++i)
     {
         SPMV_REQUIRE(n[i].format >= SPMV_FMT_COO && n[i].format <= SPMV_FMT_DIA, "plan: node %u has format %d", i, n[i].format);
@@ -93,8 +95,7 @@ int check_blob(const void* buf, int64_t len, const plan_node** nodes, int* nnode
                          n[i].coo_bins_per_xcd >= 0 && n[i].coo_bins_per_xcd <= 8 && n[i].ell_variant >= 0 && n[i].ell_variant <= 3 && n[i].tp_pcols >= 0,
                      "plan: node %u holds a parameter out of range", i);
     }
-    *nodes  = n;
-    *nnodes = (int)h.nnodes;
+    *out = std::move(n);
     return SPMV_OK;
 }
 }  // namespace
@@ -145,13 +146,10 @@ int spmv_mat_get_plan(const spmv_mat* m, void* buf, int64_t* len)
 int spmv_mat_set_plan(spmv_mat* m, const void* buf, int64_t len)
 {
     SPMV_REQUIRE(m, "spmv_mat_set_plan: null matrix");
-    const plan_node* nodes = nullptr;
-    int              n     = 0;
-    SPMV_TRY(check_blob(buf, len, &nodes, &n));
-    SPMV_REQUIRE(nodes[0].format == m->format, "spmv_mat_set_plan: the plan is for format %d, the handle holds format %d", nodes[0].format, m->format);
+    std::vector<plan_node> own;  // (a private copy: the caller's buffer may go away while copies are being built)
+    SPMV_TRY(check_blob(buf, len, &own));
+    SPMV_REQUIRE(own[0].format == m->format, "spmv_mat_set_plan: the plan is for format %d, the handle holds format %d", own[0].format, m->format);
     SPMV_HIP(hipSetDevice(m->ctx->device));
-    // (a private copy: the caller's buffer need not be 4-byte aligned, and it may go away while copies are being built)
-    std::vector<plan_node> own(nodes, nodes + n);
     m->plan_base = own.data();
     m->plan_at   = 0;
     int rc       = SPMV_OK;
@@ -179,6 +177,16 @@ int spmv_mat_set_plan(spmv_mat* m, const void* buf, int64_t len)
     return rc;
 }
 
+int spmv_plan_check(const void* buf, int64_t len, int32_t* format, int32_t* kernel, int32_t* nodes)
+{
+    std::vector<plan_node> n;
+    SPMV_TRY(check_blob(buf, len, &n));
+    if (format) *format = n[0].format;
+    if (kernel) *kernel = n[0].kernel;
+    if (nodes) *nodes = (int32_t)n.size();
+    return SPMV_OK;
+}
+
 int spmv_ctx_set_plan(spmv_ctx* ctx, const void* buf, int64_t len)
 {
     SPMV_REQUIRE(ctx, "spmv_ctx_set_plan: null context");
@@ -188,11 +196,10 @@ int spmv_ctx_set_plan(spmv_ctx* ctx, const void* buf, int64_t len)
         ctx->plan_armed = false;
         return SPMV_OK;
     }
-    const plan_node* nodes = nullptr;
-    int              n     = 0;
-    SPMV_TRY(check_blob(buf, len, &nodes, &n));
-    // stored 8-byte aligned behind its header (16 bytes): the nodes are read in place
-    ctx->plan_blob.assign((const unsigned char*)buf, (const unsigned char*)buf + sizeof(plan_header) + (size_t)n * sizeof(plan_node));
+    std::vector<plan_node> nodes;
+    SPMV_TRY(check_blob(buf, len, &nodes));
+    // stored behind its 16-byte header in the context's own (aligned) buffer: the nodes are read in place from there
+    ctx->plan_blob.assign((const unsigned char*)buf, (const unsigned char*)buf + sizeof(plan_header) + nodes.size() * sizeof(plan_node));
     return SPMV_OK;
 }
 

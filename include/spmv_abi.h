@@ -382,6 +382,10 @@ int spmv_mat_get_param(const spmv_mat* m, const char* name, int64_t* value);
 int spmv_mat_get_plan(const spmv_mat* m, void* buf, int64_t* len);
 int spmv_mat_set_plan(spmv_mat* m, const void* buf, int64_t len);
 int spmv_ctx_set_plan(spmv_ctx* ctx, const void* buf, int64_t len);
+/* The checks spmv_mat_set_plan / spmv_ctx_set_plan run on a blob, by themselves (no device, no handle: a plan received from
+ * another rank or read from a file can be looked at anywhere): SPMV_OK and the root's format, the root's kernel and the number
+ * of nodes (any pointer may be NULL), or SPMV_ERR_INVALID with the reason in spmv_last_error(). */
+int spmv_plan_check(const void* buf, int64_t len, int32_t* format, int32_t* kernel, int32_t* nodes);
 /* Copy the arrays of a handle back to the host (any pointer may be NULL to skip it).
  *   CSR: a=row_ptr[nrow+1]  b=col_ind[nnz]      v=values[nnz]
  *   COO: a=row_ind[nnz]     b=col_ind[nnz]      v=values[nnz]

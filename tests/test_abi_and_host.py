@@ -198,3 +198,53 @@ def test_split_virtual_rows_hold_every_entry_once_in_order(tmp_path):
                    check=True, timeout=120)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and " 0 violations" in r.stdout, r.stdout + r.stderr
+
+
+def test_plan_blobs_are_checked_without_a_device(pkg):
+    """spmv_plan_check: the validation spmv_mat_set_plan / spmv_ctx_set_plan run on a blob, callable anywhere (a plan received
+    from another rank, read from a file).  A node is 32 four-byte fields: format, kernel, lanes, flags, 9 panel fields, 2 split,
+    2 two-phase, 2 ELL, COO bins, 3 child indices (-1: none), 9 reserved; children come after their parent."""
+    import struct
+
+    capi = pkg.capi
+
+    def node(fmt, kernel, lanes=0, children=(-1, -1, -1), **kw):
+        f = [0] * 32
+        f[0], f[1], f[2] = fmt, kernel, lanes
+        f[12] = kw.get("rounds", 1)
+        f[14] = kw.get("split_mode", 0)
+        f[17] = kw.get("ell_variant", 0)
+        f[19] = kw.get("bins", 0)
+        f[20], f[21], f[22] = children
+        return struct.pack("<32i", *f)
+
+    def blob(*nodes, magic=0x4E4C5053, version=1, nbytes=None, count=None):
+        body = b"".join(nodes)
+        return struct.pack("<IIII", magic, version, 16 + len(body) if nbytes is None else nbytes, len(nodes) if count is None else count) + body
+
+    one = blob(node(capi.FMT_CSR, capi.CSR_PANEL, 8))
+    assert capi.plan_check(one) == (capi.FMT_CSR, capi.CSR_PANEL, 1)
+    # a COO handle that runs from its row-grouped copy, which runs the long-row split in virtual-row mode: four nodes
+    tree = blob(node(capi.FMT_COO, capi.CSR_PANEL, children=(1, -1, -1)), node(capi.FMT_CSR, capi.CSR_SPLIT, children=(2, 3, -1), split_mode=2),
+                node(capi.FMT_CSR, capi.CSR_PANEL), node(capi.FMT_CSR, capi.CSR_VECTOR, 16))
+    assert capi.plan_check(tree) == (capi.FMT_COO, capi.CSR_PANEL, 4)
+    assert capi.plan_check(blob(node(capi.FMT_CSR, capi.CSR_ELL, children=(-1, -1, 1)), node(capi.FMT_ELL, capi.CSR_VECTOR, ell_variant=3))) == (capi.FMT_CSR, capi.CSR_ELL, 2)
+    bad = {
+        "empty": b"", "header only": one[:16], "truncated": one[:-4], "magic": blob(node(1, 1), magic=0x12345678), "version": blob(node(1, 1), version=2),
+        "byte count": blob(node(1, 1), nbytes=999), "node count": blob(node(1, 1), count=2), "no nodes": blob(count=0),
+        "too many nodes": blob(*[node(1, 1)] * 65), "format": blob(node(7, 1)), "kernel": blob(node(1, 9)), "negative kernel": blob(node(1, -1)),
+        "lanes not a power of two": blob(node(1, 1, 3)), "lanes beyond a wavefront": blob(node(1, 1, 128)),
+        "child points at itself": blob(node(0, 4, children=(0, -1, -1))), "child points backwards": blob(node(1, 7, children=(1, -1, -1)), node(1, 7, children=(0, -1, -1))),
+        "child out of range": blob(node(0, 4, children=(5, -1, -1)), node(1, 1)), "row-grouped copy that is not CSR": blob(node(0, 4, children=(1, -1, -1)), node(3, 1)),
+        "ELL copy that is not ELL": blob(node(1, 8, children=(-1, -1, 1)), node(1, 1)), "split mode": blob(node(1, 7, split_mode=3)),
+        "ELL variant": blob(node(3, 1, ell_variant=4)), "COO bins": blob(node(0, 1, bins=9)), "rounds": blob(node(1, 4, rounds=17)),
+    }
+    for what, b in bad.items():
+        with pytest.raises(capi.SpmvError, match="plan") as e:
+            capi.plan_check(b)
+        assert e.value.code == -1, what  # SPMV_ERR_INVALID
+    # an unaligned buffer: the library copies the nodes out before it reads a field
+    raw = bytearray(b"\x00" + tree)
+    view = (C.c_char * len(tree)).from_buffer(raw, 1)
+    f, k, n = C.c_int32(), C.c_int32(), C.c_int32()
+    assert capi.load().spmv_plan_check(C.addressof(view), len(tree), C.byref(f), C.byref(k), C.byref(n)) == 0 and n.value == 4
