@@ -155,6 +155,20 @@ int run_sharded_synthetic(const Options& o)
         spmv_mat_destroy(coo);
         check(spmv_mat_partition_rows(whole, P, o.by_entries ? 1 : 0, bounds.data()), "spmv_mat_partition_rows");
     }
+    // Same-shape shards (uniform / band): shard 0 selects its kernel - AUTO is a measurement - and the others are built under ITS
+    // plan (spmv_mat_get_plan / spmv_ctx_set_plan), as the reference builds every shard the same way (src/mat_vec.cpp:240-268).
+    // The skewed power-law shards differ in what they hold and select for themselves.
+    std::vector<unsigned char> plan;
+    auto plan_of = [&](spmv_mat* m) {
+        std::vector<unsigned char> b;
+        int64_t                    len = 0;
+        if (spmv_mat_get_plan(m, nullptr, &len) == SPMV_OK && len > 0)
+        {
+            b.resize((size_t)len);
+            if (spmv_mat_get_plan(m, b.data(), &len) != SPMV_OK) b.clear();
+        }
+        return b;
+    };
     for (int i = 0; i < P; ++i)
     {
         int64_t r0 = 0, r1 = 0;
@@ -167,7 +181,10 @@ int run_sharded_synthetic(const Options& o)
         else
         {
             check(spmv_partition_rows(ncol64, P, i, &r0, &r1), "spmv_partition_rows");
+            if (!plan.empty()) check(spmv_ctx_set_plan(ctx[(size_t)i], plan.data(), (int64_t)plan.size()), "spmv_ctx_set_plan");
             check(spmv_gen_csr_uniform(ctx[(size_t)i], r0, r1, ncol, o.k, band, o.seed, &mat[(size_t)i]), "spmv_gen_csr_uniform(shard)");
+            if (!plan.empty()) check(spmv_ctx_set_plan(ctx[(size_t)i], nullptr, 0), "spmv_ctx_set_plan(clear)");
+            if (i == 0) plan = plan_of(mat[0]);
         }
         off[(size_t)i]     = r0;
         off[(size_t)i + 1] = r1;
@@ -306,6 +323,9 @@ int run_sharded_synthetic(const Options& o)
     printf("{\"sharded_partition\": \"%s\", \"entries_per_shard_max_over_mean\": %.4f, \"slowest_shard_ms\": %.5f, \"sum_of_shards_ms\": %.5f, "
            "\"gflops_with_one_gpu_per_shard\": %.3f, \"shards\": %s}\n",
            powerlaw && o.by_entries ? "entries" : "rows", imbalance, slowest_ms, sum_ms, slowest_ms > 0 ? 2.0 * (double)nnz_total / slowest_ms / 1e6 : 0.0, per_shard.c_str());
+    bool plans_equal = true;
+    for (int i = 1; i < P && !powerlaw; ++i) plans_equal = plans_equal && plan_of(mat[(size_t)i]) == plan_of(mat[0]);
+    if (!powerlaw) printf("### CSR NUMA shards built under shard 0's plan (%zu bytes): plans equal = %s\n", plan.size(), plans_equal ? "yes" : "NO");
     const double ms = secs * 1e3 / o.reps;
     printf("{\"harness\": \"spmv_main --sharded\", \"participants\": %d, \"gpus_present\": %d, \"exchange\": \"%s\", \"rows_per_shard\": %d, "
            "\"ncol\": %d, \"nnz_per_row\": %d, \"band\": %d, \"nnz_total\": %lld, \"reps\": %d, \"ms_per_product\": %.5f, \"gflops\": %.3f, "

@@ -268,6 +268,8 @@ def test_native_sharded_harness_on_device_generated_shards(tmp_path, pkg, orc, p
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["participants"] == parts and line["nnz_total"] == n * parts * k and line["exchange"] in ("rccl", "peer-copy")
     assert line["gflops"] > 0 and line["with_x_allgather_each_step"]["gflops"] > 0
+    # same-shape shards are built under shard 0's plan: none of them can have drawn another kernel or another parameter
+    assert re.search(r"### CSR NUMA shards built under shard 0's plan \(\d+ bytes\): plans equal = yes", r.stdout), r.stdout[-1500:]
     assert _check_sharded_rows(pkg, orc, out, n, parts, k, band, 5) == 3 * 700 * parts
 
 
