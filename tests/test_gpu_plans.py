@@ -260,3 +260,44 @@ def test_blobs_are_checked_before_anything_is_read_from_them(ctx, pkg):
     got = _product(ctx, A, ctx.vector_from(x), n)
     ref = np.bincount(rows, weights=cv * x[cc], minlength=n)
     assert np.max(np.abs(got - ref)) <= 1e-10 * np.max(np.abs(ref))
+
+
+def test_a_two_phase_handle_built_from_a_plan_can_still_run_its_piece_search(pkg, monkeypatch):
+    """What `bench.py --gpus N` does on every rank but the first: the shard is built under rank 0's plan (two-phase layout, no
+    timing launch, no piece search), and the search over where the product stream lies in THIS device's memory - no part of a
+    plan - is run afterwards with the budget the job grants ("twophase_placement_budget_mb" + "twophase_choose_pieces")."""
+    capi = pkg.capi
+    monkeypatch.delenv("SPMV_PANEL_TRIAL", raising=False)
+    monkeypatch.delenv("SPMV_TP_PLACEMENT_BUDGET_MB", raising=False)
+    ctx = capi.Context(0)
+    n, ncol, k = 4_500_000, 72_000_000, 16  # 72M entries: a product stream of 0.6 GB (searched from 512 MB on), x 16x the rows
+    A = ctx.gen_csr_uniform(0, n, ncol, k, seed=3)
+    assert A.info.kernel == capi.CSR_TWOPHASE
+    plan = A.get_plan()
+    x = ctx.gen_vector(ncol, seed=3)
+    ya, yb = ctx.vector(n), ctx.vector(n)
+    ya.fill(0.0)
+    ctx.apply(A, x, ya)
+    ctx.sync()
+    ref = ya.download()
+    del A, ya
+    ctx.set_plan(plan)
+    B = ctx.gen_csr_uniform(0, n, ncol, k, seed=3)
+    ctx.set_plan(None)
+    assert B.info.kernel == capi.CSR_TWOPHASE and B.get_plan() == plan
+    assert B.get_param("select_candidates") == 0 and B.get_param("twophase_placements_timed") == 0  # nothing was timed, nothing searched
+    B.set_param("twophase_placement_budget_mb", 3072)
+    B.set_param("twophase_choose_pieces", 1)
+    assert B.get_param("twophase_placements_timed") > 0 and B.get_param("twophase_placement_spread") >= 1000
+    assert B.get_plan() == plan  # where the pieces lie is no part of the plan
+    yb.fill(0.0)
+    ctx.apply(B, x, yb)
+    ctx.sync()
+    assert np.max(np.abs(yb.download() - ref)) <= ol.REL_TOL * k * np.max(np.abs(ref))
+    B.set_param("panel_keep_csr", 0)  # ... and what the bench does next: the CSR copy goes (its gigabytes offered to the search first)
+    yb.fill(0.0)
+    ctx.apply(B, x, yb)
+    ctx.sync()
+    assert np.max(np.abs(yb.download() - ref)) <= ol.REL_TOL * k * np.max(np.abs(ref))
+    del B
+    ctx.close()
