@@ -23,13 +23,19 @@ namespace spmv
 namespace
 {
 // UNROLL slots are fetched before the first fma so that UNROLL gathers of x are in flight per lane.
-template <int UNROLL>
+// MASKED (round 6): the handle is the ELL COPY of a CSR handle (csr_ell_copy_build) and rp is that handle's row_ptr - slots
+// beyond a row's own length are PADDING the CSR matrix does not have (value 0.0, the row's own last column) and take no part in
+// the sum, so that a row reading x[c] = +-inf ends at +-inf as in the reference's CSR loop (src/mat_vec.cpp:57-65), not at the
+// NaN of 0.0 * inf, and a row without entries is not touched at all.  A true ELL handle multiplies its padding as the
+// reference's ELL loop does (0.0 * x[0], src/mat_vec.cpp:108-117): MASKED = false is the code of rounds 1-5, unchanged.
+template <int UNROLL, bool MASKED = false>
 __global__ __launch_bounds__(kBlock) void ell_kernel(int nrow, int k, const int32_t* __restrict__ col,
                                                      const double* __restrict__ val,
-                                                     const double* __restrict__ x, double* __restrict__ y)
+                                                     const double* __restrict__ x, double* __restrict__ y, const int32_t* __restrict__ rp = nullptr)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= nrow) return;
+    const int    len    = MASKED ? rp[i + 1] - rp[i] : k;
     double       acc    = y[i];
     const size_t stride = (size_t)nrow;
     size_t       at     = (size_t)i;
@@ -48,26 +54,29 @@ __global__ __launch_bounds__(kBlock) void ell_kernel(int nrow, int k, const int3
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) xv[u] = x[c[u]];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) acc = fma(v[u], xv[u], acc);
+        for (int u = 0; u < UNROLL; ++u)
+            if (!MASKED || s + u < len) acc = fma(v[u], xv[u], acc);
         at += (size_t)UNROLL * stride;
     }
     for (; s < k; ++s)
     {
-        acc = fma(load_stream(val + at), x[load_stream(col + at)], acc);
+        const double v = load_stream(val + at), xv = x[load_stream(col + at)];
+        if (!MASKED || s < len) acc = fma(v, xv, acc);
         at += stride;
     }
-    y[i] = acc;
+    if (!MASKED || len > 0) y[i] = acc;
 }
 
 // Two adjacent rows per lane: 8-byte column loads and 16-byte value loads (1 KiB per wavefront
 // instruction).  Needs nrow even so that every slot column starts 16-byte aligned.
-template <int UNROLL>
+template <int UNROLL, bool MASKED = false>
 __global__ __launch_bounds__(kBlock) void ell_kernel_x2(int nrow, int k, const int32_t* __restrict__ col,
                                                         const double* __restrict__ val,
-                                                        const double* __restrict__ x, double* __restrict__ y)
+                                                        const double* __restrict__ x, double* __restrict__ y, const int32_t* __restrict__ rp = nullptr)
 {
     const int i = 2 * (blockIdx.x * kBlock + threadIdx.x);
     if (i >= nrow) return;  // nrow even: i+1 < nrow too
+    const int    len0 = MASKED ? rp[i + 1] - rp[i] : k, len1 = MASKED ? rp[i + 2] - rp[i + 1] : k;  // (MASKED: see ell_kernel)
     f64x2        acc    = *reinterpret_cast<const f64x2*>(y + i);
     const size_t stride = (size_t)nrow;
     size_t       at     = (size_t)i;
@@ -92,8 +101,8 @@ __global__ __launch_bounds__(kBlock) void ell_kernel_x2(int nrow, int k, const i
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
         {
-            acc.x = fma(v[u].x, xa[u], acc.x);
-            acc.y = fma(v[u].y, xb[u], acc.y);
+            if (!MASKED || s + u < len0) acc.x = fma(v[u].x, xa[u], acc.x);
+            if (!MASKED || s + u < len1) acc.y = fma(v[u].y, xb[u], acc.y);
         }
         at += (size_t)UNROLL * stride;
     }
@@ -101,11 +110,12 @@ __global__ __launch_bounds__(kBlock) void ell_kernel_x2(int nrow, int k, const i
     {
         const i32x2   c = load_stream(reinterpret_cast<const i32x2*>(col + at));
         const f64x2   v = load_stream(reinterpret_cast<const f64x2*>(val + at));
-        acc.x           = fma(v.x, x[c.x], acc.x);
-        acc.y           = fma(v.y, x[c.y], acc.y);
+        const double  xa = x[c.x], xb = x[c.y];
+        if (!MASKED || s < len0) acc.x = fma(v.x, xa, acc.x);
+        if (!MASKED || s < len1) acc.y = fma(v.y, xb, acc.y);
         at += stride;
     }
-    *reinterpret_cast<f64x2*>(y + i) = acc;
+    *reinterpret_cast<f64x2*>(y + i) = acc;  // (a row without entries gets back the y it had: the same bits)
 }
 // ---- ELL whose slots are diagonals ---------------------------------------------------------------------------------
 // ELL is what stencil and band matrices are stored in, and there slot s of most rows holds the same diagonal:
@@ -212,11 +222,11 @@ __device__ __forceinline__ void stage_x_windows(double* xs, const int32_t* __res
 // bits.  C3, A/B in one process: 0.345-0.360 -> 0.331-0.334 ms on a box where the column-major form is fast, 0.4045 ->
 // 0.400 on one where it is slow - what separates the boxes is not the stride.  Opt-in ("ell_tiled_values"): 8 more bytes
 // per slot are a poor price for that.
-template <int UNROLL, bool XWIN, bool TILED>
+template <int UNROLL, bool XWIN, bool TILED, bool MASKED = false>
 __global__ __launch_bounds__(kBlock) void ell_diag_kernel_x2(int nrow, int k, const int32_t* __restrict__ col,
                                                              const double* __restrict__ val, const double* __restrict__ x,
                                                              double* __restrict__ y, const int32_t* __restrict__ off,
-                                                             const u64* __restrict__ mask, int ncol)
+                                                             const u64* __restrict__ mask, int ncol, const int32_t* __restrict__ rp = nullptr)
 {
     extern __shared__ double xs[];  // XWIN: the stretches of x this block's conforming entries read (stage_x_windows)
     const int r0 = 2 * kBlock * (int)blockIdx.x;
@@ -227,6 +237,7 @@ __global__ __launch_bounds__(kBlock) void ell_diag_kernel_x2(int nrow, int k, co
     const u64* __restrict__ wm = mask + (size_t)wave * k;  // this wavefront's words: scalar loads
     const u64 bit = 1ull << (threadIdx.x & 63);
     const int32_t* __restrict__ xbase = off + k;
+    const int    len0 = MASKED ? rp[i + 1] - rp[i] : k, len1 = MASKED ? rp[i + 2] - rp[i + 1] : k;  // (MASKED: see ell_kernel)
     f64x2        acc    = *reinterpret_cast<const f64x2*>(y + i);
     const size_t stride = TILED ? (size_t)(2 * kBlock) : (size_t)nrow;
     size_t       at     = TILED ? (size_t)blockIdx.x * (2 * kBlock) * k + 2 * threadIdx.x : (size_t)i;
@@ -263,8 +274,8 @@ __global__ __launch_bounds__(kBlock) void ell_diag_kernel_x2(int nrow, int k, co
                     x0            = x[c.x];
                     x1            = x[c.y];
                 }
-                acc.x = fma(v[u].x, x0, acc.x);
-                acc.y = fma(v[u].y, x1, acc.y);
+                if (!MASKED || s < len0) acc.x = fma(v[u].x, x0, acc.x);
+                if (!MASKED || s < len1) acc.y = fma(v[u].y, x1, acc.y);
             }
         at += (size_t)UNROLL * stride;
     }
@@ -585,9 +596,10 @@ int ell_select_kernel(spmv_mat* m)
 // diagonals read no index at all).  The reference's user calls CSRMatrixMatVector on whatever matrix she has
 // (src/mat_vec.cpp:44-67): a CSR handle whose padding to its longest row stays below a quarter and that has no empty row
 // therefore times an ELL copy of itself as one more candidate - where its columns are local (csr_ell_copy_worth).  The copy's padding carries value 0.0 and the row's own LAST
-// column, not the reference's column 0 (convert.hip): a padded slot adds 0.0 * x[c] for a column the row reads anyway, so a
-// non-finite x[0] stays out of rows that never touch it.  (A row that does read a non-finite x[c] gets NaN from the padding
-// where the reference's CSR loop gets +-inf: the one place the copy is not the reference's arithmetic.)
+// column, not the reference's column 0 (convert.hip), so that the gathers issued for it stay inside x and near the row's other
+// gathers - and since round 6 it takes NO part in the sums: the copy's kernels are the MASKED instances (ell_kernel above), which
+// read a row's own length off the CSR handle's row_ptr.  Round 5's copy multiplied its padding: a row reading x[c] = inf got NaN
+// (0.0 * inf) where the reference's CSR loop gets inf, and an empty row read x[0].
 bool csr_ell_copy_worth(const spmv_mat* m)
 {
     if (m->format != SPMV_FMT_CSR || m->sel_no_ell || m->nrow < 2 || m->nnz < kSelectMinNnz || !m->b || !m->v) return false;
@@ -614,11 +626,13 @@ int csr_ell_copy_build(spmv_mat* m)
     SPMV_REQUIRE(m->format == SPMV_FMT_CSR && m->a && m->b && m->v, "the ELL copy is made from a CSR handle's own arrays");
     SPMV_REQUIRE((int64_t)m->nrow * m->max_row_nnz <= (int64_t)INT32_MAX - 65536 && (int64_t)m->nrow * m->max_row_nnz <= 16 * std::max<int64_t>(m->nnz, 1),
                  "an ELL copy of %d rows x %d slots for %lld entries: the padding is out of proportion", m->nrow, m->max_row_nnz, (long long)m->nnz);
-    // an EMPTY row has no column of its own to pad with: its slots would carry column 0, and y += 0.0 * x[0] writes NaN into a row
-    // the reference's CSR loop never touches when x[0] is not finite (src/mat_vec.cpp:57-65) - what pad_own_column exists to prevent
-    SPMV_REQUIRE(m->min_row_nnz >= 1, "an ELL copy of a CSR handle with an empty row: its padding would read x[0] for a row without entries");
     spmv_mat* ell = nullptr;
     SPMV_TRY(csr_to_ell(m->ctx, m, &ell, /*pad_own_column=*/true));
+    // the copy's kernels leave its padding OUT of the sums (MASKED: slots beyond a row's own length, read off this handle's
+    // row_ptr, which outlives the copy: panel_keep_csr = 0 never releases it): the copy is the CSR matrix in non-finite arithmetic
+    // too - a row that reads x[c] = inf ends at inf, a row without entries is not touched.  (The padding still carries the row's
+    // own last column, so that the gathers the kernels issue for it stay inside x and near the row's other gathers.)
+    ell->ell_rp = m->a;
     ell->pb_trial          = m->pb_trial;
     ell->sel_no_rowgrouped = true;
     plan_hand_down(m, ell, kPlanChildEll);
@@ -812,12 +826,15 @@ __global__ __launch_bounds__(kBlock) void ell_rowmajor_kernel(int nrow, int k, c
 
 // skip[i / 64] bit i % 64 = row i has a slot that is not its diagonal (col != i + off[s]); the grid covers whole words
 __global__ __launch_bounds__(kBlock) void ell_row_conform_kernel(int nrow, int k, const int32_t* __restrict__ col, const int32_t* __restrict__ off,
-                                                                 u64* __restrict__ skip)
+                                                                 u64* __restrict__ skip, const int32_t* __restrict__ rp)
 {
     const int i  = blockIdx.x * kBlock + (int)threadIdx.x;
     bool      nc = false;
     if (i < nrow)
+    {
         for (int s = 0; s < k; ++s) nc |= col[(size_t)i + (size_t)s * nrow] != i + off[s];
+        if (rp) nc |= rp[i + 1] - rp[i] < k;  // (the ELL copy of a CSR handle: a row with padding goes to the side kernel, which leaves the padding out)
+    }
     const u64 b = __ballot(nc);
     if ((threadIdx.x & 63) == 0 && (i >> 6) < (nrow + 63) / 64) skip[i >> 6] = b;
 }
@@ -827,11 +844,14 @@ __global__ __launch_bounds__(kBlock) void ell_row_conform_kernel(int nrow, int k
 // that the bits are the ELL kernels' (one lane per row walking its slots alone took 25 us for C3's 63 rows x 64 slots: a chain of
 // 64 dependent gathers - a twelfth of the DIA pass it follows; this form takes the 3 us of a launch)
 __global__ __launch_bounds__(kBlock) void ell_rows_list_kernel(int nlist, const int32_t* __restrict__ rows, int nrow, int k, const int32_t* __restrict__ col,
-                                                               const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y)
+                                                               const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y,
+                                                               const int32_t* __restrict__ rp)
 {
     const int t = (int)((blockIdx.x * kBlock + threadIdx.x) >> 6), lane = (int)(threadIdx.x & 63);
     if (t >= nlist) return;  // (uniform over the wavefront)
     const int i   = rows[t];
+    if (rp) k = rp[i + 1] - rp[i];  // (the ELL copy of a CSR handle: the row's own entries, not its padding; uniform over the wavefront)
+    if (k == 0) return;
     double    acc = y[i];
     for (int s0 = 0; s0 < k; s0 += kWave)
     {
@@ -893,7 +913,7 @@ int ell_build_dia_order(spmv_mat* m, bool only_if_worth)
     {
         if (hipMemcpyAsync(h_off.data(), m->ell_diag, sizeof(int32_t) * (size_t)k, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { rc = SPMV_ERR_HIP; break; }
         if (hipMalloc(&skip, sizeof(u64) * words) != hipSuccess) { skip = nullptr; rc = SPMV_ERR_ALLOC; break; }
-        hipLaunchKernelGGL(ell_row_conform_kernel, dim3((unsigned)ceil_div((int64_t)words * 64, kBlock)), dim3(kBlock), 0, ctx->stream, nrow, k, m->b, m->ell_diag, skip);
+        hipLaunchKernelGGL(ell_row_conform_kernel, dim3((unsigned)ceil_div((int64_t)words * 64, kBlock)), dim3(kBlock), 0, ctx->stream, nrow, k, m->b, m->ell_diag, skip, m->ell_rp);
         if (hipGetLastError() != hipSuccess || hipMemcpyAsync(h_skip.data(), skip, sizeof(u64) * words, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = SPMV_ERR_HIP; break; }
         std::vector<int32_t> nc;
@@ -997,7 +1017,7 @@ int ell_own_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
         if (A->ell_nc_count > 0)
         {
             hipLaunchKernelGGL(ell_rows_list_kernel, dim3((unsigned)ceil_div((int64_t)A->ell_nc_count * kWave, kBlock)), dim3(kBlock), 0, ctx->stream, A->ell_nc_count, A->ell_nc_rows,
-                               A->nrow, A->k, A->b, A->v, x, y);
+                               A->nrow, A->k, A->b, A->v, x, y, A->ell_rp);
             SPMV_HIP(hipGetLastError());
         }
         return SPMV_OK;
@@ -1011,15 +1031,23 @@ int ell_own_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
         const unsigned grid = (unsigned)ceil_div(A->nrow / 2, kBlock);
         const bool     xwin = A->ell_diag_lds > 0 && A->ell_diag_lds <= 5120;  // the x stretches of 512 rows fit 40 KB of LDS
         const size_t   lds  = xwin ? sizeof(double) * (size_t)A->ell_diag_lds : 0;
-#define SPMV_ELL_DIAG(U, W)                                                                                                                         \
-    do                                                                                                                                             \
-    {                                                                                                                                              \
-        if (A->ell_tval)                                                                                                                           \
-            hipLaunchKernelGGL((ell_diag_kernel_x2<U, W, true>), dim3(grid), dim3(kBlock), lds, ctx->stream, A->nrow, A->k, A->b, A->ell_tval, x, y, \
-                               A->ell_diag, (const u64*)A->ell_diag_mask, A->ncol);                                                                \
-        else                                                                                                                                       \
-            hipLaunchKernelGGL((ell_diag_kernel_x2<U, W, false>), dim3(grid), dim3(kBlock), lds, ctx->stream, A->nrow, A->k, A->b, A->v, x, y,       \
-                               A->ell_diag, (const u64*)A->ell_diag_mask, A->ncol);                                                                \
+#define SPMV_ELL_DIAG_M(U, W, T, M)                                                                                                              \
+    hipLaunchKernelGGL((ell_diag_kernel_x2<U, W, T, M>), dim3(grid), dim3(kBlock), lds, ctx->stream, A->nrow, A->k, A->b, T ? A->ell_tval : A->v, x, y, \
+                       A->ell_diag, (const u64*)A->ell_diag_mask, A->ncol, A->ell_rp)
+#define SPMV_ELL_DIAG(U, W)                                    \
+    do                                                         \
+    {                                                          \
+        if (A->ell_rp) /* the ELL copy of a CSR handle: padding left out */ \
+        {                                                      \
+            if (A->ell_tval)                                   \
+                SPMV_ELL_DIAG_M(U, W, true, true);             \
+            else                                               \
+                SPMV_ELL_DIAG_M(U, W, false, true);            \
+        }                                                      \
+        else if (A->ell_tval)                                  \
+            SPMV_ELL_DIAG_M(U, W, true, false);                \
+        else                                                   \
+            SPMV_ELL_DIAG_M(U, W, false, false);               \
     } while (0)
         // slots in flight per lane: 4 by default; lanes_per_row 4 / 8 select 8 / 2 (tools/tune.py ell: A/B)
         if (A->lanes_per_row == 4)
@@ -1035,22 +1063,35 @@ int ell_own_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
             if (xwin) SPMV_ELL_DIAG(4, true); else SPMV_ELL_DIAG(4, false);
         }
 #undef SPMV_ELL_DIAG
+#undef SPMV_ELL_DIAG_M
     }
     else if (x2)
     {
         const unsigned grid = (unsigned)ceil_div(A->nrow / 2, kBlock);
         // slots in flight per lane: 4 by default; lanes_per_row 4 / 8 select 8 / 2 (tools/tune.py ell: A/B)
+#define SPMV_ELL_X2(U)                                                                                                                                     \
+    do                                                                                                                                                     \
+    {                                                                                                                                                      \
+        if (A->ell_rp)                                                                                                                                     \
+            hipLaunchKernelGGL((ell_kernel_x2<U, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, A->nrow, A->k, A->b, A->v, x, y, A->ell_rp);           \
+        else                                                                                                                                               \
+            hipLaunchKernelGGL((ell_kernel_x2<U, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, A->nrow, A->k, A->b, A->v, x, y, (const int32_t*)nullptr); \
+    } while (0)
         if (A->lanes_per_row == 4)
-            hipLaunchKernelGGL(ell_kernel_x2<8>, dim3(grid), dim3(kBlock), 0, ctx->stream, A->nrow, A->k, A->b, A->v, x, y);
+            SPMV_ELL_X2(8);
         else if (A->lanes_per_row == 8)
-            hipLaunchKernelGGL(ell_kernel_x2<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, A->nrow, A->k, A->b, A->v, x, y);
+            SPMV_ELL_X2(2);
         else
-            hipLaunchKernelGGL(ell_kernel_x2<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, A->nrow, A->k, A->b, A->v, x, y);
+            SPMV_ELL_X2(4);
+#undef SPMV_ELL_X2
     }
     else
     {
         const unsigned grid = (unsigned)ceil_div(A->nrow, kBlock);
-        hipLaunchKernelGGL(ell_kernel<8>, dim3(grid), dim3(kBlock), 0, ctx->stream, A->nrow, A->k, A->b, A->v, x, y);
+        if (A->ell_rp)
+            hipLaunchKernelGGL((ell_kernel<8, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, A->nrow, A->k, A->b, A->v, x, y, A->ell_rp);
+        else
+            hipLaunchKernelGGL((ell_kernel<8, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, A->nrow, A->k, A->b, A->v, x, y, (const int32_t*)nullptr);
     }
     SPMV_HIP(hipGetLastError());
     return SPMV_OK;

@@ -124,12 +124,13 @@ typedef enum spmv_csr_kernel
                               min(500000, 8/u) entries: panel 0.64, split 0.29.  CSR handles only; AUTO times it where the longest
                               row is >= 4096 and 32x the mean */
     SPMV_CSR_ELL      = 8  /* an ELL copy of the handle (column-major slots, padded to the longest row with value 0.0 and the row's own
-                              last column) with the ELL kernels - diagonal slots recognised, one or two rows per lane, timed - for
+                              last column; the copy's kernels leave that padding OUT of the sums - slots beyond a row's own length,
+                              read off row_ptr - so the copy is the CSR matrix in non-finite arithmetic too) with the ELL kernels -
+                              diagonal slots recognised, one or two rows per lane, the DIA-order copy, timed - for
                               matrices of (nearly) equal rows: stencils, bands, block diagonals (tridiagonal, 8M rows: panel 0.087
                               ms, this 0.056; a band of 33: 0.163 / 0.105).  12 bytes per slot on top of the CSR arrays.  CSR
                               handles only; AUTO times it where the padding stays below a quarter, no row is empty and the columns are local
-                              (the x window of 256 rows within 2 MB, or all of x within 4 MB).  A row that
-                              reads a non-finite x[c] gets NaN from its padding where the plain CSR loop gives +-inf */
+                              (the x window of 256 rows within 2 MB, or all of x within 4 MB) */
 } spmv_csr_kernel;
 
 /* Tuning bits for spmv_mat_set_flags (speed only; results stay within the parity tolerance). */

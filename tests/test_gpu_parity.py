@@ -1276,9 +1276,9 @@ def test_panel_layout_cut_for_more_than_one_round_of_workgroups(ctx, orc, pkg):
 def test_csr_handles_of_nearly_equal_rows_may_run_from_an_ell_copy(ctx, orc, pkg, monkeypatch):
     """Round 5 (tools/sweep_structures.py: stencils, bands, block diagonals run 1.15x to 1.57x faster through an ELL handle than
     through a CSR handle's best kernel): a CSR handle whose padding to its longest row stays below a quarter and that has no
-    empty row times an ELL copy of itself (kernel SPMV_CSR_ELL).  The copy is the reference's ELL arithmetic - bit-identical to
-    an ELL handle of the same matrix - except for its padding, which carries the row's own last column instead of column 0:
-    a non-finite x[0] stays out of rows that never read it."""
+    empty row times an ELL copy of itself (kernel SPMV_CSR_ELL).  The copy's kernels add a row's entries in slot order like the
+    ELL kernels and leave its PADDING out of the sums (round 6): with finite x the bits are an ELL handle's of the same matrix,
+    and a non-finite x[c] does to a row exactly what it does under the reference's CSR loop."""
     capi = pkg.capi
     monkeypatch.delenv("SPMV_PANEL_TRIAL", raising=False)
     rng = np.random.default_rng(41)
@@ -1340,31 +1340,30 @@ def test_csr_handles_of_nearly_equal_rows_may_run_from_an_ell_copy(ctx, orc, pkg
     rp2 = np.concatenate(([0], np.cumsum(lens2))).astype(np.int32)
     B = ctx.csr(n, n, rp2, cols[keep], vals[keep])
     assert B.get_param("min_row_entries") == 0 and B.get_param("select_us_ell") == 0 and B.info.kernel != capi.CSR_ELL
-    # forced, it is refused: an empty row has no column of its own to pad with, and y += 0.0 * x[0] would write NaN into a row
-    # the reference's CSR loop never touches when x[0] is not finite (round 5 built the copy all the same)
-    with pytest.raises(capi.SpmvError, match="empty row"):
-        B.set_kernel(capi.CSR_ELL)
-    assert B.get_param("ell_copy_slots") == 0
-    B.set_kernel(capi.CSR_VECTOR)
+    # forced, it works all the same: the copy's kernels leave its padding out of the sums (round 6), so the empty row is not
+    # touched - not even by x[0] = NaN, which its padded slots (column 0, value 0.0) would otherwise multiply
+    B.set_kernel(capi.CSR_ELL)
+    assert B.info.kernel == capi.CSR_ELL and B.get_param("ell_copy_slots") == n * 7
     ref2, scale2 = np.zeros(n), np.zeros(n)
     ol.csr_spmv(orc, rp2, cols[keep], vals[keep], x, ref2)
     ol.csr_abs_row_sums(orc, rp2, cols[keep], vals[keep], x, scale2)
-    ol.assert_parity(product(B), ref2, scale2, "band with an empty row, after the refused ELL copy")
+    ol.assert_parity(product(B), ref2, scale2, "band with an empty row, ELL copy forced")
     got = product(B, dxn)
-    assert np.isfinite(got[1000]) and got[1000] == 0.0  # the empty row stays out of x[0] = NaN
-    # the ONE documented deviation of the copy (spmv_abi.h, SPMV_CSR_ELL): a short row that reads x[c] = +inf gets NaN from its
-    # padding (0.0 * inf) where the reference's CSR loop gives +inf; rows without padding, and every other kernel, give +inf
+    assert got[1000] == 0.0 and np.all(np.isnan(got[:half + 1])) and np.all(np.isfinite(got[half + 1:]))
+    # Round 5's copy had ONE deviation from the CSR loop: a short row that reads x[c] = +inf got NaN from its padding (0.0 * inf).
+    # Round 6: the padding takes no part in the sums (slots beyond a row's own length, read off the handle's row_ptr), so the copy
+    # gives +-inf exactly where every other CSR kernel and the reference (src/mat_vec.cpp:57-65) do - padded rows included
     xi = x.copy()
     xi[n - 1] = np.inf  # column n - 1: read by the last rows, which are short (padded), and by row n - 1 - half (a full row)
     dxi = ctx.vector_from(xi)
-    vals_last = vals[rp[n - 1 - half]:rp[n - half]][-1]  # the full row's entry in column n - 1
-    A.set_kernel(capi.CSR_VECTOR)
-    got = product(A, dxi)
-    assert np.all(np.isinf(got[n - 1 - half:])) and np.all(np.isfinite(got[:n - 1 - half]))
-    A.set_kernel(capi.CSR_ELL)
-    got = product(A, dxi)
-    assert np.isinf(got[n - 1 - half]) and np.sign(got[n - 1 - half]) == np.sign(vals_last)  # no padding in that row
-    assert np.all(np.isnan(got[n - half:])) and np.all(np.isfinite(got[:n - 1 - half]))  # padded rows: NaN, the documented deviation
+    refi = np.zeros(n)
+    ol.csr_spmv(orc, rp, cols, vals, xi, refi)
+    assert np.all(np.isinf(refi[n - 1 - half:])) and np.all(np.isfinite(refi[:n - 1 - half]))
+    for kernel in (capi.CSR_VECTOR, capi.CSR_ELL):
+        A.set_kernel(kernel)
+        got = product(A, dxi)
+        assert np.array_equal(np.isinf(got), np.isinf(refi)) and np.array_equal(np.sign(got[n - 1 - half:]), np.sign(refi[n - 1 - half:])), kernel
+        assert not np.any(np.isnan(got)), kernel
     # the solver's extras over the copy (generic path: fill, product, dot)
     w = rng.uniform(-1, 1, n)
     A.set_kernel(capi.CSR_ELL)
