@@ -323,7 +323,7 @@ struct spmv_mat
     int32_t             ell_nc_count = 0;
     int32_t             ell_off_min = 0, ell_off_max = 0;
     int32_t             ell_dia_order_req = -1;  // "ell_dia_order": -1 a candidate of the trial, 0 never, 1 built and used
-    const int32_t*      ell_rp = nullptr;  // the ELL COPY of a CSR handle: that handle's row_ptr (borrowed) - the kernels leave the padding out (kernels_ell.hip: MASKED)
+    bool                ell_pad_marked = false;  // the ELL COPY of a CSR handle: padding slots carry a negative column and take no part in the sums (kernels_ell.hip: MASKED)
 
     // COO / CSC / ELL: internal row-grouped copy in the panel layout (coo_build_panel, csc_analyse, ell_build_panel); owned.
     // CSR with kernel SPLIT: the copy without the long rows

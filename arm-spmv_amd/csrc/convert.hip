@@ -114,9 +114,10 @@ __global__ __launch_bounds__(kBlock) void order_rows_kernel(int nrow, const int3
 }
 
 // ---- CSR -> ELL (column-major, zero padded) --------------------------------------------------------------------
-// PAD_OWN: every slot of the row is written; the slots beyond its entries get value 0.0 and the row's own LAST column (0 for an
-// empty row) instead of the reference's column 0 - the internal ELL copy of a CSR handle (kernels_ell.hip: csr_ell_copy_build),
-// whose padding must not bring x[0] into rows that never touch it
+// PAD_OWN: every slot of the row is written; the slots beyond its entries get value 0.0 and, as their column, the COMPLEMENT of
+// the row's own last column (~c = -1 - c < 0; ~0 for an empty row) instead of the reference's column 0 - the internal ELL copy
+// of a CSR handle (kernels_ell.hip: csr_ell_copy_build).  A negative column says "padding: no part of the sum" to the copy's
+// kernels (their MASKED instances), and decodes to a column the row reads anyway for the gather they issue regardless
 template <int LPR, bool PAD_OWN>
 __global__ __launch_bounds__(kBlock) void csr_to_ell_kernel(int nrow, int k, const int32_t* __restrict__ row_ptr,
                                                             const int32_t* __restrict__ col,
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(kBlock) void csr_to_ell_kernel(int nrow, int k, con
     const int r = blockIdx.x * (kBlock / LPR) + threadIdx.x / LPR;
     if (r >= nrow) return;
     const int begin = row_ptr[r], len = row_ptr[r + 1] - begin;
-    const int pad   = PAD_OWN && len > 0 ? col[begin + len - 1] : 0;
+    const int pad   = PAD_OWN ? ~(len > 0 ? col[begin + len - 1] : 0) : 0;
     for (int s = threadIdx.x % LPR; s < (PAD_OWN ? k : len); s += LPR)
     {
         const size_t at = (size_t)r + (size_t)s * (size_t)nrow;

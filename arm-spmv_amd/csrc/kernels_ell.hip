@@ -23,19 +23,23 @@ namespace spmv
 namespace
 {
 // UNROLL slots are fetched before the first fma so that UNROLL gathers of x are in flight per lane.
-// MASKED (round 6): the handle is the ELL COPY of a CSR handle (csr_ell_copy_build) and rp is that handle's row_ptr - slots
-// beyond a row's own length are PADDING the CSR matrix does not have (value 0.0, the row's own last column) and take no part in
-// the sum, so that a row reading x[c] = +-inf ends at +-inf as in the reference's CSR loop (src/mat_vec.cpp:57-65), not at the
-// NaN of 0.0 * inf, and a row without entries is not touched at all.  A true ELL handle multiplies its padding as the
-// reference's ELL loop does (0.0 * x[0], src/mat_vec.cpp:108-117): MASKED = false is the code of rounds 1-5, unchanged.
+// MASKED (round 6): the handle is the ELL COPY of a CSR handle (csr_ell_copy_build).  Its padding slots carry value 0.0 and a
+// NEGATIVE column, the complement of the row's own last column (convert.hip): such a slot takes no part in the sum - a row that
+// reads x[c] = +-inf ends at +-inf as in the reference's CSR loop (src/mat_vec.cpp:57-65), not at the NaN of 0.0 * inf, and a row
+// without entries is not touched in its value - while the gather the kernel issues for it anyway goes to a column the row reads
+// itself.  No length array, no mask words: the information rides in the index stream the kernel reads in any case, and the
+// diagonal-slot path (which reads no index) never meets a padding slot - a conforming slot holds a real column by construction.
+// (Two earlier forms, measured against the unmasked copy on one box, tools/ab_ell_copy_masked.py: row lengths read off row_ptr
+// +5-6 % on 5- and 7-point stencils - 4 bytes per row are 6 % of their traffic; a bit per row and lengths for padded rows only
+// +1.5 / +5 %: the dependent loads stand in front of every wavefront's short life.)  A true ELL handle multiplies its padding as
+// the reference's ELL loop does (0.0 * x[0], src/mat_vec.cpp:108-117): MASKED = false is the code of rounds 1-5, unchanged.
 template <int UNROLL, bool MASKED = false>
 __global__ __launch_bounds__(kBlock) void ell_kernel(int nrow, int k, const int32_t* __restrict__ col,
                                                      const double* __restrict__ val,
-                                                     const double* __restrict__ x, double* __restrict__ y, const int32_t* __restrict__ rp = nullptr)
+                                                     const double* __restrict__ x, double* __restrict__ y)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= nrow) return;
-    const int    len    = MASKED ? rp[i + 1] - rp[i] : k;
     double       acc    = y[i];
     const size_t stride = (size_t)nrow;
     size_t       at     = (size_t)i;
@@ -52,19 +56,20 @@ __global__ __launch_bounds__(kBlock) void ell_kernel(int nrow, int k, const int3
             v[u] = load_stream(val + at + (size_t)u * stride);
         }
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) xv[u] = x[c[u]];
+        for (int u = 0; u < UNROLL; ++u) xv[u] = x[MASKED && c[u] < 0 ? ~c[u] : c[u]];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
-            if (!MASKED || s + u < len) acc = fma(v[u], xv[u], acc);
+            if (!MASKED || c[u] >= 0) acc = fma(v[u], xv[u], acc);
         at += (size_t)UNROLL * stride;
     }
     for (; s < k; ++s)
     {
-        const double v = load_stream(val + at), xv = x[load_stream(col + at)];
-        if (!MASKED || s < len) acc = fma(v, xv, acc);
+        const int    c  = load_stream(col + at);
+        const double v  = load_stream(val + at), xv = x[MASKED && c < 0 ? ~c : c];
+        if (!MASKED || c >= 0) acc = fma(v, xv, acc);
         at += stride;
     }
-    if (!MASKED || len > 0) y[i] = acc;
+    y[i] = acc;  // (a row without entries gets back the y it had: the same bits)
 }
 
 // Two adjacent rows per lane: 8-byte column loads and 16-byte value loads (1 KiB per wavefront
@@ -72,11 +77,10 @@ __global__ __launch_bounds__(kBlock) void ell_kernel(int nrow, int k, const int3
 template <int UNROLL, bool MASKED = false>
 __global__ __launch_bounds__(kBlock) void ell_kernel_x2(int nrow, int k, const int32_t* __restrict__ col,
                                                         const double* __restrict__ val,
-                                                        const double* __restrict__ x, double* __restrict__ y, const int32_t* __restrict__ rp = nullptr)
+                                                        const double* __restrict__ x, double* __restrict__ y)
 {
     const int i = 2 * (blockIdx.x * kBlock + threadIdx.x);
     if (i >= nrow) return;  // nrow even: i+1 < nrow too
-    const int    len0 = MASKED ? rp[i + 1] - rp[i] : k, len1 = MASKED ? rp[i + 2] - rp[i + 1] : k;  // (MASKED: see ell_kernel)
     f64x2        acc    = *reinterpret_cast<const f64x2*>(y + i);
     const size_t stride = (size_t)nrow;
     size_t       at     = (size_t)i;
@@ -95,14 +99,14 @@ __global__ __launch_bounds__(kBlock) void ell_kernel_x2(int nrow, int k, const i
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
         {
-            xa[u] = x[c[u].x];
-            xb[u] = x[c[u].y];
+            xa[u] = x[MASKED && c[u].x < 0 ? ~c[u].x : c[u].x];
+            xb[u] = x[MASKED && c[u].y < 0 ? ~c[u].y : c[u].y];
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
         {
-            if (!MASKED || s + u < len0) acc.x = fma(v[u].x, xa[u], acc.x);
-            if (!MASKED || s + u < len1) acc.y = fma(v[u].y, xb[u], acc.y);
+            if (!MASKED || c[u].x >= 0) acc.x = fma(v[u].x, xa[u], acc.x);
+            if (!MASKED || c[u].y >= 0) acc.y = fma(v[u].y, xb[u], acc.y);
         }
         at += (size_t)UNROLL * stride;
     }
@@ -110,12 +114,12 @@ __global__ __launch_bounds__(kBlock) void ell_kernel_x2(int nrow, int k, const i
     {
         const i32x2   c = load_stream(reinterpret_cast<const i32x2*>(col + at));
         const f64x2   v = load_stream(reinterpret_cast<const f64x2*>(val + at));
-        const double  xa = x[c.x], xb = x[c.y];
-        if (!MASKED || s < len0) acc.x = fma(v.x, xa, acc.x);
-        if (!MASKED || s < len1) acc.y = fma(v.y, xb, acc.y);
+        const double  xa = x[MASKED && c.x < 0 ? ~c.x : c.x], xb = x[MASKED && c.y < 0 ? ~c.y : c.y];
+        if (!MASKED || c.x >= 0) acc.x = fma(v.x, xa, acc.x);
+        if (!MASKED || c.y >= 0) acc.y = fma(v.y, xb, acc.y);
         at += stride;
     }
-    *reinterpret_cast<f64x2*>(y + i) = acc;  // (a row without entries gets back the y it had: the same bits)
+    *reinterpret_cast<f64x2*>(y + i) = acc;
 }
 // ---- ELL whose slots are diagonals ---------------------------------------------------------------------------------
 // ELL is what stencil and band matrices are stored in, and there slot s of most rows holds the same diagonal:
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(kBlock) void ell_diag_scan_kernel(int nrow, int k, 
         if (on)
         {
             const i32x2 c = *reinterpret_cast<const i32x2*>(col + (size_t)i + (size_t)s * nrow);
-            conf          = c.x == i + o && c.y == i + 1 + o;
+            conf          = c.x >= 0 && c.y >= 0 && c.x == i + o && c.y == i + 1 + o;  // (>= 0: a padding slot of a CSR handle's ELL copy holds a complement)
         }
         const u64 b = __ballot(conf);
         if (lane == 0 && i < nrow)  // (the grid is rounded up to whole workgroups: wavefronts past the last row pair own no words)
@@ -226,7 +230,7 @@ template <int UNROLL, bool XWIN, bool TILED, bool MASKED = false>
 __global__ __launch_bounds__(kBlock) void ell_diag_kernel_x2(int nrow, int k, const int32_t* __restrict__ col,
                                                              const double* __restrict__ val, const double* __restrict__ x,
                                                              double* __restrict__ y, const int32_t* __restrict__ off,
-                                                             const u64* __restrict__ mask, int ncol, const int32_t* __restrict__ rp = nullptr)
+                                                             const u64* __restrict__ mask, int ncol)
 {
     extern __shared__ double xs[];  // XWIN: the stretches of x this block's conforming entries read (stage_x_windows)
     const int r0 = 2 * kBlock * (int)blockIdx.x;
@@ -237,7 +241,6 @@ __global__ __launch_bounds__(kBlock) void ell_diag_kernel_x2(int nrow, int k, co
     const u64* __restrict__ wm = mask + (size_t)wave * k;  // this wavefront's words: scalar loads
     const u64 bit = 1ull << (threadIdx.x & 63);
     const int32_t* __restrict__ xbase = off + k;
-    const int    len0 = MASKED ? rp[i + 1] - rp[i] : k, len1 = MASKED ? rp[i + 2] - rp[i + 1] : k;  // (MASKED: see ell_kernel)
     f64x2        acc    = *reinterpret_cast<const f64x2*>(y + i);
     const size_t stride = TILED ? (size_t)(2 * kBlock) : (size_t)nrow;
     size_t       at     = TILED ? (size_t)blockIdx.x * (2 * kBlock) * k + 2 * threadIdx.x : (size_t)i;
@@ -253,7 +256,8 @@ __global__ __launch_bounds__(kBlock) void ell_diag_kernel_x2(int nrow, int k, co
             {
                 const int s = s0 + u;
                 double    x0, x1;
-                if (wm[s] & bit)  // nearly always the whole wavefront
+                bool      live0 = true, live1 = true;  // (MASKED: a padding slot of a CSR handle's ELL copy - see ell_kernel)
+                if (wm[s] & bit)  // nearly always the whole wavefront; a conforming slot holds a real column
                 {
                     if constexpr (XWIN)
                     {
@@ -271,11 +275,16 @@ __global__ __launch_bounds__(kBlock) void ell_diag_kernel_x2(int nrow, int k, co
                 else
                 {
                     const i32x2 c = load_stream(reinterpret_cast<const i32x2*>(col + (size_t)i + (size_t)s * nrow));
-                    x0            = x[c.x];
-                    x1            = x[c.y];
+                    if constexpr (MASKED)
+                    {
+                        live0 = c.x >= 0;
+                        live1 = c.y >= 0;
+                    }
+                    x0 = x[MASKED && c.x < 0 ? ~c.x : c.x];
+                    x1 = x[MASKED && c.y < 0 ? ~c.y : c.y];
                 }
-                if (!MASKED || s < len0) acc.x = fma(v[u].x, x0, acc.x);
-                if (!MASKED || s < len1) acc.y = fma(v[u].y, x1, acc.y);
+                if (!MASKED || live0) acc.x = fma(v[u].x, x0, acc.x);
+                if (!MASKED || live1) acc.y = fma(v[u].y, x1, acc.y);
             }
         at += (size_t)UNROLL * stride;
     }
@@ -628,11 +637,10 @@ int csr_ell_copy_build(spmv_mat* m)
                  "an ELL copy of %d rows x %d slots for %lld entries: the padding is out of proportion", m->nrow, m->max_row_nnz, (long long)m->nnz);
     spmv_mat* ell = nullptr;
     SPMV_TRY(csr_to_ell(m->ctx, m, &ell, /*pad_own_column=*/true));
-    // the copy's kernels leave its padding OUT of the sums (MASKED: slots beyond a row's own length, read off this handle's
-    // row_ptr, which outlives the copy: panel_keep_csr = 0 never releases it): the copy is the CSR matrix in non-finite arithmetic
-    // too - a row that reads x[c] = inf ends at inf, a row without entries is not touched.  (The padding still carries the row's
-    // own last column, so that the gathers the kernels issue for it stay inside x and near the row's other gathers.)
-    ell->ell_rp = m->a;
+    // the copy's padding slots carry a negative column (convert.hip: PAD_OWN) and its kernels - the MASKED instances - leave them out
+    // of the sums: the copy is the CSR matrix in non-finite arithmetic too (a row that reads x[c] = inf ends at inf, a row without
+    // entries keeps its y)
+    ell->ell_pad_marked = true;
     ell->pb_trial          = m->pb_trial;
     ell->sel_no_rowgrouped = true;
     plan_hand_down(m, ell, kPlanChildEll);
@@ -826,15 +834,16 @@ __global__ __launch_bounds__(kBlock) void ell_rowmajor_kernel(int nrow, int k, c
 
 // skip[i / 64] bit i % 64 = row i has a slot that is not its diagonal (col != i + off[s]); the grid covers whole words
 __global__ __launch_bounds__(kBlock) void ell_row_conform_kernel(int nrow, int k, const int32_t* __restrict__ col, const int32_t* __restrict__ off,
-                                                                 u64* __restrict__ skip, const int32_t* __restrict__ rp)
+                                                                 u64* __restrict__ skip)
 {
     const int i  = blockIdx.x * kBlock + (int)threadIdx.x;
     bool      nc = false;
     if (i < nrow)
-    {
-        for (int s = 0; s < k; ++s) nc |= col[(size_t)i + (size_t)s * nrow] != i + off[s];
-        if (rp) nc |= rp[i + 1] - rp[i] < k;  // (the ELL copy of a CSR handle: a row with padding goes to the side kernel, which leaves the padding out)
-    }
+        for (int s = 0; s < k; ++s)
+        {
+            const int c = col[(size_t)i + (size_t)s * nrow];
+            nc |= c < 0 || c != i + off[s];  // (c < 0: a padding slot of a CSR handle's ELL copy: the row goes to the side kernel, which leaves it out)
+        }
     const u64 b = __ballot(nc);
     if ((threadIdx.x & 63) == 0 && (i >> 6) < (nrow + 63) / 64) skip[i >> 6] = b;
 }
@@ -844,26 +853,29 @@ __global__ __launch_bounds__(kBlock) void ell_row_conform_kernel(int nrow, int k
 // that the bits are the ELL kernels' (one lane per row walking its slots alone took 25 us for C3's 63 rows x 64 slots: a chain of
 // 64 dependent gathers - a twelfth of the DIA pass it follows; this form takes the 3 us of a launch)
 __global__ __launch_bounds__(kBlock) void ell_rows_list_kernel(int nlist, const int32_t* __restrict__ rows, int nrow, int k, const int32_t* __restrict__ col,
-                                                               const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y,
-                                                               const int32_t* __restrict__ rp)
+                                                               const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y)
 {
     const int t = (int)((blockIdx.x * kBlock + threadIdx.x) >> 6), lane = (int)(threadIdx.x & 63);
     if (t >= nlist) return;  // (uniform over the wavefront)
     const int i   = rows[t];
-    if (rp) k = rp[i + 1] - rp[i];  // (the ELL copy of a CSR handle: the row's own entries, not its padding; uniform over the wavefront)
-    if (k == 0) return;
     double    acc = y[i];
     for (int s0 = 0; s0 < k; s0 += kWave)
     {
         const int s = s0 + lane;
         double    v = 0.0, xv = 0.0;
+        int       c = 0;  // (c < 0: a padding slot of a CSR handle's ELL copy - no part of the sum; a true ELL handle has none)
         if (s < k)
         {
+            c  = col[(size_t)i + (size_t)s * nrow];
             v  = val[(size_t)i + (size_t)s * nrow];
-            xv = x[col[(size_t)i + (size_t)s * nrow]];
+            xv = x[c < 0 ? ~c : c];
         }
         const int n = min(kWave, k - s0);
-        for (int j = 0; j < n; ++j) acc = fma(__shfl(v, j), __shfl(xv, j), acc);  // every lane forms the same sum, in slot order
+        for (int j = 0; j < n; ++j)  // every lane forms the same sum, in slot order
+        {
+            const double vj = __shfl(v, j), xj = __shfl(xv, j);
+            if (__shfl(c, j) >= 0) acc = fma(vj, xj, acc);
+        }
     }
     if (lane == 0) y[i] = acc;
 }
@@ -913,7 +925,7 @@ int ell_build_dia_order(spmv_mat* m, bool only_if_worth)
     {
         if (hipMemcpyAsync(h_off.data(), m->ell_diag, sizeof(int32_t) * (size_t)k, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { rc = SPMV_ERR_HIP; break; }
         if (hipMalloc(&skip, sizeof(u64) * words) != hipSuccess) { skip = nullptr; rc = SPMV_ERR_ALLOC; break; }
-        hipLaunchKernelGGL(ell_row_conform_kernel, dim3((unsigned)ceil_div((int64_t)words * 64, kBlock)), dim3(kBlock), 0, ctx->stream, nrow, k, m->b, m->ell_diag, skip, m->ell_rp);
+        hipLaunchKernelGGL(ell_row_conform_kernel, dim3((unsigned)ceil_div((int64_t)words * 64, kBlock)), dim3(kBlock), 0, ctx->stream, nrow, k, m->b, m->ell_diag, skip);
         if (hipGetLastError() != hipSuccess || hipMemcpyAsync(h_skip.data(), skip, sizeof(u64) * words, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = SPMV_ERR_HIP; break; }
         std::vector<int32_t> nc;
@@ -1017,7 +1029,7 @@ int ell_own_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
         if (A->ell_nc_count > 0)
         {
             hipLaunchKernelGGL(ell_rows_list_kernel, dim3((unsigned)ceil_div((int64_t)A->ell_nc_count * kWave, kBlock)), dim3(kBlock), 0, ctx->stream, A->ell_nc_count, A->ell_nc_rows,
-                               A->nrow, A->k, A->b, A->v, x, y, A->ell_rp);
+                               A->nrow, A->k, A->b, A->v, x, y);
             SPMV_HIP(hipGetLastError());
         }
         return SPMV_OK;
@@ -1033,11 +1045,11 @@ int ell_own_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
         const size_t   lds  = xwin ? sizeof(double) * (size_t)A->ell_diag_lds : 0;
 #define SPMV_ELL_DIAG_M(U, W, T, M)                                                                                                              \
     hipLaunchKernelGGL((ell_diag_kernel_x2<U, W, T, M>), dim3(grid), dim3(kBlock), lds, ctx->stream, A->nrow, A->k, A->b, T ? A->ell_tval : A->v, x, y, \
-                       A->ell_diag, (const u64*)A->ell_diag_mask, A->ncol, A->ell_rp)
+                       A->ell_diag, (const u64*)A->ell_diag_mask, A->ncol)
 #define SPMV_ELL_DIAG(U, W)                                    \
     do                                                         \
     {                                                          \
-        if (A->ell_rp) /* the ELL copy of a CSR handle: padding left out */ \
+        if (A->ell_pad_marked) /* the ELL copy of a CSR handle: padding left out */ \
         {                                                      \
             if (A->ell_tval)                                   \
                 SPMV_ELL_DIAG_M(U, W, true, true);             \
@@ -1072,10 +1084,10 @@ int ell_own_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
 #define SPMV_ELL_X2(U)                                                                                                                                     \
     do                                                                                                                                                     \
     {                                                                                                                                                      \
-        if (A->ell_rp)                                                                                                                                     \
-            hipLaunchKernelGGL((ell_kernel_x2<U, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, A->nrow, A->k, A->b, A->v, x, y, A->ell_rp);           \
-        else                                                                                                                                               \
-            hipLaunchKernelGGL((ell_kernel_x2<U, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, A->nrow, A->k, A->b, A->v, x, y, (const int32_t*)nullptr); \
+        if (A->ell_pad_marked)                                                                                                 \
+            hipLaunchKernelGGL((ell_kernel_x2<U, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, A->nrow, A->k, A->b, A->v, x, y);  \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((ell_kernel_x2<U, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, A->nrow, A->k, A->b, A->v, x, y); \
     } while (0)
         if (A->lanes_per_row == 4)
             SPMV_ELL_X2(8);
@@ -1088,10 +1100,10 @@ int ell_own_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
     else
     {
         const unsigned grid = (unsigned)ceil_div(A->nrow, kBlock);
-        if (A->ell_rp)
-            hipLaunchKernelGGL((ell_kernel<8, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, A->nrow, A->k, A->b, A->v, x, y, A->ell_rp);
+        if (A->ell_pad_marked)
+            hipLaunchKernelGGL((ell_kernel<8, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, A->nrow, A->k, A->b, A->v, x, y);
         else
-            hipLaunchKernelGGL((ell_kernel<8, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, A->nrow, A->k, A->b, A->v, x, y, (const int32_t*)nullptr);
+            hipLaunchKernelGGL((ell_kernel<8, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, A->nrow, A->k, A->b, A->v, x, y);
     }
     SPMV_HIP(hipGetLastError());
     return SPMV_OK;

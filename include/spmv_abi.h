@@ -124,8 +124,8 @@ typedef enum spmv_csr_kernel
                               min(500000, 8/u) entries: panel 0.64, split 0.29.  CSR handles only; AUTO times it where the longest
                               row is >= 4096 and 32x the mean */
     SPMV_CSR_ELL      = 8  /* an ELL copy of the handle (column-major slots, padded to the longest row with value 0.0 and the row's own
-                              last column; the copy's kernels leave that padding OUT of the sums - slots beyond a row's own length,
-                              read off row_ptr - so the copy is the CSR matrix in non-finite arithmetic too) with the ELL kernels -
+                              last column; the copy's kernels leave that padding OUT of the sums - its slots are marked in the
+                              copy's index stream - so the copy is the CSR matrix in non-finite arithmetic too) with the ELL kernels -
                               diagonal slots recognised, one or two rows per lane, the DIA-order copy, timed - for
                               matrices of (nearly) equal rows: stencils, bands, block diagonals (tridiagonal, 8M rows: panel 0.087
                               ms, this 0.056; a band of 33: 0.163 / 0.105).  12 bytes per slot on top of the CSR arrays.  CSR
