@@ -886,7 +886,14 @@ void CSRMatrixMatVectorNuma(const CSRMatrix& A, const Vector& x, Vector& y, int 
         if (!plan.empty()) (void)spmv_ctx_set_plan(c, plan.data(), (int64_t)plan.size());
         check(spmv_csr_upload_shard(c, s.row0, s.row1, A.ncol, rp64.data(), A.col_ind, A.values, &s.mat), "spmv_csr_upload_shard");
         if (!plan.empty())
+        {
             (void)spmv_ctx_set_plan(c, nullptr, 0);
+            // a two-phase shard built under a plan was built without the search over where its product stream lies in THIS device's
+            // memory (no part of a plan): it runs now, within the engine's default budget
+            spmv_mat_info inf;
+            if (spmv_mat_get_info(s.mat, &inf) == SPMV_OK && inf.kernel == SPMV_CSR_TWOPHASE)
+                check(spmv_mat_set_param(s.mat, "twophase_choose_pieces", 1), "twophase_choose_pieces");
+        }
         else
         {
             int64_t len = 0;

@@ -189,11 +189,14 @@ int run_sharded_synthetic(const Options& o)
         off[(size_t)i]     = r0;
         off[(size_t)i + 1] = r1;
         check(spmv_mat_get_info(mat[(size_t)i], &info[(size_t)i]), "spmv_mat_get_info");
-        if (info[(size_t)i].kernel == SPMV_CSR_TWOPHASE && o.placement_budget_mb >= 0)
+        const bool under_plan = !powerlaw && i > 0 && !plan.empty();
+        if (info[(size_t)i].kernel == SPMV_CSR_TWOPHASE && (o.placement_budget_mb >= 0 || under_plan))
         {
             // a job that has the devices to itself may grant the product stream's piece search more than the engine's 8 GB
-            // (one slow shard sets the step of all of them)
-            check(spmv_mat_set_param(mat[(size_t)i], "twophase_placement_budget_mb", o.placement_budget_mb), "twophase_placement_budget_mb");
+            // (one slow shard sets the step of all of them); and a shard built under shard 0's plan was built
+            // without any search (where the stream lies in ITS device's memory is no part of a plan): it runs now
+            if (o.placement_budget_mb >= 0)
+                check(spmv_mat_set_param(mat[(size_t)i], "twophase_placement_budget_mb", o.placement_budget_mb), "twophase_placement_budget_mb");
             check(spmv_mat_set_param(mat[(size_t)i], "twophase_choose_pieces", 1), "twophase_choose_pieces");
         }
         if (info[(size_t)i].kernel == SPMV_CSR_PANEL || info[(size_t)i].kernel == SPMV_CSR_TWOPHASE)

@@ -610,11 +610,14 @@ def main() -> None:
         if args.flags:
             A.set_flags(args.flags)
         info = A.info
-        if int(info.kernel) == 5 and args.placement_budget_mb != 8192:
+        built_under_plan = bool(shared_plan) and rank != 0
+        if int(info.kernel) == 5 and (args.placement_budget_mb != 8192 or built_under_plan):
             # The engine chose its product stream's pieces within its default budget (8 GB beyond the stream) when it built the
             # layout.  This job has the device to itself, so it grants the search more (transient: freed before the call returns);
-            # one slow rank sets the step of the whole job.  Reported under config.twophase_layout.
-            A.set_param("twophase_placement_budget_mb", args.placement_budget_mb)
+            # one slow rank sets the step of the whole job.  Reported under config.twophase_layout.  A shard built under rank 0's
+            # plan was built WITHOUT any search (where the stream lies in this device's memory is no part of a plan): it runs now.
+            if args.placement_budget_mb != 8192:
+                A.set_param("twophase_placement_budget_mb", args.placement_budget_mb)
             A.set_param("twophase_choose_pieces", 1)
         ctx.sync()
         setup_s = time.perf_counter() - t_setup  # generation + analysis + layout + trials: one-off, outside the timed region
