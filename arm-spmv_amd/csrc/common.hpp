@@ -455,7 +455,7 @@ int csc_build_rowgrouped(spmv_mat* m, int32_t force_kernel);
 void csc_drop_rowgrouped(spmv_mat* m);
 int dia_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y);
 int dia_rows_apply(spmv_ctx* ctx, int nrow, int jmax, int k, const int32_t* offsets, const double* values, const double* x, double* y, bool off_known,
-                   int off_min, int off_max, uint32_t flags, const unsigned long long* skip_rows);
+                   int off_min, int off_max, uint32_t flags, const unsigned long long* skip_rows, int stride);
 int vec_fill(spmv_ctx* ctx, double* d, int64_t n, double a);
 int vec_copy2(spmv_ctx* ctx, double* dst0, const double* src0, int64_t n0, double* dst1, const double* src1, int64_t n1);  // two copies, one launch
 int vec_dot(spmv_ctx* ctx, const double* x, const double* y, int64_t n, double* result);

@@ -816,8 +816,9 @@ namespace
 {
 constexpr int kRmChunk = 16;  // slots per tile of the transposition
 
-// rval[i * k + s] = val[i + s * nrow]: tiles of 256 rows x 16 slots through LDS, both sides in whole 128-byte lines
-__global__ __launch_bounds__(kBlock) void ell_rowmajor_kernel(int nrow, int k, const double* __restrict__ val, double* __restrict__ rval)
+// rval[i * kp + s] = val[i + s * nrow] (kp: the row stride, k rounded up to even): tiles of 256 rows x 16 slots through LDS, both
+// sides in whole 128-byte lines
+__global__ __launch_bounds__(kBlock) void ell_rowmajor_kernel(int nrow, int k, int kp, const double* __restrict__ val, double* __restrict__ rval)
 {
     __shared__ double tile[kBlock * (kRmChunk + 1)];
     const int r0 = blockIdx.x * kBlock, s0 = blockIdx.y * kRmChunk;
@@ -828,7 +829,7 @@ __global__ __launch_bounds__(kBlock) void ell_rowmajor_kernel(int nrow, int k, c
     for (int p = 0; p < kRmChunk; ++p)
     {
         const int r = rr + p * (kBlock / kRmChunk);
-        if (r0 + r < nrow && s0 + d < k) rval[(size_t)(r0 + r) * k + s0 + d] = tile[r * (kRmChunk + 1) + d];
+        if (r0 + r < nrow && s0 + d < k) rval[(size_t)(r0 + r) * kp + s0 + d] = tile[r * (kRmChunk + 1) + d];
     }
 }
 
@@ -887,7 +888,7 @@ void ell_free_dia_order(spmv_mat* m)
     (void)hipFree(m->ell_rval);
     if (m->ell_skip) (void)hipFree(m->ell_skip);
     if (m->ell_nc_rows) (void)hipFree(m->ell_nc_rows);
-    m->device_bytes -= (int64_t)sizeof(double) * m->nrow * m->k + (int64_t)sizeof(u64) * ((m->nrow + 63) / 64) + (int64_t)sizeof(int32_t) * std::max(m->ell_nc_count, 1);
+    m->device_bytes -= (int64_t)sizeof(double) * m->nrow * (m->k + (m->k & 1)) + (int64_t)sizeof(u64) * ((m->nrow + 63) / 64) + (int64_t)sizeof(int32_t) * std::max(m->ell_nc_count, 1);
     m->ell_rval     = nullptr;
     m->ell_skip     = nullptr;
     m->ell_nc_rows  = nullptr;
@@ -913,7 +914,7 @@ int ell_build_dia_order(spmv_mat* m, bool only_if_worth)
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (size_t)slots * 8 * 4 > free_b) return SPMV_OK;
     }
-    const int         k = m->k, nrow = m->nrow;
+    const int         k = m->k, nrow = m->nrow, kp = m->k + (m->k & 1);
     const size_t      words = (size_t)(nrow + 63) / 64;
     std::vector<int32_t> h_off((size_t)k);
     std::vector<u64>     h_skip(words);
@@ -932,10 +933,12 @@ int ell_build_dia_order(spmv_mat* m, bool only_if_worth)
         for (size_t w = 0; w < words; ++w)
             for (u64 b = h_skip[w]; b; b &= b - 1) nc.push_back((int32_t)(w * 64 + (size_t)__builtin_ctzll(b)));
         if (only_if_worth && (int64_t)nc.size() * 16 > nrow) break;  // too many rows for the side kernel: not a candidate (rc OK, nothing built)
-        if (hipMalloc(&rval, sizeof(double) * (size_t)slots) != hipSuccess) { rval = nullptr; rc = SPMV_ERR_ALLOC; break; }
+        // (rows padded to an even stride: the DIA kernel's 16-byte path needs every pair inside its row; the pad holds 0.0 and is never consumed)
+        if (hipMalloc(&rval, sizeof(double) * (size_t)nrow * (size_t)kp) != hipSuccess) { rval = nullptr; rc = SPMV_ERR_ALLOC; break; }
+        if (kp != k && hipMemsetAsync(rval, 0, sizeof(double) * (size_t)nrow * (size_t)kp, ctx->stream) != hipSuccess) { rc = SPMV_ERR_HIP; break; }
         if (hipMalloc(&list, sizeof(int32_t) * std::max<size_t>(nc.size(), 1)) != hipSuccess) { list = nullptr; rc = SPMV_ERR_ALLOC; break; }
         if (!nc.empty() && hipMemcpyAsync(list, nc.data(), sizeof(int32_t) * nc.size(), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = SPMV_ERR_HIP; break; }
-        hipLaunchKernelGGL(ell_rowmajor_kernel, dim3((unsigned)ceil_div(nrow, kBlock), (unsigned)ceil_div(k, kRmChunk)), dim3(kBlock), 0, ctx->stream, nrow, k, m->v, rval);
+        hipLaunchKernelGGL(ell_rowmajor_kernel, dim3((unsigned)ceil_div(nrow, kBlock), (unsigned)ceil_div(k, kRmChunk)), dim3(kBlock), 0, ctx->stream, nrow, k, kp, m->v, rval);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = SPMV_ERR_HIP; break; }  // (nc, host, goes out of scope)
         m->ell_rval     = rval;
         m->ell_skip     = skip;
@@ -943,7 +946,7 @@ int ell_build_dia_order(spmv_mat* m, bool only_if_worth)
         m->ell_nc_count = (int32_t)nc.size();
         m->ell_off_min  = *std::min_element(h_off.begin(), h_off.end());
         m->ell_off_max  = *std::max_element(h_off.begin(), h_off.end());
-        m->device_bytes += (int64_t)sizeof(double) * slots + (int64_t)sizeof(u64) * (int64_t)words + (int64_t)sizeof(int32_t) * std::max(m->ell_nc_count, 1);
+        m->device_bytes += (int64_t)sizeof(double) * nrow * kp + (int64_t)sizeof(u64) * (int64_t)words + (int64_t)sizeof(int32_t) * std::max(m->ell_nc_count, 1);
         return SPMV_OK;
     } while (0);
     if (rval) (void)hipFree(rval);
@@ -1025,7 +1028,7 @@ int ell_own_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
     {
         // the DIA kernel over the row-major copy (every row whose slots are all diagonals), then the few other rows from the
         // column-major arrays; every column of a conforming row is a real column: the bound is ncol
-        SPMV_TRY(dia_rows_apply(ctx, A->nrow, A->ncol, A->k, A->ell_diag, A->ell_rval, x, y, true, A->ell_off_min, A->ell_off_max, A->flags, A->ell_skip));
+        SPMV_TRY(dia_rows_apply(ctx, A->nrow, A->ncol, A->k, A->ell_diag, A->ell_rval, x, y, true, A->ell_off_min, A->ell_off_max, A->flags, A->ell_skip, A->k + (A->k & 1)));
         if (A->ell_nc_count > 0)
         {
             hipLaunchKernelGGL(ell_rows_list_kernel, dim3((unsigned)ceil_div((int64_t)A->ell_nc_count * kWave, kBlock)), dim3(kBlock), 0, ctx->stream, A->ell_nc_count, A->ell_nc_rows,

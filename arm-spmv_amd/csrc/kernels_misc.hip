@@ -147,8 +147,11 @@ template <bool WIDE, bool XWIN>
 __global__ __launch_bounds__(kBlock) void dia_kernel(int nrow, int jmax, int ndiags, const int32_t* __restrict__ offsets,
                                                      const double* __restrict__ val, const double* __restrict__ x,
                                                      double* __restrict__ y, int off_min, int off_max,
-                                                     const unsigned long long* __restrict__ skip_rows)
+                                                     const unsigned long long* __restrict__ skip_rows, int stride)
 {
+    // stride: doubles between two rows' values (ndiags for a DIA handle - the reference's layout; the DIA-order copy of an ELL
+    // handle with an odd number of slots pads its rows to an even stride so that the 16-byte path applies: the pad is never
+    // consumed, the loop below runs to ndiags)
     __shared__ double tile[kBlock * (kDiaChunk + 1)];
     extern __shared__ double xs[];  // XWIN: kBlock + off_max - off_min entries of x
     constexpr int PER   = WIDE ? 2 : 1;                  // diagonals per lane and load
@@ -168,11 +171,11 @@ __global__ __launch_bounds__(kBlock) void dia_kernel(int nrow, int jmax, int ndi
         for (int j = 0; j < NPASS; ++j)
         {
             const int     r = r_mine + j * RPP;
-            const double* p = val + (size_t)(r0 + r) * ndiags + d0 + d_mine;
+            const double* p = val + (size_t)(r0 + r) * stride + d0 + d_mine;
             if constexpr (WIDE)
             {
                 f64x2_t v = {0.0, 0.0};
-                if (r0 + r < nrow && d0 + d_mine < ndiags) v = __builtin_nontemporal_load((const f64x2_t*)p);  // ndiags even
+                if (r0 + r < nrow && d0 + d_mine < ndiags) v = __builtin_nontemporal_load((const f64x2_t*)p);  // stride even: the pair is 16-byte aligned and inside the row
                 stage[2 * j]     = v[0];
                 stage[2 * j + 1] = v[1];
             }
@@ -488,22 +491,22 @@ int dia_apply(spmv_ctx* ctx, const spmv_mat* A, const double* x, double* y)
     if (A->nrow == 0 || A->k == 0) return SPMV_OK;
     // a row shard (offsets shifted by its first row) keeps the bound of the whole matrix; never past the end of x
     const int jmax = std::min(A->dia_col_bound > 0 ? A->dia_col_bound : std::min(A->nrow, A->ncol), A->ncol);
-    return dia_rows_apply(ctx, A->nrow, jmax, A->k, A->a, A->v, x, y, A->dia_off_known, A->dia_off_min, A->dia_off_max, A->flags, nullptr);
+    return dia_rows_apply(ctx, A->nrow, jmax, A->k, A->a, A->v, x, y, A->dia_off_known, A->dia_off_min, A->dia_off_max, A->flags, nullptr, A->k);
 }
 
 // the DIA product over row-major values (a DIA handle's own, or the DIA-order copy of an ELL handle's values: kernels_ell.hip)
 int dia_rows_apply(spmv_ctx* ctx, int nrow, int jmax, int k, const int32_t* offsets, const double* values, const double* x, double* y, bool off_known,
-                   int off_min, int off_max, uint32_t flags, const unsigned long long* skip_rows)
+                   int off_min, int off_max, uint32_t flags, const unsigned long long* skip_rows, int stride)
 {
     if (nrow == 0 || k == 0) return SPMV_OK;
     const dim3 grid((unsigned)ceil_div(nrow, kBlock));
-    const bool wide = k % 2 == 0 && (((uintptr_t)values) & 15) == 0;
+    const bool wide = stride % 2 == 0 && stride >= k + (k & 1) && (((uintptr_t)values) & 15) == 0;  // (an odd k needs its pad: a pair never leaves the row)
     // offsets within a band of at most 1792 (known from the upload / the generator): x goes through LDS
     const bool   xwin = off_known && off_min <= off_max && (int64_t)off_max - off_min <= 1792 && !(flags & SPMV_FLAG_DIA_GLOBAL_X);
     const size_t lds  = xwin ? sizeof(double) * (size_t)(kBlock + off_max - off_min) : 0;
 #define SPMV_DIA(W, X)                                                                                                 \
     hipLaunchKernelGGL((dia_kernel<W, X>), grid, dim3(kBlock), lds, ctx->stream, nrow, jmax, k, offsets, values, x, y, \
-                       xwin ? off_min : 0, xwin ? off_max : 0, skip_rows)
+                       xwin ? off_min : 0, xwin ? off_max : 0, skip_rows, stride)
     if (wide && xwin)
         SPMV_DIA(true, true);
     else if (wide)
