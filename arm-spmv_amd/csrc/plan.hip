@@ -35,28 +35,47 @@ int collect(const spmv_mat* m, std::vector<plan_node>& out)
     n.lanes_per_row = m->lanes_per_row;
     n.flags         = m->flags;
     n.child_rowgrouped = n.child_long = n.child_ell = -1;
-    // the panel layout: what it was built with, and what a launch reads (requests first, else what the trial found, else defaults:
-    // the same precedence as panel_launch)
-    n.pb_group_rows = m->pb_group_rows;
-    n.pb_width      = m->pb_val ? m->pb_built_width : m->pb_panel_width;
-    n.pb_sort       = m->pb_val ? m->pb_built_sort : m->pb_sort;
-    n.pb_aos        = m->pb_val ? m->pb_built_layout : m->pb_aos;
+    // A plan is CANONICAL: a field is written only where the kernel that runs reads it (everything else stays 0), so that two
+    // handles in the same effective state give the same bytes whatever layouts of other kernels they still hold or once held
+    // (a handle forced to the row-parallel kernel keeps its panel layout in memory; a handle built from that plan has none).
+    const bool csr = m->format == SPMV_FMT_CSR;
+    if (csr && m->kernel == SPMV_CSR_PANEL)
     {
+        // the panel layout: what it was built with, and what a launch reads (requests first, else what the trial found, else
+        // defaults: the same precedence as panel_launch)
+        n.pb_group_rows = m->pb_group_rows;
+        n.pb_width      = m->pb_val ? m->pb_built_width : m->pb_panel_width;
+        n.pb_sort       = m->pb_val ? m->pb_built_sort : m->pb_sort;
+        n.pb_aos        = m->pb_val ? m->pb_built_layout : m->pb_aos;
         const int unroll = m->pb_unroll > 0 ? m->pb_unroll : (m->pb_unroll_tuned > 0 ? m->pb_unroll_tuned : 8);
         n.pb_unroll      = unroll >= 8 ? 8 : (unroll >= 4 ? 4 : 2);
         n.pb_pipe        = std::max(0, std::min(m->pb_pipe >= 0 ? m->pb_pipe : (m->pb_pipe_tuned > 0 ? m->pb_pipe_tuned : 1), 2));
         const int sync   = (m->pb_sync >= 0 ? m->pb_sync : m->pb_sync_tuned) & 3;
         n.pb_sync        = sync == 2 ? 3 : sync;
+        n.pb_two_per_cu  = m->pb_two_per_cu;
+        n.pb_rounds      = m->pb_val ? std::max(1, m->pb_built_rounds) : std::max(1, m->pb_rounds_req);
     }
-    n.pb_two_per_cu = m->pb_two_per_cu;
-    n.pb_rounds     = m->pb_val ? std::max(1, m->pb_built_rounds) : std::max(1, m->pb_rounds_req);
-    n.split_threshold = m->format == SPMV_FMT_CSR && m->kernel == SPMV_CSR_SPLIT ? (m->split_built_threshold > 0 ? m->split_built_threshold : csr_split_threshold(m)) : 0;
-    n.split_mode      = m->split_built_mode ? m->split_built_mode : m->split_mode;
-    n.tp_pcols        = m->tp_val ? m->tp_pcols : m->tp_pcols_req;
-    n.tp_rotate       = m->tp_rotate;
-    n.ell_variant     = m->ell_variant;
-    n.ell_tiled       = m->ell_tval ? 1 : 0;
-    n.coo_bins_per_xcd = m->format == SPMV_FMT_COO ? m->cb_bins / 8 : 0;
+    if (csr && m->kernel == SPMV_CSR_SPLIT)
+    {
+        n.split_threshold = m->split_built_threshold > 0 ? m->split_built_threshold : csr_split_threshold(m);
+        n.split_mode      = m->split_built_mode ? m->split_built_mode : m->split_mode;
+    }
+    if (csr && m->kernel == SPMV_CSR_TWOPHASE)
+    {
+        n.tp_pcols  = m->tp_val ? m->tp_pcols : m->tp_pcols_req;
+        n.tp_rotate = m->tp_rotate;
+    }
+    if (csr && m->kernel != SPMV_CSR_VECTOR && m->kernel != SPMV_CSR_LDSWIN && m->kernel != SPMV_CSR_AUTO) n.lanes_per_row = 0;  // (only the lane-group kernels read it)
+    if (csr && m->kernel != SPMV_CSR_VECTOR && m->kernel != SPMV_CSR_AUTO) n.flags = 0;  // (the tuning bits of the row-parallel kernel)
+    if (m->format == SPMV_FMT_ELL)
+    {
+        const bool own   = !(m->coo_csr && m->kernel == SPMV_CSR_PANEL);  // the format's own kernels run (else: the row-grouped copy)
+        n.ell_variant    = own ? m->ell_variant : 0;
+        n.ell_tiled      = own && m->ell_tval ? 1 : 0;
+        if (!own) n.lanes_per_row = 0;
+    }
+    if (m->format == SPMV_FMT_COO) n.coo_bins_per_xcd = m->kernel == SPMV_CSR_PANEL ? 0 : m->cb_bins / 8;
+    if (m->format == SPMV_FMT_COO || m->format == SPMV_FMT_CSC || m->format == SPMV_FMT_DIA) n.lanes_per_row = 0, n.flags = m->format == SPMV_FMT_DIA ? m->flags : 0;
     const bool from_copy = m->format != SPMV_FMT_CSR && m->coo_csr && m->kernel == SPMV_CSR_PANEL;
     const bool split     = m->format == SPMV_FMT_CSR && m->kernel == SPMV_CSR_SPLIT;
     if ((from_copy || split) && m->coo_csr) n.child_rowgrouped = collect(m->coo_csr, out);

@@ -424,6 +424,18 @@ def test_random_large_csr_shapes(ctx, orc, pkg, seed):
         ctx.apply(A, dx, dy)
         ctx.sync()
         ol.assert_parity(dy.download(), ref, scale, f"seed {seed}: {nrow} x {ncol}, {nnz} entries, {name} (kernel {A.info.kernel})")
+        if seed % 2 == 0:
+            # round 6: whatever state the handle is in, its plan rebuilds it on another handle of the same matrix - same kernel, same
+            # copies, nothing timed - and the product stays within the gate
+            plan = A.get_plan()
+            B = ctx.csr(nrow, ncol, rp, cc, cv)
+            B.set_plan(plan)
+            assert B.get_plan() == plan and B.info.kernel == A.info.kernel and B.get_param("select_candidates") == 0, name
+            dy.fill(0.0)
+            ctx.apply(B, dx, dy)
+            ctx.sync()
+            ol.assert_parity(dy.download(), ref, scale, f"seed {seed}: {nrow} x {ncol}, {nnz} entries, {name} from its plan (kernel {B.info.kernel})")
+            del B
 
 
 @pytest.mark.parametrize("seed", range(10))

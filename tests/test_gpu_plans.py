@@ -147,7 +147,9 @@ def test_plans_carry_the_copies_a_handle_runs_from(ctx, orc, pkg, monkeypatch):
         plan = S.get_plan()
         T = ctx.ell(nr, ncol, K, nr * K, ec, ev)
         T.set_plan(plan)
-        assert T.info.kernel == S.info.kernel and T.get_param("ell_variant") == S.get_param("ell_variant") and T.get_plan() == plan
+        assert T.info.kernel == S.info.kernel and T.get_plan() == plan
+        if S.info.kernel == capi.CSR_VECTOR:  # (a handle that runs from its copy has no variant in effect: plans are canonical)
+            assert T.get_param("ell_variant") == S.get_param("ell_variant")
         assert T.get_param("rowgrouped_kernel") == S.get_param("rowgrouped_kernel") and T.get_param("select_candidates") == 0
         got = _product(ctx, T, dxe, nr)
         assert np.max(np.abs(got - refe)) <= ol.REL_TOL * K
