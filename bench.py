@@ -1025,10 +1025,10 @@ def main() -> None:
                 "algorithmic_bytes_per_launch": bytes_launch,
                 "kernel_ms": round(kernel_ms, 5),
                 **(l2 or {}),
-                **({"limiter": "the gathers of x, served by the L2s per distinct 128-byte line (~0.63 lines per entry with 20000 fp64 "
-                               "accumulators per CU: see l2_frac), on top of the HBM-bound entry stream - a CU does not overlap the two "
-                               "(uniform-random columns: ~0.63 ms of stream + ~0.48 ms of gathers; profiles/r06_probe_regacc.txt); "
-                               "the 60 % target is not met on uniform-random columns (DESIGN.md 4.2)"} if l2 and l2["l2_frac"] > 0.75 else {}),
+                **({"limiter": "the L2s' 128-byte line rate (one line operation per gathered x line: ~0.63 per entry with 20000 fp64 "
+                               "accumulators per CU), not HBM: see l2_frac; the 60 % target is not met on uniform-random columns, and twice "
+                               "the accumulators per CU (register file, profiles/r06_probe_regacc.txt) do not get there either (DESIGN.md 4.2)"}
+                   if l2 and l2["l2_frac"] > 0.75 else {}),
             },
         }
         if grouped:
