@@ -14,8 +14,8 @@
 //   probe_regacc [rows] [per_row] [ncol]      defaults 10000000 32 rows
 // Prints the kernel's time per product and the largest |y - y_ref| / (|A||x|).
 // Build (here, no GPU needed): hipcc -O3 -std=c++17 --offload-arch=gfx950 -o build/tools/probe_regacc tools/probe_regacc.hip
-//   switches: -DSTREAM_FIRST=0 -DGATHER_AHEAD=0 -DCBLOCK=6 -DSTREAM_NT=0, timing experiments -DNO_COLLECT=1 -DNO_GATHER=1
-//   -DGATHER_SHAPE=1|2.  Counters: tools/pmc_probe_regacc.sh.
+//   switches: -DSUBSTEPS=2 -DSTREAM_FIRST=0 -DGATHER_AHEAD=0 -DCBLOCK=6 -DSTREAM_NT=0, timing experiments -DNO_COLLECT=1 -DNO_GATHER=1
+//   -DNO_ADDS=1 -DCOLLECT_NOLDS=1 -DGATHER_SHAPE=1|2.  Counters: tools/pmc_probe_regacc.sh.
 // RESULT (profiles/r06_probe_regacc.txt): correct, 23 % fewer L2 operations than the engine's panel kernel, and slower (C2 1.19 ms
 // against 1.114): with 154 accumulator registers per lane too little is left for the loads in flight.  Not part of the engine.
 #include <hip/hip_runtime.h>
@@ -177,6 +177,12 @@ __global__ __launch_bounds__(kThreads) void chunk_build_kernel(int k, int64_t nn
 #ifndef NO_GATHER
 #define NO_GATHER 0   // 1 = x[0] instead of the gathers
 #endif
+#ifndef NO_ADDS
+#define NO_ADDS 0       // timing experiment: the products are summed in a register instead of added into LDS
+#endif
+#ifndef COLLECT_NOLDS
+#define COLLECT_NOLDS 0 // timing experiment: the collection does its arithmetic without reading the staging array
+#endif
 #ifndef GATHER_SHAPE
 #define GATHER_SHAPE 0
 #endif
@@ -239,11 +245,16 @@ __device__ __forceinline__ void gather(const Raw& R, const double* __restrict__ 
         xv[2 * j + 1] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(x) + (((unsigned)cb + o1) << 3));
     }
 }
-__device__ __forceinline__ void adds(const Raw& R, const double (&xv)[2 * kPS], double* sb)
+__device__ __forceinline__ void adds(const Raw& R, const double (&xv)[2 * kPS], double* sb, double& g_sink)
 {
 #pragma unroll
     for (int j = 0; j < kPS; ++j)
     {
+        if (NO_ADDS)
+        {
+            g_sink += R.v[j].x * xv[2 * j] + R.v[j].y * xv[2 * j + 1] + (double)(R.w[j].x & 1u);
+            continue;
+        }
         atomicAdd(&sb[R.w[j].x & ((1u << kSlotBits) - 1u)], R.v[j].x * xv[2 * j]);
         atomicAdd(&sb[R.w[j].y & ((1u << kSlotBits) - 1u)], R.v[j].y * xv[2 * j + 1]);
     }
@@ -273,7 +284,7 @@ __device__ __forceinline__ void collect(double (&acc)[kReg], const uint64_t (&mk
             {
                 const uint64_t m   = mk[b0 + q - R0];
                 const unsigned cnt = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                v[q]               = sprev[base + (int)cnt];
+                v[q]               = COLLECT_NOLDS ? (double)cnt : sprev[base + (int)cnt];
                 base += __builtin_popcountll(m);
             }
         __builtin_amdgcn_sched_barrier(0);  // the block's LDS reads go out together ...
@@ -302,6 +313,7 @@ __global__ __launch_bounds__(kThreads) void regacc_kernel(const int* __restrict_
     for (int g = blockIdx.x; g < ngroups; g += gridDim.x)
     {
         double acc[kReg];
+        double sink = 0.0;
 #pragma unroll
         for (int r = 0; r < kReg; ++r) acc[r] = 0.0;
         for (int i = t; i < 2 * kChunk + 64; i += kThreads) stg[i] = 0.0;
@@ -309,12 +321,19 @@ __global__ __launch_bounds__(kThreads) void regacc_kernel(const int* __restrict_
         const int c0 = choff[g], c1 = choff[g + 1];
         // four register sets in turn: the stream of sub-step s + 3 is requested while s is multiplied (HBM latency is ~2 us:
         // a CU needs ~40 KB of the stream in flight)
+#if SUBSTEPS == 2
+        // two sub-steps of 8 entries per lane, two register sets: a wait for gathers also waits for every OLDER load (vmcnt
+        // counts in order), so what matters is how long ago the stream in front of them was requested - here a whole half chunk
+        Raw A, B;
+        load_raw(A, pw, pv, c0, 0, t);
+#else
         Raw A, B, C, D;
         static_assert(kSub == 4, "four sub-steps per chunk");
         load_raw(A, pw, pv, c0, 0, t);
         load_raw(B, pw, pv, c0, 1, t);
         load_raw(C, pw, pv, c0, 2, t);
-#if GATHER_AHEAD
+#endif
+#if GATHER_AHEAD && SUBSTEPS == 4
         double xa[2 * kPS], xb[2 * kPS];
         gather(A, x, cbase[c0], xa);
 #endif
@@ -330,7 +349,27 @@ __global__ __launch_bounds__(kThreads) void regacc_kernel(const int* __restrict_
             int             base  = lo;
             // the gathers of sub-step s are in flight while the stream of s + 3 is requested and a quarter of the PREVIOUS
             // chunk's sums is collected into the registers
-#if !GATHER_AHEAD
+#if SUBSTEPS == 2
+#define SUBSTEP(CUR, NXT, S)                                                                                   \
+    {                                                                                                          \
+        double   xv[2 * kPS];                                                                                  \
+        uint64_t mk[kReg * ((S) + 1) / kSub - kReg * (S) / kSub];                                              \
+        gather(CUR, x, cb, xv);                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        load_raw(NXT, pw, pv, (S) == 0 ? c : cn, ((S) + 1) % kSub, t);                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        load_masks<kReg * (S) / kSub, kReg * ((S) + 1) / kSub>(mk, mp);                                        \
+        if (!NO_COLLECT) collect<kReg * (S) / kSub, kReg * ((S) + 1) / kSub>(acc, mk, sprev, base);            \
+        if ((S) + 1 == kSub)                                                                                   \
+            for (int i = lo + lane; i < hi; i += 64) sprev[i] = 0.0;                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        adds(CUR, xv, sb, sink);                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }
+            SUBSTEP(A, B, 0)
+            SUBSTEP(B, A, 1)
+#undef SUBSTEP
+#elif !GATHER_AHEAD
 #define SUBSTEP(CUR, NXT, S)                                                                                   \
     {                                                                                                          \
         double   xv[2 * kPS];                                                                                  \
@@ -344,7 +383,7 @@ __global__ __launch_bounds__(kThreads) void regacc_kernel(const int* __restrict_
         if ((S) + 1 == kSub)                                                                                   \
             for (int i = lo + lane; i < hi; i += 64) sprev[i] = 0.0; /* this wavefront's slots, for chunk c + 1 */ \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        adds(CUR, xv, sb);                                                                                     \
+        adds(CUR, xv, sb, sink);                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
     }
             SUBSTEP(A, D, 0)
@@ -370,7 +409,7 @@ __global__ __launch_bounds__(kThreads) void regacc_kernel(const int* __restrict_
         if ((S) + 1 == kSub)                                                                                   \
             for (int i = lo + lane; i < hi; i += 64) sprev[i] = 0.0;                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        adds(CUR, XC, sb);                                                                                     \
+        adds(CUR, XC, sb, sink);                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
     }
             SUBSTEP(A, B, D, xa, xb, 0)
@@ -392,9 +431,14 @@ __global__ __launch_bounds__(kThreads) void regacc_kernel(const int* __restrict_
         load_masks<kReg * (S) / kSub, kReg * ((S) + 1) / kSub>(mk, mp);                    \
         collect<kReg * (S) / kSub, kReg * ((S) + 1) / kSub>(acc, mk, sprev, base);         \
     }
+#if SUBSTEPS == 2
+            TAIL(0) TAIL(1)
+#else
             TAIL(0) TAIL(1) TAIL(2) TAIL(3)
+#endif
 #undef TAIL
         }
+        if (NO_ADDS) acc[0] += sink;
         // (y is padded to whole groups: no bounds test, so that the loads of a block of registers go out together)
         double* yw = y + (size_t)g * kGroup + (size_t)w * kReg * 64 + lane;
 #pragma unroll
