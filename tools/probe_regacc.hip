@@ -48,9 +48,14 @@ constexpr int kThreads = kWaves * 64;
 constexpr int kReg     = KREG;                  // accumulators per lane
 constexpr int kWords   = kWaves * kReg;         // 64-bit masks per chunk
 constexpr int kGroup   = kWords * 64;           // rows per group
-constexpr int kChunk   = 8192;                  // entries per chunk
-constexpr int kPairs   = kChunk / 2 / kThreads; // pair blocks per chunk (8): a lane's 16 entries
-constexpr int kSlotBits = 13;                   // slot < 8192
+#ifndef SUPER
+#define SUPER 0  // 1: chunks of 16384 entries and ONE staging array (14336 slots), the collection after the chunk instead of beside the next
+#endif
+constexpr int kChunk   = SUPER ? 16384 : 8192;  // entries per chunk
+constexpr int kPairs   = kChunk / 2 / kThreads; // pair blocks per chunk (8 / 16): a lane's 16 / 32 entries
+constexpr int kSlotBits = SUPER ? 14 : 13;      // slot < 8192 / 14336
+constexpr int kEPL     = kChunk / kThreads;     // entries per lane and chunk
+constexpr int kStage   = SUPER ? 14336 : kChunk; // slots of one staging array
 constexpr int kWbStride = 16;                   // int32 per chunk: first slot of every wavefront, total at [8] (read through the scalar cache)
 
 __device__ __forceinline__ uint64_t mix(uint64_t z)
@@ -114,10 +119,10 @@ __global__ __launch_bounds__(kThreads) void chunk_build_kernel(int k, int64_t nn
     for (int i = t; i < kWords * 2; i += kThreads) bits[i] = 0;
     if (t == 0) s_cb = (int)((unsigned)skey[cbeg]) & ~15;
     __syncthreads();
-    int    loc[16], cc[16];
-    double vv[16];
+    int    loc[kEPL], cc[kEPL];
+    double vv[kEPL];
 #pragma unroll
-    for (int u = 0; u < 16; ++u)
+    for (int u = 0; u < kEPL; ++u)
     {
         const int64_t e = cbeg + u * kThreads + t;
         if (e < gend)
@@ -145,6 +150,7 @@ __global__ __launch_bounds__(kThreads) void chunk_build_kernel(int k, int64_t nn
             run += __popc(bits[2 * i]) + __popc(bits[2 * i + 1]);
         }
         pre[kWords] = run;
+        if (run > kStage) atomicExch(err, 2);
     }
     __syncthreads();
     const int cb = s_cb;
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(kThreads) void chunk_build_kernel(int k, int64_t nn
     if (t <= kWaves) wbase[(size_t)c * kWbStride + t] = pre[t * kReg];
     if (t == 0) cbase[c] = cb;
 #pragma unroll
-    for (int u = 0; u < 16; ++u)
+    for (int u = 0; u < kEPL; ++u)
     {
         unsigned word = 0;
         if (loc[u] >= 0)
@@ -316,11 +322,72 @@ __global__ __launch_bounds__(kThreads) void regacc_kernel(const int* __restrict_
         double sink = 0.0;
 #pragma unroll
         for (int r = 0; r < kReg; ++r) acc[r] = 0.0;
-        for (int i = t; i < 2 * kChunk + 64; i += kThreads) stg[i] = 0.0;
+        for (int i = t; i < (SUPER ? 1 : 2) * kStage + 64; i += kThreads) stg[i] = 0.0;
         __syncthreads();
         const int c0 = choff[g], c1 = choff[g + 1];
         // four register sets in turn: the stream of sub-step s + 3 is requested while s is multiplied (HBM latency is ~2 us:
         // a CU needs ~40 KB of the stream in flight)
+#if SUPER
+        // SUPER: a chunk is 16384 entries = four steps of 8 per lane; the products of the whole chunk go into ONE staging array,
+        // then barrier - collection (77 registers, once per 16384 entries) - barrier.  The first step's gathers and the second
+        // step's stream of the NEXT chunk are requested before the collection and are in flight beside it.
+        static_assert(kPS * kSub == kPairs && kSub == 4, "four steps of kPS pair blocks");
+        {
+            Raw A, B;
+            double xa[2 * kPS], xb[2 * kPS];
+            load_raw(A, pw, pv, c0, 0, t);
+            gather(A, x, cbase[c0], xa);
+            load_raw(B, pw, pv, c0, 1, t);
+            for (int c = c0; c < c1; ++c)
+            {
+                const int cb = cbase[c];
+                const int cn = c + 1 < c1 ? c + 1 : c;
+                // step 0: xa (requested before the last collection), B holds step 1's stream
+                __builtin_amdgcn_sched_barrier(0);
+                adds(A, xa, stg, sink);
+                __builtin_amdgcn_sched_barrier(0);
+                gather(B, x, cb, xb);
+                __builtin_amdgcn_sched_barrier(0);
+                load_raw(A, pw, pv, c, 2, t);
+                __builtin_amdgcn_sched_barrier(0);
+                adds(B, xb, stg, sink);  // step 1
+                __builtin_amdgcn_sched_barrier(0);
+                gather(A, x, cb, xa);
+                __builtin_amdgcn_sched_barrier(0);
+                load_raw(B, pw, pv, c, 3, t);
+                __builtin_amdgcn_sched_barrier(0);
+                adds(A, xa, stg, sink);  // step 2
+                __builtin_amdgcn_sched_barrier(0);
+                gather(B, x, cb, xb);
+                __builtin_amdgcn_sched_barrier(0);
+                load_raw(A, pw, pv, cn, 0, t);
+                __builtin_amdgcn_sched_barrier(0);
+                adds(B, xb, stg, sink);  // step 3
+                __builtin_amdgcn_sched_barrier(0);
+                gather(A, x, cbase[cn], xa);  // the next chunk's step 0 (the last chunk gathers itself once more: unused)
+                __builtin_amdgcn_sched_barrier(0);
+                load_raw(B, pw, pv, cn, 1, t);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();  // every product of chunk c is in the staging array
+                {
+                    const uint64_t* mp   = masks + (size_t)c * kWords + (size_t)w * kReg;
+                    const int       lo   = wbase[(size_t)c * kWbStride + w], hi = wbase[(size_t)c * kWbStride + w + 1];
+                    int             base = lo;
+#define PART(S)                                                                                   \
+    {                                                                                             \
+        uint64_t mk[kReg * ((S) + 1) / 4 - kReg * (S) / 4];                                       \
+        load_masks<kReg * (S) / 4, kReg * ((S) + 1) / 4>(mk, mp);                                 \
+        if (!NO_COLLECT) collect<kReg * (S) / 4, kReg * ((S) + 1) / 4>(acc, mk, stg, base);       \
+    }
+                    PART(0) PART(1) PART(2) PART(3)
+#undef PART
+                    for (int i = lo + lane; i < hi; i += 64) stg[i] = 0.0;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();  // ... and collected and cleared before chunk c + 1 adds into it
+            }
+        }
+#else
 #if SUBSTEPS == 2
         // two sub-steps of 8 entries per lane, two register sets: a wait for gathers also waits for every OLDER load (vmcnt
         // counts in order), so what matters is how long ago the stream in front of them was requested - here a whole half chunk
@@ -438,6 +505,7 @@ __global__ __launch_bounds__(kThreads) void regacc_kernel(const int* __restrict_
 #endif
 #undef TAIL
         }
+#endif  // SUPER
         if (NO_ADDS) acc[0] += sink;
         // (y is padded to whole groups: no bounds test, so that the loads of a block of registers go out together)
         double* yw = y + (size_t)g * kGroup + (size_t)w * kReg * 64 + lane;
@@ -537,14 +605,14 @@ int main(int argc, char** argv)
     CK(hipDeviceSynchronize());
     int h_err = 0;
     CK(hipMemcpy(&h_err, err, sizeof(int), hipMemcpyDeviceToHost));
-    if (h_err) return fprintf(stderr, "a chunk spans more columns than its packed words hold\n"), 1;
+    if (h_err) return fprintf(stderr, h_err == 2 ? "a chunk holds more distinct rows than the staging array has slots\n" : "a chunk spans more columns than its packed words hold\n"), 1;
     CK(hipFree(skey));
     CK(hipFree(sidx));
     const double stream_gb = ((double)nchunks * kChunk * 12 + (double)nchunks * (kWords * 8 + kWbStride * 4 + 4)) / 1e9;
     printf("layout: %d groups, %d chunks, %.3f GB streamed per product (%.3f GB = 12 bytes per stored entry)\n", ngroups, nchunks, stream_gb,
            (double)nnz * 12 / 1e9);
 
-    const size_t lds = sizeof(double) * (2 * kChunk + 64);
+    const size_t lds = sizeof(double) * ((SUPER ? 1 : 2) * kStage + 64);
     CK(hipFuncSetAttribute((const void*)regacc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = std::min(ngroups, 256);
     CK(hipMemset(y, 0, ((size_t)nrow + kGroup) * 8));
