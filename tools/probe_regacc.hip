@@ -14,7 +14,7 @@
 //   probe_regacc [rows] [per_row] [ncol]      defaults 10000000 32 rows
 // Prints the kernel's time per product and the largest |y - y_ref| / (|A||x|).
 // Build (here, no GPU needed): hipcc -O3 -std=c++17 --offload-arch=gfx950 -o build/tools/probe_regacc tools/probe_regacc.hip
-//   switches: -DSUBSTEPS=2 -DSTREAM_FIRST=0 -DGATHER_AHEAD=0 -DCBLOCK=6 -DSTREAM_NT=0, timing experiments -DNO_COLLECT=1 -DNO_GATHER=1
+//   switches: -DSUPER=1 (-DMASKS_VEC=0) -DSUBSTEPS=2 -DSTREAM_FIRST=0 -DGATHER_AHEAD=0 -DCBLOCK=6 -DSTREAM_NT=0, timing experiments -DNO_COLLECT=1 -DNO_GATHER=1
 //   -DNO_ADDS=1 -DCOLLECT_NOLDS=1 -DGATHER_SHAPE=1|2.  Counters: tools/pmc_probe_regacc.sh.
 // RESULT (profiles/r06_probe_regacc.txt): correct, 23 % fewer L2 operations than the engine's panel kernel, and slower (C2 1.19 ms
 // against 1.114): with 154 accumulator registers per lane too little is left for the loads in flight.  Not part of the engine.
@@ -189,6 +189,9 @@ __global__ __launch_bounds__(kThreads) void chunk_build_kernel(int k, int64_t nn
 #ifndef COLLECT_NOLDS
 #define COLLECT_NOLDS 0 // timing experiment: the collection does its arithmetic without reading the staging array
 #endif
+#ifndef MASKS_VEC
+#define MASKS_VEC 1      // (SUPER) the masks of a chunk come through a vector load issued at the top of the chunk
+#endif
 #ifndef GATHER_SHAPE
 #define GATHER_SHAPE 0
 #endif
@@ -271,6 +274,19 @@ __device__ __forceinline__ void adds(const Raw& R, const double (&xv)[2 * kPS], 
 #define CBLOCK 10
 #endif
 
+// the same masks out of two vector registers (lane l holds mask l, and mask 64 + l): requested by a VECTOR load a whole chunk
+// ahead - a scalar load of a line nobody has touched takes ~2 us (HBM), and the collection used to wait for four of them in turn
+template <int R0, int R1>
+__device__ __forceinline__ void masks_from_lanes(uint64_t (&mk)[R1 - R0], uint64_t v0, uint64_t v1)
+{
+#pragma unroll
+    for (int r = R0; r < R1; ++r)
+    {
+        const uint64_t v  = r < 64 ? v0 : v1;
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, r & 63), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), r & 63);
+        mk[r - R0]        = ((uint64_t)hi << 32) | lo;
+    }
+}
 template <int R0, int R1>
 __device__ __forceinline__ void load_masks(uint64_t (&mk)[R1 - R0], const uint64_t* __restrict__ mp)
 {
@@ -342,6 +358,14 @@ __global__ __launch_bounds__(kThreads) void regacc_kernel(const int* __restrict_
             {
                 const int cb = cbase[c];
                 const int cn = c + 1 < c1 ? c + 1 : c;
+                static_assert(kReg <= 128, "two mask registers per lane");
+                const uint64_t* mpv = masks + (size_t)c * kWords + (size_t)w * kReg;
+                uint64_t        vm0 = 0, vm1 = 0;
+                if (MASKS_VEC)
+                {
+                    vm0 = mpv[lane < kReg ? lane : 0];
+                    vm1 = mpv[64 + lane < kReg ? 64 + lane : 0];
+                }
                 // step 0: xa (requested before the last collection), B holds step 1's stream
                 __builtin_amdgcn_sched_barrier(0);
                 adds(A, xa, stg, sink);
@@ -376,7 +400,10 @@ __global__ __launch_bounds__(kThreads) void regacc_kernel(const int* __restrict_
 #define PART(S)                                                                                   \
     {                                                                                             \
         uint64_t mk[kReg * ((S) + 1) / 4 - kReg * (S) / 4];                                       \
-        load_masks<kReg * (S) / 4, kReg * ((S) + 1) / 4>(mk, mp);                                 \
+        if (MASKS_VEC)                                                                            \
+            masks_from_lanes<kReg * (S) / 4, kReg * ((S) + 1) / 4>(mk, vm0, vm1);                 \
+        else                                                                                      \
+            load_masks<kReg * (S) / 4, kReg * ((S) + 1) / 4>(mk, mp);                             \
         if (!NO_COLLECT) collect<kReg * (S) / 4, kReg * ((S) + 1) / 4>(acc, mk, stg, base);       \
     }
                     PART(0) PART(1) PART(2) PART(3)
